@@ -1,0 +1,176 @@
+"""TEST INFRASTRUCTURE ONLY.  Generates tests/golden/*.npz from the REAL reference.
+
+Run in the build container (where /root/reference exists):
+
+    python oracle/make_golden.py
+
+The reference modules are imported in place (oracle/reference_shim.py); weights
+and batches are the deterministic synthetic ones of oracle/visualbert_oracle.py
+(synth_state_dict / synth_batch), so a test on the GPU box can rebuild the same
+inputs from (config name, head, seed) alone and compare against the stored
+reference outputs.  Only small slices / checksums of large tensors are stored.
+
+What runs is the reference's own code:
+  TrainVisualBERTObjective.forward      pytorch_pretrained_bert/modeling.py:1373
+  BertAdam.step                         pytorch_pretrained_bert/optimization.py:239
+driven by a restatement of ModelWrapper.step (models/model_wrapper.py:64-96) and of
+the image_mask construction (models/model.py:262-268), because allennlp (needed by
+models/*.py) is not installable here.
+"""
+import os
+import sys
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+
+from oracle import visualbert_oracle as vo          # noqa: E402
+from oracle.reference_shim import load_reference, cpu_cuda_noop  # noqa: E402
+
+GOLDEN_DIR = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+# (file stem, config name, head, B, T, R, seed)
+CASES = [
+    ("tiny_pretraining", "tiny", "pretraining", 2, 32, 8, 0),     # BASELINE.json configs[0]
+    ("micro_pretraining", "micro", "pretraining", 3, 12, 5, 1),   # odd sizes: ragged tiles everywhere
+    ("micro_vqa", "micro", "vqa", 3, 10, 6, 2),
+    ("micro_nlvr", "micro", "nlvr", 2, 12, 8, 3),
+]
+
+LR, WARMUP, T_TOTAL = 5e-5, 0.1, 100
+LOGIT_STRIDE = 509
+N_STEPS = 3
+
+
+def build_reference_model(cfg_kwargs, head, sd):
+    ref_modeling, _ = load_reference()
+    kw = dict(cfg_kwargs)
+    vdim = kw.pop("visual_embedding_dim")
+    V = kw.pop("vocab_size")
+    config = ref_modeling.BertConfig(V, **kw)
+    model = ref_modeling.TrainVisualBERTObjective(config, head, visual_embedding_dim=vdim)
+    model.bert.embeddings.special_intialize()
+    missing = model.load_state_dict(sd, strict=False)
+    # the only key we do not supply is the tied decoder weight alias
+    assert set(missing.missing_keys) <= {"cls.predictions.decoder.weight"}, missing
+    assert not missing.unexpected_keys, missing
+    if head == "pretraining":
+        assert model.cls.predictions.decoder.weight is model.bert.embeddings.word_embeddings.weight
+    return model
+
+
+def reference_forward(model, batch):
+    """Restates models/model.py:262-288 (mask construction + kwargs mapping), then calls the reference."""
+    image_mask = vo.build_image_mask(batch["image_feat_variable"], batch["image_dim_variable"])
+    with cpu_cuda_noop():
+        return model(input_ids=batch["bert_input_ids"], token_type_ids=batch["bert_input_type_ids"],
+                     input_mask=batch["bert_input_mask"], visual_embeddings=batch["image_feat_variable"],
+                     position_embeddings_visual=None, image_mask=image_mask,
+                     visual_embeddings_type=batch.get("visual_embeddings_type"), image_text_alignment=None,
+                     label=batch.get("label"), flickr_position=None,
+                     masked_lm_labels=batch.get("masked_lm_labels"), is_random_next=batch.get("is_random_next"),
+                     output_all_encoded_layers=False)
+
+
+def reference_optimizer(model):
+    """models/model_wrapper.py:100-139 restated (param groups, BertAdam)."""
+    _, ref_opt = load_reference()
+    named = [n for n in model.named_parameters() if "pooler" not in n[0]]
+    no_decay = ["bias", "LayerNorm.bias", "LayerNorm.weight"]
+    groups = [
+        {"params": [p for n, p in named if not any(nd in n for nd in no_decay)], "weight_decay": 0.01},
+        {"params": [p for n, p in named if any(nd in n for nd in no_decay)], "weight_decay": 0.0},
+    ]
+    return ref_opt.BertAdam(groups, lr=LR, warmup=WARMUP, t_total=T_TOTAL)
+
+
+def head16(t):
+    return t.detach().reshape(-1)[:16].double().numpy().copy()
+
+
+def make_case(stem, cfg_name, head, B, T, R, seed):
+    cfg_kwargs = vo.CONFIGS[cfg_name]
+    cfg = vo.OracleConfig(**cfg_kwargs)
+    sd = vo.synth_state_dict(cfg, head, seed)
+    batch = vo.synth_batch(cfg, B, T, R, seed, head)
+    model = build_reference_model(cfg_kwargs, head, sd)
+    rec = OrderedDict()
+    rec["meta"] = np.array([B, T, R, seed], dtype=np.int64)
+
+    # ---- eval-mode forward (dropout off): the logits parity target
+    model.eval()
+    with torch.no_grad():
+        out = reference_forward(model, batch)
+        enc = None
+        with cpu_cuda_noop():
+            image_mask = vo.build_image_mask(batch["image_feat_variable"], batch["image_dim_variable"])
+            enc = model(input_ids=batch["bert_input_ids"], token_type_ids=batch["bert_input_type_ids"],
+                        input_mask=batch["bert_input_mask"], visual_embeddings=batch["image_feat_variable"],
+                        position_embeddings_visual=None, image_mask=image_mask,
+                        visual_embeddings_type=batch.get("visual_embeddings_type"),
+                        output_all_encoded_layers=True)
+    rec["sequence_output"] = enc["sequence_output"][-1].numpy()
+    rec["pooled_output"] = enc["pooled_output"].numpy()
+    rec["loss"] = out["loss"].double().numpy()
+    if head == "pretraining":
+        rec["masked_lm_loss"] = out["masked_lm_loss"].double().numpy()
+        rec["next_sentence_loss"] = out["next_sentence_loss"].double().numpy()
+        rec["seq_relationship_score"] = out["seq_relationship_score"].numpy()
+        lg = out["logits"]
+        rec["logits_strided"] = lg[:, :, ::LOGIT_STRIDE].numpy()
+        rec["logits_absmax"] = lg.abs().max().double().numpy()
+        rec["logits_sum"] = lg.double().sum().numpy()
+        rec["logits_argmax"] = lg.argmax(-1).numpy()
+    else:
+        rec["logits"] = out["logits"].numpy()
+        if head == "vqa":
+            rec["accuracy"] = out["accuracy"].double().numpy()
+
+    # ---- one full training step with dropout p=0 (gradient + optimizer parity)
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    model.train()
+    opt = reference_optimizer(model)
+    opt.zero_grad()
+    out = reference_forward(model, batch)
+    loss = out["loss"].mean()
+    loss.backward()
+    rec["train_loss"] = loss.detach().double().numpy()
+    gnames = []
+    for n, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        gnames.append(n)
+        rec["grad_norm/" + n] = p.grad.double().norm().numpy()
+        rec["grad_head/" + n] = head16(p.grad)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        opt.step()
+        # step 0 has LR multiplier 0 (optimization.py:166-167, progress 0 < warmup): run
+        # N_STEPS-1 more full steps on the same batch so the stored weights really moved.
+        for _ in range(N_STEPS - 1):
+            opt.zero_grad()
+            out = reference_forward(model, batch)
+            out["loss"].mean().backward()
+            opt.step()
+    rec["final_loss"] = out["loss"].mean().detach().double().numpy()
+    for n, p in model.named_parameters():
+        rec["post_norm/" + n] = p.detach().double().norm().numpy()
+        rec["post_head/" + n] = head16(p)
+        rec["delta_norm/" + n] = (p.detach() - sd[n]).double().norm().numpy()
+    rec["grad_names"] = np.array(gnames)
+    os.makedirs(GOLDEN_DIR, exist_ok=True)
+    path = os.path.join(GOLDEN_DIR, stem + ".npz")
+    np.savez_compressed(path, **rec)
+    print("wrote %s (%d KB)" % (path, os.path.getsize(path) // 1024))
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    for case in CASES:
+        make_case(*case)

@@ -1,0 +1,34 @@
+"""Shared helpers: load a golden case and compare a candidate against it."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import visualbert_oracle as vo
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = {
+    "tiny_pretraining": ("tiny", "pretraining"),
+    "micro_pretraining": ("micro", "pretraining"),
+    "micro_vqa": ("micro", "vqa"),
+    "micro_nlvr": ("micro", "nlvr"),
+}
+LR, WARMUP, T_TOTAL = 5e-5, 0.1, 100
+LOGIT_STRIDE = 509
+N_STEPS = 3
+
+
+def load_case(stem):
+    cfg_name, head = CASES[stem]
+    g = np.load(os.path.join(GOLDEN_DIR, stem + ".npz"), allow_pickle=False)
+    B, T, R, seed = [int(x) for x in g["meta"]]
+    cfg = vo.OracleConfig(**vo.CONFIGS[cfg_name])
+    sd = vo.synth_state_dict(cfg, head, seed)
+    batch = vo.synth_batch(cfg, B, T, R, seed, head)
+    return cfg, head, sd, batch, g
+
+
+def maxdiff(a, b):
+    a = torch.as_tensor(np.asarray(a)).double()
+    b = torch.as_tensor(np.asarray(b)).double()
+    return float((a - b).abs().max())

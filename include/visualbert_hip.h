@@ -1,0 +1,112 @@
+/* visualbert_hip.h -- C ABI of libvisualbert_hip.so (gfx950 / MI355X).
+ *
+ * The reference (uclanlp/visualbert) is 100 % Python and has NO FFI / plugin / operator registry
+ * (SURVEY.md section 8b); its only native-op seam is the import-time class substitution
+ *   try: from apex.normalization.fused_layer_norm import FusedLayerNorm as BertLayerNorm
+ *   (visualbert/pytorch_pretrained_bert/modeling.py:158-160)
+ * and the optimizer swap under fp16 (visualbert/models/model_wrapper.py:118-134).  This header is
+ * therefore the ABI a maintainer would bind (ctypes) to replace the ATen op
+ * sequences listed next to each entry point.  Paths below are relative to
+ * /root/reference/visualbert/pytorch_pretrained_bert/ unless they start with models/.
+ *
+ * Conventions
+ *   - plain pointers + sizes; all pointers are DEVICE pointers unless named host_*; no torch types.
+ *   - `stream` is a hipStream_t passed as void*; every call only enqueues work on it (no sync, no
+ *     allocation); the library owns no persistent device memory.
+ *   - return 0 on success, negative VB_ERR_* otherwise; nothing throws across the ABI.
+ *   - dtype: VB_F32 or VB_BF16 selects the storage type "T" of activations / GEMM operands;
+ *     statistics, losses, parameters' master copies and parameter gradients are always fp32.
+ *   - row-major everywhere; `ld*` are leading dimensions in ELEMENTS.
+ */
+#ifndef VISUALBERT_HIP_H
+#define VISUALBERT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { VB_F32 = 0, VB_BF16 = 1 };
+enum { VB_KCONTIG = 0, VB_KSTRIDED = 1 };
+enum { VB_ACT_NONE = 0, VB_ACT_GELU = 1, VB_ACT_TANH = 2, VB_ACT_GELU_GRAD = 3 };
+
+/* library / build identification: returns a static string such as "visualbert_hip gfx950 r1" */
+const char* vb_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * GEMM with fused epilogue.   C[M,N] = epi( alpha * sum_k Aop[m,k] * Bop[n,k] )
+ *   a_layout / b_layout: VB_KCONTIG  -> operand stored [rows][K]  (ld = row pitch)
+ *                        VB_KSTRIDED -> operand stored [K][rows]  (ld = k pitch)
+ *   epi: + bias[n] (fp32, may be NULL) -> act -> + addend[m,n] (T, may be NULL) -> (+= C if accumulate)
+ *   act: VB_ACT_GELU also writes the pre-activation (T) to aux_out when non-NULL;
+ *        VB_ACT_GELU_GRAD multiplies by gelu'(aux_in[m,n]) (T);  VB_ACT_TANH applies tanh.
+ *   out_dtype: dtype (T) or VB_F32.  alpha_dev (may be NULL) is an optional fp32 DEVICE scalar that
+ *   multiplies alpha (used to carry an upstream loss-gradient scalar without a host sync).
+ *   Requirements: lda, ldb multiples of 8; A, B 16-byte aligned; a K-contiguous operand must be
+ *   readable up to round_up(K, 8) per row and a K-strided one up to round_up(rows, 8) per k.
+ * Replaces: nn.Linear forward/backward at modeling.py:232-234, 271, 303, 316, 383-385, 398, 419, 451,
+ *           1220 and the GELU of :56-61 fused behind :303 / :398.
+ * ---------------------------------------------------------------------------------------------- */
+int vb_gemm(int dtype, int out_dtype, int a_layout, int b_layout,
+            const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+            int M, int N, int K, float alpha, const float* alpha_dev, const float* bias,
+            const void* addend, int64_t ld_addend, int act,
+            const void* aux_in, void* aux_out, int64_t ld_aux, int accumulate,
+            void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * BertLayerNorm (+ fused residual add and dropouts), forward and backward.
+ *   z = dropout_in(x) + resid ;  y = dropout_out( gamma * (z - mean) / sqrt(var + eps) + beta )
+ * x, resid (may be NULL), z_out (may be NULL), y: T [M,H].  mean, rstd: fp32 [M] (may be NULL).
+ * Dropout masks are regenerated from (seed, stream id, element index) -- never stored.
+ * Backward: dz (T, gradient w.r.t. z == w.r.t. resid), dx (T, = dz o mask_in/(1-p_in); may alias dz
+ * or be NULL when p_in == 0), dgamma/dbeta/dbias (fp32 [H], ACCUMULATED; any may be NULL; dbias is
+ * the column sum of dx = bias gradient of the Linear that produced x).
+ * Replaces: modeling.py:171-175 (BertLayerNorm), :272-273, :317-318 (dropout + residual + LN),
+ *           :1255-1256 (embedding LN + dropout), :400 (MLM transform LN).
+ * ---------------------------------------------------------------------------------------------- */
+int vb_ln_fwd(int dtype, const void* x, const void* resid, void* z_out, void* y, float* mean, float* rstd,
+              const float* gamma, const float* beta, int M, int H, float eps,
+              float p_in, uint32_t stream_in, float p_out, uint32_t stream_out, uint64_t seed, void* stream);
+int vb_ln_bwd(int dtype, const void* dy, const void* z, const float* mean, const float* rstd,
+              const float* gamma, void* dz, void* dx, float* dgamma, float* dbeta, float* dbias,
+              int M, int H, float p_in, uint32_t stream_in, float p_out, uint32_t stream_out,
+              uint64_t seed, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * BertEmbeddingsWithVisualEmbedding gather-add (image_text_alignment == None branch).
+ *   z[b, s<T]  = word[ids[b,s]] + pos[s] + type[type_ids[b,s]]
+ *   z[b, T+r]  = vis_proj[b,r] + pos_vis[0] + type_vis[visual_type[b,r]]      (visual position id is 0)
+ * Tables are the fp32 master parameters; vis_proj is the projection GEMM's output (T [B*R,H]).
+ * Backward scatters dz into the fp32 table gradients (ACCUMULATED) and copies the visual rows to
+ * d_vis_proj (T [B*R,H]).   Replaces: modeling.py:1213-1253 and its autograd.
+ * ---------------------------------------------------------------------------------------------- */
+int vb_embed_fwd(int dtype, const int64_t* input_ids, const int64_t* token_type_ids, const int64_t* visual_type,
+                 const void* vis_proj, const float* word, const float* pos, const float* type,
+                 const float* pos_vis, const float* type_vis, void* z,
+                 int B, int T, int R, int H, int V, int type_vocab, int max_pos, void* stream);
+int vb_embed_bwd(int dtype, const void* dz, const int64_t* input_ids, const int64_t* token_type_ids,
+                 const int64_t* visual_type, float* d_word, float* d_pos, float* d_type,
+                 float* d_pos_vis, float* d_type_vis, void* d_vis_proj,
+                 int B, int T, int R, int H, int V, int type_vocab, int max_pos, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused multi-head self-attention (head size 64).  qkv: T [B*S, 3H] (Q | K | V column blocks),
+ * mask_add: fp32 [B,S] additive key mask ((1 - mask) * -10000, modeling.py:1293-1294),
+ * ctx: T [B*S, H], lse: fp32 [B,nh,S] row log-sum-exp (saved for backward),
+ * keepbits: uint64 [B*nh * vb_attn_keepbits_words(S)] dropout keep-bits (only touched when p_drop > 0).
+ * Backward writes dqkv (T [B*S,3H]) completely; dsum_ws is an fp32 [B,nh,S] scratch.
+ * Replaces: BertSelfAttention.forward modeling.py:236-256 and its autograd.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t vb_attn_keepbits_words(int S);
+int vb_attn_fwd(int dtype, const void* qkv, const float* mask_add, void* ctx, float* lse, uint64_t* keepbits,
+                int B, int S, int nh, int head_dim, float p_drop, uint64_t seed, uint32_t stream_id, void* stream);
+int vb_attn_bwd(int dtype, const void* qkv, const float* mask_add, const void* dctx, const float* lse,
+                const uint64_t* keepbits, float* dsum_ws, void* dqkv, int B, int S, int nh, int head_dim,
+                float p_drop, uint64_t seed, uint32_t stream_id, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -23,3 +23,22 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+def _emu_lib_path():
+    return os.path.join(ROOT, "tests", "hipemu", "libvisualbert_emu.so")
+
+
+@pytest.fixture(scope="session")
+def dev():
+    """Device the kernels run on: 'cuda' on the GPU box; 'cpu' under VB_EMU=1 (kernel-logic simulator)."""
+    import torch
+    from visualbert_amd import _lib
+    if os.environ.get("VB_EMU") == "1":
+        path = _emu_lib_path()
+        if not os.path.isfile(path):
+            pytest.skip("VB_EMU=1 but %s is not built (make -C visualbert_amd/csrc emu)" % path)
+        _lib.set_library(path, "cpu")
+        return torch.device("cpu")
+    assert torch.cuda.is_available()
+    return torch.device("cuda", 0)

@@ -1,0 +1,296 @@
+"""Per-kernel parity: every C-ABI entry point against plain torch fp32 maths on the same inputs.
+fp32 kernels must agree to fp32 round-off; bf16 kernels are compared with the same maths on
+bf16-rounded inputs at a bf16-sized tolerance (stated per test)."""
+import ctypes
+import math
+
+import pytest
+import torch
+
+from visualbert_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def tol(dt, f32, bf):
+    return f32 if dt == torch.float32 else bf
+
+
+def gemm(dev, dt, A, B, M, N, K, al, bl, out_f32=False, bias=None, act=0, addend=None, aux_in=None, aux_out=None,
+         acc=None, alpha=1.0, alpha_dev=None):
+    L = _lib.lib()
+    C = acc if acc is not None else torch.full((M, N), 7.0, dtype=torch.float32 if out_f32 else dt, device=dev)
+    aux = aux_in if aux_in is not None else aux_out
+    rc = L.vb_gemm(_lib.dtype_code(dt), _lib.VB_F32 if out_f32 else _lib.dtype_code(dt), al, bl,
+                   _lib.ptr(A), A.stride(0), _lib.ptr(B), B.stride(0), _lib.ptr(C), C.stride(0), M, N, K,
+                   alpha, _lib.ptr(alpha_dev), _lib.ptr(bias), _lib.ptr(addend),
+                   addend.stride(0) if addend is not None else 0, act, _lib.ptr(aux_in), _lib.ptr(aux_out),
+                   aux.stride(0) if aux is not None else 0, 1 if acc is not None else 0, _lib.stream_ptr())
+    _lib.check(rc, "vb_gemm")
+    return C
+
+
+def padded(rows, cols, dt, dev, g):
+    """[rows, cols] view of a buffer whose leading dimension is a multiple of 8 (ABI requirement)."""
+    ld = (cols + 7) // 8 * 8
+    buf = torch.zeros(rows, ld, dtype=dt, device=dev)
+    buf[:, :cols] = torch.randn(rows, cols, generator=g).to(dt).to(dev)
+    return buf[:, :cols]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("shape", [(200, 136, 96), (130, 30, 64), (64, 257, 40)])
+def test_gemm_forward_layout(dev, dt, shape):
+    M, N, K = shape
+    g = torch.Generator().manual_seed(1)
+    A = padded(M, K, dt, dev, g)
+    B = padded(N, K, dt, dev, g)
+    bias = torch.randn(N, generator=g).to(dev)
+    C = gemm(dev, dt, A, B, M, N, K, 0, 0, bias=bias)
+    ref = A.float() @ B.float().t() + bias
+    err = (C.float() - ref).abs().max().item()
+    assert err <= tol(dt, 2e-4, 0.02 * ref.abs().max().item()), err
+    # fp32 output + GELU + pre-activation + addend
+    add = padded(M, N, dt, dev, g)
+    aux = torch.zeros(M, (N + 7) // 8 * 8, dtype=dt, device=dev)[:, :N]
+    C = gemm(dev, dt, A, B, M, N, K, 0, 0, out_f32=True, bias=bias, act=_lib.VB_ACT_GELU, addend=add, aux_out=aux)
+    ref2 = torch.nn.functional.gelu(ref) + add.float()
+    assert (C - ref2).abs().max().item() <= 2e-4
+    assert (aux.float() - ref).abs().max().item() <= tol(dt, 2e-4, 0.02 * ref.abs().max().item())
+    # tanh
+    C = gemm(dev, dt, A, B, M, N, K, 0, 0, out_f32=True, bias=bias, act=_lib.VB_ACT_TANH, alpha=0.1)
+    assert (C - torch.tanh(0.1 * (ref - bias) + bias)).abs().max().item() <= 2e-5
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("shape", [(200, 136, 72), (130, 30, 40), (70, 300, 136)])
+def test_gemm_dgrad_wgrad_layouts(dev, dt, shape):
+    M, N, K2 = shape          # dY [M,N], W [N,K2], X [M,K2]
+    g = torch.Generator().manual_seed(2)
+    dY = padded(M, N, dt, dev, g)
+    W = padded(N, K2, dt, dev, g)
+    X = padded(M, K2, dt, dev, g)
+    pre = padded(M, K2, dt, dev, g)
+    # dgrad: dX = dY W  (B operand K-strided), fused GELU' and residual-gradient addend
+    add = padded(M, K2, dt, dev, g)
+    C = gemm(dev, dt, dY, W, M, K2, N, 0, 1, out_f32=True, act=_lib.VB_ACT_GELU_GRAD, aux_in=pre, addend=add)
+    x = pre.float()
+    gelu_grad = 0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
+    ref = (dY.float() @ W.float()) * gelu_grad + add.float()
+    assert (C - ref).abs().max().item() <= 3e-4 * max(1.0, ref.abs().max().item())
+    # wgrad: dW += alpha_dev * dY^T X  (both operands K-strided, fp32 accumulate in place)
+    acc = torch.ones(N, K2, device=dev)
+    sc = torch.tensor([0.5], device=dev)
+    C = gemm(dev, dt, dY, X, N, K2, M, 1, 1, out_f32=True, acc=acc, alpha_dev=sc)
+    ref = 0.5 * (dY.float().t() @ X.float()) + 1.0
+    assert (C - ref).abs().max().item() <= 3e-4 * max(1.0, ref.abs().max().item())
+
+
+def ln_fwd(dev, dt, x, resid, gamma, beta, p_in=0.0, p_out=0.0, seed=5, want_z=True):
+    M, H = x.shape
+    L = _lib.lib()
+    y = torch.empty_like(x)
+    z = torch.empty_like(x) if want_z else None
+    mean = torch.empty(M, device=dev)
+    rstd = torch.empty(M, device=dev)
+    rc = L.vb_ln_fwd(_lib.dtype_code(dt), _lib.ptr(x), _lib.ptr(resid), _lib.ptr(z), _lib.ptr(y), _lib.ptr(mean),
+                     _lib.ptr(rstd), _lib.ptr(gamma), _lib.ptr(beta), M, H, 1e-12, p_in, 11, p_out, 12, seed,
+                     _lib.stream_ptr())
+    _lib.check(rc, "vb_ln_fwd")
+    return y, z, mean, rstd
+
+
+def ln_bwd(dev, dt, dy, z, mean, rstd, gamma, p_in=0.0, p_out=0.0, seed=5):
+    M, H = dy.shape
+    L = _lib.lib()
+    dz = torch.empty_like(dy)
+    dx = torch.empty_like(dy)
+    dg = torch.zeros(H, device=dev)
+    db = torch.zeros(H, device=dev)
+    dbias = torch.zeros(H, device=dev)
+    rc = L.vb_ln_bwd(_lib.dtype_code(dt), _lib.ptr(dy), _lib.ptr(z), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(gamma),
+                     _lib.ptr(dz), _lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db), _lib.ptr(dbias), M, H,
+                     p_in, 11, p_out, 12, seed, _lib.stream_ptr())
+    _lib.check(rc, "vb_ln_bwd")
+    return dz, dx, dg, db, dbias
+
+
+def ref_ln(z, gamma, beta):
+    u = z.mean(-1, keepdim=True)
+    s = (z - u).pow(2).mean(-1, keepdim=True)
+    return gamma * ((z - u) / torch.sqrt(s + 1e-12)) + beta
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("MH", [(37, 128), (21, 768), (9, 1024)])
+def test_layernorm_residual_fwd_bwd(dev, dt, MH):
+    M, H = MH
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(M, H, generator=g).to(dt).to(dev)
+    r = torch.randn(M, H, generator=g).to(dt).to(dev)
+    gamma = (1 + 0.1 * torch.randn(H, generator=g)).to(dev)
+    beta = (0.1 * torch.randn(H, generator=g)).to(dev)
+    y, z, mean, rstd = ln_fwd(dev, dt, x, r, gamma, beta)
+    zr = (x.float() + r.float()).requires_grad_(True)
+    yr = ref_ln(zr, gamma, beta)
+    assert (y.float() - yr).abs().max().item() <= tol(dt, 2e-5, 0.04)
+    assert (z.float() - zr).abs().max().item() <= tol(dt, 1e-6, 0.04)
+    dy = torch.randn(M, H, generator=g).to(dt).to(dev)
+    # backward consumes the stored (T-rounded) z: the reference does the same
+    zs = z.float().detach().requires_grad_(True)
+    gp = gamma.clone().requires_grad_(True)
+    bp = beta.clone().requires_grad_(True)
+    ref_ln(zs, gp, bp).backward(dy.float())
+    dz, dx, dg, db, dbias = ln_bwd(dev, dt, dy, z, mean, rstd, gamma)
+    t = tol(dt, 5e-5, 0.05)
+    assert (dz.float() - zs.grad).abs().max().item() <= t * max(1.0, zs.grad.abs().max().item())
+    assert torch.equal(dx, dz)
+    assert (dg - gp.grad).abs().max().item() <= tol(dt, 2e-4, 0.02) * max(1.0, gp.grad.abs().max().item())
+    assert (db - bp.grad).abs().max().item() <= 2e-4 * max(1.0, bp.grad.abs().max().item())
+    # dbias is summed from the fp32 dz (before rounding to T)
+    assert (dbias - zs.grad.sum(0)).abs().max().item() <= tol(dt, 2e-4, 0.01) * max(1.0, zs.grad.sum(0).abs().max().item())
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_layernorm_dropout_consistency(dev, dt):
+    """dropout masks are regenerated, not stored: forward and backward must agree on them, the keep
+    rate must be 1-p, and different stream ids must give different masks."""
+    M, H, p = 64, 768, 0.1
+    g = torch.Generator().manual_seed(4)
+    x = (1.0 + torch.rand(M, H, generator=g)).to(dt).to(dev)        # strictly positive: zeros == dropped
+    zero = torch.zeros(M, H, dtype=dt, device=dev)
+    gamma = torch.ones(H, device=dev)
+    beta = torch.zeros(H, device=dev)
+    # input dropout: z = drop(x) + 0
+    y, z, mean, rstd = ln_fwd(dev, dt, x, zero, gamma, beta, p_in=p)
+    keep_in = z.float() != 0
+    rate = keep_in.float().mean().item()
+    assert abs(rate - (1 - p)) < 0.01, rate
+    assert (z.float()[keep_in] - (x.float() / (1 - p))[keep_in]).abs().max().item() <= tol(dt, 1e-5, 0.02)
+    dy = torch.ones(M, H, dtype=dt, device=dev)
+    dz, dx, *_ = ln_bwd(dev, dt, dy * 0 + torch.randn(M, H, generator=g).to(dt).to(dev), z, mean, rstd, gamma, p_in=p)
+    assert torch.equal(dx.float() != 0, keep_in & (dz.float() != 0))
+    sel = keep_in & (dz.float() != 0)
+    assert (dx.float()[sel] - dz.float()[sel] / (1 - p)).abs().max().item() <= tol(dt, 1e-5, 0.02) * 5
+    # output dropout: y = drop(LN(x))
+    y2, _, _, _ = ln_fwd(dev, dt, x, None, gamma, beta, p_out=p, want_z=False)
+    y0, _, _, _ = ln_fwd(dev, dt, x, None, gamma, beta, want_z=False)
+    keep_out = y2.float() != 0
+    assert abs(keep_out.float().mean().item() - (1 - p)) < 0.01
+    assert (keep_out != keep_in).any()                               # stream ids 11 vs 12 differ
+    assert (y2.float()[keep_out] - y0.float()[keep_out] / (1 - p)).abs().max().item() <= tol(dt, 1e-5, 0.05)
+    # a different seed gives a different mask
+    _, z3, _, _ = ln_fwd(dev, dt, x, zero, gamma, beta, p_in=p, seed=6)
+    assert ((z3.float() != 0) != keep_in).any()
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_embedding_fwd_bwd(dev, dt):
+    B, T, R, H, V, TV, P = 5, 12, 6, 128, 50, 2, 64
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(0, V, (B, T), generator=g).to(dev)
+    tt = torch.randint(0, TV, (B, T), generator=g).to(dev)
+    vt = torch.randint(0, TV, (B, R), generator=g).to(dev)
+    word = torch.randn(V, H, generator=g).to(dev)
+    pos = torch.randn(P, H, generator=g).to(dev)
+    typ = torch.randn(TV, H, generator=g).to(dev)
+    posv = torch.randn(P, H, generator=g).to(dev)
+    typv = torch.randn(TV, H, generator=g).to(dev)
+    vp = torch.randn(B * R, H, generator=g).to(dt).to(dev)
+    z = torch.empty(B, T + R, H, dtype=dt, device=dev)
+    L = _lib.lib()
+    rc = L.vb_embed_fwd(_lib.dtype_code(dt), _lib.ptr(ids), _lib.ptr(tt), _lib.ptr(vt), _lib.ptr(vp), _lib.ptr(word),
+                        _lib.ptr(pos), _lib.ptr(typ), _lib.ptr(posv), _lib.ptr(typv), _lib.ptr(z), B, T, R, H, V, TV, P,
+                        _lib.stream_ptr())
+    _lib.check(rc, "vb_embed_fwd")
+    text = word[ids] + pos[:T].unsqueeze(0) + typ[tt]
+    vis = vp.float().view(B, R, H) + posv[0] + typv[vt]
+    ref = torch.cat((text, vis), 1)
+    assert (z.float() - ref).abs().max().item() <= tol(dt, 1e-6, 0.04)
+    dz = torch.randn(B, T + R, H, generator=g).to(dt).to(dev)
+    dw = torch.ones(V, H, device=dev); dp = torch.ones(P, H, device=dev); dty = torch.ones(TV, H, device=dev)
+    dpv = torch.ones(P, H, device=dev); dtv = torch.ones(TV, H, device=dev)
+    dvp = torch.empty(B * R, H, dtype=dt, device=dev)
+    rc = L.vb_embed_bwd(_lib.dtype_code(dt), _lib.ptr(dz), _lib.ptr(ids), _lib.ptr(tt), _lib.ptr(vt), _lib.ptr(dw),
+                        _lib.ptr(dp), _lib.ptr(dty), _lib.ptr(dpv), _lib.ptr(dtv), _lib.ptr(dvp), B, T, R, H, V, TV, P,
+                        _lib.stream_ptr())
+    _lib.check(rc, "vb_embed_bwd")
+    d = dz.float()
+    rw = torch.ones(V, H, device=dev).index_put_((ids.reshape(-1),), d[:, :T].reshape(-1, H), accumulate=True)
+    rp = torch.ones(P, H, device=dev); rp[:T] += d[:, :T].sum(0)
+    rt = torch.ones(TV, H, device=dev).index_put_((tt.reshape(-1),), d[:, :T].reshape(-1, H), accumulate=True)
+    rpv = torch.ones(P, H, device=dev); rpv[0] += d[:, T:].sum((0, 1))
+    rtv = torch.ones(TV, H, device=dev).index_put_((vt.reshape(-1),), d[:, T:].reshape(-1, H), accumulate=True)
+    for a, b in ((dw, rw), (dp, rp), (dty, rt), (dpv, rpv), (dtv, rtv)):
+        assert (a - b).abs().max().item() <= 1e-4
+    assert torch.equal(dvp.view(B, R, H), dz[:, T:])
+
+
+def attn_ref(qkv, mask_add, nh, keep=None, p=0.0):
+    """plain fp32 restatement of modeling.py:236-256 on packed qkv [B,S,3H]."""
+    B, S, H3 = qkv.shape
+    H = H3 // 3
+    d = H // nh
+    q, k, v = [x.view(B, S, nh, d).permute(0, 2, 1, 3) for x in qkv.split(H, dim=-1)]
+    s = q @ k.transpose(-1, -2) / math.sqrt(d) + mask_add.view(B, 1, 1, S)
+    pr = torch.softmax(s, -1)
+    if keep is not None:
+        pr = pr * keep / (1 - p)
+    ctx = (pr @ v).permute(0, 2, 1, 3).reshape(B, S, H)
+    return ctx, torch.logsumexp(s, -1)
+
+
+def decode_keepbits(bits, B, nh, S):
+    """uint64 keep-bits -> bool [B,nh,S(query),S(key)] (layout documented in attention.hip)."""
+    nw = bits.numel() // (B * nh * S * 4)
+    w = bits.view(B * nh, S, 4, nw).cpu()
+    keep = torch.zeros(B * nh, S, S, dtype=torch.bool)
+    for key in range(S):
+        kf, g, r = key // 16, (key % 16) // 4, key % 4
+        word = w[:, :, g, kf // 16]
+        keep[:, :, key] = ((word >> ((kf % 16) * 4 + r)) & 1).bool()
+    return keep.view(B, nh, S, S)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("cfg", [(2, 40, 2, 0.0), (1, 164, 2, 0.0), (2, 23, 3, 0.1), (1, 164, 1, 0.1)])
+def test_attention_fwd_bwd(dev, dt, cfg):
+    B, S, nh, p = cfg
+    H = nh * 64
+    g = torch.Generator().manual_seed(6)
+    qkv = (0.7 * torch.randn(B, S, 3 * H, generator=g)).to(dt).to(dev)
+    lens = torch.randint(S // 2, S + 1, (B,), generator=g)
+    mask = (torch.arange(S).unsqueeze(0) < lens.unsqueeze(1)).float()
+    mask[:, S // 3] = 0                                             # a masked slot in the middle (padded text)
+    mask_add = ((1 - mask) * -10000.0).to(dev)
+    L = _lib.lib()
+    ctx = torch.empty(B, S, H, dtype=dt, device=dev)
+    lse = torch.empty(B, nh, S, device=dev)
+    nwords = L.vb_attn_keepbits_words(S)
+    bits = torch.zeros(B * nh * nwords, dtype=torch.int64, device=dev)
+    rc = L.vb_attn_fwd(_lib.dtype_code(dt), _lib.ptr(qkv), _lib.ptr(mask_add), _lib.ptr(ctx), _lib.ptr(lse),
+                       _lib.ptr(bits), B, S, nh, 64, p, 77, 3, _lib.stream_ptr())
+    _lib.check(rc, "vb_attn_fwd")
+    keep = None
+    if p > 0:
+        keep = decode_keepbits(bits, B, nh, S).to(dev).float()
+        valid = keep[:, :, :, :]
+        rate = valid.mean().item()
+        assert abs(rate - (1 - p)) < 0.02, rate
+    qr = qkv.float().detach().requires_grad_(True)
+    ctx_r, lse_r = attn_ref(qr, mask_add, nh, keep, p)
+    t = tol(dt, 2e-5, 0.03)
+    assert (ctx.float() - ctx_r).abs().max().item() <= t, (ctx.float() - ctx_r).abs().max().item()
+    assert (lse - lse_r).abs().max().item() <= tol(dt, 2e-5, 2e-3)
+    dctx = torch.randn(B, S, H, generator=g).to(dt).to(dev)
+    ctx_r.backward(dctx.float())
+    dqkv = torch.full((B, S, 3 * H), float("nan"), dtype=dt, device=dev)
+    ws = torch.empty(B, nh, S, device=dev)
+    rc = L.vb_attn_bwd(_lib.dtype_code(dt), _lib.ptr(qkv), _lib.ptr(mask_add), _lib.ptr(dctx), _lib.ptr(lse),
+                       _lib.ptr(bits), _lib.ptr(ws), _lib.ptr(dqkv), B, S, nh, 64, p, 77, 3, _lib.stream_ptr())
+    _lib.check(rc, "vb_attn_bwd")
+    gmax = qr.grad.abs().max().item()
+    err = (dqkv.float() - qr.grad).abs().max().item()
+    assert err <= tol(dt, 5e-5, 0.04) * max(1.0, gmax), (err, gmax)

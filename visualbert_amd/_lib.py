@@ -1,0 +1,102 @@
+"""ctypes binding of libvisualbert_hip.so (the C ABI declared in include/visualbert_hip.h).
+
+There is NO fallback: if the gfx950 library is missing or an entry point returns non-zero, a
+RuntimeError is raised.  Build it with `python -c "import __graft_entry__ as g; g.build()"` or
+`make -C visualbert_amd/csrc`.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "libvisualbert_hip.so")
+
+VB_F32, VB_BF16 = 0, 1
+VB_KCONTIG, VB_KSTRIDED = 0, 1
+VB_ACT_NONE, VB_ACT_GELU, VB_ACT_TANH, VB_ACT_GELU_GRAD = 0, 1, 2, 3
+
+_i, _i64, _f, _p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+_u32, _u64 = ctypes.c_uint32, ctypes.c_uint64
+
+# name -> (restype, argtypes); kept in the order of include/visualbert_hip.h
+SIGNATURES = {
+    "vb_version": (ctypes.c_char_p, []),
+    "vb_gemm": (_i, [_i, _i, _i, _i, _p, _i64, _p, _i64, _p, _i64, _i, _i, _i, _f, _p, _p, _p, _i64, _i,
+                     _p, _p, _i64, _i, _p]),
+    "vb_ln_fwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _f, _u32, _f, _u32, _u64, _p]),
+    "vb_ln_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _u32, _f, _u32, _u64, _p]),
+    "vb_embed_fwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "vb_embed_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "vb_attn_keepbits_words": (_i64, [_i]),
+    "vb_attn_fwd": (_i, [_i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _u64, _u32, _p]),
+    "vb_attn_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _u64, _u32, _p]),
+}
+
+_ERRORS = {-1: "VB_ERR_ARG (bad argument)", -2: "VB_ERR_LAUNCH (hip launch failed)",
+           -3: "VB_ERR_UNSUPPORTED (shape/dtype not supported by this kernel)"}
+
+_lib = None
+_lib_path = None
+_device_type = "cuda"
+
+
+def set_library(path, device_type="cuda"):
+    """Select the shared object to bind.  The product never calls this (DEFAULT_LIB on `cuda`);
+    tests/conftest.py uses it to point the same Python code at the developer-only kernel-logic
+    simulator (tests/hipemu) when VB_EMU=1."""
+    global _lib, _lib_path, _device_type
+    _lib, _lib_path, _device_type = None, path, device_type
+
+
+def device_type():
+    return _device_type
+
+
+def lib():
+    global _lib, _lib_path
+    if _lib is not None:
+        return _lib
+    path = _lib_path or DEFAULT_LIB
+    if not os.path.isfile(path):
+        raise RuntimeError(
+            "visualbert_amd: %s not found -- the HIP extension is required (no CPU fallback exists). "
+            "Build it: python -c 'import __graft_entry__ as g; g.build()'" % path)
+    L = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(L, name)
+        except AttributeError:
+            raise RuntimeError("visualbert_amd: %s does not export %s (stale build?)" % (path, name))
+        fn.restype = res
+        fn.argtypes = args
+    _lib, _lib_path = L, path
+    return L
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("visualbert_amd: %s failed: %s" % (what, _ERRORS.get(rc, "error %d" % rc)))
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  Tensors must live on the library's device."""
+    if t is None:
+        return None
+    if t.device.type != _device_type:
+        raise RuntimeError("visualbert_amd: tensor on %s, library runs on %s" % (t.device, _device_type))
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    if _device_type == "cuda":
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return None
+
+
+def dtype_code(dt):
+    if dt == torch.float32:
+        return VB_F32
+    if dt == torch.bfloat16:
+        return VB_BF16
+    raise RuntimeError("visualbert_amd: unsupported dtype %s (fp32 / bf16 only)" % dt)

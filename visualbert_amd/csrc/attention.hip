@@ -1,0 +1,520 @@
+// attention.hip -- fused multi-head self-attention over the concatenated [text ; visual] sequence.
+//
+// Replaces BertSelfAttention.forward after the Q/K/V Linears
+//   (pytorch_pretrained_bert/modeling.py:236-256: transpose_for_scores, QK^T / sqrt(d), + additive
+//    mask, softmax, dropout on the probabilities, .V, merge heads) and its autograd backward.
+// The S x S score / probability tensors never exist in HBM: what is saved for backward is the
+// per-row log-sum-exp (fp32) and, when dropout is on, one keep-bit per probability.
+//
+// Layout in HBM: qkv is token-major [B*S, 3H] exactly as the packed Q|K|V Linear writes it (head h of
+// Q at columns h*64.., K at H + h*64.., V at 2H + h*64..: one 128-byte line per (token, head) in bf16);
+// ctx / dctx are [B*S, H]; dqkv mirrors qkv.  Head size is 64 (BERT-base 768/12, config-1 128/2).
+//
+// MFMA formulation (16x16x32 fragments, wave = 64 lanes).  S = 164 fits on chip, so one workgroup
+// owns one (batch, head) and stages K / V (or Q / dO) in LDS once.
+//   forward  : S^T = K Q^T  (lane <-> query, registers <-> keys)  -> softmax reductions are in-lane +
+//              2 shuffles; P^T feeds O^T = V^T P^T straight from registers (no LDS round trip) because
+//              the MFMA K index may be any permutation as long as A and B agree (guide T12).
+//   backward A (per query block): S^T, dP^T = V dO^T, dS^T, dQ^T = K^T dS^T, and D = rowsum(P o dP).
+//   backward B (per key block)  : S = Q K^T, dP = dO V^T (lane <-> key, registers <-> queries), then
+//              dV^T += dO^T P and dK^T += Q^T dS with the query index as the MFMA K index.
+// Transposed operands (V^T, K^T, Q^T, dO^T) are built while staging into LDS.
+#include "vb_rt.h"
+#include "../../include/visualbert_hip.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int D = 64;
+
+template <typename T> struct LT;   // LDS tile geometry
+template <> struct LT<bf16> {
+    static constexpr int RB = 128, CPR = 8, KPT = 2, TPAD = 8;
+    VB_DEVICE int sw(int row) { return (row ^ (row >> 3)) & 7; }
+};
+template <> struct LT<float> {
+    static constexpr int RB = 256, CPR = 16, KPT = 1, TPAD = 16;
+    VB_DEVICE int sw(int row) { return (row & 7) << 1; }
+};
+template <typename T> VB_DEVICE int rm_off(int row, int c) { return row * LT<T>::RB + ((c ^ LT<T>::sw(row)) << 4); }
+template <typename T> constexpr int tr_pitch(int nk) { return nk * (int)sizeof(T) + LT<T>::TPAD; }
+template <typename T> constexpr int rm_bytes(int nrows) { return nrows * LT<T>::RB; }
+template <typename T> constexpr int tr_bytes(int nk) { return D * tr_pitch<T>(nk); }
+
+// ---- staging ---------------------------------------------------------------------------------
+// row-major [nrows][64] tile from X[(row0 + r) * ldx + c0 + d], rows >= S zero-filled
+template <typename T>
+VB_DEVICE void stage_rm(unsigned char* lds, const T* X, long ldx, long row0, int c0, int S, int nrows, int t) {
+    constexpr int CPR = LT<T>::CPR, EPC = 16 / (int)sizeof(T);
+    for (int idx = t; idx < nrows * CPR; idx += NT) {
+        const int r = idx / CPR, c = idx % CPR;
+        u32x4 v = u32x4{0u, 0u, 0u, 0u};
+        if (r < S) v = *(const u32x4*)(X + (row0 + r) * ldx + c0 + c * EPC);
+        *(u32x4*)(lds + rm_off<T>(r, c)) = v;
+    }
+}
+// transposed [64][nk] tile: element (d, r) = X[(row0 + r) * ldx + c0 + d], r >= S zero-filled
+VB_DEVICE void stage_tr(unsigned char* lds, const bf16* X, long ldx, long row0, int c0, int S, int nk, int t) {
+    const int pitch = tr_pitch<bf16>(nk);
+    for (int idx = t; idx < (nk / 2) * 8; idx += NT) {
+        const int dc = idx & 7, r = (idx >> 3) * 2;
+        u32x4 x0 = u32x4{0u, 0u, 0u, 0u}, x1 = x0;
+        if (r < S) x0 = *(const u32x4*)(X + (row0 + r) * ldx + c0 + dc * 8);
+        if (r + 1 < S) x1 = *(const u32x4*)(X + (row0 + r + 1) * ldx + c0 + dc * 8);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const uint32_t a = x0[w], b = x1[w];
+            *(uint32_t*)(lds + (dc * 8 + 2 * w) * pitch + r * 2) = (a & 0xFFFFu) | (b << 16);
+            *(uint32_t*)(lds + (dc * 8 + 2 * w + 1) * pitch + r * 2) = (a >> 16) | (b & 0xFFFF0000u);
+        }
+    }
+}
+VB_DEVICE void stage_tr(unsigned char* lds, const float* X, long ldx, long row0, int c0, int S, int nk, int t) {
+    const int pitch = tr_pitch<float>(nk);
+    for (int idx = t; idx < nk * 8; idx += NT) {
+        const int dc = idx & 7, r = idx >> 3;
+        u32x4 x0 = u32x4{0u, 0u, 0u, 0u}, x1 = x0;
+        if (r < S) {
+            x0 = *(const u32x4*)(X + (row0 + r) * ldx + c0 + dc * 8);
+            x1 = *(const u32x4*)(X + (row0 + r) * ldx + c0 + dc * 8 + 4);
+        }
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            *(uint32_t*)(lds + (dc * 8 + w) * pitch + r * 4) = x0[w];
+            *(uint32_t*)(lds + (dc * 8 + 4 + w) * pitch + r * 4) = x1[w];
+        }
+    }
+}
+
+// ---- fragments -------------------------------------------------------------------------------
+// 8 consecutive d (d0 = ks*32 + g*8) of row `row` of a row-major LDS tile
+VB_DEVICE bf16x8 frag_rm(const unsigned char* lds, int row, int ks, int g, bf16) {
+    return *(const bf16x8*)(lds + rm_off<bf16>(row, ks * 4 + g));
+}
+VB_DEVICE f32x8 frag_rm(const unsigned char* lds, int row, int ks, int g, float) {
+    const int c = 2 * (ks * 4 + g);
+    f32x4 lo = *(const f32x4*)(lds + rm_off<float>(row, c));
+    f32x4 hi = *(const f32x4*)(lds + rm_off<float>(row, c + 1));
+    return f32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+// same 8 elements straight from global memory (row pointer already offset to the head's column 0)
+VB_DEVICE bf16x8 frag_g(const bf16* rowp, int ks, int g, bool ok) {
+    if (!ok) { bf16x8 z; for (int j = 0; j < 8; ++j) z[j] = (bf16)0.0f; return z; }
+    return *(const bf16x8*)(rowp + ks * 32 + g * 8);
+}
+VB_DEVICE f32x8 frag_g(const float* rowp, int ks, int g, bool ok) {
+    if (!ok) return f32x8{0, 0, 0, 0, 0, 0, 0, 0};
+    f32x4 lo = *(const f32x4*)(rowp + ks * 32 + g * 8), hi = *(const f32x4*)(rowp + ks * 32 + g * 8 + 4);
+    return f32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+// A fragment from a transposed tile: row d, MFMA k index (g, j) <-> r = 32*ks + 16*(j>>2) + 4*g + (j&3)
+VB_DEVICE bf16x8 frag_tr(const unsigned char* lds, int pitch, int d, int ks, int g, bf16) {
+    const unsigned char* p = lds + d * pitch + (32 * ks + 4 * g) * 2;
+    bf16x4 lo = *(const bf16x4*)p, hi = *(const bf16x4*)(p + 32);
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+VB_DEVICE f32x8 frag_tr(const unsigned char* lds, int pitch, int d, int ks, int g, float) {
+    const unsigned char* p = lds + d * pitch + (32 * ks + 4 * g) * 4;
+    f32x4 lo = *(const f32x4*)p, hi = *(const f32x4*)(p + 64);
+    return f32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+// B fragment from two C-layout fragments (regs of frag 2ks -> j 0..3, frag 2ks+1 -> j 4..7)
+VB_DEVICE void pack_b(bf16x8& o, const f32x4& a, const f32x4& b) {
+    o = bf16x8{(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], (bf16)b[0], (bf16)b[1], (bf16)b[2], (bf16)b[3]};
+}
+VB_DEVICE void pack_b(f32x8& o, const f32x4& a, const f32x4& b) {
+    o = f32x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+VB_DEVICE void store4(bf16* p, const f32x4& v) { *(bf16x4*)p = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]}; }
+VB_DEVICE void store4(float* p, const f32x4& v) { *(f32x4*)p = v; }
+
+struct AttnArgs {
+    const void* qkv; const float* mask_add; void* ctx; float* lse; uint64_t* keepbits;   // forward
+    const void* dctx; void* dqkv; float* dsum;                                            // backward
+    int B, S, nh; float scale; float p; float inv_keep; uint32_t thresh; uint32_t stream; uint64_t seed;
+};
+
+// keep-bits: one uint64 per (b, h, q, g = key&15>>2, word w): nibble (kf & 15) of word (kf >> 4)
+// holds keys kf*16 + g*4 + {0..3}.  Written by forward, read by both backward passes.
+VB_DEVICE long keep_index(const AttnArgs& a, int bh, int q, int g, int w, int nw) {
+    return (((long)bh * a.S + q) * 4 + g) * nw + w;
+}
+
+// =================================================================================================
+// forward
+// =================================================================================================
+template <typename T, int NKF>
+VB_KERNEL VB_LAUNCH_BOUNDS(NT) attn_fwd_kernel(AttnArgs a) {
+    constexpr int NK = NKF * 16, NKS = NKF / 2, NW = (NKF + 15) / 16;
+    VB_DYN_SMEM(smem);
+    unsigned char* ldsK = smem;
+    unsigned char* ldsVT = ldsK + rm_bytes<T>(NK);
+    float* ldsMask = (float*)(ldsVT + tr_bytes<T>(NK));
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, lg = lane >> 4;
+    const int bh = blockIdx.x, b = bh / a.nh, h = bh % a.nh;
+    const int S = a.S, H = a.nh * D;
+    const long ldx = 3L * H, row0 = (long)b * S;
+    const T* qkv = (const T*)a.qkv;
+
+    stage_rm<T>(ldsK, qkv, ldx, row0, H + h * D, S, NK, t);
+    stage_tr(ldsVT, qkv, ldx, row0, 2 * H + h * D, S, NK, t);
+    for (int k = t; k < NK; k += NT) ldsMask[k] = k < S ? a.mask_add[(long)b * S + k] : -INFINITY;
+    __syncthreads();
+
+    const int nqf = (S + 15) / 16;
+    for (int qf = wave; qf < nqf; qf += 4) {
+        const int q = qf * 16 + li;
+        const bool qok = q < S;
+        const T* qrow = qkv + (row0 + (qok ? q : 0)) * ldx + h * D;
+        typename VecOf<T>::v8 qb[2];
+        qb[0] = frag_g(qrow, 0, lg, qok);
+        qb[1] = frag_g(qrow, 1, lg, qok);
+
+        f32x4 st[NKF];
+        float m = -INFINITY;
+#pragma unroll
+        for (int kf = 0; kf < NKF; ++kf) {
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (kf * 16 < S) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) acc = vb_mma(frag_rm(ldsK, kf * 16 + li, ks, lg, T()), qb[ks], acc);
+            }
+            const f32x4 mk = *(const f32x4*)(ldsMask + kf * 16 + lg * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                acc[r] = acc[r] * a.scale + mk[r];      // -inf for keys >= S
+                m = fmaxf(m, acc[r]);
+            }
+            st[kf] = acc;
+        }
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int kf = 0; kf < NKF; ++kf)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { st[kf][r] = expf(st[kf][r] - m); sum += st[kf][r]; }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+        if (a.lse && lg == 0 && qok) a.lse[(long)bh * S + q] = m + logf(sum);
+
+        // normalise, dropout (keep-bits recorded), round to T as the MFMA B operand
+        uint64_t bits[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) bits[w] = 0;
+#pragma unroll
+        for (int kp = 0; kp < NKS; ++kp) {
+            if (a.p > 0.f) {
+                // one Philox call covers this lane's 8 probabilities of fragments 2kp, 2kp+1
+                const uint64_t grp = ((((uint64_t)bh * S + q) * 4 + lg) << 5) + kp;
+                Philox8 rnd = philox4x32_10(a.seed, grp, a.stream);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int kf = 2 * kp + (e >> 2), r = e & 3;
+                    const bool keep = philox_keep(rnd, e, a.thresh);
+                    st[kf][r] = keep ? st[kf][r] * inv * a.inv_keep : 0.f;
+                    if (keep) bits[kf >> 4] |= (uint64_t)1 << ((kf & 15) * 4 + r);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) st[2 * kp + (e >> 2)][e & 3] *= inv;
+            }
+        }
+        if (a.p > 0.f && a.keepbits && qok) {
+#pragma unroll
+            for (int w = 0; w < NW; ++w) a.keepbits[keep_index(a, bh, q, lg, w, NW)] = bits[w];
+        }
+        typename VecOf<T>::v8 pb[NKS];
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) pack_b(pb[ks], st[2 * ks], st[2 * ks + 1]);
+
+        T* crow = (T*)a.ctx + (row0 + (qok ? q : 0)) * H + h * D;
+#pragma unroll
+        for (int df = 0; df < 4; ++df) {
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                if (ks * 32 < S)
+                    acc = vb_mma(frag_tr(ldsVT, tr_pitch<T>(NK), df * 16 + li, ks, lg, T()), pb[ks], acc);
+            }
+            if (qok) store4(crow + df * 16 + lg * 4, acc);     // lane: query q, d = df*16 + lg*4 + 0..3
+        }
+    }
+}
+
+// =================================================================================================
+// backward, pass A: dQ and D = rowsum(P o dP)   (per query block, all keys)
+// =================================================================================================
+template <typename T, int NKF>
+VB_KERNEL VB_LAUNCH_BOUNDS(NT) attn_bwd_dq_kernel(AttnArgs a) {
+    constexpr int NK = NKF * 16, NKS = NKF / 2, NW = (NKF + 15) / 16;
+    VB_DYN_SMEM(smem);
+    unsigned char* ldsK = smem;
+    unsigned char* ldsV = ldsK + rm_bytes<T>(NK);
+    unsigned char* ldsKT = ldsV + rm_bytes<T>(NK);
+    float* ldsMask = (float*)(ldsKT + tr_bytes<T>(NK));
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, lg = lane >> 4;
+    const int bh = blockIdx.x, b = bh / a.nh, h = bh % a.nh;
+    const int S = a.S, H = a.nh * D;
+    const long ldx = 3L * H, row0 = (long)b * S;
+    const T* qkv = (const T*)a.qkv;
+
+    stage_rm<T>(ldsK, qkv, ldx, row0, H + h * D, S, NK, t);
+    stage_rm<T>(ldsV, qkv, ldx, row0, 2 * H + h * D, S, NK, t);
+    stage_tr(ldsKT, qkv, ldx, row0, H + h * D, S, NK, t);
+    for (int k = t; k < NK; k += NT) ldsMask[k] = k < S ? a.mask_add[(long)b * S + k] : -INFINITY;
+    __syncthreads();
+
+    const int nqf = (S + 15) / 16;
+    for (int qf = wave; qf < nqf; qf += 4) {
+        const int q = qf * 16 + li;
+        const bool qok = q < S;
+        const T* qrow = qkv + (row0 + (qok ? q : 0)) * ldx + h * D;
+        const T* dorow = (const T*)a.dctx + (row0 + (qok ? q : 0)) * H + h * D;
+        typename VecOf<T>::v8 qb[2], dob[2];
+        qb[0] = frag_g(qrow, 0, lg, qok); qb[1] = frag_g(qrow, 1, lg, qok);
+        dob[0] = frag_g(dorow, 0, lg, qok); dob[1] = frag_g(dorow, 1, lg, qok);
+        const float lse = qok ? a.lse[(long)bh * S + q] : 0.f;
+        uint64_t bits[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w)
+            bits[w] = (a.p > 0.f && qok) ? a.keepbits[keep_index(a, bh, q, lg, w, NW)] : ~(uint64_t)0;
+
+        f32x4 pt[NKF], dpt[NKF];
+        float dsum = 0.f;
+#pragma unroll
+        for (int kf = 0; kf < NKF; ++kf) {
+            f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = s;
+            if (kf * 16 < S) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    s = vb_mma(frag_rm(ldsK, kf * 16 + li, ks, lg, T()), qb[ks], s);
+                    dp = vb_mma(frag_rm(ldsV, kf * 16 + li, ks, lg, T()), dob[ks], dp);
+                }
+            }
+            const f32x4 mk = *(const f32x4*)(ldsMask + kf * 16 + lg * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = expf(s[r] * a.scale + mk[r] - lse);            // 0 for keys >= S
+                const bool keep = (bits[kf >> 4] >> ((kf & 15) * 4 + r)) & 1;
+                const float dpv = keep ? dp[r] * a.inv_keep : 0.f;
+                dsum += p * dpv;
+                s[r] = p; dp[r] = dpv;
+            }
+            pt[kf] = s; dpt[kf] = dp;
+        }
+        dsum += __shfl_xor(dsum, 16);
+        dsum += __shfl_xor(dsum, 32);
+        if (a.dsum && lg == 0 && qok) a.dsum[(long)bh * S + q] = dsum;
+        // dS^T = P o (dP - D) * scale, rounded to T as the MFMA B operand
+        typename VecOf<T>::v8 dsb[NKS];
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            f32x4 x0, x1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                x0[r] = pt[2 * ks][r] * (dpt[2 * ks][r] - dsum) * a.scale;
+                x1[r] = pt[2 * ks + 1][r] * (dpt[2 * ks + 1][r] - dsum) * a.scale;
+            }
+            pack_b(dsb[ks], x0, x1);
+        }
+        T* dqrow = (T*)a.dqkv + (row0 + (qok ? q : 0)) * ldx + h * D;
+#pragma unroll
+        for (int df = 0; df < 4; ++df) {
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                if (ks * 32 < S)
+                    acc = vb_mma(frag_tr(ldsKT, tr_pitch<T>(NK), df * 16 + li, ks, lg, T()), dsb[ks], acc);
+            }
+            if (qok) store4(dqrow + df * 16 + lg * 4, acc);
+        }
+    }
+}
+
+// =================================================================================================
+// backward, pass B: dK and dV.  grid = (B*nh, ceil(key fragments / 4)): a wave owns ONE 16-key
+// fragment and sweeps all queries in chunks of QC; Q / dO (row-major and transposed), lse, D and the
+// keep-bits of a chunk are staged in LDS per chunk, so LDS use is independent of S.
+// =================================================================================================
+constexpr int QC = 64;
+
+template <typename T, int NKF>
+VB_KERNEL VB_LAUNCH_BOUNDS(NT) attn_bwd_dkv_kernel(AttnArgs a) {
+    constexpr int NW = (NKF + 15) / 16;
+    VB_DYN_SMEM(smem);
+    unsigned char* ldsQ = smem;
+    unsigned char* ldsDO = ldsQ + rm_bytes<T>(QC);
+    unsigned char* ldsQT = ldsDO + rm_bytes<T>(QC);
+    unsigned char* ldsDOT = ldsQT + tr_bytes<T>(QC);
+    float* ldsLse = (float*)(ldsDOT + tr_bytes<T>(QC));
+    float* ldsD = ldsLse + QC;
+    uint64_t* ldsBits = (uint64_t*)(ldsD + QC);           // [QC][4][NW]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, lg = lane >> 4;
+    const int bh = blockIdx.x, b = bh / a.nh, h = bh % a.nh;
+    const int S = a.S, H = a.nh * D;
+    const long ldx = 3L * H, row0 = (long)b * S;
+    const T* qkv = (const T*)a.qkv;
+    const T* dctx = (const T*)a.dctx;
+
+    const int kf = blockIdx.y * 4 + wave;
+    const int key = kf * 16 + li;
+    const bool wave_on = kf * 16 < S;                      // wave-uniform
+    const bool kok = key < S;
+    const T* krow = qkv + (row0 + (kok ? key : 0)) * ldx + H + h * D;
+    const T* vrow = qkv + (row0 + (kok ? key : 0)) * ldx + 2 * H + h * D;
+    typename VecOf<T>::v8 kb[2], vb[2];
+    kb[0] = frag_g(krow, 0, lg, kok); kb[1] = frag_g(krow, 1, lg, kok);
+    vb[0] = frag_g(vrow, 0, lg, kok); vb[1] = frag_g(vrow, 1, lg, kok);
+    const float mk = kok ? a.mask_add[(long)b * S + key] : -INFINITY;
+    f32x4 dkT[4], dvT[4];
+#pragma unroll
+    for (int df = 0; df < 4; ++df) { dkT[df] = f32x4{0.f, 0.f, 0.f, 0.f}; dvT[df] = dkT[df]; }
+
+    for (int q0 = 0; q0 < S; q0 += QC) {
+        __syncthreads();                                   // previous chunk fully consumed
+        stage_rm<T>(ldsQ, qkv, ldx, row0 + q0, h * D, S - q0, QC, t);
+        stage_rm<T>(ldsDO, dctx, (long)H, row0 + q0, h * D, S - q0, QC, t);
+        stage_tr(ldsQT, qkv, ldx, row0 + q0, h * D, S - q0, QC, t);
+        stage_tr(ldsDOT, dctx, (long)H, row0 + q0, h * D, S - q0, QC, t);
+        for (int k = t; k < QC; k += NT) {
+            const int q = q0 + k;
+            ldsLse[k] = q < S ? a.lse[(long)bh * S + q] : INFINITY;   // exp(x - inf) = 0 for padded queries
+            ldsD[k] = q < S ? a.dsum[(long)bh * S + q] : 0.f;
+        }
+        for (int i = t; i < QC * 4 * NW; i += NT) {
+            const int q = q0 + i / (4 * NW);
+            ldsBits[i] = (a.p > 0.f && q < S) ? a.keepbits[((long)bh * S + q0) * 4 * NW + i] : ~(uint64_t)0;
+        }
+        __syncthreads();
+        if (!wave_on) continue;
+#pragma unroll
+        for (int qc = 0; qc < QC / 32; ++qc) {
+            if (q0 + qc * 32 >= S) continue;
+            f32x4 pd[2], dsv[2];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int qf = 2 * qc + hf;                // fragment index inside the chunk
+                f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = s;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    s = vb_mma(frag_rm(ldsQ, qf * 16 + li, ks, lg, T()), kb[ks], s);
+                    dp = vb_mma(frag_rm(ldsDO, qf * 16 + li, ks, lg, T()), vb[ks], dp);
+                }
+                // lane: key = kf*16 + li (column), queries q0 + qf*16 + lg*4 + r (rows)
+                const f32x4 lse4 = *(const f32x4*)(ldsLse + qf * 16 + lg * 4);
+                const f32x4 d4 = *(const f32x4*)(ldsD + qf * 16 + lg * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ql = qf * 16 + lg * 4 + r;
+                    const float p = expf(s[r] * a.scale + mk - lse4[r]);
+                    const uint64_t w = ldsBits[(ql * 4 + (li >> 2)) * NW + (kf >> 4)];
+                    const bool keep = (w >> ((kf & 15) * 4 + (li & 3))) & 1;
+                    const float pdrop = keep ? p * a.inv_keep : 0.f;
+                    const float dpv = keep ? dp[r] * a.inv_keep : 0.f;
+                    pd[hf][r] = pdrop;
+                    dsv[hf][r] = p * (dpv - d4[r]) * a.scale;
+                }
+            }
+            typename VecOf<T>::v8 pb, dsb;
+            pack_b(pb, pd[0], pd[1]);
+            pack_b(dsb, dsv[0], dsv[1]);
+#pragma unroll
+            for (int df = 0; df < 4; ++df) {
+                dvT[df] = vb_mma(frag_tr(ldsDOT, tr_pitch<T>(QC), df * 16 + li, qc, lg, T()), pb, dvT[df]);
+                dkT[df] = vb_mma(frag_tr(ldsQT, tr_pitch<T>(QC), df * 16 + li, qc, lg, T()), dsb, dkT[df]);
+            }
+        }
+    }
+    if (kok) {
+        T* dkrow = (T*)a.dqkv + (row0 + key) * ldx + H + h * D;
+        T* dvrow = (T*)a.dqkv + (row0 + key) * ldx + 2 * H + h * D;
+#pragma unroll
+        for (int df = 0; df < 4; ++df) {
+            store4(dkrow + df * 16 + lg * 4, dkT[df]);
+            store4(dvrow + df * 16 + lg * 4, dvT[df]);
+        }
+    }
+}
+
+template <typename T, int NKF> size_t fwd_smem() { return rm_bytes<T>(NKF * 16) + tr_bytes<T>(NKF * 16) + NKF * 16 * 4; }
+template <typename T, int NKF> size_t dq_smem() { return 2 * rm_bytes<T>(NKF * 16) + tr_bytes<T>(NKF * 16) + NKF * 16 * 4; }
+template <typename T, int NKF> size_t dkv_smem() {
+    return 2 * rm_bytes<T>(QC) + 2 * tr_bytes<T>(QC) + 2 * QC * 4 + (size_t)QC * 4 * ((NKF + 15) / 16) * 8;
+}
+
+constexpr size_t kMaxLds = 160 * 1024;
+
+template <typename T, int NKF>
+int launch_all(int which, const AttnArgs& a, hipStream_t s) {
+    dim3 grid((unsigned)(a.B * a.nh)), block(NT);
+    if (which == 0) {
+        const size_t sm = fwd_smem<T, NKF>();
+        if (sm > kMaxLds) return VB_ERR_UNSUPPORTED;
+        VB_LAUNCH((attn_fwd_kernel<T, NKF>), grid, block, sm, s, a);
+    } else {
+        const size_t sm1 = dq_smem<T, NKF>(), sm2 = dkv_smem<T, NKF>();
+        if (sm1 > kMaxLds || sm2 > kMaxLds) return VB_ERR_UNSUPPORTED;
+        VB_LAUNCH((attn_bwd_dq_kernel<T, NKF>), grid, block, sm1, s, a);
+        dim3 grid2((unsigned)(a.B * a.nh), (unsigned)(((a.S + 15) / 16 + 3) / 4));
+        VB_LAUNCH((attn_bwd_dkv_kernel<T, NKF>), grid2, block, sm2, s, a);
+    }
+    return vb_check_launch();
+}
+
+template <typename T>
+int dispatch_nkf(int which, const AttnArgs& a, hipStream_t s) {
+    const int nkf = ((a.S + 31) / 32) * 2;          // key fragments, padded to an even count
+    if (nkf <= 4) return launch_all<T, 4>(which, a, s);
+    if (nkf <= 8) return launch_all<T, 8>(which, a, s);
+    if (nkf <= 12) return launch_all<T, 12>(which, a, s);
+    if (nkf <= 16) return launch_all<T, 16>(which, a, s);
+    if (nkf <= 32) return launch_all<T, 32>(which, a, s);
+    return VB_ERR_UNSUPPORTED;
+}
+
+int fill_args(AttnArgs& a, int B, int S, int nh, int head_dim, float p, uint64_t seed, uint32_t stream_id) {
+    if (B <= 0 || S <= 0 || nh <= 0 || head_dim != D || p < 0.f || p >= 1.f) return VB_ERR_ARG;
+    a.B = B; a.S = S; a.nh = nh; a.scale = 0.125f;           // 1/sqrt(64), modeling.py:242
+    a.p = p; a.inv_keep = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+    a.thresh = (uint32_t)(p * 65536.0f + 0.5f); a.stream = stream_id; a.seed = seed;
+    return VB_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t vb_attn_keepbits_words(int S) {
+    const int nkf = ((S + 31) / 32) * 2;
+    const int nkft = nkf <= 4 ? 4 : nkf <= 8 ? 8 : nkf <= 12 ? 12 : nkf <= 16 ? 16 : 32;
+    return (int64_t)S * 4 * ((nkft + 15) / 16);               // uint64 words per (batch, head)
+}
+
+extern "C" int vb_attn_fwd(int dtype, const void* qkv, const float* mask_add, void* ctx, float* lse,
+                           uint64_t* keepbits, int B, int S, int nh, int head_dim,
+                           float p_drop, uint64_t seed, uint32_t stream_id, void* stream) {
+    AttnArgs a{};
+    int rc = fill_args(a, B, S, nh, head_dim, p_drop, seed, stream_id);
+    if (rc) return rc;
+    if (!qkv || !mask_add || !ctx || (p_drop > 0.f && !keepbits)) return VB_ERR_ARG;
+    a.qkv = qkv; a.mask_add = mask_add; a.ctx = ctx; a.lse = lse; a.keepbits = keepbits;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == VB_BF16) return dispatch_nkf<bf16>(0, a, s);
+    if (dtype == VB_F32) return dispatch_nkf<float>(0, a, s);
+    return VB_ERR_ARG;
+}
+
+extern "C" int vb_attn_bwd(int dtype, const void* qkv, const float* mask_add, const void* dctx, const float* lse,
+                           const uint64_t* keepbits, float* dsum_ws, void* dqkv, int B, int S, int nh, int head_dim,
+                           float p_drop, uint64_t seed, uint32_t stream_id, void* stream) {
+    AttnArgs a{};
+    int rc = fill_args(a, B, S, nh, head_dim, p_drop, seed, stream_id);
+    if (rc) return rc;
+    if (!qkv || !mask_add || !dctx || !lse || !dsum_ws || !dqkv || (p_drop > 0.f && !keepbits)) return VB_ERR_ARG;
+    a.qkv = qkv; a.mask_add = mask_add; a.dctx = dctx; a.lse = (float*)lse; a.keepbits = (uint64_t*)keepbits;
+    a.dsum = dsum_ws; a.dqkv = dqkv;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == VB_BF16) return dispatch_nkf<bf16>(1, a, s);
+    if (dtype == VB_F32) return dispatch_nkf<float>(1, a, s);
+    return VB_ERR_ARG;
+}

@@ -1,0 +1,351 @@
+// gemm.hip -- MFMA GEMM for every Linear on the VisualBERT training path (forward, dgrad, wgrad).
+//
+//   C[M,N] = epilogue( sum_k Aop[m,k] * Bop[n,k] )
+//
+// Replaces the cuBLAS calls behind nn.Linear / F.linear in the reference:
+//   forward  y = x W^T          pytorch_pretrained_bert/modeling.py:232-234 (Q,K,V, packed), :271 (attn out),
+//                               :303 (FFN in), :316 (FFN out), :1220 (region projection), :383-385 (pooler),
+//                               :398 (MLM transform), :419 (tied decoder), :451 (seq_relationship)
+//   dgrad    dx = dy W           autograd of the same lines
+//   wgrad    dW += dy^T x        autograd of the same lines (fp32 accumulate straight into the grad arena)
+//
+// Operand layouts (per operand, independent):
+//   VB_KCONTIG : stored [rows][K], K contiguous   (x, dy as A; W as B in forward)
+//   VB_KSTRIDED: stored [K][rows], rows contiguous (W as B in dgrad; dy and x in wgrad)
+// K-strided tiles are transposed in registers on their way into LDS, so no transposed copies of
+// weights or activations ever exist in HBM.
+//
+// Tile: 128x128 per workgroup of 4 waves (2x2, 64x64 per wave = 4x4 MFMA 16x16 fragments, 64 fp32
+// accumulators per lane).  LDS rows are always 128 B (64 bf16 / 32 fp32 of K) with a 16-byte-chunk XOR
+// swizzle; fragments are read with ds_read_b128.  The accumulators leave through LDS so that the
+// epilogue (bias, GELU, GELU', residual addend, fp32 accumulate) works on 8 consecutive columns per
+// lane and every global store is a full 128-byte row segment.
+#include "vb_rt.h"
+#include "../../include/visualbert_hip.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, NT = 256;
+constexpr int EPI_PITCH = 64 * 4 + 16;          // bytes per staged fp32 row of a wave's 32x64 slab
+constexpr int EPI_BYTES_PER_WAVE = 32 * EPI_PITCH;
+constexpr int SMEM_BYTES = (4 * EPI_BYTES_PER_WAVE > 2 * 128 * 128) ? 4 * EPI_BYTES_PER_WAVE : 2 * 128 * 128;
+
+template <typename T> struct TT {
+    static constexpr int EPC = 16 / (int)sizeof(T);   // elements per 16-byte chunk
+    static constexpr int BK = 8 * EPC;                // K extent of one LDS tile (128 B per row)
+    static constexpr int KSTEPS = BK / 32;            // MFMA K steps (of 32) per tile
+};
+
+VB_DEVICE int swz(int row) { return (row ^ (row >> 3)) & 7; }
+VB_DEVICE int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ swz(row)) << 4); }
+
+struct GemmArgs {
+    const void* A; const void* B; void* C;
+    long lda, ldb, ldc;
+    int M, N, K;
+    const float* bias;
+    const void* addend; long ld_addend;
+    const void* aux_in; void* aux_out; long ld_aux;
+    float alpha;
+    const float* alpha_dev;
+    int act, accumulate;
+    int tiles_m, tiles_n;
+};
+
+// ---- global -> register staging -------------------------------------------------------------
+template <typename T>
+VB_DEVICE void zero_tail(u32x4& v, int kvalid) {      // keep the first kvalid (< EPC) elements
+    T* e = (T*)&v;
+#pragma unroll
+    for (int j = 0; j < TT<T>::EPC; ++j) if (j >= kvalid) e[j] = from_f32<T>(0.0f);
+}
+
+// K-contiguous operand: 128 rows x 8 chunks; thread t -> chunk t&7, rows (t>>3) + 32 i
+template <typename T>
+VB_DEVICE void gload_kcontig(u32x4 (&r)[4], const T* P, long ld, int R, int K, int r0, int k0, int t) {
+    const int c = t & 7, rr = t >> 3;
+    const int k = k0 + c * TT<T>::EPC;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int row = r0 + rr + 32 * i;
+        row = row < R ? row : R - 1;
+        if (k < K) {
+            r[i] = *(const u32x4*)(P + (long)row * ld + k);
+            if (k + TT<T>::EPC > K) zero_tail<T>(r[i], K - k);
+        } else {
+            r[i] = u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+}
+template <typename T>
+VB_DEVICE void sstore_kcontig(const u32x4 (&r)[4], unsigned char* lds, int t) {
+    const int c = t & 7, rr = t >> 3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *(u32x4*)(lds + lds_off(rr + 32 * i, c)) = r[i];
+}
+
+// K-strided operand: a thread owns EPC k-rows x 8 tile rows; threads [tbase, tbase+128)
+//   rc = u & 15 -> tile rows rc*8 .. rc*8+7 ; kc = u >> 4 -> k = k0 + kc*EPC .. +EPC-1
+template <typename T>
+VB_DEVICE void gload_kstrided(u32x4 (&r)[8], const T* P, long ld, int R, int K, int r0, int k0, int u) {
+    constexpr int EPC = TT<T>::EPC;
+    constexpr int VPR = 8 / EPC;                     // 16-byte vectors per 8 rows (1 bf16, 2 fp32)
+    const int rc = u & 15, kc = u >> 4;
+    const int row = r0 + rc * 8;
+#pragma unroll
+    for (int kk = 0; kk < EPC; ++kk) {
+        const int k = k0 + kc * EPC + kk;
+        const bool ok = (k < K) && (row < R);
+#pragma unroll
+        for (int v = 0; v < VPR; ++v) {
+            if (ok) r[kk * VPR + v] = *(const u32x4*)(P + (long)k * ld + row + v * EPC);
+            else r[kk * VPR + v] = u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+}
+VB_DEVICE void sstore_kstrided_bf16(const u32x4 (&r)[8], unsigned char* lds, int u) {
+    const int rc = u & 15, kc = u >> 4;
+    // r[kk][jp]: k = kk, rows (2jp, 2jp+1) packed lo/hi.  out row j chunk word kp = k (2kp, 2kp+1)
+#pragma unroll
+    for (int jp = 0; jp < 4; ++jp) {
+        u32x4 lo, hi;
+#pragma unroll
+        for (int kp = 0; kp < 4; ++kp) {
+            uint32_t w0 = r[2 * kp][jp], w1 = r[2 * kp + 1][jp];
+            lo[kp] = (w0 & 0xFFFFu) | (w1 << 16);
+            hi[kp] = (w0 >> 16) | (w1 & 0xFFFF0000u);
+        }
+        *(u32x4*)(lds + lds_off(rc * 8 + 2 * jp, kc)) = lo;
+        *(u32x4*)(lds + lds_off(rc * 8 + 2 * jp + 1, kc)) = hi;
+    }
+}
+VB_DEVICE void sstore_kstrided_f32(const u32x4 (&r)[8], unsigned char* lds, int u) {
+    const int rc = u & 15, kc = u >> 4;
+    // r[kk*2 + v][e]: k = kk (0..3), row = v*4 + e
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        u32x4 o;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) o[kk] = r[kk * 2 + (j >> 2)][j & 3];
+        *(u32x4*)(lds + lds_off(rc * 8 + j, kc)) = o;
+    }
+}
+VB_DEVICE void sstore_kstrided(const u32x4 (&r)[8], unsigned char* lds, int u, bf16) { sstore_kstrided_bf16(r, lds, u); }
+VB_DEVICE void sstore_kstrided(const u32x4 (&r)[8], unsigned char* lds, int u, float) { sstore_kstrided_f32(r, lds, u); }
+
+// ---- LDS -> MFMA fragment ----------------------------------------------------------------------
+VB_DEVICE bf16x8 load_frag(const unsigned char* lds, int row, int ks, int g, bf16) {
+    return *(const bf16x8*)(lds + lds_off(row, ks * 4 + g));
+}
+VB_DEVICE f32x8 load_frag(const unsigned char* lds, int row, int ks, int g, float) {
+    f32x4 lo = *(const f32x4*)(lds + lds_off(row, 2 * g));
+    f32x4 hi = *(const f32x4*)(lds + lds_off(row, 2 * g + 1));
+    (void)ks;
+    return f32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+// XCD-aware, bijective remap of the linear workgroup id: hardware places workgroup b on XCD b % 8
+// (observed, speed only); give each XCD a contiguous run of logical tiles so that tiles sharing an
+// A row-panel hit the same L2 (guide T1, bijective form for nwg % 8 != 0).
+VB_DEVICE int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+template <typename T, typename TO, int AL, int BL>
+VB_KERNEL VB_LAUNCH_BOUNDS(NT) gemm_kernel(GemmArgs g) {
+    constexpr int EPC = TT<T>::EPC, BK = TT<T>::BK, KSTEPS = TT<T>::KSTEPS;
+    (void)EPC;
+    VB_DYN_SMEM(smem);
+    unsigned char* ldsA = smem;
+    unsigned char* ldsB = smem + 128 * 128;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 15, lg = lane >> 4;
+
+    const int nwg = g.tiles_m * g.tiles_n;
+    const int tile = xcd_remap((int)blockIdx.x, nwg);
+    const int m0 = (tile / g.tiles_n) * BM, n0 = (tile % g.tiles_n) * BN;
+
+    const T* A = (const T*)g.A;
+    const T* B = (const T*)g.B;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // staging registers: K-contiguous uses 4 vectors, K-strided 8 (by threads [0,128) for A, or for B when
+    // A is K-contiguous; by threads [128,256) for B when both are K-strided)
+    u32x4 ra[AL == VB_KCONTIG ? 4 : 8];
+    u32x4 rb[BL == VB_KCONTIG ? 4 : 8];
+    constexpr int B_TBASE = (AL == VB_KSTRIDED && BL == VB_KSTRIDED) ? 128 : 0;
+    const bool a_active = (AL == VB_KCONTIG) || (t < 128);
+    const bool b_active = (BL == VB_KCONTIG) || (t >= B_TBASE && t < B_TBASE + 128);
+
+    const int nk = (g.K + BK - 1) / BK;
+
+    auto gload = [&](int kt) {
+        const int k0 = kt * BK;
+        if constexpr (AL == VB_KCONTIG) gload_kcontig<T>(ra, A, g.lda, g.M, g.K, m0, k0, t);
+        else { if (a_active) gload_kstrided<T>(ra, A, g.lda, g.M, g.K, m0, k0, t); }
+        if constexpr (BL == VB_KCONTIG) gload_kcontig<T>(rb, B, g.ldb, g.N, g.K, n0, k0, t);
+        else { if (b_active) gload_kstrided<T>(rb, B, g.ldb, g.N, g.K, n0, k0, t - B_TBASE); }
+    };
+    auto sstore = [&]() {
+        if constexpr (AL == VB_KCONTIG) sstore_kcontig<T>(ra, ldsA, t);
+        else { if (a_active) sstore_kstrided(ra, ldsA, t, T()); }
+        if constexpr (BL == VB_KCONTIG) sstore_kcontig<T>(rb, ldsB, t);
+        else { if (b_active) sstore_kstrided(rb, ldsB, t - B_TBASE, T()); }
+    };
+
+    gload(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();                 // previous tile's fragment reads are done
+        sstore();
+        __syncthreads();
+        if (kt + 1 < nk) gload(kt + 1);  // in flight during the MFMAs below
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            typename VecOf<T>::v8 fa[4], fb[4];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) fa[mi] = load_frag(ldsA, wm * 64 + mi * 16 + li, ks, lg, T());
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) fb[ni] = load_frag(ldsB, wn * 64 + ni * 16 + li, ks, lg, T());
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = vb_mma(fa[mi], fb[ni], acc[mi][ni]);
+        }
+    }
+
+    // ---------------- epilogue: accumulators -> LDS (wave-private slab) -> row-contiguous vectors
+    unsigned char* slab = smem + wave * EPI_BYTES_PER_WAVE;
+    TO* C = (TO*)g.C;
+    const float alpha = g.alpha_dev ? g.alpha * g.alpha_dev[0] : g.alpha;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        __syncthreads();                 // LDS free (pass 0: main loop done; pass 1: previous reads done)
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = mh * 16 + lg * 4 + r, col = ni * 16 + li;
+                    *(float*)(slab + row * EPI_PITCH + col * 4) = acc[pass * 2 + mh][ni][r];
+                }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = it * 8 + (lane >> 3), cc = lane & 7;
+            const int m = m0 + wm * 64 + pass * 32 + row;
+            const int n = n0 + wn * 64 + cc * 8;
+            if (m >= g.M || n >= g.N) continue;
+            float v[8];
+            {
+                f32x4 lo = *(const f32x4*)(slab + row * EPI_PITCH + cc * 32);
+                f32x4 hi = *(const f32x4*)(slab + row * EPI_PITCH + cc * 32 + 16);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v[j] = lo[j]; v[4 + j] = hi[j]; }
+            }
+            const bool full = (n + 8 <= g.N);
+            const int nv = full ? 8 : g.N - n;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] *= alpha;
+            if (g.bias) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (j < nv) v[j] += g.bias[n + j];
+            }
+            if (g.act == VB_ACT_GELU) {
+                if (g.aux_out) {                                  // pre-activation, kept for backward
+                    T* ao = (T*)g.aux_out + (long)m * g.ld_aux + n;
+                    if (full && (g.ld_aux & 7) == 0) store8(ao, v);
+                    else for (int j = 0; j < nv; ++j) ao[j] = from_f32<T>(v[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
+            } else if (g.act == VB_ACT_TANH) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = tanhf(v[j]);
+            } else if (g.act == VB_ACT_GELU_GRAD) {
+                const T* ai = (const T*)g.aux_in + (long)m * g.ld_aux + n;
+                float x[8];
+                if (full && (g.ld_aux & 7) == 0) load8(x, ai);
+                else for (int j = 0; j < 8; ++j) x[j] = j < nv ? to_f32(ai[j]) : 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] *= gelu_grad_f(x[j]);
+            }
+            if (g.addend) {
+                const T* ad = (const T*)g.addend + (long)m * g.ld_addend + n;
+                float x[8];
+                if (full && (g.ld_addend & 7) == 0) load8(x, ad);
+                else for (int j = 0; j < 8; ++j) x[j] = j < nv ? to_f32(ad[j]) : 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += x[j];
+            }
+            TO* cp = C + (long)m * g.ldc + n;
+            if (g.accumulate) {
+                float x[8];
+                if (full && (g.ldc & 7) == 0) load8(x, cp);
+                else for (int j = 0; j < 8; ++j) x[j] = j < nv ? to_f32(cp[j]) : 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += x[j];
+            }
+            if (full && (g.ldc & 7) == 0) store8(cp, v);
+            else for (int j = 0; j < nv; ++j) cp[j] = from_f32<TO>(v[j]);
+        }
+    }
+}
+
+template <typename T, typename TO, int AL, int BL>
+int launch_gemm(const GemmArgs& g, hipStream_t stream) {
+    dim3 grid((unsigned)(g.tiles_m * g.tiles_n)), block(NT);
+    VB_LAUNCH((gemm_kernel<T, TO, AL, BL>), grid, block, SMEM_BYTES, stream, g);
+    return vb_check_launch();
+}
+
+template <typename T>
+int dispatch(int out_dtype_is_f32, int al, int bl, const GemmArgs& g, hipStream_t s) {
+    if (al == VB_KCONTIG && bl == VB_KCONTIG)
+        return out_dtype_is_f32 ? launch_gemm<T, float, VB_KCONTIG, VB_KCONTIG>(g, s)
+                                : launch_gemm<T, T, VB_KCONTIG, VB_KCONTIG>(g, s);
+    if (al == VB_KCONTIG && bl == VB_KSTRIDED)
+        return out_dtype_is_f32 ? launch_gemm<T, float, VB_KCONTIG, VB_KSTRIDED>(g, s)
+                                : launch_gemm<T, T, VB_KCONTIG, VB_KSTRIDED>(g, s);
+    if (al == VB_KSTRIDED && bl == VB_KSTRIDED)
+        return out_dtype_is_f32 ? launch_gemm<T, float, VB_KSTRIDED, VB_KSTRIDED>(g, s)
+                                : launch_gemm<T, T, VB_KSTRIDED, VB_KSTRIDED>(g, s);
+    return VB_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+extern "C" int vb_gemm(int dtype, int out_dtype, int a_layout, int b_layout,
+                       const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                       int M, int N, int K, float alpha, const float* alpha_dev, const float* bias,
+                       const void* addend, int64_t ld_addend, int act,
+                       const void* aux_in, void* aux_out, int64_t ld_aux, int accumulate,
+                       void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C) return VB_ERR_ARG;
+    if (dtype != VB_F32 && dtype != VB_BF16) return VB_ERR_ARG;
+    if (out_dtype != VB_F32 && out_dtype != dtype) return VB_ERR_ARG;
+    const int epc = dtype == VB_BF16 ? 8 : 4;
+    // vector loads are 16 bytes: leading dimensions and base pointers must keep them aligned
+    if ((lda % 8) || (ldb % 8) || (((uintptr_t)A | (uintptr_t)B) & 15)) return VB_ERR_ARG;
+    (void)epc;
+    if (act == VB_ACT_GELU_GRAD && !aux_in) return VB_ERR_ARG;
+    GemmArgs g;
+    g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+    g.bias = bias; g.addend = addend; g.ld_addend = ld_addend; g.aux_in = aux_in; g.aux_out = aux_out;
+    g.ld_aux = ld_aux; g.alpha = alpha; g.alpha_dev = alpha_dev; g.act = act; g.accumulate = accumulate;
+    g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
+    hipStream_t s = (hipStream_t)stream;
+    const int of32 = (out_dtype == VB_F32) ? 1 : 0;
+    if (dtype == VB_BF16) return dispatch<bf16>(of32 && true, a_layout, b_layout, g, s);
+    return dispatch<float>(1, a_layout, b_layout, g, s);
+}

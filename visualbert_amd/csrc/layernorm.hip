@@ -1,0 +1,406 @@
+// layernorm.hip -- HBM-bound row kernels of the VisualBERT training path:
+//   * BertLayerNorm forward / backward with the residual add and both dropouts fused
+//       reference: BertLayerNorm.forward  pytorch_pretrained_bert/modeling.py:171-175
+//                  BertSelfOutput.forward :270-274, BertOutput.forward :315-319
+//                  (dense -> dropout -> LayerNorm(x + input)), embeddings LN+dropout :1255-1257,
+//                  BertPredictionHeadTransform LN :400
+//   * BertEmbeddingsWithVisualEmbedding gather-add forward / scatter-add backward
+//       reference: modeling.py:1198-1253 (image_text_alignment=None branch)
+//
+// Thread mapping: a HALF-wave (32 lanes) owns one row; a lane owns 8-element chunks
+// {l, l+32, l+64, ...} (16-byte bf16 / 32-byte fp32 accesses, a half-wave instruction covers 512 B of
+// one row).  Row statistics are fp32, two-pass in registers (mean, then centred second moment: the
+// reference's formula, biased variance, eps inside the sqrt).  Column reductions (dgamma, dbeta,
+// bias gradient, position/type embedding gradients) are accumulated per lane in registers across
+// the rows a half-wave visits, reduced across the workgroup in LDS and added to HBM once per block.
+#include "vb_rt.h"
+#include "../../include/visualbert_hip.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int HW_PER_BLOCK = NT / 32;
+constexpr int MAX_NC = 4;            // H <= 1024
+
+struct DropSpec {
+    float p; float scale; uint32_t thresh; uint32_t stream; uint64_t seed;
+};
+static inline DropSpec make_drop(float p, uint64_t seed, uint32_t stream) {
+    DropSpec d; d.p = p; d.scale = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+    d.thresh = (uint32_t)(p * 65536.0f + 0.5f); d.stream = stream; d.seed = seed;
+    return d;
+}
+// multiply v[0..8) by the keep mask / (1-p) of group (element index >> 3)
+VB_DEVICE void apply_dropout8(float (&v)[8], const DropSpec& d, uint64_t group) {
+    Philox8 r = philox4x32_10(d.seed, group, d.stream);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = philox_keep(r, j, d.thresh) ? v[j] * d.scale : 0.0f;
+}
+
+struct LnFwdArgs {
+    const void* x; const void* resid; void* z_out; void* y; float* mean; float* rstd;
+    const float* gamma; const float* beta; int M, H; float eps; DropSpec din, dout;
+};
+
+template <typename T, int NC>
+VB_KERNEL VB_LAUNCH_BOUNDS(NT) ln_fwd_kernel(LnFwdArgs a) {
+    const int l32 = threadIdx.x & 31, hw = threadIdx.x >> 5;
+    const int H = a.H;
+    const float invH = 1.0f / (float)H;
+    // the trip count is uniform per workgroup (wave shuffles below need all 64 lanes); a half-wave
+    // whose row is past the end just keeps its lanes predicated off
+    for (int base = blockIdx.x * HW_PER_BLOCK; base < a.M; base += gridDim.x * HW_PER_BLOCK) {
+        const int row = base + hw;
+        const bool act = row < a.M;
+        float v[NC][8];
+        float s = 0.f;
+#pragma unroll
+        for (int ci = 0; ci < NC; ++ci) {
+            const int col = (l32 + 32 * ci) * 8;
+            if (act && col < H) {
+                const long e = (long)row * H + col;
+                load8(v[ci], (const T*)a.x + e);
+                if (a.din.p > 0.f) apply_dropout8(v[ci], a.din, (uint64_t)e >> 3);
+                if (a.resid) {
+                    float r[8]; load8(r, (const T*)a.resid + e);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[ci][j] += r[j];
+                }
+                if (a.z_out) store8((T*)a.z_out + e, v[ci]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s += v[ci][j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[ci][j] = 0.f;
+            }
+        }
+        const float mean = half_sum(s) * invH;
+        float q = 0.f;
+#pragma unroll
+        for (int ci = 0; ci < NC; ++ci) {
+            const int col = (l32 + 32 * ci) * 8;
+            if (act && col < H) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float d = v[ci][j] - mean; q += d * d; }
+            }
+        }
+        const float var = half_sum(q) * invH;
+        const float rstd = 1.0f / sqrtf(var + a.eps);
+#pragma unroll
+        for (int ci = 0; ci < NC; ++ci) {
+            const int col = (l32 + 32 * ci) * 8;
+            if (act && col < H) {
+                float gm[8], bt[8], o[8];
+                load8(gm, a.gamma + col); load8(bt, a.beta + col);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = gm[j] * ((v[ci][j] - mean) * rstd) + bt[j];
+                const long e = (long)row * H + col;
+                if (a.dout.p > 0.f) apply_dropout8(o, a.dout, (uint64_t)e >> 3);
+                store8((T*)a.y + e, o);
+            }
+        }
+        if (act && l32 == 0) {
+            if (a.mean) a.mean[row] = mean;
+            if (a.rstd) a.rstd[row] = rstd;
+        }
+    }
+}
+
+struct LnBwdArgs {
+    const void* dy; const void* z; const float* mean; const float* rstd; const float* gamma;
+    void* dz; void* dx; float* dgamma; float* dbeta; float* dbias; int M, H; DropSpec din, dout;
+};
+
+// add this block's per-lane column partials (one value per owned column) into LDS, then into HBM
+template <int NC>
+VB_DEVICE void block_colsum_flush(float (&acc)[NC][8], float* lds, float* out, int H, int l32) {
+    for (int i = threadIdx.x; i < H; i += NT) lds[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int ci = 0; ci < NC; ++ci) {
+        const int col = (l32 + 32 * ci) * 8;
+        if (col < H) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) atomicAdd(&lds[col + j], acc[ci][j]);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < H; i += NT) atomicAdd(&out[i], lds[i]);
+    __syncthreads();
+}
+
+template <typename T, int NC>
+VB_KERNEL VB_LAUNCH_BOUNDS(NT) ln_bwd_kernel(LnBwdArgs a) {
+    VB_DYN_SMEM(smem);
+    float* lds = (float*)smem;
+    const int l32 = threadIdx.x & 31, hw = threadIdx.x >> 5;
+    const int H = a.H;
+    const float invH = 1.0f / (float)H;
+    float acc_g[NC][8], acc_b[NC][8], acc_x[NC][8];
+#pragma unroll
+    for (int ci = 0; ci < NC; ++ci)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { acc_g[ci][j] = 0.f; acc_b[ci][j] = 0.f; acc_x[ci][j] = 0.f; }
+
+    for (int base = blockIdx.x * HW_PER_BLOCK; base < a.M; base += gridDim.x * HW_PER_BLOCK) {
+        const int row = base + hw;
+        const bool act = row < a.M;
+        const float mean = act ? a.mean[row] : 0.f, rstd = act ? a.rstd[row] : 0.f;
+        float dy[NC][8], xh[NC][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int ci = 0; ci < NC; ++ci) {
+            const int col = (l32 + 32 * ci) * 8;
+            if (act && col < H) {
+                const long e = (long)row * H + col;
+                load8(dy[ci], (const T*)a.dy + e);
+                if (a.dout.p > 0.f) apply_dropout8(dy[ci], a.dout, (uint64_t)e >> 3);
+                float zz[8], gm[8];
+                load8(zz, (const T*)a.z + e);
+                load8(gm, a.gamma + col);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    xh[ci][j] = (zz[j] - mean) * rstd;
+                    acc_g[ci][j] += dy[ci][j] * xh[ci][j];
+                    acc_b[ci][j] += dy[ci][j];
+                    dy[ci][j] *= gm[j];                       // g = dy * gamma
+                    s1 += dy[ci][j];
+                    s2 += dy[ci][j] * xh[ci][j];
+                }
+            }
+        }
+        s1 = half_sum(s1) * invH;
+        s2 = half_sum(s2) * invH;
+#pragma unroll
+        for (int ci = 0; ci < NC; ++ci) {
+            const int col = (l32 + 32 * ci) * 8;
+            if (act && col < H) {
+                const long e = (long)row * H + col;
+                float dz[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dz[j] = rstd * (dy[ci][j] - s1 - xh[ci][j] * s2);
+                store8((T*)a.dz + e, dz);
+                if (a.dx) {
+                    if (a.din.p > 0.f) apply_dropout8(dz, a.din, (uint64_t)e >> 3);
+                    if (a.dx != a.dz) store8((T*)a.dx + e, dz);
+                }
+                if (a.dbias) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc_x[ci][j] += dz[j];
+                }
+            }
+        }
+    }
+    if (a.dgamma) block_colsum_flush<NC>(acc_g, lds, a.dgamma, H, l32);
+    if (a.dbeta) block_colsum_flush<NC>(acc_b, lds, a.dbeta, H, l32);
+    if (a.dbias) block_colsum_flush<NC>(acc_x, lds, a.dbias, H, l32);
+}
+
+// ---------------------------------------------------------------------------------------------
+struct EmbArgs {
+    const int64_t* ids; const int64_t* type_ids; const int64_t* vis_type;
+    const void* vis_proj; const float* word; const float* pos; const float* type;
+    const float* pos_vis; const float* type_vis; void* z;
+    int B, T, R, H, V, TV, P;
+};
+
+template <typename TT_, int NC>
+VB_KERNEL VB_LAUNCH_BOUNDS(NT) embed_fwd_kernel(EmbArgs a) {
+    const int l32 = threadIdx.x & 31, hw = threadIdx.x >> 5;
+    const int S = a.T + a.R, H = a.H;
+    const long rows = (long)a.B * S;
+    for (long row = (long)blockIdx.x * HW_PER_BLOCK + hw; row < rows; row += (long)gridDim.x * HW_PER_BLOCK) {
+        const int b = (int)(row / S), s = (int)(row % S);
+        const float *t0, *t1, *t2;
+        const TT_* vp = nullptr;
+        if (s < a.T) {
+            long id = a.ids[(long)b * a.T + s]; id = id < 0 ? 0 : (id >= a.V ? a.V - 1 : id);
+            long tt = a.type_ids ? a.type_ids[(long)b * a.T + s] : 0; tt = tt < 0 ? 0 : (tt >= a.TV ? a.TV - 1 : tt);
+            t0 = a.word + id * H; t1 = a.pos + (long)(s < a.P ? s : a.P - 1) * H; t2 = a.type + tt * H;
+        } else {
+            const int r = s - a.T;
+            long vt = a.vis_type ? a.vis_type[(long)b * a.R + r] : 0; vt = vt < 0 ? 0 : (vt >= a.TV ? a.TV - 1 : vt);
+            vp = (const TT_*)a.vis_proj + ((long)b * a.R + r) * H;
+            t0 = nullptr; t1 = a.pos_vis; t2 = a.type_vis + vt * H;      // visual position id is always 0
+        }
+#pragma unroll
+        for (int ci = 0; ci < NC; ++ci) {
+            const int col = (l32 + 32 * ci) * 8;
+            if (col < H) {
+                float v[8], x[8];
+                if (t0) load8(v, t0 + col); else load8(v, vp + col);
+                load8(x, t1 + col);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += x[j];
+                load8(x, t2 + col);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += x[j];
+                store8((TT_*)a.z + row * H + col, v);
+            }
+        }
+    }
+}
+
+struct EmbBwdArgs {
+    const void* dz; const int64_t* ids; const int64_t* type_ids; const int64_t* vis_type;
+    float* d_word; float* d_pos; float* d_type; float* d_pos_vis; float* d_type_vis; void* d_vis_proj;
+    int B, T, R, H, V, TV, P;
+};
+
+// one workgroup per sequence position s: the position-embedding gradient of s is owned by exactly
+// one workgroup (register accumulate over the batch); word rows are scattered with fp32 atomics;
+// the (tiny) type tables are reduced in LDS first.
+template <typename TT_, int NC>
+VB_KERNEL VB_LAUNCH_BOUNDS(NT) embed_bwd_kernel(EmbBwdArgs a) {
+    VB_DYN_SMEM(smem);
+    float* lds_pos = (float*)smem;                 // [H]
+    float* lds_type = lds_pos + a.H;               // [TV][H]
+    const int l32 = threadIdx.x & 31, hw = threadIdx.x >> 5;
+    const int S = a.T + a.R, H = a.H, s = blockIdx.x;
+    const bool text = s < a.T;
+    for (int i = threadIdx.x; i < H * (1 + a.TV); i += NT) lds_pos[i] = 0.f;
+    __syncthreads();
+    float acc[NC][8];
+#pragma unroll
+    for (int ci = 0; ci < NC; ++ci)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[ci][j] = 0.f;
+    for (int b = hw; b < a.B; b += HW_PER_BLOCK) {
+        const long row = (long)b * S + s;
+        long id = 0, tt = 0;
+        if (text) {
+            id = a.ids[(long)b * a.T + s]; id = id < 0 ? 0 : (id >= a.V ? a.V - 1 : id);
+            tt = a.type_ids ? a.type_ids[(long)b * a.T + s] : 0;
+        } else {
+            tt = a.vis_type ? a.vis_type[(long)b * a.R + (s - a.T)] : 0;
+        }
+        tt = tt < 0 ? 0 : (tt >= a.TV ? a.TV - 1 : tt);
+#pragma unroll
+        for (int ci = 0; ci < NC; ++ci) {
+            const int col = (l32 + 32 * ci) * 8;
+            if (col < H) {
+                float v[8];
+                load8(v, (const TT_*)a.dz + row * H + col);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    acc[ci][j] += v[j];
+                    atomicAdd(&lds_type[tt * H + col + j], v[j]);
+                }
+                if (text) {
+                    if (a.d_word) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) atomicAdd(&a.d_word[id * H + col + j], v[j]);
+                    }
+                } else if (a.d_vis_proj) {
+                    store8((TT_*)a.d_vis_proj + ((long)b * a.R + (s - a.T)) * H + col, v);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int ci = 0; ci < NC; ++ci) {
+        const int col = (l32 + 32 * ci) * 8;
+        if (col < H) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) atomicAdd(&lds_pos[col + j], acc[ci][j]);
+        }
+    }
+    __syncthreads();
+    float* dpos = text ? (a.d_pos ? a.d_pos + (long)(s < a.P ? s : a.P - 1) * H : nullptr) : a.d_pos_vis;
+    float* dtype = text ? a.d_type : a.d_type_vis;
+    for (int i = threadIdx.x; i < H; i += NT) {
+        if (dpos) {
+            if (text) dpos[i] += lds_pos[i];                 // sole owner of this row
+            else atomicAdd(&dpos[i], lds_pos[i]);            // all visual slots share position row 0
+        }
+    }
+    if (dtype) {
+        for (int i = threadIdx.x; i < H * a.TV; i += NT) atomicAdd(&dtype[i], lds_type[i]);
+    }
+}
+
+#define VB_DISPATCH_NC(KERNEL, T, H, grid, smem, stream, args)                                  \
+    do {                                                                                        \
+        const int nc_ = ((H) / 8 + 31) / 32;                                                    \
+        if (nc_ <= 1) VB_LAUNCH((KERNEL<T, 1>), grid, dim3(NT), smem, stream, args);            \
+        else if (nc_ == 2) VB_LAUNCH((KERNEL<T, 2>), grid, dim3(NT), smem, stream, args);       \
+        else if (nc_ == 3) VB_LAUNCH((KERNEL<T, 3>), grid, dim3(NT), smem, stream, args);       \
+        else VB_LAUNCH((KERNEL<T, 4>), grid, dim3(NT), smem, stream, args);                     \
+    } while (0)
+
+static inline bool bad_h(int H) { return H <= 0 || (H % 8) != 0 || H > 8 * 32 * MAX_NC; }
+static inline unsigned row_grid(long rows, int cap) {
+    long g = (rows + HW_PER_BLOCK - 1) / HW_PER_BLOCK;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+}  // namespace
+
+extern "C" int vb_ln_fwd(int dtype, const void* x, const void* resid, void* z_out, void* y, float* mean, float* rstd,
+                         const float* gamma, const float* beta, int M, int H, float eps,
+                         float p_in, uint32_t stream_in, float p_out, uint32_t stream_out, uint64_t seed,
+                         void* stream) {
+    if (!x || !y || !gamma || !beta || M <= 0 || bad_h(H)) return VB_ERR_ARG;
+    if (p_in < 0.f || p_in >= 1.f || p_out < 0.f || p_out >= 1.f) return VB_ERR_ARG;
+    LnFwdArgs a{x, resid, z_out, y, mean, rstd, gamma, beta, M, H, eps, make_drop(p_in, seed, stream_in),
+                make_drop(p_out, seed, stream_out)};
+    dim3 grid(row_grid(M, 4096));
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == VB_BF16) VB_DISPATCH_NC(ln_fwd_kernel, bf16, H, grid, 0, s, a);
+    else if (dtype == VB_F32) VB_DISPATCH_NC(ln_fwd_kernel, float, H, grid, 0, s, a);
+    else return VB_ERR_ARG;
+    return vb_check_launch();
+}
+
+extern "C" int vb_ln_bwd(int dtype, const void* dy, const void* z, const float* mean, const float* rstd,
+                         const float* gamma, void* dz, void* dx, float* dgamma, float* dbeta, float* dbias,
+                         int M, int H, float p_in, uint32_t stream_in, float p_out, uint32_t stream_out,
+                         uint64_t seed, void* stream) {
+    if (!dy || !z || !mean || !rstd || !gamma || !dz || M <= 0 || bad_h(H)) return VB_ERR_ARG;
+    if (p_in > 0.f && (!dx || dx == dz)) return VB_ERR_ARG;   // dropped and un-dropped grads differ
+    LnBwdArgs a{dy, z, mean, rstd, gamma, dz, dx, dgamma, dbeta, dbias, M, H, make_drop(p_in, seed, stream_in),
+                make_drop(p_out, seed, stream_out)};
+    dim3 grid(row_grid(M, 512));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t smem = (size_t)H * sizeof(float);
+    if (dtype == VB_BF16) VB_DISPATCH_NC(ln_bwd_kernel, bf16, H, grid, smem, s, a);
+    else if (dtype == VB_F32) VB_DISPATCH_NC(ln_bwd_kernel, float, H, grid, smem, s, a);
+    else return VB_ERR_ARG;
+    return vb_check_launch();
+}
+
+extern "C" int vb_embed_fwd(int dtype, const int64_t* input_ids, const int64_t* token_type_ids,
+                            const int64_t* visual_type, const void* vis_proj, const float* word, const float* pos,
+                            const float* type, const float* pos_vis, const float* type_vis, void* z,
+                            int B, int T, int R, int H, int V, int type_vocab, int max_pos, void* stream) {
+    if (!input_ids || !word || !pos || !type || !z || B <= 0 || T <= 0 || R < 0 || bad_h(H)) return VB_ERR_ARG;
+    if (R > 0 && (!vis_proj || !pos_vis || !type_vis)) return VB_ERR_ARG;
+    if (type_vocab <= 0 || type_vocab > 8 || max_pos <= 0 || V <= 0) return VB_ERR_ARG;
+    EmbArgs a{input_ids, token_type_ids, visual_type, vis_proj, word, pos, type, pos_vis, type_vis, z,
+              B, T, R, H, V, type_vocab, max_pos};
+    dim3 grid(row_grid((long)B * (T + R), 4096));
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == VB_BF16) VB_DISPATCH_NC(embed_fwd_kernel, bf16, H, grid, 0, s, a);
+    else if (dtype == VB_F32) VB_DISPATCH_NC(embed_fwd_kernel, float, H, grid, 0, s, a);
+    else return VB_ERR_ARG;
+    return vb_check_launch();
+}
+
+extern "C" int vb_embed_bwd(int dtype, const void* dz, const int64_t* input_ids, const int64_t* token_type_ids,
+                            const int64_t* visual_type, float* d_word, float* d_pos, float* d_type,
+                            float* d_pos_vis, float* d_type_vis, void* d_vis_proj,
+                            int B, int T, int R, int H, int V, int type_vocab, int max_pos, void* stream) {
+    if (!dz || !input_ids || B <= 0 || T <= 0 || R < 0 || bad_h(H)) return VB_ERR_ARG;
+    if (type_vocab <= 0 || type_vocab > 8 || max_pos <= 0 || V <= 0) return VB_ERR_ARG;
+    EmbBwdArgs a{dz, input_ids, token_type_ids, visual_type, d_word, d_pos, d_type, d_pos_vis, d_type_vis,
+                 d_vis_proj, B, T, R, H, V, type_vocab, max_pos};
+    dim3 grid((unsigned)(T + R));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t smem = (size_t)H * (1 + type_vocab) * sizeof(float);
+    if (dtype == VB_BF16) VB_DISPATCH_NC(embed_bwd_kernel, bf16, H, grid, smem, s, a);
+    else if (dtype == VB_F32) VB_DISPATCH_NC(embed_bwd_kernel, float, H, grid, smem, s, a);
+    else return VB_ERR_ARG;
+    return vb_check_launch();
+}

@@ -1,0 +1,178 @@
+// vb_rt.h -- device-runtime vocabulary shared by every kernel file.
+//
+// Product build (default): HIP for gfx950 only.  Wave = 64 lanes, MFMA builtins, LDS.
+// -DVB_EMU: the same kernel sources compiled as host C++ against tests/hipemu (developer-only
+//           kernel-logic simulator; never shipped, never loaded by the visualbert_amd package).
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef VB_EMU
+#include "hipemu.h"
+#define VB_KERNEL static void
+#define VB_DEVICE static inline
+#define VB_LAUNCH_BOUNDS(n)
+#define VB_DYN_SMEM(name) unsigned char* name = ::hipemu::blk()->smem
+#define VB_LAUNCH(kernel, grid, block, smem, stream, ...) \
+    ::hipemu::launch((grid), (block), (smem), [=]() { kernel(__VA_ARGS__); })
+#else
+#include <hip/hip_runtime.h>
+#define VB_KERNEL __global__ void
+#define VB_DEVICE static __device__ __forceinline__
+#define VB_LAUNCH_BOUNDS(n) __launch_bounds__(n)
+// all LDS lives in the dynamic region, 16-byte aligned base (cdna guide, Guideline 17)
+#define VB_DYN_SMEM(name)                                                            \
+    extern __shared__ __attribute__((aligned(16))) unsigned char vb_dyn_smem_raw[];  \
+    unsigned char* name = vb_dyn_smem_raw
+#define VB_LAUNCH(kernel, grid, block, smem, stream, ...) \
+    hipLaunchKernelGGL(kernel, (grid), (block), (smem), (stream), __VA_ARGS__)
+#endif
+
+typedef __bf16 bf16;
+typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+// ------------------------------------------------------------------------------------------
+// Element-type traits: T in {float, bf16}.  A "fragment" is always 8 consecutive K elements
+// per lane (16 B for bf16, 32 B for fp32) so that bf16 and fp32 kernels share ALL index maths.
+// ------------------------------------------------------------------------------------------
+template <typename T> struct VecOf;
+template <> struct VecOf<float> { typedef f32x8 v8; typedef f32x4 v4; };
+template <> struct VecOf<bf16> { typedef bf16x8 v8; typedef bf16x4 v4; };
+
+VB_DEVICE float to_f32(float x) { return x; }
+VB_DEVICE float to_f32(bf16 x) { return (float)x; }
+VB_DEVICE void cvt_f32(float x, float& o) { o = x; }
+VB_DEVICE void cvt_f32(float x, bf16& o) { o = (bf16)x; }                 // RNE; v_cvt_pk_bf16_f32 on gfx950
+template <typename T> VB_DEVICE T from_f32(float x) { T o; cvt_f32(x, o); return o; }
+
+// 8 consecutive elements <-> 8 floats (16-byte vector accesses; p must be 16-byte aligned)
+VB_DEVICE void load8(float (&v)[8], const bf16* p) {
+    bf16x8 x = *(const bf16x8*)p;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (float)x[j];
+}
+VB_DEVICE void load8(float (&v)[8], const float* p) {
+    f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = a[j]; v[4 + j] = b[j]; }
+}
+VB_DEVICE void store8(bf16* p, const float (&v)[8]) {
+    bf16x8 x;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = (bf16)v[j];
+    *(bf16x8*)p = x;
+}
+VB_DEVICE void store8(float* p, const float (&v)[8]) {
+    *(f32x4*)p = f32x4{v[0], v[1], v[2], v[3]};
+    *(f32x4*)(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+}
+
+// ------------------------------------------------------------------------------------------
+// MFMA: one 16x16 output fragment, K step of 32.
+//   A operand: lane l holds A[i = l&15][k = (l>>4)*8 + j], j = 0..7
+//   B operand: lane l holds B[k = (l>>4)*8 + j][n = l&15]
+//   C/D      : lane l, reg r -> row = (l>>4)*4 + r, col = l&15
+// bf16: v_mfma_f32_16x16x32_bf16.  fp32: eight chained v_mfma_f32_16x16x4_f32 -- instruction j
+// consumes element j of both fragments, i.e. its hardware k index (l>>4) stands for the true
+// k = (l>>4)*8 + j; the pairing of A and B elements is identical to the bf16 form, and the result
+// is an exact fp32 fma chain (guide section 3 "FP32-input MFMA").
+// ------------------------------------------------------------------------------------------
+#ifdef VB_EMU
+VB_DEVICE f32x4 vb_mma(bf16x8 a, bf16x8 b, f32x4 c) {
+    float fa[8], fb[8], fc[4];
+    for (int j = 0; j < 8; ++j) { fa[j] = (float)a[j]; fb[j] = (float)b[j]; }
+    for (int r = 0; r < 4; ++r) fc[r] = c[r];
+    ::hipemu::mma_16x16x32(fa, fb, fc);
+    f32x4 o; for (int r = 0; r < 4; ++r) o[r] = fc[r];
+    return o;
+}
+VB_DEVICE f32x4 vb_mma(f32x8 a, f32x8 b, f32x4 c) {
+    float fa[8], fb[8], fc[4];
+    for (int j = 0; j < 8; ++j) { fa[j] = a[j]; fb[j] = b[j]; }
+    for (int r = 0; r < 4; ++r) fc[r] = c[r];
+    ::hipemu::mma_16x16x32(fa, fb, fc);
+    f32x4 o; for (int r = 0; r < 4; ++r) o[r] = fc[r];
+    return o;
+}
+#else
+VB_DEVICE f32x4 vb_mma(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+VB_DEVICE f32x4 vb_mma(f32x8 a, f32x8 b, f32x4 c) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], c, 0, 0, 0);
+    return c;
+}
+#endif
+
+// ------------------------------------------------------------------------------------------
+// wave (64-lane) reductions
+// ------------------------------------------------------------------------------------------
+VB_DEVICE float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+VB_DEVICE float wave_max(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
+    return v;
+}
+// reduction across the 32 lanes of a half-wave (lanes [0,32) and [32,64) independently)
+VB_DEVICE float half_sum(float v) {
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// Counter-based RNG for dropout: Philox4x32-10 keyed by (seed), counter = (group, stream).
+// One call yields 128 bits = eight 16-bit uniforms; element e of group g is dropped iff
+// u16[e] < thresh16, thresh16 = round(p * 65536).  Any kernel (forward or backward, any thread
+// mapping) regenerates the same mask from (seed, stream, element index) -- no mask tensor in HBM.
+// ------------------------------------------------------------------------------------------
+struct Philox8 { uint32_t w[4]; };
+VB_DEVICE Philox8 philox4x32_10(uint64_t seed, uint64_t group, uint32_t stream) {
+    uint32_t c0 = (uint32_t)group, c1 = (uint32_t)(group >> 32), c2 = stream, c3 = 0x5ca1ab1eu;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    Philox8 o; o.w[0] = c0; o.w[1] = c1; o.w[2] = c2; o.w[3] = c3;
+    return o;
+}
+// keep-mask bit e (0..7) of a group
+VB_DEVICE bool philox_keep(const Philox8& r, int e, uint32_t thresh16) {
+    uint32_t u = (r.w[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu;
+    return u >= thresh16;
+}
+
+VB_DEVICE float gelu_f(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
+VB_DEVICE float gelu_grad_f(float x) {
+    // d/dx [x * Phi(x)] = Phi(x) + x * phi(x)
+    float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+#define VB_OK 0
+#define VB_ERR_ARG (-1)
+#define VB_ERR_LAUNCH (-2)
+#define VB_ERR_UNSUPPORTED (-3)
+
+static inline int vb_check_launch() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? VB_OK : VB_ERR_LAUNCH;
+}

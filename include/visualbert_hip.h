@@ -106,6 +106,67 @@ int vb_attn_bwd(int dtype, const void* qkv, const float* mask_add, const void* d
                 const uint64_t* keepbits, float* dsum_ws, void* dqkv, int B, int S, int nh, int head_dim,
                 float p_drop, uint64_t seed, uint32_t stream_id, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Losses.  logits are fp32 with leading dimension ld_logits (pad columns are ignored).
+ * vb_ce_fwd_bwd: CrossEntropyLoss(ignore_index) mean over counted rows -> loss[0]; acc2 is an fp32[2]
+ *   scratch {sum, count}; dlogits (T, may be NULL) receives d loss / d logits for an upstream gradient
+ *   of 1, INCLUDING zeroed pad columns up to ld_dlogits and all-zero rows for ignored labels.
+ *   Replaces modeling.py:1471-1477 (masked LM, image-text match), :1563-1565 (NLVR2) and autograd.
+ * vb_kldiv_fwd_bwd: KLDivLoss(batchmean)(log_softmax(logits), target) -> loss[0]; score[0] (may be NULL)
+ *   = mean VQA score of compute_score_with_logits; dlogits fp32 (may be NULL).
+ *   Replaces modeling.py:1517-1523 and :1697-1711.
+ * ---------------------------------------------------------------------------------------------- */
+int vb_ce_fwd_bwd(int dtype, const float* logits, int64_t ld_logits, const int64_t* labels, int ignore_index,
+                  float* acc2, float* loss, void* dlogits, int64_t ld_dlogits, int M, int V, void* stream);
+int vb_kldiv_fwd_bwd(const float* logits, int64_t ld_logits, const float* target, int64_t ld_target,
+                     float* loss, float* score, float* dlogits, int64_t ld_dlogits, int M, int V, void* stream);
+
+/* Heads with a tiny output width (seq_relationship 768->2, modeling.py:451; NLVR2 768->2, :1558).
+ * x: T [M,K]; W: fp32 master [N,K]; y / dy: fp32 [M,N].  Backward: dx (T, overwritten, may be NULL),
+ * dW / db fp32 ACCUMULATED (may be NULL); scale_dev: optional fp32 device scalar (upstream gradient). */
+int vb_small_linear_fwd(int dtype, const void* x, int64_t ldx, const float* W, const float* bias, float* y,
+                        int M, int N, int K, void* stream);
+int vb_small_linear_bwd(int dtype, const float* dy, const void* x, int64_t ldx, const float* W,
+                        void* dx, int64_t lddx, float* dW, float* db, const float* scale_dev,
+                        int M, int N, int K, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused multi-tensor BertAdam over a flat fp32 arena (params / grads / exp_avg / exp_avg_sq share one
+ * layout).  tensor_table: int64[n_tensors][4] = {arena offset, numel, bf16-shadow offset or -1,
+ * flags (bit0 optimise, bit1 weight decay)}; chunk_table: int64[n_chunks][4] = {tensor id, arena
+ * offset, length, 0}.  norm2_ws: fp32[n_tensors] scratch; step_counters: int32[n_tensors] (state).
+ * schedule: 0 none, 1 warmup_linear(warmup, t_total).  bf16_shadow may be NULL.
+ * Replaces BertAdam.step, optimization.py:239-304 (+ WarmupLinearSchedule :164-173).
+ * ---------------------------------------------------------------------------------------------- */
+int vb_bert_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                      void* bf16_shadow, const int64_t* chunk_table, int n_chunks,
+                      const int64_t* tensor_table, int n_tensors, float* norm2_ws, int* step_counters,
+                      float lr, float b1, float b2, float eps, float weight_decay,
+                      float max_grad_norm, float warmup, float t_total, int schedule, void* stream);
+int vb_refresh_bf16_shadow(const float* params, void* bf16_shadow, const int64_t* chunk_table,
+                           int n_chunks, const int64_t* tensor_table, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Input preparation (integer work, bit-exact): image_mask[b,r] = r < image_dim[b] (models/model.py:262-268,
+ * or image_mask given), attention_mask = cat(input_mask, image_mask) (modeling.py:1417), additive mask
+ * (1 - m) * -10000 (:1293-1294), LM labels extended with -1 over visual slots (:1419-1426).
+ * ---------------------------------------------------------------------------------------------- */
+int vb_prepare_inputs(const int64_t* input_mask, const int64_t* image_dim, const int64_t* image_mask,
+                      const int64_t* masked_lm_labels, int64_t* attention_mask, float* mask_add,
+                      int64_t* labels_ext, int B, int T, int R, void* stream);
+/* elementwise dtype conversion (VB_F32 / VB_BF16 in any combination) */
+int vb_cast(int src_dtype, const void* src, int dst_dtype, void* dst, int64_t n, void* stream);
+/* VQA head gather (modeling.py:1503-1505): out[b] = x[b, input_mask[b].sum() - 2]; index_out int64[B] */
+int vb_gather_rows(int dtype, const void* x, const int64_t* input_mask, void* out, int64_t* index_out,
+                   int B, int S, int T, int H, void* stream);
+int vb_scatter_rows(int dtype, const void* dout, const int64_t* index, void* dx, int B, int S, int H, void* stream);
+
+/* bias gradients: out[n] += scale * sum_m x[m,n]  (x: T [M,N], out fp32, scale_dev optional device scalar) */
+int vb_colsum(int dtype, const void* x, int64_t ld, float* out, const float* scale_dev, int M, int N, void* stream);
+/* dx = dy * act'(aux): act = VB_ACT_GELU (aux = pre-activation, modeling.py:56-61) or VB_ACT_TANH
+ * (aux = tanh output, BertPooler modeling.py:385).  Contiguous T[n]. */
+int vb_act_bwd(int dtype, const void* dy, const void* aux, void* dx, int64_t n, int act, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

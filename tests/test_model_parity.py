@@ -1,0 +1,133 @@
+"""Whole-path parity of the HIP model against (a) golden outputs of the REAL reference
+(tests/golden, fp32 mode, logits tolerance 1e-3 as BASELINE.json's north_star states -- measured
+error is ~1e-5) and (b) the oracle restatement in bf16-emulation mode (bf16 kernels)."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import visualbert_oracle as vo
+from golden_util import CASES, LR, WARMUP, T_TOTAL, LOGIT_STRIDE, N_STEPS, load_case, maxdiff
+
+pytestmark = pytest.mark.gpu
+
+
+def build_model(cfg, head, sd, dev, dtype=torch.float32, dropout=None):
+    from visualbert_amd.modeling import BertConfig
+    from visualbert_amd.model import VisualBERTFixedImageEmbedding
+    hd = cfg.hidden_dropout_prob if dropout is None else dropout
+    ad = cfg.attention_probs_dropout_prob if dropout is None else dropout
+    bc = BertConfig(cfg.vocab_size, hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers,
+                    num_attention_heads=cfg.num_attention_heads, intermediate_size=cfg.intermediate_size,
+                    hidden_dropout_prob=hd, attention_probs_dropout_prob=ad,
+                    max_position_embeddings=cfg.max_position_embeddings, type_vocab_size=cfg.type_vocab_size)
+    model = VisualBERTFixedImageEmbedding(config=bc, training_head_type=head,
+                                          visual_embedding_dim=cfg.visual_embedding_dim, compute_dtype=dtype)
+    model = model.to(dev)
+    own = model.bert.state_dict()
+    with torch.no_grad():
+        for k, v in sd.items():
+            own[k].copy_(v)
+    return model
+
+
+def to_dev(batch, dev):
+    return {k: v.to(dev) for k, v in batch.items()}
+
+
+@pytest.mark.parametrize("stem", sorted(CASES))
+def test_fp32_forward_matches_reference_golden(dev, stem):
+    cfg, head, sd, batch, g = load_case(stem)
+    model = build_model(cfg, head, sd, dev)
+    model.eval()
+    with torch.no_grad():
+        out = model(**to_dev(batch, dev))
+        enc = model(**to_dev(batch, dev), output_all_encoded_layers=True)
+    assert maxdiff(enc["sequence_output"][-1].float().cpu(), g["sequence_output"]) < 1e-3
+    assert maxdiff(enc["pooled_output"].float().cpu(), g["pooled_output"]) < 1e-3
+    assert abs(float(out["loss"]) - float(g["loss"])) < 1e-3
+    if head == "pretraining":
+        lg = out["logits"].float().cpu()
+        err = maxdiff(lg[:, :, ::LOGIT_STRIDE], g["logits_strided"])
+        assert err < 1e-3, err                                           # north_star: logits within 1e-3
+        assert err < 1e-4, err                                           # what fp32 kernels actually deliver
+        assert abs(float(lg.abs().max()) - float(g["logits_absmax"])) < 1e-3
+        assert maxdiff(out["seq_relationship_score"].cpu(), g["seq_relationship_score"]) < 1e-4
+        assert abs(float(out["masked_lm_loss"]) - float(g["masked_lm_loss"])) < 1e-4
+        assert abs(float(out["next_sentence_loss"]) - float(g["next_sentence_loss"])) < 1e-4
+        assert np.array_equal(lg.argmax(-1).numpy(), g["logits_argmax"])  # token indexing bit-exact
+    else:
+        assert maxdiff(out["logits"].float().cpu().reshape(g["logits"].shape), g["logits"]) < 1e-4
+    if head == "vqa":
+        assert abs(float(out["accuracy"]) - float(g["accuracy"])) < 1e-6
+
+
+@pytest.mark.parametrize("stem", sorted(CASES))
+def test_fp32_train_steps_match_reference_golden(dev, stem):
+    """gradients (dropout p=0) and N_STEPS fused BertAdam steps against the reference's own run."""
+    from visualbert_amd.model import ModelWrapper, AttrDict
+    cfg, head, sd, batch, g = load_case(stem)
+    model = build_model(cfg, head, sd, dev, dropout=0.0)
+    model.train()
+    args = AttrDict(train_batch_size=1, learning_rate=LR, warmup_proportion=WARMUP, num_train_epochs=1,
+                    gradient_accumulation_steps=1)
+    mw = ModelWrapper(args, T_TOTAL, model=model)
+    b = to_dev(batch, dev)
+    out = mw.step(b)
+    assert abs(float(out["loss"]) - float(g["train_loss"])) < 1e-4
+    named = dict(model.bert.named_parameters())
+    gnames = set(str(x) for x in g["grad_names"])
+    assert gnames <= set(named.keys())
+    for n, p in named.items():
+        if n not in gnames:                       # the reference leaves .grad = None (e.g. the unused pooler)
+            assert float(p.grad.abs().max()) == 0.0, n
+            continue
+        ref_norm = float(g["grad_norm/" + n])
+        gr = p.grad.detach().float().cpu()
+        assert abs(float(gr.double().norm()) - ref_norm) <= 2e-3 * ref_norm + 1e-6, (n, float(gr.norm()), ref_norm)
+        assert maxdiff(gr.reshape(-1)[:16], g["grad_head/" + n]) <= 2e-3 * max(ref_norm, 1e-3), n
+    for _ in range(N_STEPS - 1):
+        out = mw.step(b)
+    assert abs(float(out["loss"]) - float(g["final_loss"])) < 1e-4
+    for n, p in named.items():
+        assert maxdiff(p.detach().cpu().reshape(-1)[:16], g["post_head/" + n]) < 2e-6, n
+        d = float((p.detach().cpu() - sd[n]).double().norm())
+        assert abs(d - float(g["delta_norm/" + n])) <= 5e-3 * float(g["delta_norm/" + n]) + 1e-7, n
+
+
+@pytest.mark.parametrize("stem", ["micro_pretraining", "tiny_pretraining"])
+def test_bf16_matches_bf16_oracle(dev, stem):
+    """bf16 kernels against the oracle with bf16 rounding at the same storage points (DESIGN.md numeric
+    contract); the bf16-vs-fp32-reference gap is printed, not asserted."""
+    cfg, head, sd, batch, g = load_case(stem)
+    model = build_model(cfg, head, sd, dev, dtype=torch.bfloat16)
+    model.eval()
+    with torch.no_grad():
+        out = model(**to_dev(batch, dev))
+        ref = vo.objective_forward(sd, cfg, head, mode="bf16", **batch)
+    lg = out["logits"].float().cpu()
+    err = float((lg - ref["logits"]).abs().max())
+    gap = maxdiff(lg[:, :, ::LOGIT_STRIDE], g["logits_strided"])
+    print("bf16 logits: vs bf16-oracle %.3e, vs fp32 reference %.3e (absmax %.2f)" % (err, gap, float(g["logits_absmax"])))
+    assert err < 2e-2, err
+    assert abs(float(out["loss"]) - float(ref["loss"])) < 2e-2
+    assert gap < 0.1
+
+
+def test_dropout_training_step_runs_and_is_seed_deterministic(dev):
+    cfg, head, sd, batch, g = load_case("micro_pretraining")
+    losses = []
+    for rep in range(2):
+        torch.manual_seed(123)
+        from visualbert_amd import ops
+        ops.reset_seed_counter()
+        model = build_model(cfg, head, sd, dev)
+        model.train()
+        out = model(**to_dev(batch, dev))
+        out["loss"].backward()
+        losses.append(float(out["loss"]))
+        gn = float(model.bert.arena.grad.norm())
+        assert np.isfinite(gn) and gn > 0
+    assert losses[0] == losses[1]
+    assert abs(losses[0] - float(g["loss"])) > 1e-6      # dropout really changed the forward

@@ -31,6 +31,18 @@ SIGNATURES = {
     "vb_attn_keepbits_words": (_i64, [_i]),
     "vb_attn_fwd": (_i, [_i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _u64, _u32, _p]),
     "vb_attn_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _u64, _u32, _p]),
+    "vb_ce_fwd_bwd": (_i, [_i, _p, _i64, _p, _i, _p, _p, _p, _i64, _i, _i, _p]),
+    "vb_kldiv_fwd_bwd": (_i, [_p, _i64, _p, _i64, _p, _p, _p, _i64, _i, _i, _p]),
+    "vb_small_linear_fwd": (_i, [_i, _p, _i64, _p, _p, _p, _i, _i, _i, _p]),
+    "vb_small_linear_bwd": (_i, [_i, _p, _p, _i64, _p, _p, _i64, _p, _p, _p, _i, _i, _i, _p]),
+    "vb_bert_adam_step": (_i, [_p, _p, _p, _p, _p, _p, _i, _p, _i, _p, _p, _f, _f, _f, _f, _f, _f, _f, _f, _i, _p]),
+    "vb_refresh_bf16_shadow": (_i, [_p, _p, _p, _i, _p, _p]),
+    "vb_prepare_inputs": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "vb_cast": (_i, [_i, _p, _i, _p, _i64, _p]),
+    "vb_gather_rows": (_i, [_i, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "vb_scatter_rows": (_i, [_i, _p, _p, _p, _i, _i, _i, _p]),
+    "vb_colsum": (_i, [_i, _p, _i64, _p, _p, _i, _i, _p]),
+    "vb_act_bwd": (_i, [_i, _p, _p, _p, _i64, _i, _p]),
 }
 
 _ERRORS = {-1: "VB_ERR_ARG (bad argument)", -2: "VB_ERR_LAUNCH (hip launch failed)",

@@ -1,2 +1,232 @@
+// loss.hip -- losses and the tiny task heads of the VisualBERT training path.
+//   * CrossEntropyLoss(ignore_index) forward + backward in one sweep over fp32 logits
+//       reference: TrainVisualBERTObjective.forward, pytorch_pretrained_bert/modeling.py:1471-1477
+//                  (masked-LM over [B*S, V] with ignore_index=-1, image-text-match over [B, 2]) and
+//                  :1563-1565 (NLVR2, CrossEntropyLoss())
+//   * KLDivLoss(batchmean) on log_softmax + VQA score            modeling.py:1517-1523, :1697-1711
+//   * "small linear": heads whose output width is tiny (seq_relationship 768->2, NLVR2 768->2),
+//     where an MFMA tile would be >98 % padding                  modeling.py:451, :1558
+//
+// Memory plan for the [B*S, V] masked-LM logits (V = 30522, fp32, leading dimension padded to a
+// multiple of 64): one workgroup per row.  ~88 % of rows carry label -1: they are never read -- only
+// their dlogits row is zero-filled.  A labelled row is read twice (online max/sum, then gradient);
+// its 122 KB stay L2-resident between the two sweeps.
 #include "vb_rt.h"
 #include "../../include/visualbert_hip.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+VB_DEVICE float block_reduce_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int w = 0; w < NT / 64; ++w) r += red[w];
+    return r;
+}
+VB_DEVICE float block_reduce_max(float v, float* red) {
+    v = wave_max(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float r = red[0];
+    for (int w = 1; w < NT / 64; ++w) r = fmaxf(r, red[w]);
+    return r;
+}
+
+// acc[0] = sum of row losses, acc[1] = number of counted rows (as float)
+VB_KERNEL VB_LAUNCH_BOUNDS(NT) ce_count_kernel(const int64_t* labels, int M, int V, int ignore_index, float* acc) {
+    VB_DYN_SMEM(smem);
+    float* red = (float*)smem;
+    float c = 0.f;
+    for (int i = threadIdx.x; i < M; i += NT) {
+        const int64_t l = labels[i];
+        c += (l != ignore_index && l >= 0 && l < V) ? 1.f : 0.f;
+    }
+    c = block_reduce_sum(c, red);
+    if (threadIdx.x == 0) { acc[0] = 0.f; acc[1] = c; }
+}
+
+template <typename T>
+VB_KERNEL VB_LAUNCH_BOUNDS(NT) ce_row_kernel(const float* logits, long ld, const int64_t* labels, int ignore_index,
+                                            float* acc, T* dlogits, long ldd, int M, int V) {
+    VB_DYN_SMEM(smem);
+    float* red = (float*)smem;
+    const int row = blockIdx.x;
+    const int64_t label = labels[row];
+    const bool counted = (label != ignore_index && label >= 0 && label < V);
+    T* drow = dlogits ? dlogits + (long)row * ldd : nullptr;
+    if (!counted) {                                      // workgroup-uniform branch
+        if (drow) for (long j = threadIdx.x; j < ldd; j += NT) drow[j] = from_f32<T>(0.f);
+        return;
+    }
+    const float* x = logits + (long)row * ld;
+    float m = -INFINITY, s = 0.f;                        // online max / sum-exp
+    for (int j = threadIdx.x; j < V; j += NT) {
+        const float v = x[j];
+        if (v > m) { s = s * expf(m - v) + 1.f; m = v; }
+        else s += expf(v - m);
+    }
+    const float gm = block_reduce_max(m, red);
+    s = (m == -INFINITY) ? 0.f : s * expf(m - gm);
+    const float gs = block_reduce_sum(s, red);
+    const float lse = gm + logf(gs);
+    if (threadIdx.x == 0) atomicAdd(&acc[0], lse - x[label]);
+    if (drow) {
+        const float invc = 1.0f / acc[1];
+        for (long j = threadIdx.x; j < ldd; j += NT) {
+            float gval = 0.f;
+            if (j < V) gval = (expf(x[j] - lse) - (j == label ? 1.f : 0.f)) * invc;
+            drow[j] = from_f32<T>(gval);
+        }
+    }
+}
+
+// loss[0] = acc[0] / acc[1]   (NaN when nothing is counted, like the reference)
+VB_KERNEL ce_finish_kernel(const float* acc, float* loss) {
+    if (threadIdx.x == 0) loss[0] = acc[0] / acc[1];
+}
+
+// KLDivLoss(reduction=batchmean)(log_softmax(logits), target) + gradient + VQA score, one block per row
+VB_KERNEL VB_LAUNCH_BOUNDS(NT) kldiv_row_kernel(const float* logits, long ld, const float* target, long ldt,
+                                               float* loss, float* score, float* dlogits, long ldd, int M, int V) {
+    VB_DYN_SMEM(smem);
+    float* red = (float*)smem;
+    const int row = blockIdx.x;
+    const float* x = logits + (long)row * ld;
+    const float* tg = target + (long)row * ldt;
+    float m = -INFINITY;
+    for (int j = threadIdx.x; j < V; j += NT) m = fmaxf(m, x[j]);
+    m = block_reduce_max(m, red);
+    float s = 0.f, tsum = 0.f;
+    for (int j = threadIdx.x; j < V; j += NT) { s += expf(x[j] - m); tsum += tg[j]; }
+    s = block_reduce_sum(s, red);
+    tsum = block_reduce_sum(tsum, red);
+    const float lse = m + logf(s);
+    float l = 0.f;
+    // argmax over classes 1..V-1 (masked_unk_softmax zeroes class 0), first index on ties
+    float bv = -INFINITY; int bi = V;
+    for (int j = threadIdx.x; j < V; j += NT) {
+        const float tj = tg[j], lsm = x[j] - lse;
+        if (tj > 0.f) l += tj * (logf(tj) - lsm);
+        if (j >= 1 && (x[j] > bv || (x[j] == bv && j < bi))) { bv = x[j]; bi = j; }
+        if (dlogits) dlogits[(long)row * ldd + j] = (expf(lsm) * tsum - tj) / (float)M;
+    }
+    l = block_reduce_sum(l, red);
+    const float gbv = block_reduce_max(bv, red);
+    // smallest index among the maxima
+    float cand = (bv == gbv) ? (float)bi : 3.0e38f;
+    cand = -block_reduce_max(-cand, red);
+    if (threadIdx.x == 0) {
+        atomicAdd(loss, l / (float)M);
+        if (score) {
+            const int am = (int)cand;
+            atomicAdd(score, (am >= 0 && am < V) ? tg[am] / (float)M : 0.f);
+        }
+    }
+}
+
+// ---- small linear -------------------------------------------------------------------------------
+template <typename T>
+VB_KERNEL VB_LAUNCH_BOUNDS(NT) small_linear_fwd_kernel(const T* x, long ldx, const float* W, const float* bias,
+                                                      float* y, int M, int N, int K) {
+    // one wave per (m, n)
+    const int lane = threadIdx.x & 63;
+    const int wid = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    const bool act = wid < M * N;                        // wave-uniform
+    const int m = act ? wid / N : 0, n = act ? wid % N : 0;
+    float s = 0.f;
+    if (act) for (int k = lane; k < K; k += 64) s += to_f32(x[(long)m * ldx + k]) * W[(long)n * K + k];
+    s = wave_sum(s);
+    if (act && lane == 0) y[(long)m * N + n] = s + (bias ? bias[n] : 0.f);
+}
+
+template <typename T>
+VB_KERNEL VB_LAUNCH_BOUNDS(NT) small_linear_bwd_kernel(const float* dy, const T* x, long ldx, const float* W,
+                                                      T* dx, long lddx, float* dW, float* db,
+                                                      const float* scale_dev, int M, int N, int K) {
+    const float sc = scale_dev ? scale_dev[0] : 1.f;
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i < M * K) {                                     // dx[m,k] = sum_n dy[m,n] W[n,k]
+        if (dx) {
+            const int m = i / K, k = i % K;
+            float s = 0.f;
+            for (int n = 0; n < N; ++n) s += dy[(long)m * N + n] * W[(long)n * K + k];
+            dx[(long)m * lddx + k] = from_f32<T>(s * sc);
+        }
+    }
+    if (i < N * K) {                                     // dW[n,k] += sum_m dy[m,n] x[m,k]
+        if (dW) {
+            const int n = i / K, k = i % K;
+            float s = 0.f;
+            for (int m = 0; m < M; ++m) s += dy[(long)m * N + n] * to_f32(x[(long)m * ldx + k]);
+            dW[i] += s * sc;
+        }
+    }
+    if (i < N && db) {
+        float s = 0.f;
+        for (int m = 0; m < M; ++m) s += dy[(long)m * N + i];
+        db[i] += s * sc;
+    }
+}
+
+}  // namespace
+
+extern "C" int vb_ce_fwd_bwd(int dtype, const float* logits, int64_t ld_logits, const int64_t* labels,
+                             int ignore_index, float* acc2, float* loss, void* dlogits, int64_t ld_dlogits,
+                             int M, int V, void* stream) {
+    if (!logits || !labels || !acc2 || !loss || M <= 0 || V <= 0) return VB_ERR_ARG;
+    if (dlogits && ld_dlogits < V) return VB_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    VB_LAUNCH(ce_count_kernel, dim3(1), dim3(NT), 64, s, labels, M, V, ignore_index, acc2);
+    if (dtype == VB_BF16)
+        VB_LAUNCH(ce_row_kernel<bf16>, dim3((unsigned)M), dim3(NT), 64, s, logits, (long)ld_logits, labels,
+                  ignore_index, acc2, (bf16*)dlogits, (long)ld_dlogits, M, V);
+    else if (dtype == VB_F32)
+        VB_LAUNCH(ce_row_kernel<float>, dim3((unsigned)M), dim3(NT), 64, s, logits, (long)ld_logits, labels,
+                  ignore_index, acc2, (float*)dlogits, (long)ld_dlogits, M, V);
+    else return VB_ERR_ARG;
+    VB_LAUNCH(ce_finish_kernel, dim3(1), dim3(64), 0, s, (const float*)acc2, loss);
+    return vb_check_launch();
+}
+
+extern "C" int vb_kldiv_fwd_bwd(const float* logits, int64_t ld_logits, const float* target, int64_t ld_target,
+                                float* loss, float* score, float* dlogits, int64_t ld_dlogits, int M, int V,
+                                void* stream) {
+    if (!logits || !target || !loss || M <= 0 || V <= 0) return VB_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(loss, 0, sizeof(float), s) != hipSuccess) return VB_ERR_LAUNCH;
+    if (score && hipMemsetAsync(score, 0, sizeof(float), s) != hipSuccess) return VB_ERR_LAUNCH;
+    VB_LAUNCH(kldiv_row_kernel, dim3((unsigned)M), dim3(NT), 64, s, logits, (long)ld_logits, target, (long)ld_target,
+              loss, score, dlogits, (long)ld_dlogits, M, V);
+    return vb_check_launch();
+}
+
+extern "C" int vb_small_linear_fwd(int dtype, const void* x, int64_t ldx, const float* W, const float* bias, float* y,
+                                   int M, int N, int K, void* stream) {
+    if (!x || !W || !y || M <= 0 || N <= 0 || K <= 0) return VB_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)((M * N + NT / 64 - 1) / (NT / 64)));
+    if (dtype == VB_BF16) VB_LAUNCH(small_linear_fwd_kernel<bf16>, grid, dim3(NT), 0, s, (const bf16*)x, (long)ldx, W, bias, y, M, N, K);
+    else if (dtype == VB_F32) VB_LAUNCH(small_linear_fwd_kernel<float>, grid, dim3(NT), 0, s, (const float*)x, (long)ldx, W, bias, y, M, N, K);
+    else return VB_ERR_ARG;
+    return vb_check_launch();
+}
+
+extern "C" int vb_small_linear_bwd(int dtype, const float* dy, const void* x, int64_t ldx, const float* W,
+                                   void* dx, int64_t lddx, float* dW, float* db, const float* scale_dev,
+                                   int M, int N, int K, void* stream) {
+    if (!dy || !x || !W || M <= 0 || N <= 0 || K <= 0) return VB_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int work = (M > N ? M : N) * K;
+    dim3 grid((unsigned)((work + NT - 1) / NT));
+    if (dtype == VB_BF16) VB_LAUNCH(small_linear_bwd_kernel<bf16>, grid, dim3(NT), 0, s, dy, (const bf16*)x, (long)ldx, W, (bf16*)dx, (long)lddx, dW, db, scale_dev, M, N, K);
+    else if (dtype == VB_F32) VB_LAUNCH(small_linear_bwd_kernel<float>, grid, dim3(NT), 0, s, dy, (const float*)x, (long)ldx, W, (float*)dx, (long)lddx, dW, db, scale_dev, M, N, K);
+    else return VB_ERR_ARG;
+    return vb_check_launch();
+}

@@ -1,7 +1,206 @@
+// misc.hip -- small data-movement kernels around the hot path: input preparation (integer work,
+// bit-exact with the reference), dtype casts, row gather / scatter for the VQA head.
+#include "vb_rt.h"
+#include "../../include/visualbert_hip.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+// models/model.py:262-268: image_mask[b,r] = (r < image_dim[b]);
+// modeling.py:1417: attention_mask = cat(input_mask, image_mask);  :1293-1294: (1 - mask) * -10000;
+// modeling.py:1419-1426: LM labels extended with -1 over the visual slots.
+VB_KERNEL VB_LAUNCH_BOUNDS(NT) prepare_inputs_kernel(const int64_t* input_mask, const int64_t* image_dim,
+                                                    const int64_t* image_mask_in, const int64_t* lm_labels,
+                                                    int64_t* attention_mask, float* mask_add, int64_t* labels_ext,
+                                                    int B, int T, int R) {
+    const int S = T + R;
+    const long n = (long)B * S;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
+        const int b = (int)(i / S), s = (int)(i % S);
+        int64_t mval, lab;
+        if (s < T) {
+            mval = input_mask[(long)b * T + s];
+            lab = lm_labels ? lm_labels[(long)b * T + s] : -1;
+        } else {
+            const int r = s - T;
+            mval = image_mask_in ? image_mask_in[(long)b * R + r] : ((int64_t)r < image_dim[b] ? 1 : 0);
+            lab = -1;
+        }
+        attention_mask[i] = mval;
+        mask_add[i] = (1.0f - (float)mval) * -10000.0f;
+        if (labels_ext) labels_ext[i] = lab;
+    }
+}
+
+template <typename TI, typename TO>
+VB_KERNEL VB_LAUNCH_BOUNDS(NT) cast_kernel(const TI* in, TO* out, long n) {
+    for (long i = ((long)blockIdx.x * NT + threadIdx.x) * 8; i < n; i += (long)gridDim.x * NT * 8) {
+        if (i + 8 <= n && ((((uintptr_t)(in + i)) | ((uintptr_t)(out + i))) & 15) == 0) {
+            float v[8]; load8(v, in + i); store8(out + i, v);
+        } else {
+            for (long j = i; j < n && j < i + 8; ++j) out[j] = from_f32<TO>(to_f32(in[j]));
+        }
+    }
+}
+
+// out[b, :] = x[b, index[b], :]   (VQA head: hidden state at position input_mask.sum(1) - 2, modeling.py:1503-1505)
+template <typename T>
+VB_KERNEL VB_LAUNCH_BOUNDS(NT) gather_rows_kernel(const T* x, const int64_t* input_mask, T* out, int64_t* index_out,
+                                                 int B, int S, int Tlen, int H) {
+    const int b = blockIdx.x;
+    long cnt = 0;
+    for (int s = 0; s < Tlen; ++s) cnt += input_mask[(long)b * Tlen + s];
+    long idx = cnt - 2;
+    if (idx < 0) idx += S;                   // torch.gather would raise; keep in range
+    if (idx >= S) idx = S - 1;
+    if (threadIdx.x == 0 && index_out) index_out[b] = cnt - 2;
+    for (int j = threadIdx.x; j < H; j += NT) out[(long)b * H + j] = x[((long)b * S + idx) * H + j];
+}
+template <typename T>
+VB_KERNEL VB_LAUNCH_BOUNDS(NT) scatter_rows_kernel(const T* dout, const int64_t* index, T* dx, int B, int S, int H) {
+    const int b = blockIdx.x;
+    long idx = index[b];
+    if (idx < 0) idx += S;
+    if (idx >= S) idx = S - 1;
+    for (int j = threadIdx.x; j < H; j += NT) dx[((long)b * S + idx) * H + j] = dout[(long)b * H + j];
+}
+
+
+// column sums of a T [M,N] matrix, ACCUMULATED into fp32 out[N] (bias gradients):
+// a lane owns 8 consecutive columns, a wave 512; the 4 waves of a block take interleaved rows.
+template <typename T>
+VB_KERNEL VB_LAUNCH_BOUNDS(NT) colsum_kernel(const T* x, long ld, float* out, const float* scale_dev, int M, int N,
+                                            int rows_per_block) {
+    VB_DYN_SMEM(smem);
+    float* red = (float*)smem;                       // [4][512]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = blockIdx.x * 512 + lane * 8;
+    const int r0 = blockIdx.y * rows_per_block;
+    const int r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    if (col < N) {
+        const bool vec = (col + 8 <= N) && ((ld & 7) == 0);
+        for (int r = r0 + wave; r < r1; r += 4) {
+            const T* p = x + (long)r * ld + col;
+            if (vec) {
+                float v[8]; load8(v, p);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += v[j];
+            } else {
+                for (int j = 0; j < 8 && col + j < N; ++j) acc[j] += to_f32(p[j]);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[wave * 512 + lane * 8 + j] = acc[j];
+    __syncthreads();
+    const float sc = scale_dev ? scale_dev[0] : 1.f;
+    for (int c = threadIdx.x; c < 512; c += NT) {
+        const int cc = blockIdx.x * 512 + c;
+        if (cc < N) atomicAdd(&out[cc], (red[c] + red[512 + c] + red[1024 + c] + red[1536 + c]) * sc);
+    }
+}
+
+// dx = dy * act'(.)  for act in {GELU (aux = pre-activation), TANH (aux = tanh output)}
+template <typename T>
+VB_KERNEL VB_LAUNCH_BOUNDS(NT) act_bwd_kernel(const T* dy, const T* aux, T* dx, long n, int act) {
+    for (long i = ((long)blockIdx.x * NT + threadIdx.x) * 8; i < n; i += (long)gridDim.x * NT * 8) {
+        if (i + 8 <= n) {
+            float g[8], a[8];
+            load8(g, dy + i); load8(a, aux + i);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[j] *= (act == VB_ACT_GELU) ? gelu_grad_f(a[j]) : (1.0f - a[j] * a[j]);
+            store8(dx + i, g);
+        } else {
+            for (long j = i; j < n; ++j) {
+                const float a = to_f32(aux[j]);
+                dx[j] = from_f32<T>(to_f32(dy[j]) * ((act == VB_ACT_GELU) ? gelu_grad_f(a) : (1.0f - a * a)));
+            }
+        }
+    }
+}
+
+}  // namespace
+
 extern "C" const char* vb_version(void) {
 #ifdef VB_EMU
     return "visualbert_hip EMULATOR (developer tool, not the product) r1";
 #else
     return "visualbert_hip gfx950 r1";
 #endif
+}
+
+extern "C" int vb_prepare_inputs(const int64_t* input_mask, const int64_t* image_dim, const int64_t* image_mask,
+                                 const int64_t* masked_lm_labels, int64_t* attention_mask, float* mask_add,
+                                 int64_t* labels_ext, int B, int T, int R, void* stream) {
+    if (!input_mask || !attention_mask || !mask_add || B <= 0 || T <= 0 || R < 0) return VB_ERR_ARG;
+    if (R > 0 && !image_dim && !image_mask) return VB_ERR_ARG;
+    const long n = (long)B * (T + R);
+    dim3 grid((unsigned)((n + NT - 1) / NT > 1024 ? 1024 : (n + NT - 1) / NT));
+    VB_LAUNCH(prepare_inputs_kernel, grid, dim3(NT), 0, (hipStream_t)stream, input_mask, image_dim, image_mask,
+              masked_lm_labels, attention_mask, mask_add, labels_ext, B, T, R);
+    return vb_check_launch();
+}
+
+extern "C" int vb_cast(int src_dtype, const void* src, int dst_dtype, void* dst, int64_t n, void* stream) {
+    if (!src || !dst || n <= 0) return VB_ERR_ARG;
+    long blocks = (n / 8 + NT - 1) / NT + 1;
+    if (blocks > 4096) blocks = 4096;
+    dim3 grid((unsigned)blocks);
+    hipStream_t s = (hipStream_t)stream;
+    if (src_dtype == VB_F32 && dst_dtype == VB_BF16) VB_LAUNCH((cast_kernel<float, bf16>), grid, dim3(NT), 0, s, (const float*)src, (bf16*)dst, (long)n);
+    else if (src_dtype == VB_BF16 && dst_dtype == VB_F32) VB_LAUNCH((cast_kernel<bf16, float>), grid, dim3(NT), 0, s, (const bf16*)src, (float*)dst, (long)n);
+    else if (src_dtype == VB_F32 && dst_dtype == VB_F32) VB_LAUNCH((cast_kernel<float, float>), grid, dim3(NT), 0, s, (const float*)src, (float*)dst, (long)n);
+    else if (src_dtype == VB_BF16 && dst_dtype == VB_BF16) VB_LAUNCH((cast_kernel<bf16, bf16>), grid, dim3(NT), 0, s, (const bf16*)src, (bf16*)dst, (long)n);
+    else return VB_ERR_ARG;
+    return vb_check_launch();
+}
+
+extern "C" int vb_gather_rows(int dtype, const void* x, const int64_t* input_mask, void* out, int64_t* index_out,
+                              int B, int S, int T, int H, void* stream) {
+    if (!x || !input_mask || !out || B <= 0 || S <= 0 || T <= 0 || H <= 0) return VB_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == VB_BF16) VB_LAUNCH(gather_rows_kernel<bf16>, dim3((unsigned)B), dim3(NT), 0, s, (const bf16*)x, input_mask, (bf16*)out, index_out, B, S, T, H);
+    else if (dtype == VB_F32) VB_LAUNCH(gather_rows_kernel<float>, dim3((unsigned)B), dim3(NT), 0, s, (const float*)x, input_mask, (float*)out, index_out, B, S, T, H);
+    else return VB_ERR_ARG;
+    return vb_check_launch();
+}
+
+extern "C" int vb_scatter_rows(int dtype, const void* dout, const int64_t* index, void* dx, int B, int S, int H,
+                               void* stream) {
+    if (!dout || !index || !dx || B <= 0 || S <= 0 || H <= 0) return VB_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == VB_BF16) VB_LAUNCH(scatter_rows_kernel<bf16>, dim3((unsigned)B), dim3(NT), 0, s, (const bf16*)dout, index, (bf16*)dx, B, S, H);
+    else if (dtype == VB_F32) VB_LAUNCH(scatter_rows_kernel<float>, dim3((unsigned)B), dim3(NT), 0, s, (const float*)dout, index, (float*)dx, B, S, H);
+    else return VB_ERR_ARG;
+    return vb_check_launch();
+}
+
+extern "C" int vb_colsum(int dtype, const void* x, int64_t ld, float* out, const float* scale_dev, int M, int N,
+                         void* stream) {
+    if (!x || !out || M <= 0 || N <= 0) return VB_ERR_ARG;
+    int rb = (M + 63) / 64;                     // <= 64 row blocks
+    if (rb < 16) rb = 16;
+    dim3 grid((unsigned)((N + 511) / 512), (unsigned)((M + rb - 1) / rb));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t smem = 4 * 512 * sizeof(float);
+    if (dtype == VB_BF16) VB_LAUNCH(colsum_kernel<bf16>, grid, dim3(NT), smem, s, (const bf16*)x, (long)ld, out, scale_dev, M, N, rb);
+    else if (dtype == VB_F32) VB_LAUNCH(colsum_kernel<float>, grid, dim3(NT), smem, s, (const float*)x, (long)ld, out, scale_dev, M, N, rb);
+    else return VB_ERR_ARG;
+    return vb_check_launch();
+}
+
+extern "C" int vb_act_bwd(int dtype, const void* dy, const void* aux, void* dx, int64_t n, int act, void* stream) {
+    if (!dy || !aux || !dx || n <= 0 || (act != VB_ACT_GELU && act != VB_ACT_TANH)) return VB_ERR_ARG;
+    if (((uintptr_t)dy | (uintptr_t)aux | (uintptr_t)dx) & 15) return VB_ERR_ARG;
+    long blocks = (n / 8 + NT - 1) / NT + 1;
+    if (blocks > 4096) blocks = 4096;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == VB_BF16) VB_LAUNCH(act_bwd_kernel<bf16>, dim3((unsigned)blocks), dim3(NT), 0, s, (const bf16*)dy, (const bf16*)aux, (bf16*)dx, (long)n, act);
+    else if (dtype == VB_F32) VB_LAUNCH(act_bwd_kernel<float>, dim3((unsigned)blocks), dim3(NT), 0, s, (const float*)dy, (const float*)aux, (float*)dx, (long)n, act);
+    else return VB_ERR_ARG;
+    return vb_check_launch();
 }

@@ -1,2 +1,126 @@
+// optim.hip -- fused multi-tensor BertAdam over the flat parameter arena.
+//
+// Replaces BertAdam.step (pytorch_pretrained_bert/optimization.py:239-304), a Python loop over ~200
+// tensors with ~10 small kernels each, by three launches over one contiguous fp32 arena:
+//   1. per-TENSOR gradient sum of squares (the reference clips every tensor separately to
+//      max_grad_norm with clip_grad_norm_, optimization.py:272-273)
+//   2. update: m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; u = m / (sqrt(v) + e) + wd * p ;
+//      p -= lr * schedule(step) * u      -- no bias correction, eps OUTSIDE the sqrt, decoupled weight
+//      decay, LR multiplier from the per-tensor step counter read BEFORE its increment (:292,297);
+//      the bf16 shadow copy that the MFMA GEMMs read is refreshed in the same pass
+//   3. step counters += 1
+// HBM traffic per parameter: read p, g, m, v (16 B) + write p, m, v (12 B) [+ 2 B shadow] = 28-30 B.
+// Everything the step needs lives on the device (chunk table, step counters, hyper-parameters): no
+// host<->device traffic per step, so the step can sit in a captured graph.
 #include "vb_rt.h"
 #include "../../include/visualbert_hip.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+struct AdamHyper {
+    float lr, b1, b2, eps, max_grad_norm, warmup, t_total, weight_decay;
+    int schedule;      // 0 = none (multiplier 1), 1 = warmup_linear
+};
+
+// chunk table entry layout (int64 x 4): tensor id, arena offset of the chunk, length, unused
+// tensor table entry layout (int64 x 4): arena offset, numel, shadow offset (-1: none), flags (bit0: optimise, bit1: decay)
+
+VB_KERNEL VB_LAUNCH_BOUNDS(NT) adam_norm_kernel(const float* grads, const int64_t* chunks, float* norm2) {
+    VB_DYN_SMEM(smem);
+    float* red = (float*)smem;
+    const int64_t* c = chunks + (long)blockIdx.x * 4;
+    const long off = c[1], len = c[2];
+    float s = 0.f;
+    for (long i = threadIdx.x; i < len; i += NT) { const float g = grads[off + i]; s += g * g; }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&norm2[c[0]], red[0] + red[1] + red[2] + red[3]);
+}
+
+VB_DEVICE float schedule_mult(const AdamHyper& h, int step) {
+    if (h.schedule == 0 || h.t_total < 0.f) return 1.0f;
+    // optimization.py:55-73 and :164-173, evaluated in double like the reference's Python floats
+    const double progress = (double)step / (double)h.t_total;
+    const double w = h.warmup > 0.f ? (double)h.warmup : 0.0;
+    double r;
+    if (progress < w) r = progress / w;
+    else { r = (progress - 1.0) / (w - 1.0); if (r < 0.0) r = 0.0; }
+    return (float)r;
+}
+
+VB_KERNEL VB_LAUNCH_BOUNDS(NT) adam_update_kernel(float* params, const float* grads, float* m, float* v, bf16* shadow,
+                                                 const int64_t* chunks, const int64_t* tensors, const float* norm2,
+                                                 const int* steps, AdamHyper h) {
+    const int64_t* c = chunks + (long)blockIdx.x * 4;
+    const long tid = c[0], off = c[1], len = c[2];
+    const int64_t* te = tensors + tid * 4;
+    const long t_off = te[0], sh_off = te[2], flags = te[3];
+    if (!(flags & 1)) return;
+    const float wd = (flags & 2) ? h.weight_decay : 0.0f;
+    float clip = 1.0f;
+    if (h.max_grad_norm > 0.f) {
+        const float cc = h.max_grad_norm / (sqrtf(norm2[tid]) + 1e-6f);
+        clip = cc < 1.0f ? cc : 1.0f;
+    }
+    const float lr = h.lr * schedule_mult(h, steps[tid]);
+    for (long i = threadIdx.x; i < len; i += NT) {
+        const long e = off + i;
+        const float g = grads[e] * clip;
+        const float p = params[e];
+        const float mm = m[e] * h.b1 + (1.0f - h.b1) * g;
+        const float vv = v[e] * h.b2 + (1.0f - h.b2) * g * g;
+        float u = mm / (sqrtf(vv) + h.eps);
+        if (wd > 0.f) u += wd * p;
+        const float pn = p - lr * u;
+        m[e] = mm; v[e] = vv; params[e] = pn;
+        if (shadow && sh_off >= 0) shadow[sh_off + (e - t_off)] = (bf16)pn;
+    }
+}
+
+VB_KERNEL adam_step_inc_kernel(int* steps, const int64_t* tensors, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && (tensors[(long)i * 4 + 3] & 1)) steps[i] += 1;
+}
+
+VB_KERNEL VB_LAUNCH_BOUNDS(NT) shadow_refresh_kernel(const float* params, bf16* shadow, const int64_t* chunks,
+                                                    const int64_t* tensors) {
+    const int64_t* c = chunks + (long)blockIdx.x * 4;
+    const long tid = c[0], off = c[1], len = c[2];
+    const long t_off = tensors[tid * 4], sh_off = tensors[tid * 4 + 2];
+    if (sh_off < 0) return;
+    for (long i = threadIdx.x; i < len; i += NT) shadow[sh_off + (off + i - t_off)] = (bf16)params[off + i];
+}
+
+}  // namespace
+
+extern "C" int vb_bert_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                                 void* bf16_shadow, const int64_t* chunk_table, int n_chunks,
+                                 const int64_t* tensor_table, int n_tensors, float* norm2_ws, int* step_counters,
+                                 float lr, float b1, float b2, float eps, float weight_decay,
+                                 float max_grad_norm, float warmup, float t_total, int schedule, void* stream) {
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !chunk_table || !tensor_table || !norm2_ws || !step_counters)
+        return VB_ERR_ARG;
+    if (n_chunks <= 0 || n_tensors <= 0 || (schedule != 0 && schedule != 1)) return VB_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    AdamHyper h{lr, b1, b2, eps, max_grad_norm, warmup, t_total, weight_decay, schedule};
+    if (max_grad_norm > 0.f) {
+        if (hipMemsetAsync(norm2_ws, 0, sizeof(float) * (size_t)n_tensors, s) != hipSuccess) return VB_ERR_LAUNCH;
+        VB_LAUNCH(adam_norm_kernel, dim3((unsigned)n_chunks), dim3(NT), 64, s, grads, chunk_table, norm2_ws);
+    }
+    VB_LAUNCH(adam_update_kernel, dim3((unsigned)n_chunks), dim3(NT), 0, s, params, grads, exp_avg, exp_avg_sq,
+              (bf16*)bf16_shadow, chunk_table, tensor_table, (const float*)norm2_ws, (const int*)step_counters, h);
+    VB_LAUNCH(adam_step_inc_kernel, dim3((unsigned)((n_tensors + 63) / 64)), dim3(64), 0, s, step_counters,
+              tensor_table, n_tensors);
+    return vb_check_launch();
+}
+
+extern "C" int vb_refresh_bf16_shadow(const float* params, void* bf16_shadow, const int64_t* chunk_table,
+                                      int n_chunks, const int64_t* tensor_table, void* stream) {
+    if (!params || !bf16_shadow || !chunk_table || !tensor_table || n_chunks <= 0) return VB_ERR_ARG;
+    VB_LAUNCH(shadow_refresh_kernel, dim3((unsigned)n_chunks), dim3(NT), 0, (hipStream_t)stream, params,
+              (bf16*)bf16_shadow, chunk_table, tensor_table);
+    return vb_check_launch();
+}

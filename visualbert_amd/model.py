@@ -1,0 +1,136 @@
+"""Boundary callers of the hot path, restated without AllenNLP (which cannot be installed here):
+
+  VisualBERTFixedImageEmbedding   visualbert/models/model.py:191-301  (task model: builds image_mask from
+                                  image_dim_variable, forwards the batch kwargs to TrainVisualBERTObjective)
+  ModelWrapper                    visualbert/models/model_wrapper.py:34-147 (step(): zero_grad -> forward ->
+                                  loss.mean() -> backward -> optimizer.step; optimizer param groups)
+
+Same keyword names, same `args` keys (train_batch_size, learning_rate, warmup_proportion,
+num_train_epochs, gradient_accumulation_steps, fp16, model.{...}).  One process per GPU: where the
+reference wraps the model in nn.DataParallel (model_wrapper.py:146), this wrapper takes an optional
+visualbert_amd.parallel.DataParallelGradSync that all-reduces the flat gradient arena over RCCL.
+"""
+import torch
+from torch import nn
+
+from . import ops
+from .modeling import BertConfig, TrainVisualBERTObjective
+from .optimization import BertAdam
+
+
+class VisualBERTFixedImageEmbedding(nn.Module):
+    """models/model.py:191-301 without the AllenNLP Model base / metrics objects."""
+
+    def __init__(self, config=None, bert_model_name=None, training_head_type="pretraining", visual_embedding_dim=2048,
+                 hard_cap_seq_len=None, cut_first="text", embedding_strategy="plain", bypass_transformer=False,
+                 random_initialize=True, output_attention_weights=False, special_visual_initialize=True,
+                 compute_dtype=torch.float32, class_embs=True, cnn_loss_ratio=0.0):
+        super(VisualBERTFixedImageEmbedding, self).__init__()
+        if config is None:
+            if bert_model_name is None:
+                config = BertConfig(30522)
+            else:
+                import os
+                config = BertConfig.from_json_file(os.path.join(bert_model_name, "bert_config.json"))
+        self.bert = TrainVisualBERTObjective(config, training_head_type, visual_embedding_dim=visual_embedding_dim,
+                                             hard_cap_seq_len=hard_cap_seq_len, cut_first=cut_first,
+                                             embedding_strategy=embedding_strategy,
+                                             bypass_transformer=bypass_transformer,
+                                             output_attention_weights=output_attention_weights,
+                                             compute_dtype=compute_dtype)
+        if special_visual_initialize:
+            self.bert.bert.embeddings.special_intialize()            # models/model.py:224-225
+        self.training_head_type = training_head_type
+        self.cnn_loss_ratio = cnn_loss_ratio
+
+    def forward(self, bert_input_ids, bert_input_mask, bert_input_type_ids, image_dim_variable=None,
+                image_feat_variable=None, image_text_alignment=None, visual_embeddings_type=None, label=None,
+                flickr_position=None, masked_lm_labels=None, is_random_next=None, output_all_encoded_layers=False):
+        if image_feat_variable is not None:
+            # models/model.py:262-268: image_mask = arange(R) < image_dim_variable  (int64, bit-exact)
+            R = image_feat_variable.size(-2)
+            ar = torch.arange(R, device=image_feat_variable.device).expand(*image_feat_variable.size()[:-1])
+            dim = image_dim_variable
+            if dim.dim() < ar.dim():
+                dim = dim.unsqueeze(-1)
+            image_mask = (ar < dim).long()
+        else:
+            image_mask = None
+        output_dict = self.bert(
+            input_ids=bert_input_ids, token_type_ids=bert_input_type_ids, input_mask=bert_input_mask,
+            visual_embeddings=image_feat_variable, position_embeddings_visual=None, image_mask=image_mask,
+            visual_embeddings_type=visual_embeddings_type, image_text_alignment=image_text_alignment, label=label,
+            flickr_position=flickr_position, masked_lm_labels=masked_lm_labels, is_random_next=is_random_next,
+            output_all_encoded_layers=output_all_encoded_layers)
+        output_dict["cnn_regularization_loss"] = None
+        return output_dict
+
+
+class AttrDict(dict):
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+class ModelWrapper(object):
+    """models/model_wrapper.py:34-147, one process per GPU."""
+
+    def __init__(self, args, train_dataset_length, model=None, grad_sync=None, device=None):
+        self.args = args if isinstance(args, AttrDict) else AttrDict(args)
+        self.device = device
+        if model is None:
+            m = dict(self.args.get("model", {}))
+            m.pop("type", None)
+            dtype = torch.bfloat16 if self.args.get("fp16", False) else torch.float32
+            model = VisualBERTFixedImageEmbedding(compute_dtype=dtype, **m)
+        self.model = model.to(device) if device is not None else model
+        self.grad_sync = grad_sync
+        self.initialize_opimizer(self.args, train_dataset_length)
+        self.global_step = 0
+        self.called_time = 0
+
+    def train(self):
+        self.model.train()
+
+    def eval(self):
+        self.model.eval()
+
+    def initialize_opimizer(self, args, train_dataset_length):            # (sic) models/model_wrapper.py:100
+        param_optimizer = [n for n in self.model.named_parameters() if "pooler" not in n[0]]
+        no_decay = ["bias", "LayerNorm.bias", "LayerNorm.weight"]
+        groups = [
+            {"params": [p for n, p in param_optimizer if not any(nd in n for nd in no_decay)], "weight_decay": 0.01},
+            {"params": [p for n, p in param_optimizer if any(nd in n for nd in no_decay)], "weight_decay": 0.0}]
+        steps = int(train_dataset_length / args.train_batch_size / args.get("gradient_accumulation_steps", 1)) * \
+            args.get("num_train_epochs", 1)
+        self.num_train_optimization_steps = steps
+        self.optimizer = BertAdam(groups, lr=args.learning_rate, warmup=args.warmup_proportion, t_total=steps)
+
+    def step(self, batch, eval_mode=False):
+        if eval_mode:
+            with torch.no_grad():
+                output_dict = self.model(**batch)
+                if output_dict["loss"] is not None:
+                    output_dict["loss"] = output_dict["loss"].mean()
+                return output_dict
+        self.optimizer.zero_grad()
+        if self.grad_sync is not None:
+            self.grad_sync.begin_step()
+        output_dict = self.model(**batch)
+        loss = output_dict["loss"].mean()
+        gas = self.args.get("gradient_accumulation_steps", 1)
+        if gas > 1:
+            loss = loss / gas
+        loss.backward()
+        if self.grad_sync is not None:
+            self.grad_sync.finish_step()
+        if (self.called_time + 1) % gas == 0:
+            self.optimizer.step()
+            self.global_step += 1
+        self.called_time += 1
+        return output_dict

@@ -1,0 +1,231 @@
+"""BertAdam and the LR schedules of the reference, with the update running as ONE fused multi-tensor
+HIP kernel sequence over the flat parameter arena (visualbert_amd/csrc/optim.hip).
+
+API mirrors visualbert/pytorch_pretrained_bert/optimization.py:
+  _LRSchedule / ConstantLR / WarmupCosineSchedule / WarmupConstantSchedule / WarmupLinearSchedule (:37-173),
+  BertAdam(params, lr, warmup, t_total, schedule, b1, b2, e, weight_decay, max_grad_norm) (:185-304).
+The device kernel implements the schedules the reference's training path uses: 'warmup_linear'
+(the default, models/model_wrapper.py:136-139) and 'none'; the others are host-side formulas kept
+for API parity and raise if handed to the fused step.
+"""
+import math
+
+import torch
+from torch.optim import Optimizer
+
+from . import _lib
+
+
+class _LRSchedule(object):
+    warn_t_total = False
+
+    def __init__(self, warmup=0.002, t_total=-1, **kw):
+        if not 0.0 <= warmup < 1.0 and not warmup == -1:
+            raise ValueError("Invalid warmup: {} - should be in [0.0, 1.0[ or -1".format(warmup))
+        warmup = max(warmup, 0.)
+        self.warmup, self.t_total = float(warmup), float(t_total)
+
+    def get_lr(self, step, nowarn=False):
+        if self.t_total < 0:
+            return 1.
+        return self.get_lr_(float(step) / self.t_total)
+
+    def get_lr_(self, progress):
+        return 1.
+
+
+class ConstantLR(_LRSchedule):
+    def get_lr_(self, progress):
+        return 1.
+
+
+class WarmupCosineSchedule(_LRSchedule):
+    warn_t_total = True
+
+    def __init__(self, warmup=0.002, t_total=-1, cycles=.5, **kw):
+        super(WarmupCosineSchedule, self).__init__(warmup=warmup, t_total=t_total, **kw)
+        self.cycles = cycles
+
+    def get_lr_(self, progress):
+        if progress < self.warmup:
+            return progress / self.warmup
+        progress = (progress - self.warmup) / (1 - self.warmup)
+        return 0.5 * (1. + math.cos(math.pi * self.cycles * 2 * progress))
+
+
+class WarmupConstantSchedule(_LRSchedule):
+    def get_lr_(self, progress):
+        if progress < self.warmup:
+            return progress / self.warmup
+        return 1.
+
+
+class WarmupLinearSchedule(_LRSchedule):
+    warn_t_total = True
+
+    def get_lr_(self, progress):
+        if progress < self.warmup:
+            return progress / self.warmup
+        return max((progress - 1.) / (self.warmup - 1.), 0.)
+
+
+SCHEDULES = {None: ConstantLR, "none": ConstantLR, "warmup_cosine": WarmupCosineSchedule,
+             "warmup_constant": WarmupConstantSchedule, "warmup_linear": WarmupLinearSchedule}
+
+
+class BertAdam(Optimizer):
+    """BERT's Adam: per-tensor gradient clipping, no bias correction, decoupled weight decay, eps outside
+    the sqrt, LR schedule evaluated from a per-tensor step counter (optimization.py:239-304).
+
+    All parameters must live in one visualbert_amd ParameterArena (every model built by
+    visualbert_amd.modeling does).  State (exp_avg = 'next_m', exp_avg_sq = 'next_v', step counters)
+    is held as flat device buffers."""
+
+    def __init__(self, params, lr=None, warmup=-1, t_total=-1, schedule='warmup_linear', b1=0.9, b2=0.999, e=1e-6,
+                 weight_decay=0.01, max_grad_norm=1.0, **kwargs):
+        if lr is None or lr < 0.0:
+            raise ValueError("Invalid learning rate: {} - should be >= 0.0".format(lr))
+        if not isinstance(schedule, _LRSchedule) and schedule not in SCHEDULES:
+            raise ValueError("Invalid schedule parameter: {}".format(schedule))
+        if not 0.0 <= b1 < 1.0:
+            raise ValueError("Invalid b1 parameter: {} - should be in [0.0, 1.0[".format(b1))
+        if not 0.0 <= b2 < 1.0:
+            raise ValueError("Invalid b2 parameter: {} - should be in [0.0, 1.0[".format(b2))
+        if not e >= 0.0:
+            raise ValueError("Invalid epsilon value: {} - should be >= 0.0".format(e))
+        if not isinstance(schedule, _LRSchedule):
+            schedule = SCHEDULES[schedule](warmup=warmup, t_total=t_total)
+        defaults = dict(lr=lr, schedule=schedule, b1=b1, b2=b2, e=e, weight_decay=weight_decay,
+                        max_grad_norm=max_grad_norm)
+        super(BertAdam, self).__init__(params, defaults)
+        self._fused = None
+
+    # -- fused state -------------------------------------------------------------------------------
+    def _build(self):
+        arena = None
+        member = {}
+        g0 = self.param_groups[0]
+        for gi, group in enumerate(self.param_groups):
+            for k in ("lr", "b1", "b2", "e", "max_grad_norm"):
+                if group[k] != g0[k]:
+                    raise NotImplementedError("fused BertAdam: groups may differ in weight_decay only (as in "
+                                              "models/model_wrapper.py:108-112); %s differs" % k)
+            if type(group["schedule"]) is not type(g0["schedule"]) or \
+                    group["schedule"].warmup != g0["schedule"].warmup or group["schedule"].t_total != g0["schedule"].t_total:
+                raise NotImplementedError("fused BertAdam: one schedule for all groups")
+            for p in group["params"]:
+                a = getattr(p, "_vb_arena", None)
+                if a is None:
+                    raise RuntimeError("visualbert_amd.BertAdam: parameter is not arena-managed (build the model "
+                                       "with visualbert_amd.modeling; no per-tensor fallback exists)")
+                if arena is None:
+                    arena = a
+                elif a is not arena:
+                    raise RuntimeError("visualbert_amd.BertAdam: parameters from different arenas")
+                member[id(p)] = group["weight_decay"]
+        wds = sorted(set(v for v in member.values() if v > 0.0))
+        if len(wds) > 1:
+            raise NotImplementedError("fused BertAdam: a single non-zero weight_decay value")
+        sch = g0["schedule"]
+        if isinstance(sch, WarmupLinearSchedule):
+            code = 1
+        elif isinstance(sch, ConstantLR) or sch.t_total < 0:
+            code = 0
+        else:
+            raise NotImplementedError("fused BertAdam: schedule %s has no device kernel" % type(sch).__name__)
+        opt_flags = [id(p) in member for p in arena.params]
+        dec_flags = [member.get(id(p), 0.0) > 0.0 for p in arena.params]
+        tt, ct, nt, nc = arena.tables(opt_flags, dec_flags)
+        dev = arena.device
+        self._fused = dict(arena=arena, tt=tt, ct=ct, nt=nt, nc=nc, code=code, wd=wds[0] if wds else 0.0,
+                           m=torch.zeros_like(arena.data), v=torch.zeros_like(arena.data),
+                           norm2=torch.zeros(nt, dtype=torch.float32, device=dev),
+                           steps=torch.zeros(nt, dtype=torch.int32, device=dev))
+        return self._fused
+
+    def fused(self):
+        f = self._fused
+        if f is None or f["arena"] is not getattr(self.param_groups[0]["params"][0], "_vb_arena", None):
+            f = self._build()
+        return f
+
+    def zero_grad(self, set_to_none=False):
+        """one memset of the flat gradient arena; .grad stays a view into it (set_to_none is ignored on
+        purpose: the kernels accumulate straight into these views)."""
+        self.fused()["arena"].zero_grad()
+
+    def get_lr(self):
+        f = self.fused()
+        g = self.param_groups[0]
+        steps = f["steps"].tolist()
+        flags = f["tt"].view(-1, 4)[:, 3].tolist()
+        return [g["lr"] * g["schedule"].get_lr(s) for s, fl in zip(steps, flags) if fl & 1]
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        f = self.fused()
+        a = f["arena"]
+        g = self.param_groups[0]
+        sch = g["schedule"]
+        L = _lib.lib()
+        rc = L.vb_bert_adam_step(_lib.ptr(a.data), _lib.ptr(a.grad), _lib.ptr(f["m"]), _lib.ptr(f["v"]),
+                                 _lib.ptr(a.shadow), _lib.ptr(f["ct"]), f["nc"], _lib.ptr(f["tt"]), f["nt"],
+                                 _lib.ptr(f["norm2"]), _lib.ptr(f["steps"]), float(g["lr"]), float(g["b1"]),
+                                 float(g["b2"]), float(g["e"]), float(f["wd"]), float(g["max_grad_norm"]),
+                                 float(sch.warmup), float(sch.t_total), f["code"], _lib.stream_ptr())
+        _lib.check(rc, "vb_bert_adam_step")
+        # the kernel refreshed the bf16 shadows of every optimised 2-D parameter
+        member = set()
+        for group in self.param_groups:
+            for p in group["params"]:
+                member.add(id(p))
+        for p in a.params:
+            if p.dim() == 2 and id(p) in member:
+                p._vb_shadow_ver = p._version
+        return loss
+
+    # -- checkpoint compatibility: per-parameter {'step', 'next_m', 'next_v'} like the reference ------
+    def state_dict(self):
+        f = self.fused()
+        a = f["arena"]
+        steps = f["steps"].tolist()
+        state = {}
+        idx = {id(p): i for i, p in enumerate(a.params)}
+        k = 0
+        groups = []
+        for group in self.param_groups:
+            ids = []
+            for p in group["params"]:
+                i = idx[id(p)]
+                o, n = a.offsets[i], p.numel()
+                state[k] = dict(step=steps[i], next_m=f["m"][o:o + n].view(p.shape).clone(),
+                                next_v=f["v"][o:o + n].view(p.shape).clone())
+                ids.append(k)
+                k += 1
+            gd = {kk: vv for kk, vv in group.items() if kk not in ("params", "schedule")}
+            gd["params"] = ids
+            gd["schedule"] = type(group["schedule"]).__name__
+            groups.append(gd)
+        return dict(state=state, param_groups=groups)
+
+    def load_state_dict(self, sd):
+        f = self.fused()
+        a = f["arena"]
+        idx = {id(p): i for i, p in enumerate(a.params)}
+        steps = f["steps"].tolist()
+        k = 0
+        for group in self.param_groups:
+            for p in group["params"]:
+                st = sd["state"].get(k)
+                if st is not None:
+                    i = idx[id(p)]
+                    o, n = a.offsets[i], p.numel()
+                    f["m"][o:o + n].view(p.shape).copy_(st["next_m"])
+                    f["v"][o:o + n].view(p.shape).copy_(st["next_v"])
+                    steps[i] = int(st["step"])
+                k += 1
+        f["steps"].copy_(torch.tensor(steps, dtype=torch.int32))

@@ -1,0 +1,211 @@
+#!/usr/bin/env python
+"""bench.py -- VisualBERT pre-training throughput on MI355X (BASELINE.json metric).
+
+One "step" = ModelWrapper.step on one synthetic COCO-shaped batch: zero_grad -> forward (region
+projection, embeddings, 12 BertLayers, pooler, MLM + image-text-match heads, losses) -> backward ->
+gradient all-reduce (N > 1) -> fused BertAdam.  Nothing is skipped inside the timed region: dropout
+is on (p = 0.1), the tied 30522-wide decoder runs over all 164 positions like the reference, and the
+optimizer updates all 111.5 M optimised parameters.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     -- dominant kernel (the MFMA GEMM instantiation with the largest total time): algorithmic
+                  FLOPs per launch / HIP-event duration per launch, against the dense bf16 MFMA peak
+  cpu_baseline -- the oracle restatement of the reference (oracle/visualbert_oracle.py, "port") timed on
+                  this node's host cores on a bounded sample (rank 0, N = 1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_F32_TFLOPS = 157.3
+
+
+def flops_per_sample(L, H, I, V, S, R, Dv):
+    """forward FLOPs (multiply-add = 2); training = 3x."""
+    head = 2 * S * H * H + 2 * S * H * V + 4 * H
+    fwd = 2 * R * Dv * H + L * (8 * S * H * H + 4 * S * S * H + 4 * S * H * I) + 2 * H * H + head
+    return 3 * fwd
+
+
+def cpu_baseline(batch_size, T, R, steps=3):
+    """the oracle (a restatement of TrainVisualBERTObjective + ModelWrapper.step + BertAdam) on host cores."""
+    from oracle import visualbert_oracle as vo
+    cfg = vo.OracleConfig(**vo.CONFIGS["base"])
+    sd = vo.synth_state_dict(cfg, "pretraining", 0, perturb=False)
+    batch = vo.synth_batch(cfg, batch_size, T, R, 0, "pretraining", ragged=False)
+    state = {}
+    vo.train_step(sd, cfg, "pretraining", batch, state, 5e-5, 0.1, 1000)          # warm-up
+    t0 = time.time()
+    for _ in range(steps):
+        vo.train_step(sd, cfg, "pretraining", batch, state, 5e-5, 0.1, 1000)
+    dt = (time.time() - t0) / steps
+    return dict(value=round(batch_size / dt, 3), unit="samples/s", cores=torch.get_num_threads(), kind="port",
+                sample="%d full fp32 training steps (forward+backward+BertAdam, dropout off) of BERT-base VisualBERT, "
+                       "batch %d x (%d tok + %d regions), oracle/visualbert_oracle.py on torch CPU, %d threads, "
+                       "%.2f s/step" % (steps, batch_size, T, R, torch.get_num_threads(), dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--text-len", type=int, default=128)
+    ap.add_argument("--regions", type=int, default=36)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-GEMM HIP-event timing")
+    ap.add_argument("--no-overlap", action="store_true")
+    ap.add_argument("--h2d", action="store_true", help="also time a run that streams each batch from pinned host memory")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (see docstring)" % args.gpus)
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from visualbert_amd import ops
+    from visualbert_amd.data import synthetic_pretraining_batch, FeatureStager
+    from visualbert_amd.model import AttrDict, ModelWrapper, VisualBERTFixedImageEmbedding
+    from visualbert_amd.modeling import BertConfig
+    from visualbert_amd.parallel import DataParallelGradSync
+
+    L, H, I, V, Dv = 12, 768, 3072, 30522, 2048
+    T, R = args.text_len, args.regions
+    S = T + R
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    torch.manual_seed(1234)
+    config = BertConfig(V, hidden_size=H, num_hidden_layers=L, num_attention_heads=H // 64, intermediate_size=I)
+    model = VisualBERTFixedImageEmbedding(config=config, training_head_type="pretraining", visual_embedding_dim=Dv,
+                                          compute_dtype=dtype).to(dev)
+    model.train()
+    sync = None
+    if world > 1:
+        sync = DataParallelGradSync(model.bert, overlap=not args.no_overlap)
+        sync.broadcast_parameters(0)
+    B = args.batch
+    total_steps = args.steps + args.warmup + 10
+    mw = ModelWrapper(AttrDict(train_batch_size=B * world, learning_rate=5e-5, warmup_proportion=0.1,
+                               num_train_epochs=1, gradient_accumulation_steps=1),
+                      total_steps * B * world, model=model, grad_sync=sync)
+    batch = synthetic_pretraining_batch(B, T, R, Dv, V, seed=rank, device=dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        mw.step(batch)
+    prof = None
+    if not args.no_profile:
+        prof = ops.GemmProfiler()
+        ops.set_gemm_profiler(prof)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        mw.step(batch)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ops.set_gemm_profiler(None)
+    et = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(et, op=dist.ReduceOp.MAX)
+    elapsed = float(et.item())
+    loss = float(mw.step(batch)["loss"])
+
+    h2d = None
+    if args.h2d:
+        stager = FeatureStager(dev)
+        host = synthetic_pretraining_batch(B, T, R, Dv, V, seed=rank, device="cpu")
+        nxt, ev = stager.stage(host, 0)
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            cur, cur_ev = nxt, ev
+            nxt, ev = stager.stage(host, (i + 1) & 1)             # prefetch the next batch while this one trains
+            torch.cuda.current_stream().wait_event(cur_ev)
+            mw.step(cur)
+        barrier()
+        h2d = B * world * args.steps / (time.perf_counter() - t1)
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = B * world * args.steps / elapsed
+    fps = flops_per_sample(L, H, I, V, S, R, Dv)
+    peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS
+
+    if rank == 0:
+        roofline = None
+        if prof is not None:
+            summ = prof.summary()
+            if summ:
+                key, d = max(summ.items(), key=lambda kv: kv[1]["ms"])
+                ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+                names = {0: "Kcontig", 1: "Kstrided"}
+                roofline = dict(bound="mfma", achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
+                                traffic=None,
+                                kernel="gemm_kernel<%s->%s, A %s, B %s>" % (key[0].replace("torch.", ""),
+                                                                             key[1].replace("torch.", ""),
+                                                                             names[key[2]], names[key[3]]),
+                                launches_per_step=d["launches"] / args.steps,
+                                avg_launch_us=round(d["ms"] * 1e3 / d["launches"], 2),
+                                gflop_per_launch=round(d["flops"] / d["launches"] / 1e9, 3),
+                                all_gemm_tflops=round(sum(x["flops"] for x in summ.values()) /
+                                                      (sum(x["ms"] for x in summ.values()) * 1e-3) / 1e12, 2),
+                                gemm_ms_per_step=round(sum(x["ms"] for x in summ.values()) / args.steps, 3),
+                                by_kernel={"%s|%s|A%d|B%d" % (k[0][6:], k[1][6:], k[2], k[3]):
+                                           dict(ms_per_step=round(v["ms"] / args.steps, 3),
+                                                tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1))
+                                           for k, v in summ.items()})
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(args.cpu_batch, T, R)
+        out = {
+            "metric": "pretrain samples/sec (BERT-base, 36 regions+128 tok)",
+            "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: BERT-base 12L/768 VisualBERT, %d regions x %d-d + %d text "
+                                   "tokens (S=%d), MLM + image-text-match pre-training step incl. dropout, dense "
+                                   "30522-wide decoder, BertAdam" % (R, Dv, T, S),
+                       "per_gpu_batch": B, "global_batch": B * world, "seq_len": S, "parallelism": "dp%d" % world,
+                       "grad_allreduce": "fp32 RCCL, %s" % ("overlapped with backward" if not args.no_overlap else "after backward")},
+            "train_gflop_per_sample": round(fps / 1e9, 2),
+            "step_mfu": round(value * fps / (world * peak * 1e12), 4),
+            "final_loss": round(loss, 4),
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        if h2d is not None:
+            out["samples_per_s_with_pinned_h2d"] = round(h2d, 2)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,59 @@
+"""Synthetic COCO-shaped pre-training batches and pinned-host staging of region features.
+
+The reference's dataloaders (visualbert/dataloaders/coco_dataset.py:169-233, bert_field.py:79-109,
+vcr.py:457-475) need AllenNLP, COCO on disk and a vocabulary file; none exist here.  This module
+produces batches with the same keys / dtypes / shapes that VisualBERTFixedImageEmbedding.forward takes
+(visualbert/models/model.py:234-260).  Detectron region features stay
+pre-extracted off-GPU: FeatureStager keeps them in pinned host memory and streams each batch with an
+asynchronous host-to-device copy (hipMemcpyAsync underneath) on a side stream, double-buffered.
+"""
+import torch
+
+
+def synthetic_pretraining_batch(B, T=128, R=36, Dv=2048, vocab=30522, seed=0, device="cpu", ragged=False):
+    g = torch.Generator().manual_seed(4000 + seed)
+    ids = torch.randint(0, vocab, (B, T), generator=g, dtype=torch.int64)
+    if ragged:
+        lens = torch.randint(max(T // 2, 3), T + 1, (B,), generator=g, dtype=torch.int64)
+        dims = torch.randint(max(R // 2, 1), R + 1, (B,), generator=g, dtype=torch.int64)
+    else:
+        lens = torch.full((B,), T, dtype=torch.int64)
+        dims = torch.full((B,), R, dtype=torch.int64)
+    ar = torch.arange(T).unsqueeze(0)
+    mask = (ar < lens.unsqueeze(1)).to(torch.int64)
+    ids = ids * mask
+    type_ids = ((ar >= (lens.unsqueeze(1) // 2)).to(torch.int64)) * mask
+    feats = 5.0 * torch.rand((B, R, Dv), generator=g, dtype=torch.float32)      # fc6-after-ReLU-like, >= 0
+    feats = feats * (torch.arange(R).unsqueeze(0) < dims.unsqueeze(1)).unsqueeze(-1).float()
+    sel = (torch.rand((B, T), generator=g) < 0.15) & (mask == 1)
+    sel[:, 1] = True                                                            # >= 1 masked token per sample
+    labels = torch.where(sel, ids, torch.full_like(ids, -1))
+    nxt = torch.randint(0, 2, (B,), generator=g, dtype=torch.int64)
+    batch = dict(bert_input_ids=ids, bert_input_mask=mask, bert_input_type_ids=type_ids, image_dim_variable=dims,
+                 image_feat_variable=feats, masked_lm_labels=labels, is_random_next=nxt)
+    return {k: v.to(device) for k, v in batch.items()}
+
+
+class FeatureStager(object):
+    """Double-buffered pinned-host -> HBM streaming of a batch dict (the features are 295 KB/sample)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.stream = torch.cuda.Stream(device=device)
+        self._pinned = {}
+
+    def stage(self, host_batch, slot=0):
+        """enqueue async copies of `host_batch` (CPU tensors) on the side stream; returns (device batch, event)."""
+        out = {}
+        with torch.cuda.stream(self.stream):
+            for k, v in host_batch.items():
+                key = (slot, k)
+                pin = self._pinned.get(key)
+                if pin is None or pin.shape != v.shape or pin.dtype != v.dtype:
+                    pin = torch.empty(v.shape, dtype=v.dtype, pin_memory=True)
+                    self._pinned[key] = pin
+                pin.copy_(v)
+                out[k] = pin.to(self.device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        return out, ev

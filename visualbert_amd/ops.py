@@ -105,6 +105,40 @@ def cast(src, dst):
     return dst
 
 
+class GemmProfiler(object):
+    """HIP-event timing of every vb_gemm launch on the stream it is launched on (bench.py's roofline
+    leg).  Keyed by kernel instantiation: (dtype, out dtype, A layout, B layout)."""
+
+    def __init__(self):
+        self.records = []
+
+    def launch(self, key, flops, fn):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn()
+        e1.record()
+        self.records.append((key, flops, e0, e1))
+        return r
+
+    def summary(self):
+        """call after torch.cuda.synchronize(): {key: dict(ms, flops, launches)}"""
+        out = {}
+        for key, flops, e0, e1 in self.records:
+            d = out.setdefault(key, dict(ms=0.0, flops=0.0, launches=0))
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += flops
+            d["launches"] += 1
+        return out
+
+
+_profiler = [None]
+
+
+def set_gemm_profiler(p):
+    _profiler[0] = p
+
+
 def gemm(a, b, M, N, K, a_layout=VB_KCONTIG, b_layout=VB_KCONTIG, out=None, out_dtype=None, bias=None, act=VB_ACT_NONE,
          addend=None, aux_in=None, aux_out=None, accumulate=False, alpha=1.0, alpha_dev=None):
     dt = a.dtype
@@ -113,11 +147,19 @@ def gemm(a, b, M, N, K, a_layout=VB_KCONTIG, b_layout=VB_KCONTIG, out=None, out_
     if out is None:
         out = alloc2d(M, N, out_dtype or dt, a.device)
     aux = aux_in if aux_in is not None else aux_out
-    rc = _lib.lib().vb_gemm(_lib.dtype_code(dt), _lib.dtype_code(out.dtype), a_layout, b_layout,
-                            ptr(a), _ld(a), ptr(b), _ld(b), ptr(out), _ld(out), M, N, K, float(alpha), ptr(alpha_dev),
-                            ptr(bias), ptr(addend), _ld(addend) if addend is not None else 0, act,
-                            ptr(aux_in), ptr(aux_out), _ld(aux) if aux is not None else 0, 1 if accumulate else 0,
-                            stream_ptr())
+
+    def run():
+        return _lib.lib().vb_gemm(_lib.dtype_code(dt), _lib.dtype_code(out.dtype), a_layout, b_layout,
+                                  ptr(a), _ld(a), ptr(b), _ld(b), ptr(out), _ld(out), M, N, K, float(alpha),
+                                  ptr(alpha_dev), ptr(bias), ptr(addend), _ld(addend) if addend is not None else 0,
+                                  act, ptr(aux_in), ptr(aux_out), _ld(aux) if aux is not None else 0,
+                                  1 if accumulate else 0, stream_ptr())
+    prof = _profiler[0]
+    if prof is not None:
+        key = (str(dt), str(out.dtype), a_layout, b_layout)
+        rc = prof.launch(key, 2.0 * M * N * K, run)
+    else:
+        rc = run()
     check(rc, "vb_gemm")
     return out
 

@@ -129,5 +129,5 @@ def test_dropout_training_step_runs_and_is_seed_deterministic(dev):
         losses.append(float(out["loss"]))
         gn = float(model.bert.arena.grad.norm())
         assert np.isfinite(gn) and gn > 0
-    assert losses[0] == losses[1]
+    assert abs(losses[0] - losses[1]) < 1e-5     # same masks; only atomic summation order may differ
     assert abs(losses[0] - float(g["loss"])) > 1e-6      # dropout really changed the forward

@@ -121,17 +121,16 @@ def main():
 
     for _ in range(args.warmup):
         mw.step(batch)
-    prof = None
-    if not args.no_profile:
-        prof = ops.GemmProfiler()
-        ops.set_gemm_profiler(prof)
+    prof = not args.no_profile
+    if prof:
+        ops.gemm_profile_start()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         mw.step(batch)
     barrier()
     elapsed = time.perf_counter() - t0
-    ops.set_gemm_profiler(None)
+    summ = ops.gemm_profile_stop() if prof else None
     et = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(et, op=dist.ReduceOp.MAX)
@@ -160,25 +159,22 @@ def main():
 
     if rank == 0:
         roofline = None
-        if prof is not None:
-            summ = prof.summary()
+        if summ is not None:
             if summ:
                 key, d = max(summ.items(), key=lambda kv: kv[1]["ms"])
                 ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
-                names = {0: "Kcontig", 1: "Kstrided"}
                 roofline = dict(bound="mfma", achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
                                 traffic=None,
-                                kernel="gemm_kernel<%s->%s, A %s, B %s>" % (key[0].replace("torch.", ""),
-                                                                             key[1].replace("torch.", ""),
-                                                                             names[key[2]], names[key[3]]),
+                                kernel=ops.gemm_key_name(key),
                                 launches_per_step=d["launches"] / args.steps,
                                 avg_launch_us=round(d["ms"] * 1e3 / d["launches"], 2),
                                 gflop_per_launch=round(d["flops"] / d["launches"] / 1e9, 3),
                                 all_gemm_tflops=round(sum(x["flops"] for x in summ.values()) /
                                                       (sum(x["ms"] for x in summ.values()) * 1e-3) / 1e12, 2),
                                 gemm_ms_per_step=round(sum(x["ms"] for x in summ.values()) / args.steps, 3),
-                                by_kernel={"%s|%s|A%d|B%d" % (k[0][6:], k[1][6:], k[2], k[3]):
+                                by_kernel={ops.gemm_key_name(k):
                                            dict(ms_per_step=round(v["ms"] / args.steps, 3),
+                                                launches_per_step=v["launches"] / args.steps,
                                                 tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1))
                                            for k, v in summ.items()})
         cpu = None

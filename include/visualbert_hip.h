@@ -72,7 +72,10 @@ int vb_ln_fwd(int dtype, const void* x, const void* resid, void* z_out, void* y,
 int vb_ln_bwd(int dtype, const void* dy, const void* z, const float* mean, const float* rstd,
               const float* gamma, void* dz, void* dx, float* dgamma, float* dbeta, float* dbias,
               int M, int H, float p_in, uint32_t stream_in, float p_out, uint32_t stream_out,
-              uint64_t seed, void* stream);
+              uint64_t seed, float* ws, void* stream);
+/* ws (optional, vb_ln_bwd_ws_bytes(M,H) bytes): per-block partial column sums -> two-stage reduction with no
+ * global atomics; NULL falls back to fp32 atomics on dgamma/dbeta/dbias. */
+int64_t vb_ln_bwd_ws_bytes(int M, int H);
 
 /* ------------------------------------------------------------------------------------------------
  * BertEmbeddingsWithVisualEmbedding gather-add (image_text_alignment == None branch).
@@ -145,6 +148,12 @@ int vb_bert_adam_step(float* params, const float* grads, float* exp_avg, float* 
                       float max_grad_norm, float warmup, float t_total, int schedule, void* stream);
 int vb_refresh_bf16_shadow(const float* params, void* bf16_shadow, const int64_t* chunk_table,
                            int n_chunks, const int64_t* tensor_table, void* stream);
+/* W^T copies of the bf16 GEMM weights (so dgrad dx = dy W is a K-contiguous x K-contiguous GEMM):
+ * tensor_table5: int64[n][5] = {src offset in bf16_shadow, R, C, dst offset in bf16_shadow_t, dst ld};
+ * tile_table3: int64[n_tiles][3] = {tensor, 64-row tile, 64-col tile}. Pad columns of the destination are
+ * never written (allocate it zeroed). */
+int vb_refresh_transposed_shadow(const void* bf16_shadow, void* bf16_shadow_t, const int64_t* tensor_table5,
+                                 const int64_t* tile_table3, int n_tiles, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Input preparation (integer work, bit-exact): image_mask[b,r] = r < image_dim[b] (models/model.py:262-268,
@@ -166,6 +175,41 @@ int vb_colsum(int dtype, const void* x, int64_t ld, float* out, const float* sca
 /* dx = dy * act'(aux): act = VB_ACT_GELU (aux = pre-activation, modeling.py:56-61) or VB_ACT_TANH
  * (aux = tanh output, BertPooler modeling.py:385).  Contiguous T[n]. */
 int vb_act_bwd(int dtype, const void* dy, const void* aux, void* dx, int64_t n, int act, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * One whole BertLayer per call (modeling.py:331-341): host-side sequencing of the entry points above
+ * (7 launches forward, 15 backward) so the caller pays one FFI call per layer and direction.
+ *   weights[VB_LW_COUNT]: matrices in T ([3H,H] packed q|k|v, [H,H], [I,H], [H,I]); biases and LayerNorm
+ *                         parameters fp32.   grads[VB_LW_COUNT]: fp32 accumulation targets, same order.
+ *   saved  : vb_bert_layer_saved_bytes() bytes written by forward, read by backward (qkv, ctx, lse,
+ *            keep-bits, pre-LN sums + statistics, attention output, FFN pre-activation and activation)
+ *   scratch: vb_bert_layer_scratch_bytes() bytes of temporaries, reusable by every layer on one stream
+ *   h_in/h_out/d_out/d_in: T [B*S, H];  mask_add: fp32 [B,S].  Dropout sites use stream ids sid..sid+4.
+ * ---------------------------------------------------------------------------------------------- */
+enum { VB_LW_QKV_W = 0, VB_LW_QKV_B, VB_LW_AO_W, VB_LW_AO_B, VB_LW_LN1_G, VB_LW_LN1_B,
+       VB_LW_FI_W, VB_LW_FI_B, VB_LW_FO_W, VB_LW_FO_B, VB_LW_LN2_G, VB_LW_LN2_B, VB_LW_COUNT };
+/* optional transposed weights for backward (weights_t[4], entries may be NULL -> K-strided read of weights[]):
+ * W^T as T [in, ld >= out] for QKV, attention-out, FFN-in, FFN-out; ld_t[4] their leading dimensions */
+enum { VB_LWT_QKV = 0, VB_LWT_AO, VB_LWT_FI, VB_LWT_FO, VB_LWT_COUNT };
+int64_t vb_bert_layer_saved_bytes(int dtype, int B, int S, int H, int I, int nh, float p_attn);
+int64_t vb_bert_layer_scratch_bytes(int dtype, int B, int S, int H, int I, int nh);
+int vb_bert_layer_fwd(int dtype, const void* h_in, const float* mask_add, void* h_out,
+                      void* saved, void* scratch, const void* const* weights,
+                      int B, int S, int H, int I, int nh, float p_hidden, float p_attn, float eps,
+                      uint64_t seed, uint32_t sid, void* stream);
+int vb_bert_layer_bwd(int dtype, const void* h_in, const float* mask_add, const void* d_out, void* d_in,
+                      const void* saved, void* scratch, const void* const* weights, void* const* grads,
+                      const void* const* weights_t, const int64_t* ld_t,
+                      int B, int S, int H, int I, int nh, float p_hidden, float p_attn,
+                      uint64_t seed, uint32_t sid, void* stream);
+
+/* Optional HIP-event timing of every vb_gemm launch (measurement aid for bench.py's roofline object):
+ * vb_gemm_profile(1) starts recording an event pair around each launch on the launch stream,
+ * vb_gemm_profile_read() (after a device synchronise) returns per-launch {milliseconds, algorithmic FLOPs
+ * 2MNK, key}; key bits: 8 = fp32 operands (else bf16), 4 = fp32 output, 2 = A K-strided, 1 = B K-strided.
+ * vb_gemm_profile(0) stops and frees the events. */
+int vb_gemm_profile(int enable);
+int64_t vb_gemm_profile_read(double* ms, double* flops, int* key, int64_t max_records);
 
 #ifdef __cplusplus
 }

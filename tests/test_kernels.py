@@ -41,7 +41,7 @@ def padded(rows, cols, dt, dev, g):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("shape", [(200, 136, 96), (130, 30, 64), (64, 257, 40)])
+@pytest.mark.parametrize("shape", [(200, 136, 96), (130, 30, 64), (64, 257, 40), (150, 140, 192)])  # last: LDS-direct, 3 K tiles
 def test_gemm_forward_layout(dev, dt, shape):
     M, N, K = shape
     g = torch.Generator().manual_seed(1)
@@ -65,7 +65,7 @@ def test_gemm_forward_layout(dev, dt, shape):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("shape", [(200, 136, 72), (130, 30, 40), (70, 300, 136)])
+@pytest.mark.parametrize("shape", [(200, 136, 72), (130, 30, 40), (70, 300, 136), (1100, 136, 72)])  # last: split-K wgrad
 def test_gemm_dgrad_wgrad_layouts(dev, dt, shape):
     M, N, K2 = shape          # dY [M,N], W [N,K2], X [M,K2]
     g = torch.Generator().manual_seed(2)
@@ -102,7 +102,7 @@ def ln_fwd(dev, dt, x, resid, gamma, beta, p_in=0.0, p_out=0.0, seed=5, want_z=T
     return y, z, mean, rstd
 
 
-def ln_bwd(dev, dt, dy, z, mean, rstd, gamma, p_in=0.0, p_out=0.0, seed=5):
+def ln_bwd(dev, dt, dy, z, mean, rstd, gamma, p_in=0.0, p_out=0.0, seed=5, two_stage=True):
     M, H = dy.shape
     L = _lib.lib()
     dz = torch.empty_like(dy)
@@ -110,9 +110,12 @@ def ln_bwd(dev, dt, dy, z, mean, rstd, gamma, p_in=0.0, p_out=0.0, seed=5):
     dg = torch.zeros(H, device=dev)
     db = torch.zeros(H, device=dev)
     dbias = torch.zeros(H, device=dev)
+    ws = torch.empty(L.vb_ln_bwd_ws_bytes(M, H) // 4, device=dev) if two_stage else None
     rc = L.vb_ln_bwd(_lib.dtype_code(dt), _lib.ptr(dy), _lib.ptr(z), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(gamma),
                      _lib.ptr(dz), _lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db), _lib.ptr(dbias), M, H,
-                     p_in, 11, p_out, 12, seed, _lib.stream_ptr())
+                     p_in, 11, p_out, 12, seed,
+                     _lib.ptr(ws),
+                     _lib.stream_ptr())
     _lib.check(rc, "vb_ln_bwd")
     return dz, dx, dg, db, dbias
 
@@ -144,6 +147,9 @@ def test_layernorm_residual_fwd_bwd(dev, dt, MH):
     bp = beta.clone().requires_grad_(True)
     ref_ln(zs, gp, bp).backward(dy.float())
     dz, dx, dg, db, dbias = ln_bwd(dev, dt, dy, z, mean, rstd, gamma)
+    _, _, dg2, db2, dbias2 = ln_bwd(dev, dt, dy, z, mean, rstd, gamma, two_stage=False)   # atomics path
+    for u, v in ((dg, dg2), (db, db2), (dbias, dbias2)):
+        assert (u - v).abs().max().item() <= 1e-4 * max(1.0, v.abs().max().item())
     t = tol(dt, 5e-5, 0.05)
     assert (dz.float() - zs.grad).abs().max().item() <= t * max(1.0, zs.grad.abs().max().item())
     assert torch.equal(dx, dz)

@@ -131,3 +131,31 @@ def test_dropout_training_step_runs_and_is_seed_deterministic(dev):
         assert np.isfinite(gn) and gn > 0
     assert abs(losses[0] - losses[1]) < 1e-5     # same masks; only atomic summation order may differ
     assert abs(losses[0] - float(g["loss"])) > 1e-6      # dropout really changed the forward
+
+
+@pytest.mark.parametrize("stem", ["micro_pretraining", "tiny_pretraining"])
+def test_bf16_gradients_track_bf16_oracle(dev, stem):
+    """bf16 backward (W^T shadows + LDS-direct dgrad, split-K wgrad, fused layer call): every parameter's
+    gradient must point the same way as the bf16-emulating oracle's (cosine >= 0.99, norm within 5 %)."""
+    cfg, head, sd, batch, g = load_case(stem)
+    model = build_model(cfg, head, sd, dev, dtype=torch.bfloat16, dropout=0.0)
+    model.train()
+    out = model(**to_dev(batch, dev))
+    out["loss"].backward()
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = vo.objective_forward(leaves, cfg, head, mode="bf16", **batch)
+    ref["loss"].backward()
+    worst = 1.0
+    for n, p in model.bert.named_parameters():
+        rg = leaves[n].grad
+        if rg is None:
+            continue
+        mg = p.grad.detach().float().cpu()
+        rn, mn = float(rg.norm()), float(mg.norm())
+        if rn < 1e-7 or n.endswith("key.bias"):     # d/d(key bias) is identically 0 (softmax shift invariance): noise
+            continue
+        cos = float((rg * mg).sum() / (rn * mn + 1e-30))
+        worst = min(worst, cos)
+        assert cos > 0.99, (n, cos)
+        assert abs(mn - rn) <= 0.05 * rn, (n, mn, rn)
+    print("bf16 gradients: worst cosine vs bf16 oracle %.5f" % worst)

@@ -25,7 +25,8 @@ SIGNATURES = {
     "vb_gemm": (_i, [_i, _i, _i, _i, _p, _i64, _p, _i64, _p, _i64, _i, _i, _i, _f, _p, _p, _p, _i64, _i,
                      _p, _p, _i64, _i, _p]),
     "vb_ln_fwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _f, _u32, _f, _u32, _u64, _p]),
-    "vb_ln_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _u32, _f, _u32, _u64, _p]),
+    "vb_ln_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _u32, _f, _u32, _u64, _p, _p]),
+    "vb_ln_bwd_ws_bytes": (_i64, [_i, _i]),
     "vb_embed_fwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "vb_embed_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "vb_attn_keepbits_words": (_i64, [_i]),
@@ -37,12 +38,19 @@ SIGNATURES = {
     "vb_small_linear_bwd": (_i, [_i, _p, _p, _i64, _p, _p, _i64, _p, _p, _p, _i, _i, _i, _p]),
     "vb_bert_adam_step": (_i, [_p, _p, _p, _p, _p, _p, _i, _p, _i, _p, _p, _f, _f, _f, _f, _f, _f, _f, _f, _i, _p]),
     "vb_refresh_bf16_shadow": (_i, [_p, _p, _p, _i, _p, _p]),
+    "vb_refresh_transposed_shadow": (_i, [_p, _p, _p, _p, _i, _p]),
     "vb_prepare_inputs": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "vb_cast": (_i, [_i, _p, _i, _p, _i64, _p]),
     "vb_gather_rows": (_i, [_i, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "vb_scatter_rows": (_i, [_i, _p, _p, _p, _i, _i, _i, _p]),
     "vb_colsum": (_i, [_i, _p, _i64, _p, _p, _i, _i, _p]),
     "vb_act_bwd": (_i, [_i, _p, _p, _p, _i64, _i, _p]),
+    "vb_gemm_profile": (_i, [_i]),
+    "vb_gemm_profile_read": (_i64, [_p, _p, _p, _i64]),
+    "vb_bert_layer_saved_bytes": (_i64, [_i, _i, _i, _i, _i, _i, _f]),
+    "vb_bert_layer_scratch_bytes": (_i64, [_i, _i, _i, _i, _i, _i]),
+    "vb_bert_layer_fwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _f, _u64, _u32, _p]),
+    "vb_bert_layer_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _u64, _u32, _p]),
 }
 
 _ERRORS = {-1: "VB_ERR_ARG (bad argument)", -2: "VB_ERR_LAUNCH (hip launch failed)",

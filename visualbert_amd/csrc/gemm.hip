@@ -17,18 +17,30 @@
 //
 // Tile: 128x128 per workgroup of 4 waves (2x2, 64x64 per wave = 4x4 MFMA 16x16 fragments, 64 fp32
 // accumulators per lane).  LDS rows are always 128 B (64 bf16 / 32 fp32 of K) with a 16-byte-chunk XOR
-// swizzle; fragments are read with ds_read_b128.  The accumulators leave through LDS so that the
-// epilogue (bias, GELU, GELU', residual addend, fp32 accumulate) works on 8 consecutive columns per
-// lane and every global store is a full 128-byte row segment.
+// swizzle; fragments are read with ds_read_b128.  LDS is double-buffered (2 x 32 KB): one barrier
+// per K tile, the next tile's loads fly under the current tile's MFMAs.
+//   * K-contiguous operand, K a multiple of the tile: global_load_lds_dwordx4 straight into LDS (no
+//     VGPR staging, no ds_write); the swizzle is applied to the per-lane SOURCE address because the
+//     LDS image of such a load is lane-linear (guide rule 21).
+//   * K-strided operand (or a ragged K tail): staged through registers, transposed 8x8 on the way.
+// Split-K (wgrad only, fp32 accumulate): the token dimension is the reduction, the output is only
+// [out,in] -- 36..144 tiles for BERT-base -- so the reduction is cut into `splits` slices that add
+// their partial tile with fire-and-forget fp32 atomics (the output is an accumulator anyway).
+// The accumulators leave through LDS so that the epilogue (bias, GELU, GELU', residual addend, fp32
+// accumulate) works on 8 consecutive columns per lane and every global store is a full 128-byte row
+// segment.
 #include "vb_rt.h"
 #include "../../include/visualbert_hip.h"
+#include <vector>
 
 namespace {
 
 constexpr int BM = 128, BN = 128, NT = 256;
 constexpr int EPI_PITCH = 64 * 4 + 16;          // bytes per staged fp32 row of a wave's 32x64 slab
 constexpr int EPI_BYTES_PER_WAVE = 32 * EPI_PITCH;
-constexpr int SMEM_BYTES = (4 * EPI_BYTES_PER_WAVE > 2 * 128 * 128) ? 4 * EPI_BYTES_PER_WAVE : 2 * 128 * 128;
+constexpr int TILE_BYTES = 128 * 128;            // one operand tile in LDS
+constexpr int SMEM_BYTES = 4 * TILE_BYTES;       // [A0 | B0 | A1 | B1]  (>= the epilogue's 4 slabs)
+static_assert(4 * EPI_BYTES_PER_WAVE <= SMEM_BYTES, "epilogue slabs must fit the staging buffers");
 
 template <typename T> struct TT {
     static constexpr int EPC = 16 / (int)sizeof(T);   // elements per 16-byte chunk
@@ -50,6 +62,8 @@ struct GemmArgs {
     const float* alpha_dev;
     int act, accumulate;
     int tiles_m, tiles_n;
+    int splits, kt_per_split;     // split-K: slice s covers K tiles [s*kt_per_split, (s+1)*kt_per_split)
+    int fast_a, fast_b;           // operand may be copied with global_load_lds (K-contiguous, no K tail)
 };
 
 // ---- global -> register staging -------------------------------------------------------------
@@ -82,6 +96,22 @@ VB_DEVICE void sstore_kcontig(const u32x4 (&r)[4], unsigned char* lds, int t) {
     const int c = t & 7, rr = t >> 3;
 #pragma unroll
     for (int i = 0; i < 4; ++i) *(u32x4*)(lds + lds_off(rr + 32 * i, c)) = r[i];
+}
+
+// K-contiguous operand, direct global -> LDS: wave w issues 4 instructions; instruction i covers tile
+// rows (4w+i)*8 .. +7 (1 KiB of LDS, lane-linear): lane -> row = +lane/8, LDS chunk slot c' = lane%8,
+// which must hold global chunk c = c' ^ swz(row)  (the same involution the fragment reads apply)
+template <typename T>
+VB_DEVICE void glds_kcontig(unsigned char* lds, const T* P, long ld, int R, int r0, int k0, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rbase = (wave * 4 + i) * 8;
+        const int row = rbase + (lane >> 3);
+        const int c = (lane & 7) ^ swz(row);
+        int grow = r0 + row;
+        grow = grow < R ? grow : R - 1;
+        vb_glds16(P + (long)grow * ld + k0 + c * TT<T>::EPC, lds + rbase * 128);
+    }
 }
 
 // K-strided operand: a thread owns EPC k-rows x 8 tile rows; threads [tbase, tbase+128)
@@ -158,8 +188,6 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) gemm_kernel(GemmArgs g) {
     constexpr int EPC = TT<T>::EPC, BK = TT<T>::BK, KSTEPS = TT<T>::KSTEPS;
     (void)EPC;
     VB_DYN_SMEM(smem);
-    unsigned char* ldsA = smem;
-    unsigned char* ldsB = smem + 128 * 128;
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
@@ -167,7 +195,8 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) gemm_kernel(GemmArgs g) {
     const int li = lane & 15, lg = lane >> 4;
 
     const int nwg = g.tiles_m * g.tiles_n;
-    const int tile = xcd_remap((int)blockIdx.x, nwg);
+    const int split = (int)blockIdx.x / nwg;
+    const int tile = xcd_remap((int)blockIdx.x % nwg, nwg);
     const int m0 = (tile / g.tiles_n) * BM, n0 = (tile % g.tiles_n) * BN;
 
     const T* A = (const T*)g.A;
@@ -179,36 +208,60 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) gemm_kernel(GemmArgs g) {
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // staging registers: K-contiguous uses 4 vectors, K-strided 8 (by threads [0,128) for A, or for B when
-    // A is K-contiguous; by threads [128,256) for B when both are K-strided)
+    // register staging (K-strided operands, or K-contiguous with a ragged tail): K-contiguous uses 4
+    // vectors, K-strided 8 (threads [0,128) for A, or for B when A is K-contiguous; [128,256) for B when
+    // both are K-strided)
     u32x4 ra[AL == VB_KCONTIG ? 4 : 8];
     u32x4 rb[BL == VB_KCONTIG ? 4 : 8];
     constexpr int B_TBASE = (AL == VB_KSTRIDED && BL == VB_KSTRIDED) ? 128 : 0;
     const bool a_active = (AL == VB_KCONTIG) || (t < 128);
     const bool b_active = (BL == VB_KCONTIG) || (t >= B_TBASE && t < B_TBASE + 128);
+    const bool glds_a = (AL == VB_KCONTIG) && g.fast_a;
+    const bool glds_b = (BL == VB_KCONTIG) && g.fast_b;
 
-    const int nk = (g.K + BK - 1) / BK;
+    const int nk_all = (g.K + BK - 1) / BK;
+    const int kt0 = split * g.kt_per_split;
+    const int kt1 = (kt0 + g.kt_per_split < nk_all) ? kt0 + g.kt_per_split : nk_all;
 
-    auto gload = [&](int kt) {
+    // issue(): start moving K tile `kt` towards LDS buffer `buf`; commit(): finish it for the
+    // register-staged operands (LDS-direct copies need no commit, only the barrier)
+    auto issue = [&](int kt, int buf) {
         const int k0 = kt * BK;
-        if constexpr (AL == VB_KCONTIG) gload_kcontig<T>(ra, A, g.lda, g.M, g.K, m0, k0, t);
-        else { if (a_active) gload_kstrided<T>(ra, A, g.lda, g.M, g.K, m0, k0, t); }
-        if constexpr (BL == VB_KCONTIG) gload_kcontig<T>(rb, B, g.ldb, g.N, g.K, n0, k0, t);
-        else { if (b_active) gload_kstrided<T>(rb, B, g.ldb, g.N, g.K, n0, k0, t - B_TBASE); }
+        unsigned char* la = smem + buf * 2 * TILE_BYTES;
+        unsigned char* lb = la + TILE_BYTES;
+        if constexpr (AL == VB_KCONTIG) {
+            if (glds_a) glds_kcontig<T>(la, A, g.lda, g.M, m0, k0, wave, lane);
+            else gload_kcontig<T>(ra, A, g.lda, g.M, g.K, m0, k0, t);
+        } else {
+            if (a_active) gload_kstrided<T>(ra, A, g.lda, g.M, g.K, m0, k0, t);
+        }
+        if constexpr (BL == VB_KCONTIG) {
+            if (glds_b) glds_kcontig<T>(lb, B, g.ldb, g.N, n0, k0, wave, lane);
+            else gload_kcontig<T>(rb, B, g.ldb, g.N, g.K, n0, k0, t);
+        } else {
+            if (b_active) gload_kstrided<T>(rb, B, g.ldb, g.N, g.K, n0, k0, t - B_TBASE);
+        }
     };
-    auto sstore = [&]() {
-        if constexpr (AL == VB_KCONTIG) sstore_kcontig<T>(ra, ldsA, t);
-        else { if (a_active) sstore_kstrided(ra, ldsA, t, T()); }
-        if constexpr (BL == VB_KCONTIG) sstore_kcontig<T>(rb, ldsB, t);
-        else { if (b_active) sstore_kstrided(rb, ldsB, t - B_TBASE, T()); }
+    auto commit = [&](int buf) {
+        unsigned char* la = smem + buf * 2 * TILE_BYTES;
+        unsigned char* lb = la + TILE_BYTES;
+        if constexpr (AL == VB_KCONTIG) { if (!glds_a) sstore_kcontig<T>(ra, la, t); }
+        else { if (a_active) sstore_kstrided(ra, la, t, T()); }
+        if constexpr (BL == VB_KCONTIG) { if (!glds_b) sstore_kcontig<T>(rb, lb, t); }
+        else { if (b_active) sstore_kstrided(rb, lb, t - B_TBASE, T()); }
     };
 
-    gload(0);
-    for (int kt = 0; kt < nk; ++kt) {
-        __syncthreads();                 // previous tile's fragment reads are done
-        sstore();
+    if (kt0 < kt1) issue(kt0, 0);
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int buf = (kt - kt0) & 1;
+        commit(buf);
+        // one barrier per K tile: (a) this tile is in LDS (register-staged stores done; LDS-direct copies
+        // drained by the vmcnt(0) the barrier carries), (b) every wave has finished reading the OTHER
+        // buffer (tile kt-1), which issue() below starts to overwrite
         __syncthreads();
-        if (kt + 1 < nk) gload(kt + 1);  // in flight during the MFMAs below
+        if (kt + 1 < kt1) issue(kt + 1, buf ^ 1);
+        const unsigned char* ldsA = smem + buf * 2 * TILE_BYTES;
+        const unsigned char* ldsB = ldsA + TILE_BYTES;
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
             typename VecOf<T>::v8 fa[4], fb[4];
@@ -289,6 +342,13 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) gemm_kernel(GemmArgs g) {
                 for (int j = 0; j < 8; ++j) v[j] += x[j];
             }
             TO* cp = C + (long)m * g.ldc + n;
+            if (g.splits > 1) {                                   // fp32 accumulator, partial tile
+                if constexpr (sizeof(TO) == 4) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) if (j < nv) vb_atomic_add_noret((float*)cp + j, v[j]);
+                }
+                continue;
+            }
             if (g.accumulate) {
                 float x[8];
                 if (full && (g.ldc & 7) == 0) load8(x, cp);
@@ -302,9 +362,30 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) gemm_kernel(GemmArgs g) {
     }
 }
 
+// ---- optional per-launch HIP-event timing (bench.py's roofline leg) -----------------------------------
+// Events are recorded on the stream the kernel is launched on, immediately around the launch, so the
+// elapsed time is the kernel's own duration even when the host is the bottleneck.
+#ifndef VB_EMU
+struct ProfRec { hipEvent_t e0, e1; double flops; int key; };
+static std::vector<ProfRec>* g_prof = nullptr;
+#endif
+
 template <typename T, typename TO, int AL, int BL>
 int launch_gemm(const GemmArgs& g, hipStream_t stream) {
-    dim3 grid((unsigned)(g.tiles_m * g.tiles_n)), block(NT);
+    dim3 grid((unsigned)(g.tiles_m * g.tiles_n * g.splits)), block(NT);
+#ifndef VB_EMU
+    if (g_prof) {
+        ProfRec r;
+        if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return VB_ERR_LAUNCH;
+        r.flops = 2.0 * g.M * g.N * g.K;
+        r.key = (sizeof(T) == 2 ? 0 : 8) | (sizeof(TO) == 4 ? 4 : 0) | (AL << 1) | BL;
+        (void)hipEventRecord(r.e0, stream);
+        VB_LAUNCH((gemm_kernel<T, TO, AL, BL>), grid, block, SMEM_BYTES, stream, g);
+        (void)hipEventRecord(r.e1, stream);
+        g_prof->push_back(r);
+        return vb_check_launch();
+    }
+#endif
     VB_LAUNCH((gemm_kernel<T, TO, AL, BL>), grid, block, SMEM_BYTES, stream, g);
     return vb_check_launch();
 }
@@ -344,8 +425,59 @@ extern "C" int vb_gemm(int dtype, int out_dtype, int a_layout, int b_layout,
     g.bias = bias; g.addend = addend; g.ld_addend = ld_addend; g.aux_in = aux_in; g.aux_out = aux_out;
     g.ld_aux = ld_aux; g.alpha = alpha; g.alpha_dev = alpha_dev; g.act = act; g.accumulate = accumulate;
     g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
+    const int bk = dtype == VB_BF16 ? 64 : 32;
+    const int nk = (K + bk - 1) / bk;
+    // LDS-direct copies need whole K tiles (a masked lane would leave stale LDS behind)
+    g.fast_a = (a_layout == VB_KCONTIG && (K % bk) == 0) ? 1 : 0;
+    g.fast_b = (b_layout == VB_KCONTIG && (K % bk) == 0) ? 1 : 0;
+    // split-K only where the result is an fp32 accumulator without an element-wise epilogue
+    g.splits = 1; g.kt_per_split = nk;
+    const int tiles = g.tiles_m * g.tiles_n;
+    if (accumulate && out_dtype == VB_F32 && !bias && !addend && act == VB_ACT_NONE && tiles < 256 && nk >= 16) {
+        int want = (512 + tiles - 1) / tiles;
+        int maxs = nk / 8;
+        if (want > maxs) want = maxs;
+        if (want > 1) {
+            g.kt_per_split = (nk + want - 1) / want;
+            g.splits = (nk + g.kt_per_split - 1) / g.kt_per_split;
+        }
+    }
     hipStream_t s = (hipStream_t)stream;
     const int of32 = (out_dtype == VB_F32) ? 1 : 0;
     if (dtype == VB_BF16) return dispatch<bf16>(of32 && true, a_layout, b_layout, g, s);
     return dispatch<float>(1, a_layout, b_layout, g, s);
+}
+
+extern "C" int vb_gemm_profile(int enable) {
+#ifndef VB_EMU
+    if (g_prof) {
+        for (auto& r : *g_prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+        delete g_prof;
+        g_prof = nullptr;
+    }
+    if (enable) g_prof = new std::vector<ProfRec>();
+#else
+    (void)enable;
+#endif
+    return VB_OK;
+}
+
+extern "C" int64_t vb_gemm_profile_read(double* ms, double* flops, int* key, int64_t max_records) {
+#ifndef VB_EMU
+    if (!g_prof) return 0;
+    int64_t n = 0;
+    for (auto& r : *g_prof) {
+        if (n >= max_records) break;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, r.e0, r.e1) != hipSuccess) return -1;   // caller must synchronise first
+        if (ms) ms[n] = t;
+        if (flops) flops[n] = r.flops;
+        if (key) key[n] = r.key;
+        ++n;
+    }
+    return n;
+#else
+    (void)ms; (void)flops; (void)key; (void)max_records;
+    return 0;
+#endif
 }

@@ -1,0 +1,203 @@
+// layer.hip -- host-side sequencing of one whole BertLayer (forward: 7 launches, backward: 15) behind a
+// single C-ABI call each, so the Python side pays two FFI calls per layer instead of ~22 op dispatches.
+// Pure orchestration: every launch goes through the same entry points the per-op ABI exposes.
+//
+// Replaces BertLayer.forward and its autograd backward
+//   (pytorch_pretrained_bert/modeling.py:331-341 = BertAttention :276-293 [BertSelfAttention :231-261,
+//    BertSelfOutput :270-274] -> BertIntermediate :302-305 -> BertOutput :315-319).
+#include "vb_rt.h"
+#include "../../include/visualbert_hip.h"
+
+namespace {
+
+struct Dims { int B, S, H, I, nh; long M; size_t es; };
+
+inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// saved-for-backward workspace of one layer
+struct Saved {
+    unsigned char *qkv, *ctx, *z1, *a_out, *pre, *inter, *z2;
+    float *lse, *mean1, *rstd1, *mean2, *rstd2;
+    uint64_t* keepbits;
+    size_t total;
+};
+
+Saved carve_saved(unsigned char* base, const Dims& d, bool attn_dropout) {
+    Saved s;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { unsigned char* p = base ? base + o : nullptr; o += al(bytes); return p; };
+    s.qkv = take((size_t)d.M * 3 * d.H * d.es);
+    s.ctx = take((size_t)d.M * d.H * d.es);
+    s.z1 = take((size_t)d.M * d.H * d.es);
+    s.a_out = take((size_t)d.M * d.H * d.es);
+    s.pre = take((size_t)d.M * d.I * d.es);
+    s.inter = take((size_t)d.M * d.I * d.es);
+    s.z2 = take((size_t)d.M * d.H * d.es);
+    s.lse = (float*)take((size_t)d.B * d.nh * d.S * 4);
+    s.mean1 = (float*)take((size_t)d.M * 4);
+    s.rstd1 = (float*)take((size_t)d.M * 4);
+    s.mean2 = (float*)take((size_t)d.M * 4);
+    s.rstd2 = (float*)take((size_t)d.M * 4);
+    s.keepbits = (uint64_t*)take(attn_dropout ? (size_t)d.B * d.nh * vb_attn_keepbits_words(d.S) * 8 : 0);
+    s.total = o;
+    return s;
+}
+
+// scratch (temporaries, reusable by every layer on the same stream)
+struct Scratch {
+    unsigned char *t_h0, *t_h1, *t_h2, *t_h3, *t_i, *t_3h;
+    float* dsum;
+    float* ln_ws;
+    size_t total;
+};
+Scratch carve_scratch(unsigned char* base, const Dims& d) {
+    Scratch s;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { unsigned char* p = base ? base + o : nullptr; o += al(bytes); return p; };
+    s.t_h0 = take((size_t)d.M * d.H * d.es);
+    s.t_h1 = take((size_t)d.M * d.H * d.es);
+    s.t_h2 = take((size_t)d.M * d.H * d.es);
+    s.t_h3 = take((size_t)d.M * d.H * d.es);
+    s.t_i = take((size_t)d.M * d.I * d.es);
+    s.t_3h = take((size_t)d.M * 3 * d.H * d.es);
+    s.dsum = (float*)take((size_t)d.B * d.nh * d.S * 4);
+    s.ln_ws = (float*)take((size_t)vb_ln_bwd_ws_bytes((int)d.M, d.H));
+    s.total = o;
+    return s;
+}
+
+bool fill_dims(Dims& d, int dtype, int B, int S, int H, int I, int nh) {
+    if (B <= 0 || S <= 0 || H <= 0 || I <= 0 || nh <= 0 || nh * 64 != H || (H % 8) || (I % 8)) return false;
+    if (dtype != VB_F32 && dtype != VB_BF16) return false;
+    d.B = B; d.S = S; d.H = H; d.I = I; d.nh = nh; d.M = (long)B * S; d.es = dtype == VB_BF16 ? 2 : 4;
+    return true;
+}
+
+#define VB_TRY(expr) do { int rc_ = (expr); if (rc_ != VB_OK) return rc_; } while (0)
+
+}  // namespace
+
+extern "C" int64_t vb_bert_layer_saved_bytes(int dtype, int B, int S, int H, int I, int nh, float p_attn) {
+    Dims d;
+    if (!fill_dims(d, dtype, B, S, H, I, nh)) return -1;
+    return (int64_t)carve_saved(nullptr, d, p_attn > 0.f).total;
+}
+extern "C" int64_t vb_bert_layer_scratch_bytes(int dtype, int B, int S, int H, int I, int nh) {
+    Dims d;
+    if (!fill_dims(d, dtype, B, S, H, I, nh)) return -1;
+    return (int64_t)carve_scratch(nullptr, d).total;
+}
+
+// weights[]: VB_LW_* order (T for matrices read by the GEMMs, fp32 for biases / LayerNorm)
+extern "C" int vb_bert_layer_fwd(int dtype, const void* h_in, const float* mask_add, void* h_out,
+                                 void* saved, void* scratch, const void* const* weights,
+                                 int B, int S, int H, int I, int nh, float p_hidden, float p_attn, float eps,
+                                 uint64_t seed, uint32_t sid, void* stream) {
+    Dims d;
+    if (!fill_dims(d, dtype, B, S, H, I, nh) || !h_in || !mask_add || !h_out || !saved || !scratch || !weights)
+        return VB_ERR_ARG;
+    Saved sv = carve_saved((unsigned char*)saved, d, p_attn > 0.f);
+    Scratch sc = carve_scratch((unsigned char*)scratch, d);
+    const int M = (int)d.M;
+    const void* wqkv = weights[VB_LW_QKV_W]; const float* bqkv = (const float*)weights[VB_LW_QKV_B];
+    const void* wo = weights[VB_LW_AO_W]; const float* bo = (const float*)weights[VB_LW_AO_B];
+    const float* g1 = (const float*)weights[VB_LW_LN1_G]; const float* b1 = (const float*)weights[VB_LW_LN1_B];
+    const void* wi = weights[VB_LW_FI_W]; const float* bi = (const float*)weights[VB_LW_FI_B];
+    const void* wo2 = weights[VB_LW_FO_W]; const float* bo2 = (const float*)weights[VB_LW_FO_B];
+    const float* g2 = (const float*)weights[VB_LW_LN2_G]; const float* b2 = (const float*)weights[VB_LW_LN2_B];
+
+    // 1. packed Q|K|V projection
+    VB_TRY(vb_gemm(dtype, dtype, VB_KCONTIG, VB_KCONTIG, h_in, H, wqkv, H, sv.qkv, 3 * H, M, 3 * H, H, 1.f, nullptr,
+                   bqkv, nullptr, 0, VB_ACT_NONE, nullptr, nullptr, 0, 0, stream));
+    // 2. fused attention
+    VB_TRY(vb_attn_fwd(dtype, sv.qkv, mask_add, sv.ctx, sv.lse, sv.keepbits, B, S, nh, 64, p_attn, seed, sid, stream));
+    // 3. attention output projection
+    VB_TRY(vb_gemm(dtype, dtype, VB_KCONTIG, VB_KCONTIG, sv.ctx, H, wo, H, sc.t_h0, H, M, H, H, 1.f, nullptr, bo,
+                   nullptr, 0, VB_ACT_NONE, nullptr, nullptr, 0, 0, stream));
+    // 4. dropout + residual + LayerNorm
+    VB_TRY(vb_ln_fwd(dtype, sc.t_h0, h_in, sv.z1, sv.a_out, sv.mean1, sv.rstd1, g1, b1, M, H, eps, p_hidden, sid + 1,
+                     0.f, 0, seed, stream));
+    // 5. FFN in + erf-GELU (pre-activation kept for backward)
+    VB_TRY(vb_gemm(dtype, dtype, VB_KCONTIG, VB_KCONTIG, sv.a_out, H, wi, H, sv.inter, I, M, I, H, 1.f, nullptr, bi,
+                   nullptr, 0, VB_ACT_GELU, nullptr, sv.pre, I, 0, stream));
+    // 6. FFN out
+    VB_TRY(vb_gemm(dtype, dtype, VB_KCONTIG, VB_KCONTIG, sv.inter, I, wo2, I, sc.t_h1, H, M, H, I, 1.f, nullptr, bo2,
+                   nullptr, 0, VB_ACT_NONE, nullptr, nullptr, 0, 0, stream));
+    // 7. dropout + residual + LayerNorm
+    VB_TRY(vb_ln_fwd(dtype, sc.t_h1, sv.a_out, sv.z2, h_out, sv.mean2, sv.rstd2, g2, b2, M, H, eps, p_hidden, sid + 4,
+                     0.f, 0, seed, stream));
+    return VB_OK;
+}
+
+// grads[]: fp32 accumulation targets in VB_LW_* order (all required)
+extern "C" int vb_bert_layer_bwd(int dtype, const void* h_in, const float* mask_add, const void* d_out, void* d_in,
+                                 const void* saved, void* scratch, const void* const* weights, void* const* grads,
+                                 const void* const* weights_t, const int64_t* ld_t,
+                                 int B, int S, int H, int I, int nh, float p_hidden, float p_attn,
+                                 uint64_t seed, uint32_t sid, void* stream) {
+    Dims d;
+    if (!fill_dims(d, dtype, B, S, H, I, nh) || !h_in || !mask_add || !d_out || !d_in || !saved || !scratch ||
+        !weights || !grads)
+        return VB_ERR_ARG;
+    Saved sv = carve_saved((unsigned char*)saved, d, p_attn > 0.f);
+    Scratch sc = carve_scratch((unsigned char*)scratch, d);
+    const int M = (int)d.M;
+    const void* wqkv = weights[VB_LW_QKV_W];
+    const void* wo = weights[VB_LW_AO_W];
+    const float* g1 = (const float*)weights[VB_LW_LN1_G];
+    const void* wi = weights[VB_LW_FI_W];
+    const void* wo2 = weights[VB_LW_FO_W];
+    const float* g2 = (const float*)weights[VB_LW_LN2_G];
+    float* G[VB_LW_COUNT];
+    for (int i = 0; i < VB_LW_COUNT; ++i) { G[i] = (float*)grads[i]; if (!G[i]) return VB_ERR_ARG; }
+    // dgrad dx[M,in] = dy[M,out] W[out,in]: with W^T [in, ld>=out] both operands are K-contiguous (LDS-direct
+    // loads); otherwise W is read K-strided and transposed on the fly
+    auto dgrad = [&](const void* dy, int n_out, const void* w, int which_t, int n_in, void* dx, const void* addend,
+                     int act, const void* aux) -> int {
+        const void* wt = weights_t ? weights_t[which_t] : nullptr;
+        if (wt)
+            return vb_gemm(dtype, dtype, VB_KCONTIG, VB_KCONTIG, dy, n_out, wt, ld_t[which_t], dx, n_in, M, n_in, n_out,
+                           1.f, nullptr, nullptr, addend, n_in, act, aux, nullptr, n_in, 0, stream);
+        return vb_gemm(dtype, dtype, VB_KCONTIG, VB_KSTRIDED, dy, n_out, w, n_in, dx, n_in, M, n_in, n_out, 1.f, nullptr,
+                       nullptr, addend, n_in, act, aux, nullptr, n_in, 0, stream);
+    };
+
+    unsigned char* dz2 = sc.t_h0;                        // d(a_out) through the residual of the output LN
+    unsigned char* dfo = p_hidden > 0.f ? sc.t_h1 : dz2; // d(FFN-out dense output)
+    // 1. output LayerNorm backward (+ bias gradient of the FFN-out dense as a by-product)
+    VB_TRY(vb_ln_bwd(dtype, d_out, sv.z2, sv.mean2, sv.rstd2, g2, dz2, dfo, G[VB_LW_LN2_G], G[VB_LW_LN2_B],
+                     G[VB_LW_FO_B], M, H, p_hidden, sid + 4, 0.f, 0, seed, sc.ln_ws, stream));
+    // 2. wgrad FFN-out: dW[H,I] += dfo^T inter
+    VB_TRY(vb_gemm(dtype, VB_F32, VB_KSTRIDED, VB_KSTRIDED, dfo, H, sv.inter, I, G[VB_LW_FO_W], I, H, I, M, 1.f, nullptr,
+                   nullptr, nullptr, 0, VB_ACT_NONE, nullptr, nullptr, 0, 1, stream));
+    // 3. dgrad FFN-out with GELU' folded into the epilogue: dpre = (dfo Wo2) * gelu'(pre)
+    VB_TRY(dgrad(dfo, H, wo2, VB_LWT_FO, I, sc.t_i, nullptr, VB_ACT_GELU_GRAD, sv.pre));
+    // 4. bias gradient FFN-in
+    VB_TRY(vb_colsum(dtype, sc.t_i, I, G[VB_LW_FI_B], nullptr, M, I, stream));
+    // 5. wgrad FFN-in: dW[I,H] += dpre^T a_out
+    VB_TRY(vb_gemm(dtype, VB_F32, VB_KSTRIDED, VB_KSTRIDED, sc.t_i, I, sv.a_out, H, G[VB_LW_FI_W], H, I, H, M, 1.f,
+                   nullptr, nullptr, nullptr, 0, VB_ACT_NONE, nullptr, nullptr, 0, 1, stream));
+    // 6. dgrad FFN-in + residual gradient: da = dpre Wi + dz2
+    VB_TRY(dgrad(sc.t_i, I, wi, VB_LWT_FI, H, sc.t_h2, dz2, VB_ACT_NONE, nullptr));
+    // 7. attention-output LayerNorm backward
+    unsigned char* dz1 = sc.t_h0;
+    unsigned char* dao = p_hidden > 0.f ? sc.t_h1 : dz1;
+    VB_TRY(vb_ln_bwd(dtype, sc.t_h2, sv.z1, sv.mean1, sv.rstd1, g1, dz1, dao, G[VB_LW_LN1_G], G[VB_LW_LN1_B],
+                     G[VB_LW_AO_B], M, H, p_hidden, sid + 1, 0.f, 0, seed, sc.ln_ws, stream));
+    // 8. wgrad attention-out: dW[H,H] += dao^T ctx
+    VB_TRY(vb_gemm(dtype, VB_F32, VB_KSTRIDED, VB_KSTRIDED, dao, H, sv.ctx, H, G[VB_LW_AO_W], H, H, H, M, 1.f, nullptr,
+                   nullptr, nullptr, 0, VB_ACT_NONE, nullptr, nullptr, 0, 1, stream));
+    // 9. dgrad attention-out: dctx = dao Wo
+    VB_TRY(dgrad(dao, H, wo, VB_LWT_AO, H, sc.t_h3, nullptr, VB_ACT_NONE, nullptr));
+    // 10-11. attention backward (dQ pass, dK/dV pass)
+    VB_TRY(vb_attn_bwd(dtype, sv.qkv, mask_add, sc.t_h3, sv.lse, sv.keepbits, sc.dsum, sc.t_3h, B, S, nh, 64, p_attn,
+                       seed, sid, stream));
+    // 12. bias gradient QKV
+    VB_TRY(vb_colsum(dtype, sc.t_3h, 3 * H, G[VB_LW_QKV_B], nullptr, M, 3 * H, stream));
+    // 13. wgrad QKV: dW[3H,H] += dqkv^T h_in
+    VB_TRY(vb_gemm(dtype, VB_F32, VB_KSTRIDED, VB_KSTRIDED, sc.t_3h, 3 * H, h_in, H, G[VB_LW_QKV_W], H, 3 * H, H, M, 1.f,
+                   nullptr, nullptr, nullptr, 0, VB_ACT_NONE, nullptr, nullptr, 0, 1, stream));
+    // 14. dgrad QKV + residual gradient: dh = dqkv Wqkv + dz1
+    VB_TRY(dgrad(sc.t_3h, 3 * H, wqkv, VB_LWT_QKV, H, d_in, dz1, VB_ACT_NONE, nullptr));
+    return VB_OK;
+}

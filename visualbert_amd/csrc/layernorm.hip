@@ -109,11 +109,13 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) ln_fwd_kernel(LnFwdArgs a) {
 struct LnBwdArgs {
     const void* dy; const void* z; const float* mean; const float* rstd; const float* gamma;
     void* dz; void* dx; float* dgamma; float* dbeta; float* dbias; int M, H; DropSpec din, dout;
+    float* partials;     // [gridDim.x][3][H] when the two-stage column reduction is used, else NULL
 };
 
-// add this block's per-lane column partials (one value per owned column) into LDS, then into HBM
+// add this block's per-lane column partials (one value per owned column) into LDS, then either into
+// this block's row of the partials workspace (two-stage, no global atomics) or straight into HBM
 template <int NC>
-VB_DEVICE void block_colsum_flush(float (&acc)[NC][8], float* lds, float* out, int H, int l32) {
+VB_DEVICE void block_colsum_flush(float (&acc)[NC][8], float* lds, float* out, int H, int l32, float* part = nullptr) {
     for (int i = threadIdx.x; i < H; i += NT) lds[i] = 0.f;
     __syncthreads();
 #pragma unroll
@@ -125,8 +127,28 @@ VB_DEVICE void block_colsum_flush(float (&acc)[NC][8], float* lds, float* out, i
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < H; i += NT) atomicAdd(&out[i], lds[i]);
+    if (part) { for (int i = threadIdx.x; i < H; i += NT) part[i] = lds[i]; }
+    else { for (int i = threadIdx.x; i < H; i += NT) atomicAdd(&out[i], lds[i]); }
     __syncthreads();
+}
+
+// second stage: out[c] += sum over blocks of partials[b][which][c]
+VB_KERNEL VB_LAUNCH_BOUNDS(NT) ln_bwd_reduce_kernel(const float* partials, int nblocks, int H, float* dgamma,
+                                                   float* dbeta, float* dbias) {
+    const int c = blockIdx.x * NT + threadIdx.x;
+    const int which = blockIdx.y;
+    float* out = which == 0 ? dgamma : (which == 1 ? dbeta : dbias);
+    if (c >= H || !out) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = 0;
+    for (; b + 4 <= nblocks; b += 4) {
+        s0 += partials[((long)(b + 0) * 3 + which) * H + c];
+        s1 += partials[((long)(b + 1) * 3 + which) * H + c];
+        s2 += partials[((long)(b + 2) * 3 + which) * H + c];
+        s3 += partials[((long)(b + 3) * 3 + which) * H + c];
+    }
+    for (; b < nblocks; ++b) s0 += partials[((long)b * 3 + which) * H + c];
+    out[c] += (s0 + s1) + (s2 + s3);
 }
 
 template <typename T, int NC>
@@ -191,9 +213,10 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) ln_bwd_kernel(LnBwdArgs a) {
             }
         }
     }
-    if (a.dgamma) block_colsum_flush<NC>(acc_g, lds, a.dgamma, H, l32);
-    if (a.dbeta) block_colsum_flush<NC>(acc_b, lds, a.dbeta, H, l32);
-    if (a.dbias) block_colsum_flush<NC>(acc_x, lds, a.dbias, H, l32);
+    float* part = a.partials ? a.partials + (long)blockIdx.x * 3 * H : nullptr;
+    if (a.dgamma) block_colsum_flush<NC>(acc_g, lds, a.dgamma, H, l32, part);
+    if (a.dbeta) block_colsum_flush<NC>(acc_b, lds, a.dbeta, H, l32, part ? part + H : nullptr);
+    if (a.dbias) block_colsum_flush<NC>(acc_x, lds, a.dbias, H, l32, part ? part + 2 * H : nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -354,20 +377,28 @@ extern "C" int vb_ln_fwd(int dtype, const void* x, const void* resid, void* z_ou
     return vb_check_launch();
 }
 
+extern "C" int64_t vb_ln_bwd_ws_bytes(int M, int H) {
+    return (int64_t)row_grid(M, 1024) * 3 * H * (int64_t)sizeof(float);
+}
+
 extern "C" int vb_ln_bwd(int dtype, const void* dy, const void* z, const float* mean, const float* rstd,
                          const float* gamma, void* dz, void* dx, float* dgamma, float* dbeta, float* dbias,
                          int M, int H, float p_in, uint32_t stream_in, float p_out, uint32_t stream_out,
-                         uint64_t seed, void* stream) {
+                         uint64_t seed, float* ws, void* stream) {
     if (!dy || !z || !mean || !rstd || !gamma || !dz || M <= 0 || bad_h(H)) return VB_ERR_ARG;
     if (p_in > 0.f && (!dx || dx == dz)) return VB_ERR_ARG;   // dropped and un-dropped grads differ
     LnBwdArgs a{dy, z, mean, rstd, gamma, dz, dx, dgamma, dbeta, dbias, M, H, make_drop(p_in, seed, stream_in),
-                make_drop(p_out, seed, stream_out)};
-    dim3 grid(row_grid(M, 512));
+                make_drop(p_out, seed, stream_out), ws};
+    dim3 grid(row_grid(M, ws ? 1024 : 256));
     hipStream_t s = (hipStream_t)stream;
     const size_t smem = (size_t)H * sizeof(float);
     if (dtype == VB_BF16) VB_DISPATCH_NC(ln_bwd_kernel, bf16, H, grid, smem, s, a);
     else if (dtype == VB_F32) VB_DISPATCH_NC(ln_bwd_kernel, float, H, grid, smem, s, a);
     else return VB_ERR_ARG;
+    if (ws && (dgamma || dbeta || dbias)) {
+        dim3 g2((unsigned)((H + NT - 1) / NT), 3);
+        VB_LAUNCH(ln_bwd_reduce_kernel, g2, dim3(NT), 0, s, (const float*)ws, (int)grid.x, H, dgamma, dbeta, dbias);
+    }
     return vb_check_launch();
 }
 

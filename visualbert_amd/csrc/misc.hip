@@ -83,7 +83,17 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) colsum_kernel(const T* x, long ld, float* out, co
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
     if (col < N) {
         const bool vec = (col + 8 <= N) && ((ld & 7) == 0);
-        for (int r = r0 + wave; r < r1; r += 4) {
+        int r = r0 + wave;
+        if (vec) {
+            for (; r + 12 < r1; r += 16) {                         // 4 independent 16-byte loads in flight
+                float v0[8], v1[8], v2[8], v3[8];
+                load8(v0, x + (long)r * ld + col); load8(v1, x + (long)(r + 4) * ld + col);
+                load8(v2, x + (long)(r + 8) * ld + col); load8(v3, x + (long)(r + 12) * ld + col);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += (v0[j] + v1[j]) + (v2[j] + v3[j]);
+            }
+        }
+        for (; r < r1; r += 4) {
             const T* p = x + (long)r * ld + col;
             if (vec) {
                 float v[8]; load8(v, p);
@@ -182,8 +192,8 @@ extern "C" int vb_scatter_rows(int dtype, const void* dout, const int64_t* index
 extern "C" int vb_colsum(int dtype, const void* x, int64_t ld, float* out, const float* scale_dev, int M, int N,
                          void* stream) {
     if (!x || !out || M <= 0 || N <= 0) return VB_ERR_ARG;
-    int rb = (M + 63) / 64;                     // <= 64 row blocks
-    if (rb < 16) rb = 16;
+    int rb = 64;                                // rows per block (4 waves x 16 rows)
+    while ((long)((M + rb - 1) / rb) * ((N + 511) / 512) > 4096) rb *= 2;
     dim3 grid((unsigned)((N + 511) / 512), (unsigned)((M + rb - 1) / rb));
     hipStream_t s = (hipStream_t)stream;
     const size_t smem = 4 * 512 * sizeof(float);

@@ -94,6 +94,34 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) shadow_refresh_kernel(const float* params, bf16* 
     for (long i = threadIdx.x; i < len; i += NT) shadow[sh_off + (off + i - t_off)] = (bf16)params[off + i];
 }
 
+
+// multi-tensor tiled transpose of bf16 weight shadows: for every GEMM weight W [R,C] keep W^T [C, R_pad]
+// so that dgrad (dx = dy W) runs as a K-contiguous x K-contiguous GEMM with LDS-direct loads.
+// tensors: int64[n][5] = {src offset, R, C, dst offset, dst ld}; tiles: int64[n_tiles][3] = {tensor, tile row, tile col}
+VB_KERNEL VB_LAUNCH_BOUNDS(NT) shadow_transpose_kernel(const bf16* src, bf16* dst, const int64_t* tensors,
+                                                      const int64_t* tiles) {
+    VB_DYN_SMEM(smem);
+    bf16* tile = (bf16*)smem;                       // [64][66]
+    const int64_t* tl = tiles + (long)blockIdx.x * 3;
+    const int64_t* te = tensors + tl[0] * 5;
+    const long soff = te[0], R = te[1], C = te[2], doff = te[3], dld = te[4];
+    const long r0 = tl[1] * 64, c0 = tl[2] * 64;
+    for (int i = threadIdx.x; i < 64 * 8; i += NT) {
+        const int r = i >> 3, cc = (i & 7) * 8;
+        const long gr = r0 + r, gc = c0 + cc;
+        bf16 v[8];
+        for (int j = 0; j < 8; ++j) v[j] = (gr < R && gc + j < C) ? src[soff + gr * C + gc + j] : (bf16)0.0f;
+        for (int j = 0; j < 8; ++j) tile[r * 66 + cc + j] = v[j];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 8; i += NT) {
+        const int c = i >> 3, rr = (i & 7) * 8;      // output row = source column
+        const long gc = c0 + c, gr = r0 + rr;
+        if (gc >= C) continue;
+        for (int j = 0; j < 8; ++j) if (gr + j < R) dst[doff + gc * dld + gr + j] = tile[(rr + j) * 66 + c];
+    }
+}
+
 }  // namespace
 
 extern "C" int vb_bert_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
@@ -122,5 +150,13 @@ extern "C" int vb_refresh_bf16_shadow(const float* params, void* bf16_shadow, co
     if (!params || !bf16_shadow || !chunk_table || !tensor_table || n_chunks <= 0) return VB_ERR_ARG;
     VB_LAUNCH(shadow_refresh_kernel, dim3((unsigned)n_chunks), dim3(NT), 0, (hipStream_t)stream, params,
               (bf16*)bf16_shadow, chunk_table, tensor_table);
+    return vb_check_launch();
+}
+
+extern "C" int vb_refresh_transposed_shadow(const void* bf16_shadow, void* bf16_shadow_t, const int64_t* tensor_table5,
+                                            const int64_t* tile_table3, int n_tiles, void* stream) {
+    if (!bf16_shadow || !bf16_shadow_t || !tensor_table5 || !tile_table3 || n_tiles <= 0) return VB_ERR_ARG;
+    VB_LAUNCH(shadow_transpose_kernel, dim3((unsigned)n_tiles), dim3(NT), 64 * 66 * 2, (hipStream_t)stream,
+              (const bf16*)bf16_shadow, (bf16*)bf16_shadow_t, tensor_table5, tile_table3);
     return vb_check_launch();
 }

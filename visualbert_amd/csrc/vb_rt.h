@@ -113,6 +113,25 @@ VB_DEVICE f32x4 vb_mma(f32x8 a, f32x8 b, f32x4 c) {
 #endif
 
 // ------------------------------------------------------------------------------------------
+// Direct global -> LDS copy, 16 bytes per lane (global_load_lds_dwordx4): the source address is per
+// lane, the destination is `lds_wave_base + lane * 16` with a WAVE-UNIFORM base (it travels in M0).
+// Data is visible to LDS readers after the wave's vmcnt drains and a workgroup barrier
+// (hipcc's __syncthreads() emits the vmcnt(0) while such a load is in flight).
+// ------------------------------------------------------------------------------------------
+#ifdef VB_EMU
+VB_DEVICE void vb_glds16(const void* gsrc, unsigned char* lds_wave_base) {
+    memcpy(lds_wave_base + ::hipemu::cur()->lane * 16, gsrc, 16);
+}
+VB_DEVICE void vb_atomic_add_noret(float* p, float v) { ::hipemu::atomic_add_f32(p, v); }
+#else
+VB_DEVICE void vb_glds16(const void* gsrc, unsigned char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+VB_DEVICE void vb_atomic_add_noret(float* p, float v) { unsafeAtomicAdd(p, v); }   // global_atomic_add_f32, no return
+#endif
+
+// ------------------------------------------------------------------------------------------
 // wave (64-lane) reductions
 // ------------------------------------------------------------------------------------------
 VB_DEVICE float wave_sum(float v) {

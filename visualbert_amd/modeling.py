@@ -123,6 +123,57 @@ class ParameterArena(object):
         # buckets for the gradient all-reduce: contiguous [start, end) ranges, in arena order
         self.bucket_of = bucket_of
         self._tables = None
+        self._build_transposed()
+
+    # -- W^T shadows (bf16): dgrad dx = dy W then reads both operands K-contiguously ------------------
+    def _build_transposed(self):
+        ents = []                                   # (param list, src offset, R, C)
+        i = 0
+        while i < len(self.params):
+            n, p, o = self.names[i], self.params[i], self.offsets[i]
+            if n.endswith(".attention.self.query.weight") and i + 2 < len(self.params) and \
+                    self.names[i + 1].endswith(".key.weight") and self.names[i + 2].endswith(".value.weight") and \
+                    self.offsets[i + 1] == o + p.numel() and self.offsets[i + 2] == o + 2 * p.numel():
+                ents.append(([p, self.params[i + 1], self.params[i + 2]], o, 3 * p.size(0), p.size(1)))
+                i += 3
+                continue
+            if p.dim() == 2 and (n.endswith("dense.weight") or n.endswith("word_embeddings.weight")):
+                ents.append(([p], o, p.size(0), p.size(1)))
+            i += 1
+        off = 0
+        table, tiles = [], []
+        self._t_entries = []
+        for ti, (plist, so, R, C) in enumerate(ents):
+            ld = ops.round_up(R, 64)
+            table += [so, R, C, off, ld]
+            for tr in range((R + 63) // 64):
+                for tc in range((C + 63) // 64):
+                    tiles += [ti, tr, tc]
+            self._t_entries.append((plist, off, R, C, ld))
+            off += C * ld
+        self.shadow_t = torch.zeros(max(off, 1), dtype=torch.bfloat16, device=self.device)
+        self._t_table = torch.tensor(table, dtype=torch.int64).to(self.device) if table else None
+        self._t_tiles = torch.tensor(tiles, dtype=torch.int64).to(self.device) if tiles else None
+        self._t_ntiles = len(tiles) // 3
+        for plist, o, R, C, ld in self._t_entries:
+            view = self.shadow_t[o:o + C * ld].as_strided((C, R), (ld, 1), o)
+            for p in plist:
+                p._vb_shadow_t_ver = -1
+            if len(plist) == 1:
+                plist[0]._vb_shadow_t = view
+            else:
+                plist[0]._vb_packed_shadow_t = view
+
+    def refresh_transposed(self):
+        if self._t_table is None:
+            return
+        _lib.check(_lib.lib().vb_refresh_transposed_shadow(_lib.ptr(self.shadow), _lib.ptr(self.shadow_t),
+                                                           _lib.ptr(self._t_table), _lib.ptr(self._t_tiles),
+                                                           self._t_ntiles, _lib.stream_ptr()),
+                   "vb_refresh_transposed_shadow")
+        for plist, _, _, _, _ in self._t_entries:
+            for p in plist:
+                p._vb_shadow_t_ver = p._vb_shadow_ver
 
     def range_of(self, names_prefixes):
         lo, hi = None, None
@@ -216,7 +267,12 @@ class BertSelfAttention(nn.Module):
 
     def _pack(self):
         """(re)establish adjacency of q/k/v storage when the parameters are not arena-managed."""
+        key = (self.query.weight.data_ptr(), self.key.weight.data_ptr(), self.value.weight.data_ptr(),
+               self.query.bias.data_ptr())
+        if getattr(self, "_pack_key", None) == key:
+            return                                        # storage unchanged since the last check
         if self._adjacent():
+            self._pack_key = key
             return
         if getattr(self.query.weight, "_vb_arena", None) is not None:
             raise RuntimeError("visualbert_amd: q/k/v parameters are arena-managed but not adjacent")
@@ -320,6 +376,21 @@ class _PackedWeight(object):
                 p._vb_shadow_ver = p._version
         else:
             o._packed_shadow_ver = v
+
+    # W^T [H, 3H] (arena-managed bf16 only)
+    @property
+    def _vb_shadow_t(self):
+        return getattr(self._o.query.weight, "_vb_packed_shadow_t", None)
+
+    @property
+    def _vb_shadow_t_ver(self):
+        o = self._o
+        ok = all(getattr(p, "_vb_shadow_t_ver", -1) == p._version for p in (o.query.weight, o.key.weight, o.value.weight))
+        return self._version if ok else -1
+
+    @property
+    def _vb_arena(self):
+        return getattr(self._o.query.weight, "_vb_arena", None)
 
 
 class _PackedLinearFn(torch.autograd.Function):
@@ -455,6 +526,21 @@ class BertLayer(nn.Module):
             raise NotImplementedError("output_attention_weights")
         if self.grad_ready_hook is not None and torch.is_grad_enabled() and hidden_states.requires_grad:
             hidden_states = _GradReadyFn.apply(hidden_states, self)
+        at, im, om = self.attention, self.intermediate, self.output
+        sa, so = at.self, at.output
+        B, S, H = hidden_states.shape
+        mask_add = attention_mask.reshape(B, S)
+        if mask_add.dtype != torch.float32 or not mask_add.is_contiguous():
+            mask_add = mask_add.to(torch.float32).contiguous()
+        return ops.BertLayerFn.apply(
+            hidden_states, mask_add, self, _drop_p(om.dropout, self.training), _drop_p(sa.dropout, self.training),
+            sa.query.weight, sa.query.bias, sa.key.weight, sa.key.bias, sa.value.weight, sa.value.bias,
+            so.dense.weight, so.dense.bias, so.LayerNorm.weight, so.LayerNorm.bias,
+            im.dense.weight, im.dense.bias, om.dense.weight, om.dense.bias, om.LayerNorm.weight, om.LayerNorm.bias)
+
+    def forward_unfused(self, hidden_states, attention_mask):
+        """the same layer as two autograd nodes (attention block, FFN block) -- kept for tests that compare
+        the single-call path against the op-by-op path."""
         attention_output = self.attention(hidden_states, attention_mask)
         im, om = self.intermediate, self.output
         return ops.FFNBlockFn.apply(attention_output, im, om, _drop_p(om.dropout, self.training), om._sid,

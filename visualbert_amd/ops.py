@@ -84,6 +84,20 @@ def weight_for(p, dtype):
     return sh
 
 
+def weight_t_for(p, dtype):
+    """W^T (bf16, [in, out] with a padded leading dimension) for dgrad, or None when the parameter has no
+    arena-managed transposed shadow (fp32 mode, stand-alone modules): dgrad then reads W K-strided."""
+    if dtype != torch.bfloat16:
+        return None
+    wt = getattr(p, "_vb_shadow_t", None)
+    if wt is None:
+        return None
+    if p._vb_shadow_t_ver != p._version:
+        weight_for(p, dtype)                       # bf16 shadow first, then all transposes in one launch
+        p._vb_arena.refresh_transposed()
+    return wt
+
+
 def grad_target(p):
     """(fp32 tensor to accumulate into, direct?)"""
     g = getattr(p, "_vb_grad", None)
@@ -105,38 +119,37 @@ def cast(src, dst):
     return dst
 
 
-class GemmProfiler(object):
-    """HIP-event timing of every vb_gemm launch on the stream it is launched on (bench.py's roofline
-    leg).  Keyed by kernel instantiation: (dtype, out dtype, A layout, B layout)."""
-
-    def __init__(self):
-        self.records = []
-
-    def launch(self, key, flops, fn):
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
-        r = fn()
-        e1.record()
-        self.records.append((key, flops, e0, e1))
-        return r
-
-    def summary(self):
-        """call after torch.cuda.synchronize(): {key: dict(ms, flops, launches)}"""
-        out = {}
-        for key, flops, e0, e1 in self.records:
-            d = out.setdefault(key, dict(ms=0.0, flops=0.0, launches=0))
-            d["ms"] += e0.elapsed_time(e1)
-            d["flops"] += flops
-            d["launches"] += 1
-        return out
+def gemm_profile_start():
+    """HIP-event timing of every vb_gemm launch, recorded inside the library on the launch stream."""
+    check(_lib.lib().vb_gemm_profile(1), "vb_gemm_profile")
 
 
-_profiler = [None]
+def gemm_profile_stop():
+    """call after torch.cuda.synchronize(): {key: dict(ms, flops, launches)}; key = kernel instantiation."""
+    import ctypes
+    L = _lib.lib()
+    cap = 1 << 20
+    ms = (ctypes.c_double * cap)()
+    fl = (ctypes.c_double * cap)()
+    ky = (ctypes.c_int * cap)()
+    n = L.vb_gemm_profile_read(ms, fl, ky, cap)
+    if n < 0:
+        raise RuntimeError("vb_gemm_profile_read failed (device not synchronised?)")
+    out = {}
+    for i in range(n):
+        d = out.setdefault(ky[i], dict(ms=0.0, flops=0.0, launches=0))
+        d["ms"] += ms[i]
+        d["flops"] += fl[i]
+        d["launches"] += 1
+    L.vb_gemm_profile(0)
+    return out
 
 
-def set_gemm_profiler(p):
-    _profiler[0] = p
+def gemm_key_name(key):
+    return "gemm_kernel<%s->%s, A %s, B %s>" % ("fp32" if key & 8 else "bf16",
+                                                "fp32" if (key & 4 or key & 8) else "bf16",
+                                                "Kstrided" if key & 2 else "Kcontig",
+                                                "Kstrided" if key & 1 else "Kcontig")
 
 
 def gemm(a, b, M, N, K, a_layout=VB_KCONTIG, b_layout=VB_KCONTIG, out=None, out_dtype=None, bias=None, act=VB_ACT_NONE,
@@ -154,13 +167,7 @@ def gemm(a, b, M, N, K, a_layout=VB_KCONTIG, b_layout=VB_KCONTIG, out=None, out_
                                   ptr(alpha_dev), ptr(bias), ptr(addend), _ld(addend) if addend is not None else 0,
                                   act, ptr(aux_in), ptr(aux_out), _ld(aux) if aux is not None else 0,
                                   1 if accumulate else 0, stream_ptr())
-    prof = _profiler[0]
-    if prof is not None:
-        key = (str(dt), str(out.dtype), a_layout, b_layout)
-        rc = prof.launch(key, 2.0 * M * N * K, run)
-    else:
-        rc = run()
-    check(rc, "vb_gemm")
+    check(run(), "vb_gemm")
     return out
 
 
@@ -171,10 +178,14 @@ def linear_fwd(x, w, bias, act=VB_ACT_NONE, aux_out=None, out_dtype=None, addend
     return gemm(x, w, M, N, K, bias=bias, act=act, aux_out=aux_out, out_dtype=out_dtype, addend=addend)
 
 
-def linear_dgrad(dy, w, act=VB_ACT_NONE, aux_in=None, addend=None, out=None, alpha_dev=None):
-    """dx = (dy w) [* gelu'(aux_in)] [+ addend]; dy [M,N], w [N,K] read K-strided."""
+def linear_dgrad(dy, w, act=VB_ACT_NONE, aux_in=None, addend=None, out=None, alpha_dev=None, wt=None, k_pad=None):
+    """dx = (dy w) [* gelu'(aux_in)] [+ addend]; dy [M,N], w [N,K].  With wt = w^T ([K, ld >= N]) both operands
+    are K-contiguous (LDS-direct loads); otherwise w is read K-strided.  k_pad: reduce over this many
+    columns instead of N when BOTH dy and wt are zero-padded that far (ragged vocabulary)."""
     M, N = dy.shape
     K = w.shape[1]
+    if wt is not None:
+        return gemm(dy, wt, M, K, k_pad or N, act=act, aux_in=aux_in, addend=addend, out=out, alpha_dev=alpha_dev)
     return gemm(dy, w, M, K, N, b_layout=VB_KSTRIDED, act=act, aux_in=aux_in, addend=addend, out=out,
                 alpha_dev=alpha_dev)
 
@@ -224,9 +235,10 @@ def ln_bwd(dy, z, mean, rstd, gamma, dgamma, dbeta, dbias=None, p_in=0.0, sid_in
         dy = dy.contiguous()
     dz = torch.empty((M, H), dtype=dy.dtype, device=dy.device)
     dx = torch.empty((M, H), dtype=dy.dtype, device=dy.device) if p_in > 0.0 else dz
+    ws = torch.empty(_lib.lib().vb_ln_bwd_ws_bytes(M, H) // 4, dtype=torch.float32, device=dy.device)
     check(_lib.lib().vb_ln_bwd(_lib.dtype_code(dy.dtype), ptr(dy), ptr(z), ptr(mean), ptr(rstd), ptr(gamma), ptr(dz),
                                ptr(dx), ptr(dgamma), ptr(dbeta), ptr(dbias), M, H, float(p_in), sid_in, float(p_out),
-                               sid_out, seed, stream_ptr()), "vb_ln_bwd")
+                               sid_out, seed, ptr(ws), stream_ptr()), "vb_ln_bwd")
     return dz, dx
 
 
@@ -319,7 +331,7 @@ class LinearFn(torch.autograd.Function):
         w = weight_for(ctx.weight, x2.dtype)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = linear_dgrad(dy2, w).reshape(ctx.x_shape)
+            dx = linear_dgrad(dy2, w, wt=weight_t_for(ctx.weight, x2.dtype)).reshape(ctx.x_shape)
         gw, direct_w = grad_target(ctx.weight)
         linear_wgrad(dy2, x2, gw)
         gb_out = None
@@ -502,6 +514,112 @@ class FFNBlockFn(torch.autograd.Function):
                 grad_result(g_ln_w, d1), grad_result(g_ln_b, d2))
 
 
+_scratch = {}
+
+
+def layer_scratch(nbytes, device):
+    """one reusable scratch buffer per device (all layers run on one stream, strictly in sequence)."""
+    buf = _scratch.get(device)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _scratch[device] = buf
+    return buf
+
+
+def _ptr_array(items):
+    import ctypes
+    arr = (ctypes.c_void_p * len(items))()
+    for i, t in enumerate(items):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+class BertLayerFn(torch.autograd.Function):
+    """A whole BertLayer (modeling.py:331-341) as ONE autograd node: forward and backward are one C-ABI
+    call each (vb_bert_layer_fwd / vb_bert_layer_bwd, csrc/layer.hip sequences the 7 + 15 launches)."""
+
+    @staticmethod
+    def forward(ctx, h, mask_add, layer, p_hidden, p_attn, *params):
+        B, S, H = h.shape
+        at, im, om = layer.attention, layer.intermediate, layer.output
+        sa, so = at.self, at.output
+        h2 = h.reshape(B * S, H)
+        if not h2.is_contiguous():
+            h2 = h2.contiguous()
+        dt = h2.dtype
+        code = _lib.dtype_code(dt)
+        I = im.dense.weight.size(0)
+        nh = sa.num_attention_heads
+        L = _lib.lib()
+        nsaved = L.vb_bert_layer_saved_bytes(code, B, S, H, I, nh, float(p_attn))
+        nscr = L.vb_bert_layer_scratch_bytes(code, B, S, H, I, nh)
+        if nsaved < 0 or nscr < 0:
+            raise RuntimeError("visualbert_amd: unsupported BertLayer shape B=%d S=%d H=%d I=%d heads=%d" % (B, S, H, I, nh))
+        saved = torch.empty(nsaved, dtype=torch.uint8, device=h2.device)
+        scratch = layer_scratch(nscr, h2.device)
+        out = torch.empty((B * S, H), dtype=dt, device=h2.device)
+        wqkv = weight_for(sa.qkv_weight, dt)
+        weights = [wqkv, sa.qkv_bias, weight_for(so.dense.weight, dt), so.dense.bias.detach(),
+                   so.LayerNorm.weight.detach(), so.LayerNorm.bias.detach(),
+                   weight_for(im.dense.weight, dt), im.dense.bias.detach(),
+                   weight_for(om.dense.weight, dt), om.dense.bias.detach(),
+                   om.LayerNorm.weight.detach(), om.LayerNorm.bias.detach()]
+        seed = next_seed()
+        sid = layer.attention._sid
+        check(L.vb_bert_layer_fwd(code, ptr(h2), ptr(mask_add), ptr(out), ptr(saved), ptr(scratch), _ptr_array(weights),
+                                  B, S, H, I, nh, float(p_hidden), float(p_attn), float(so.LayerNorm.variance_epsilon),
+                                  seed, sid, stream_ptr()), "vb_bert_layer_fwd")
+        ctx.layer = layer
+        ctx.cfg = (B, S, H, I, nh, p_hidden, p_attn, seed, sid)
+        ctx.save_for_backward(h2, mask_add, saved)
+        return out.view(B, S, H)
+
+    @staticmethod
+    def backward(ctx, dy):
+        h2, mask_add, saved = ctx.saved_tensors
+        B, S, H, I, nh, p_hidden, p_attn, seed, sid = ctx.cfg
+        layer = ctx.layer
+        at, im, om = layer.attention, layer.intermediate, layer.output
+        sa, so = at.self, at.output
+        dt = h2.dtype
+        code = _lib.dtype_code(dt)
+        dy2 = dy.reshape(B * S, H)
+        if dy2.dtype != dt:
+            dy2 = dy2.to(dt)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        L = _lib.lib()
+        scratch = layer_scratch(L.vb_bert_layer_scratch_bytes(code, B, S, H, I, nh), h2.device)
+        weights = [weight_for(sa.qkv_weight, dt), sa.qkv_bias, weight_for(so.dense.weight, dt), so.dense.bias.detach(),
+                   so.LayerNorm.weight.detach(), so.LayerNorm.bias.detach(),
+                   weight_for(im.dense.weight, dt), im.dense.bias.detach(),
+                   weight_for(om.dense.weight, dt), om.dense.bias.detach(),
+                   om.LayerNorm.weight.detach(), om.LayerNorm.bias.detach()]
+        g_qkv_w, g_qkv_b, direct_qkv = sa.qkv_grad_targets()
+        rest = [so.dense.weight, so.dense.bias, so.LayerNorm.weight, so.LayerNorm.bias, im.dense.weight, im.dense.bias,
+                om.dense.weight, om.dense.bias, om.LayerNorm.weight, om.LayerNorm.bias]
+        tg = [grad_target(p) for p in rest]
+        grads = [g_qkv_w, g_qkv_b] + [t[0] for t in tg]
+        d_in = torch.empty((B * S, H), dtype=dt, device=h2.device)
+        import ctypes
+        wts = [weight_t_for(sa.qkv_weight, dt), weight_t_for(so.dense.weight, dt), weight_t_for(im.dense.weight, dt),
+               weight_t_for(om.dense.weight, dt)]
+        wt_arr = (ctypes.c_void_p * 4)()
+        ld_arr = (ctypes.c_int64 * 4)()
+        for i, w_ in enumerate(wts):
+            wt_arr[i] = w_.data_ptr() if w_ is not None else None
+            ld_arr[i] = w_.stride(0) if w_ is not None else 0
+        check(L.vb_bert_layer_bwd(code, ptr(h2), ptr(mask_add), ptr(dy2), ptr(d_in), ptr(saved), ptr(scratch),
+                                  _ptr_array(weights), _ptr_array(grads), wt_arr, ld_arr, B, S, H, I, nh,
+                                  float(p_hidden), float(p_attn), seed, sid, stream_ptr()), "vb_bert_layer_bwd")
+        if direct_qkv:
+            gq = [None] * 6
+        else:
+            gw, gb = g_qkv_w.view(3, H, H), g_qkv_b.view(3, H)
+            gq = [gw[0], gb[0], gw[1], gb[1], gw[2], gb[2]]
+        return (d_in.view(B, S, H), None, None, None, None, *gq, *[grad_result(g, d) for g, d in tg])
+
+
 class EmbeddingsFn(torch.autograd.Function):
     """BertEmbeddingsWithVisualEmbedding.forward (modeling.py:1198-1257, image_text_alignment=None):
     region projection GEMM, gather-add of the five tables, concat, LayerNorm, dropout."""
@@ -607,7 +725,7 @@ class MLMHeadLossFn(torch.autograd.Function):
         if labels is not None:
             acc = torch.empty(2, dtype=torch.float32, device=s2.device)
             loss = torch.empty(1, dtype=torch.float32, device=s2.device)
-            dlogits = alloc2d(B * S, V, dt, s2.device)
+            dlogits = torch.empty((B * S, round_up(V, 64)), dtype=dt, device=s2.device)[:, :V]
             lab = labels.reshape(-1).contiguous()
             check(_lib.lib().vb_ce_fwd_bwd(_lib.dtype_code(dt), ptr(logits), _ld(logits), ptr(lab), -1, ptr(acc),
                                            ptr(loss), ptr(dlogits), _ld(dlogits), B * S, V, stream_ptr()),
@@ -634,7 +752,11 @@ class MLMHeadLossFn(torch.autograd.Function):
         dt = s2.dtype
         up = _upstream_scalar(dloss)
         E = weight_for(ctx.word_weight, dt)
-        dtn = linear_dgrad(dlogits, E, alpha_dev=up)
+        Et = weight_t_for(ctx.word_weight, dt)
+        k_pad = None
+        if Et is not None and Et.stride(0) == _ld(dlogits) and (Et.stride(0) % 64) == 0:
+            k_pad = Et.stride(0)                    # both pads are zero: reduce over whole K tiles (LDS-direct)
+        dtn = linear_dgrad(dlogits, E, alpha_dev=up, wt=Et, k_pad=k_pad)
         g_E, d1 = grad_target(ctx.word_weight)
         linear_wgrad(dlogits, tn, g_E, alpha_dev=up)
         g_db, d2 = grad_target(head.bias)
@@ -647,7 +769,7 @@ class MLMHeadLossFn(torch.autograd.Function):
         g_tb, d6 = grad_target(tr.dense.bias)
         linear_wgrad(dpre, s2, g_tw)
         colsum(dpre, g_tb)
-        dseq = linear_dgrad(dpre, weight_for(tr.dense.weight, dt))
+        dseq = linear_dgrad(dpre, weight_for(tr.dense.weight, dt), wt=weight_t_for(tr.dense.weight, dt))
         return (dseq.view(B, S, H), None, None, grad_result(g_E, d1), grad_result(g_db, d2), grad_result(g_tw, d5),
                 grad_result(g_tb, d6), grad_result(g_lw, d3), grad_result(g_lb, d4))
 

@@ -186,6 +186,7 @@ class BertAdam(Optimizer):
         for p in a.params:
             if p.dim() == 2 and id(p) in member:
                 p._vb_shadow_ver = p._version
+        a.refresh_transposed()                       # W^T copies for the next backward (one launch)
         return loss
 
     # -- checkpoint compatibility: per-parameter {'step', 'next_m', 'next_v'} like the reference ------

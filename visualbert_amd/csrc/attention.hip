@@ -193,7 +193,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
         for (int kf = 0; kf < NKF; ++kf)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { st[kf][r] = expf(st[kf][r] - m); sum += st[kf][r]; }
+            for (int r = 0; r < 4; ++r) { st[kf][r] = fast_exp(st[kf][r] - m); sum += st[kf][r]; }
         sum += __shfl_xor(sum, 16);
         sum += __shfl_xor(sum, 32);
         const float inv = 1.0f / sum;
@@ -296,7 +296,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) attn_bwd_dq_kernel(AttnArgs a) {
             const f32x4 mk = *(const f32x4*)(ldsMask + kf * 16 + lg * 4);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = expf(s[r] * a.scale + mk[r] - lse);            // 0 for keys >= S
+                const float p = fast_exp(s[r] * a.scale + mk[r] - lse);            // 0 for keys >= S
                 const bool keep = (bits[kf >> 4] >> ((kf & 15) * 4 + r)) & 1;
                 const float dpv = keep ? dp[r] * a.inv_keep : 0.f;
                 dsum += p * dpv;
@@ -408,7 +408,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) attn_bwd_dkv_kernel(AttnArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int ql = qf * 16 + lg * 4 + r;
-                    const float p = expf(s[r] * a.scale + mk - lse4[r]);
+                    const float p = fast_exp(s[r] * a.scale + mk - lse4[r]);
                     const uint64_t w = ldsBits[(ql * 4 + (li >> 2)) * NW + (kf >> 4)];
                     const bool keep = (w >> ((kf & 15) * 4 + (li & 3))) & 1;
                     const float pdrop = keep ? p * a.inv_keep : 0.f;

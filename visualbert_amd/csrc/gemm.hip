@@ -293,6 +293,19 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) gemm_kernel(GemmArgs g) {
                     *(float*)(slab + row * EPI_PITCH + col * 4) = acc[pass * 2 + mh][ni][r];
                 }
         __syncthreads();
+        if (g.splits > 1) {
+            // partial tile of an fp32 accumulator: one fire-and-forget atomic per element, a wave covering
+            // 64 CONSECUTIVE columns of one row per instruction (4 cache lines, not 64 scattered words)
+            if constexpr (sizeof(TO) == 4) {
+                const int n = n0 + wn * 64 + lane;
+                for (int row = 0; row < 32; ++row) {
+                    const int m = m0 + wm * 64 + pass * 32 + row;
+                    if (m < g.M && n < g.N)
+                        vb_atomic_add_noret((float*)C + (long)m * g.ldc + n, alpha * *(const float*)(slab + row * EPI_PITCH + lane * 4));
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int row = it * 8 + (lane >> 3), cc = lane & 7;
@@ -342,13 +355,6 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) gemm_kernel(GemmArgs g) {
                 for (int j = 0; j < 8; ++j) v[j] += x[j];
             }
             TO* cp = C + (long)m * g.ldc + n;
-            if (g.splits > 1) {                                   // fp32 accumulator, partial tile
-                if constexpr (sizeof(TO) == 4) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) if (j < nv) vb_atomic_add_noret((float*)cp + j, v[j]);
-                }
-                continue;
-            }
             if (g.accumulate) {
                 float x[8];
                 if (full && (g.ldc & 7) == 0) load8(x, cp);
@@ -434,7 +440,7 @@ extern "C" int vb_gemm(int dtype, int out_dtype, int a_layout, int b_layout,
     g.splits = 1; g.kt_per_split = nk;
     const int tiles = g.tiles_m * g.tiles_n;
     if (accumulate && out_dtype == VB_F32 && !bias && !addend && act == VB_ACT_NONE && tiles < 256 && nk >= 16) {
-        int want = (512 + tiles - 1) / tiles;
+        int want = (320 + tiles - 1) / tiles;
         int maxs = nk / 8;
         if (want > maxs) want = maxs;
         if (want > 1) {

@@ -112,43 +112,52 @@ struct LnBwdArgs {
     float* partials;     // [gridDim.x][3][H] when the two-stage column reduction is used, else NULL
 };
 
-// add this block's per-lane column partials (one value per owned column) into LDS, then either into
-// this block's row of the partials workspace (two-stage, no global atomics) or straight into HBM
+// reduce this block's per-lane column partials across its 8 half-waves through LDS ([8][H] floats, plain
+// stores -- no LDS atomics), then write them to this block's row of the partials workspace (two-stage
+// path, no global atomics) or add them to HBM with fp32 atomics
 template <int NC>
-VB_DEVICE void block_colsum_flush(float (&acc)[NC][8], float* lds, float* out, int H, int l32, float* part = nullptr) {
-    for (int i = threadIdx.x; i < H; i += NT) lds[i] = 0.f;
+VB_DEVICE void block_colsum_flush(float (&acc)[NC][8], float* lds, float* out, int H, int l32, int hw,
+                                  float* part = nullptr) {
     __syncthreads();
 #pragma unroll
     for (int ci = 0; ci < NC; ++ci) {
         const int col = (l32 + 32 * ci) * 8;
         if (col < H) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) atomicAdd(&lds[col + j], acc[ci][j]);
+            *(f32x4*)(lds + hw * H + col) = f32x4{acc[ci][0], acc[ci][1], acc[ci][2], acc[ci][3]};
+            *(f32x4*)(lds + hw * H + col + 4) = f32x4{acc[ci][4], acc[ci][5], acc[ci][6], acc[ci][7]};
         }
     }
     __syncthreads();
-    if (part) { for (int i = threadIdx.x; i < H; i += NT) part[i] = lds[i]; }
-    else { for (int i = threadIdx.x; i < H; i += NT) atomicAdd(&out[i], lds[i]); }
-    __syncthreads();
+    for (int i = threadIdx.x; i < H; i += NT) {
+        float s = 0.f;
+#pragma unroll
+        for (int h = 0; h < HW_PER_BLOCK; ++h) s += lds[h * H + i];
+        if (part) part[i] = s;
+        else atomicAdd(&out[i], s);
+    }
 }
 
-// second stage: out[c] += sum over blocks of partials[b][which][c]
-VB_KERNEL VB_LAUNCH_BOUNDS(NT) ln_bwd_reduce_kernel(const float* partials, int nblocks, int H, float* dgamma,
-                                                   float* dbeta, float* dbias) {
-    const int c = blockIdx.x * NT + threadIdx.x;
+// second stage: out[c] += sum over blocks of partials[b][which][c].  1024 threads = 32 columns x 32 row
+// groups: coalesced 128-byte reads, 32 independent chains per column, LDS tree at the end.
+VB_KERNEL VB_LAUNCH_BOUNDS(1024) ln_bwd_reduce_kernel(const float* partials, int nblocks, int H, float* dgamma,
+                                                     float* dbeta, float* dbias) {
+    VB_DYN_SMEM(smem);
+    float* red = (float*)smem;                         // [32][33]
+    const int cx = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cx;
     const int which = blockIdx.y;
     float* out = which == 0 ? dgamma : (which == 1 ? dbeta : dbias);
-    if (c >= H || !out) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int b = 0;
-    for (; b + 4 <= nblocks; b += 4) {
-        s0 += partials[((long)(b + 0) * 3 + which) * H + c];
-        s1 += partials[((long)(b + 1) * 3 + which) * H + c];
-        s2 += partials[((long)(b + 2) * 3 + which) * H + c];
-        s3 += partials[((long)(b + 3) * 3 + which) * H + c];
+    float s = 0.f;
+    if (c < H && out) {
+        for (int b = rg; b < nblocks; b += 32) s += partials[((long)b * 3 + which) * H + c];
     }
-    for (; b < nblocks; ++b) s0 += partials[((long)b * 3 + which) * H + c];
-    out[c] += (s0 + s1) + (s2 + s3);
+    red[rg * 33 + cx] = s;
+    __syncthreads();
+    if (rg == 0 && c < H && out) {
+        float t = 0.f;
+        for (int r = 0; r < 32; ++r) t += red[r * 33 + cx];
+        out[c] += t;
+    }
 }
 
 template <typename T, int NC>
@@ -214,9 +223,9 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) ln_bwd_kernel(LnBwdArgs a) {
         }
     }
     float* part = a.partials ? a.partials + (long)blockIdx.x * 3 * H : nullptr;
-    if (a.dgamma) block_colsum_flush<NC>(acc_g, lds, a.dgamma, H, l32, part);
-    if (a.dbeta) block_colsum_flush<NC>(acc_b, lds, a.dbeta, H, l32, part ? part + H : nullptr);
-    if (a.dbias) block_colsum_flush<NC>(acc_x, lds, a.dbias, H, l32, part ? part + 2 * H : nullptr);
+    if (a.dgamma) block_colsum_flush<NC>(acc_g, lds, a.dgamma, H, l32, hw, part);
+    if (a.dbeta) block_colsum_flush<NC>(acc_b, lds, a.dbeta, H, l32, hw, part ? part + H : nullptr);
+    if (a.dbias) block_colsum_flush<NC>(acc_x, lds, a.dbias, H, l32, hw, part ? part + 2 * H : nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -378,7 +387,7 @@ extern "C" int vb_ln_fwd(int dtype, const void* x, const void* resid, void* z_ou
 }
 
 extern "C" int64_t vb_ln_bwd_ws_bytes(int M, int H) {
-    return (int64_t)row_grid(M, 1024) * 3 * H * (int64_t)sizeof(float);
+    return (int64_t)row_grid(M, 512) * 3 * H * (int64_t)sizeof(float);
 }
 
 extern "C" int vb_ln_bwd(int dtype, const void* dy, const void* z, const float* mean, const float* rstd,
@@ -389,15 +398,16 @@ extern "C" int vb_ln_bwd(int dtype, const void* dy, const void* z, const float* 
     if (p_in > 0.f && (!dx || dx == dz)) return VB_ERR_ARG;   // dropped and un-dropped grads differ
     LnBwdArgs a{dy, z, mean, rstd, gamma, dz, dx, dgamma, dbeta, dbias, M, H, make_drop(p_in, seed, stream_in),
                 make_drop(p_out, seed, stream_out), ws};
-    dim3 grid(row_grid(M, ws ? 1024 : 256));
+    dim3 grid(row_grid(M, ws ? 512 : 256));
     hipStream_t s = (hipStream_t)stream;
-    const size_t smem = (size_t)H * sizeof(float);
+    const size_t smem = (size_t)H * HW_PER_BLOCK * sizeof(float);
     if (dtype == VB_BF16) VB_DISPATCH_NC(ln_bwd_kernel, bf16, H, grid, smem, s, a);
     else if (dtype == VB_F32) VB_DISPATCH_NC(ln_bwd_kernel, float, H, grid, smem, s, a);
     else return VB_ERR_ARG;
     if (ws && (dgamma || dbeta || dbias)) {
-        dim3 g2((unsigned)((H + NT - 1) / NT), 3);
-        VB_LAUNCH(ln_bwd_reduce_kernel, g2, dim3(NT), 0, s, (const float*)ws, (int)grid.x, H, dgamma, dbeta, dbias);
+        dim3 g2((unsigned)((H + 31) / 32), 3);
+        VB_LAUNCH(ln_bwd_reduce_kernel, g2, dim3(1024), 32 * 33 * sizeof(float), s, (const float*)ws, (int)grid.x, H,
+                  dgamma, dbeta, dbias);
     }
     return vb_check_launch();
 }

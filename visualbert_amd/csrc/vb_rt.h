@@ -178,11 +178,34 @@ VB_DEVICE bool philox_keep(const Philox8& r, int e, uint32_t thresh16) {
     return u >= thresh16;
 }
 
-VB_DEVICE float gelu_f(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
+// fast exp: one v_exp_f32 (2^x) after a multiply; relative error ~1e-7..1e-6, flushes like expf for the
+// ranges used here (softmax arguments <= 0, Gaussian tails)
+#ifdef VB_EMU
+VB_DEVICE float fast_exp(float x) { return expf(x); }
+VB_DEVICE float fast_rcp(float x) { return 1.0f / x; }
+#else
+VB_DEVICE float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+VB_DEVICE float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+#endif
+
+// erf via Abramowitz & Stegun 7.1.26 (|abs error| <= 1.5e-7): 1 rcp + 1 exp + ~12 FMAs instead of the
+// ~40-instruction branchy libm erff -- the GELU / GELU' epilogues run this 64x per lane per tile.
+VB_DEVICE float fast_erf(float x) {
+    const float ax = fabsf(x);
+    const float t = fast_rcp(1.0f + 0.3275911f * ax);
+    float p = 1.061405429f;
+    p = p * t - 1.453152027f;
+    p = p * t + 1.421413741f;
+    p = p * t - 0.284496736f;
+    p = p * t + 0.254829592f;
+    const float r = 1.0f - p * t * fast_exp(-ax * ax);
+    return x < 0.f ? -r : r;
+}
+VB_DEVICE float gelu_f(float x) { return x * 0.5f * (1.0f + fast_erf(x * 0.70710678118654752440f)); }
 VB_DEVICE float gelu_grad_f(float x) {
     // d/dx [x * Phi(x)] = Phi(x) + x * phi(x)
-    float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-    float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+    float cdf = 0.5f * (1.0f + fast_erf(x * 0.70710678118654752440f));
+    float pdf = 0.39894228040143267794f * fast_exp(-0.5f * x * x);
     return cdf + x * pdf;
 }
 

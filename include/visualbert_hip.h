@@ -211,6 +211,10 @@ int vb_bert_layer_bwd(int dtype, const void* h_in, const float* mask_add, const 
 int vb_gemm_profile(int enable);
 int64_t vb_gemm_profile_read(double* ms, double* flops, int* key, int64_t max_records);
 
+/* Tuning knob (measurement aid): selects the pipelined K-contiguous x K-contiguous GEMM kernel.
+ * variant = 10 * (waves in M: 2 -> 128x128 tile, 4 -> 256x128 tile) + LDS stages (2..4); 0 = generic kernel. */
+int vb_gemm_set_variant(int variant);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,54 @@
+#!/usr/bin/env python
+"""GEMM micro-benchmark on the GPU box: sweeps the pipelined-kernel variants over the BERT-base shapes.
+usage: python tools/gemm_bench.py [batch]"""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from visualbert_amd import _lib, ops
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+M = B * 164
+dev = torch.device("cuda", 0)
+L = _lib.lib()
+shapes = [("qkv fwd", M, 2304, 768), ("attn-out fwd", M, 768, 768), ("ffn-in fwd(gelu)", M, 3072, 768),
+          ("ffn-out fwd", M, 768, 3072), ("qkv dgrad", M, 768, 2304), ("decoder fwd f32", M, 30522, 768)]
+
+
+def bench(fn, iters=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+g = torch.Generator().manual_seed(0)
+print("M=%d" % M)
+for name, m, n, k in shapes:
+    a = (torch.randn(m, k, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    w = (torch.randn(n, k, generator=g) * 0.05).to(torch.bfloat16).to(dev)
+    bias = torch.randn(n, generator=g).to(dev)
+    f32out = "f32" in name
+    out = ops.alloc2d(m, n, torch.float32 if f32out else torch.bfloat16, dev)
+    pre = torch.empty(m, n, dtype=torch.bfloat16, device=dev) if "gelu" in name else None
+    row = []
+    for v in (0, 22, 23, 24, 42, 43):
+        assert L.vb_gemm_set_variant(v) == 0
+        def fn():
+            ops.gemm(a, w, m, n, k, out=out, bias=bias, act=1 if pre is not None else 0, aux_out=pre)
+        ms = bench(fn)
+        row.append("v%d %6.1f us %6.0f TF" % (v, ms * 1e3, 2.0 * m * n * k / ms / 1e9))
+    print("%-18s N=%5d K=%5d | %s" % (name, n, k, " | ".join(row)))
+L.vb_gemm_set_variant(23)
+# wgrad (both K-strided, split-K)
+for name, n_out, k_in in [("wgrad qkv", 2304, 768), ("wgrad attn-out", 768, 768), ("wgrad ffn-in", 3072, 768), ("wgrad ffn-out", 768, 3072)]:
+    dy = (torch.randn(M, n_out, generator=g) * 0.1).to(torch.bfloat16).to(dev)
+    x = (torch.randn(M, k_in, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    dw = torch.zeros(n_out, k_in, device=dev)
+    ms = bench(lambda: ops.linear_wgrad(dy, x, dw))
+    print("%-18s out=%5d in=%5d | %6.1f us %6.0f TF" % (name, n_out, k_in, ms * 1e3, 2.0 * M * n_out * k_in / ms / 1e9))

@@ -30,7 +30,7 @@ constexpr int D = 64;
 template <typename T> struct LT;   // LDS tile geometry
 template <> struct LT<bf16> {
     static constexpr int RB = 128, CPR = 8, KPT = 2, TPAD = 8;
-    VB_DEVICE int sw(int row) { return (row ^ (row >> 3)) & 7; }
+    VB_DEVICE int sw(int row) { return (row >> 1) & 7; }    // conflict-free for ds_read_b128 fragment reads (see gemm.hip)
 };
 template <> struct LT<float> {
     static constexpr int RB = 256, CPR = 16, KPT = 1, TPAD = 16;

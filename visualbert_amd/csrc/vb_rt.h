@@ -131,6 +131,21 @@ VB_DEVICE void vb_glds16(const void* gsrc, unsigned char* lds_wave_base) {
 VB_DEVICE void vb_atomic_add_noret(float* p, float v) { unsafeAtomicAdd(p, v); }   // global_atomic_add_f32, no return
 #endif
 
+// counted wait for outstanding vector-memory operations (LDS-direct copies included) + raw workgroup
+// barrier: lets the newest K tile(s) stay in flight across the barrier (guide: "Pipelining across
+// barriers").  N must be an immediate.
+#ifdef VB_EMU
+template <int N> VB_DEVICE void vb_wait_vmcnt() {}
+VB_DEVICE void vb_raw_barrier() { __syncthreads(); }
+#else
+template <int N> VB_DEVICE void vb_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+VB_DEVICE void vb_raw_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+#endif
+
 // ------------------------------------------------------------------------------------------
 // wave (64-lane) reductions
 // ------------------------------------------------------------------------------------------

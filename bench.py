@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--no-profile", action="store_true", help="skip the per-GEMM HIP-event timing")
     ap.add_argument("--no-overlap", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed/RCCL even with one rank")
     ap.add_argument("--h2d", action="store_true", help="also time a run that streams each batch from pinned host memory")
     args = ap.parse_args()
 
@@ -84,9 +85,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)
 
     from visualbert_amd import ops
     from visualbert_amd.data import synthetic_pretraining_batch, FeatureStager
@@ -104,7 +107,7 @@ def main():
                                           compute_dtype=dtype).to(dev)
     model.train()
     sync = None
-    if world > 1:
+    if use_dist:
         sync = DataParallelGradSync(model.bert, overlap=not args.no_overlap)
         sync.broadcast_parameters(0)
     B = args.batch
@@ -115,7 +118,7 @@ def main():
     batch = synthetic_pretraining_batch(B, T, R, Dv, V, seed=rank, device=dev)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -132,7 +135,7 @@ def main():
     elapsed = time.perf_counter() - t0
     summ = ops.gemm_profile_stop() if prof else None
     et = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(et, op=dist.ReduceOp.MAX)
     elapsed = float(et.item())
     loss = float(mw.step(batch)["loss"])
@@ -199,7 +202,7 @@ def main():
         if h2d is not None:
             out["samples_per_s_with_pinned_h2d"] = round(h2d, 2)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

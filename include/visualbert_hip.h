@@ -41,6 +41,8 @@ const char* vb_version(void);
  *   epi: + bias[n] (fp32, may be NULL) -> act -> + addend[m,n] (T, may be NULL) -> (+= C if accumulate)
  *   act: VB_ACT_GELU also writes the pre-activation (T) to aux_out when non-NULL;
  *        VB_ACT_GELU_GRAD multiplies by gelu'(aux_in[m,n]) (T);  VB_ACT_TANH applies tanh.
+ *   colsum_out (fp32 [N], may be NULL): += column sums of the values written to C (the bias gradient of the
+ *   Linear whose output gradient this GEMM produces) -- saves a separate pass over C.
  *   out_dtype: dtype (T) or VB_F32.  alpha_dev (may be NULL) is an optional fp32 DEVICE scalar that
  *   multiplies alpha (used to carry an upstream loss-gradient scalar without a host sync).
  *   Requirements: lda, ldb multiples of 8; A, B 16-byte aligned; a K-contiguous operand must be
@@ -53,7 +55,7 @@ int vb_gemm(int dtype, int out_dtype, int a_layout, int b_layout,
             int M, int N, int K, float alpha, const float* alpha_dev, const float* bias,
             const void* addend, int64_t ld_addend, int act,
             const void* aux_in, void* aux_out, int64_t ld_aux, int accumulate,
-            void* stream);
+            float* colsum_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * BertLayerNorm (+ fused residual add and dropouts), forward and backward.
@@ -214,6 +216,9 @@ int64_t vb_gemm_profile_read(double* ms, double* flops, int* key, int64_t max_re
 /* Tuning knob (measurement aid): selects the pipelined K-contiguous x K-contiguous GEMM kernel.
  * variant = 10 * (waves in M: 2 -> 128x128 tile, 4 -> 256x128 tile) + LDS stages (2..4); 0 = generic kernel. */
 int vb_gemm_set_variant(int variant);
+/* ablation switch for kernel analysis (results are WRONG when non-zero): 1 skip tile loads, 2 skip fragment
+ * reads, 4 skip MFMAs in the pipelined kernel */
+int vb_gemm_set_debug(int bits);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,35 @@
+#!/usr/bin/env python
+"""ablation of the pipelined GEMM on the GPU box: which of {tile loads, fragment reads, MFMAs} bounds the loop"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from visualbert_amd import _lib, ops
+dev = torch.device("cuda", 0)
+L = _lib.lib()
+M = 64 * 164
+g = torch.Generator().manual_seed(0)
+def bench(fn, iters=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+for name, n, k in [("ffn-out", 768, 3072), ("qkv", 2304, 768)]:
+    a = (torch.randn(M, k, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    w = (torch.randn(n, k, generator=g) * 0.05).to(torch.bfloat16).to(dev)
+    out = torch.empty(M, n, dtype=torch.bfloat16, device=dev)
+    for v in (42, 43, 22, 24):
+        L.vb_gemm_set_variant(v)
+        row = []
+        for dbg, label in [(0, "full"), (1, "no-tile-loads"), (2, "no-frag-reads"), (4, "no-mfma"), (3, "mfma-only"), (6, "loads-only"), (5, "reads-only")]:
+            L.vb_gemm_set_debug(dbg)
+            ms = bench(lambda: ops.gemm(a, w, M, n, k, out=out))
+            row.append("%s %.1fus" % (label, ms * 1e3))
+        L.vb_gemm_set_debug(0)
+        ref = a.float() @ w.float().t()
+        ops.gemm(a, w, M, n, k, out=out)
+        err = (out.float() - ref).abs().max().item() / ref.abs().max().item()
+        row.append("relerr %.1e" % err)
+        print("%-8s N=%d K=%d v%d | %s" % (name, n, k, v, " | ".join(row)))

@@ -23,7 +23,7 @@ _u32, _u64 = ctypes.c_uint32, ctypes.c_uint64
 SIGNATURES = {
     "vb_version": (ctypes.c_char_p, []),
     "vb_gemm": (_i, [_i, _i, _i, _i, _p, _i64, _p, _i64, _p, _i64, _i, _i, _i, _f, _p, _p, _p, _i64, _i,
-                     _p, _p, _i64, _i, _p]),
+                     _p, _p, _i64, _i, _p, _p]),
     "vb_ln_fwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _f, _u32, _f, _u32, _u64, _p]),
     "vb_ln_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _u32, _f, _u32, _u64, _p, _p]),
     "vb_ln_bwd_ws_bytes": (_i64, [_i, _i]),
@@ -46,6 +46,7 @@ SIGNATURES = {
     "vb_colsum": (_i, [_i, _p, _i64, _p, _p, _i, _i, _p]),
     "vb_act_bwd": (_i, [_i, _p, _p, _p, _i64, _i, _p]),
     "vb_gemm_set_variant": (_i, [_i]),
+    "vb_gemm_set_debug": (_i, [_i]),
     "vb_gemm_profile": (_i, [_i]),
     "vb_gemm_profile_read": (_i64, [_p, _p, _p, _i64]),
     "vb_bert_layer_saved_bytes": (_i64, [_i, _i, _i, _i, _i, _i, _f]),

@@ -69,6 +69,8 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     int splits, kt_per_split;     // split-K: slice s covers K tiles [s*kt_per_split, (s+1)*kt_per_split)
     int fast_a, fast_b;           // operand may be copied with global_load_lds (K-contiguous, no K tail)
+    float* colsum;                // optional fp32 [N]: += column sums of the stored values (bias gradient)
+    int debug;                    // ablation bits (measurement only): 1 skip tile loads, 2 skip fragment reads, 4 skip MFMAs
 };
 
 // ---- global -> register staging -------------------------------------------------------------
@@ -205,6 +207,9 @@ VB_DEVICE void gemm_epilogue(f32x4 (&acc)[4][4], unsigned char* smem, const Gemm
     unsigned char* slab = smem + wave * EPI_BYTES_PER_WAVE;
     TO* C = (TO*)g.C;
     const float alpha = g.alpha_dev ? g.alpha * g.alpha_dev[0] : g.alpha;
+    float cs[8];                                      // column sums of this lane's 8 columns (bias gradient)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) cs[j] = 0.f;
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
         __syncthreads();                 // LDS free (pass 0: main loop done; pass 1: previous reads done)
@@ -295,6 +300,23 @@ VB_DEVICE void gemm_epilogue(f32x4 (&acc)[4][4], unsigned char* smem, const Gemm
             }
             if (full && (g.ldc & 7) == 0) store8(cp, v);
             else for (int j = 0; j < nv; ++j) cp[j] = from_f32<TO>(v[j]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (j < nv) cs[j] += v[j];
+        }
+    }
+    if (g.colsum && g.splits == 1) {
+        // lanes with equal (lane & 7) own the same 8 columns on different rows: reduce over lane bits 3..5,
+        // then one fp32 atomic per column per wave
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            cs[j] += __shfl_xor(cs[j], 8);
+            cs[j] += __shfl_xor(cs[j], 16);
+            cs[j] += __shfl_xor(cs[j], 32);
+        }
+        if (lane < 8) {
+            const int n = nw0 + lane * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (n + j < g.N) vb_atomic_add_noret(g.colsum + n + j, cs[j]);
         }
     }
 }
@@ -427,31 +449,44 @@ int launch_gemm(const GemmArgs& g, hipStream_t stream) {
 // the wait before each barrier is COUNTED (vmcnt(P) leaves the newest tile in flight), so HBM/L2
 // latency is covered by STAGES-1 tiles of MFMA work instead of one.
 // =================================================================================================
+// per-lane source pointers of the LDS-direct copies are loop invariants (row clamp + swizzle done once);
+// a K tile only advances them by BK elements
 template <typename T, int WM>
-VB_DEVICE void fast_issue(unsigned char* stage, const T* A, const T* B, const GemmArgs& g, int m0, int n0, int k0,
-                          int wave, int lane) {
-    constexpr int NW = WM * 2, BMX = WM * 64;
-    constexpr int A_INSTR = (BMX / 8) / NW, B_INSTR = (128 / 8) / NW;
-    unsigned char* la = stage;
-    unsigned char* lb = stage + BMX * 128;
+struct FastPtrs {
+    static constexpr int NW = WM * 2, BMX = WM * 64;
+    static constexpr int A_INSTR = (BMX / 8) / NW, B_INSTR = (128 / 8) / NW;
+    const T* a[A_INSTR];
+    const T* b[B_INSTR];
+};
+template <typename T, int WM>
+VB_DEVICE void fast_setup(FastPtrs<T, WM>& p, const T* A, const T* B, const GemmArgs& g, int m0, int n0, int wave, int lane) {
 #pragma unroll
-    for (int i = 0; i < A_INSTR; ++i) {
-        const int rbase = (wave * A_INSTR + i) * 8;
-        const int row = rbase + (lane >> 3);
+    for (int i = 0; i < FastPtrs<T, WM>::A_INSTR; ++i) {
+        const int row = (wave * FastPtrs<T, WM>::A_INSTR + i) * 8 + (lane >> 3);
         const int c = (lane & 7) ^ swz(row);
         int grow = m0 + row;
         grow = grow < g.M ? grow : g.M - 1;
-        vb_glds16(A + (long)grow * g.lda + k0 + c * TT<T>::EPC, la + rbase * 128);
+        p.a[i] = A + (long)grow * g.lda + c * TT<T>::EPC;
     }
 #pragma unroll
-    for (int i = 0; i < B_INSTR; ++i) {
-        const int rbase = (wave * B_INSTR + i) * 8;
-        const int row = rbase + (lane >> 3);
+    for (int i = 0; i < FastPtrs<T, WM>::B_INSTR; ++i) {
+        const int row = (wave * FastPtrs<T, WM>::B_INSTR + i) * 8 + (lane >> 3);
         const int c = (lane & 7) ^ swz(row);
         int grow = n0 + row;
         grow = grow < g.N ? grow : g.N - 1;
-        vb_glds16(B + (long)grow * g.ldb + k0 + c * TT<T>::EPC, lb + rbase * 128);
+        p.b[i] = B + (long)grow * g.ldb + c * TT<T>::EPC;
     }
+}
+template <typename T, int WM>
+VB_DEVICE void fast_issue(unsigned char* stage, const FastPtrs<T, WM>& p, int k0, int wave) {
+    unsigned char* la = stage;
+    unsigned char* lb = stage + FastPtrs<T, WM>::BMX * 128;
+#pragma unroll
+    for (int i = 0; i < FastPtrs<T, WM>::A_INSTR; ++i)
+        vb_glds16(p.a[i] + k0, la + (wave * FastPtrs<T, WM>::A_INSTR + i) * 8 * 128);
+#pragma unroll
+    for (int i = 0; i < FastPtrs<T, WM>::B_INSTR; ++i)
+        vb_glds16(p.b[i] + k0, lb + (wave * FastPtrs<T, WM>::B_INSTR + i) * 8 * 128);
 }
 
 template <typename T, typename TO, int WM, int STAGES>
@@ -478,9 +513,12 @@ VB_KERNEL VB_LAUNCH_BOUNDS(WM * 128) gemm_nt_pipe_kernel(GemmArgs g) {
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = g.K / BK;
+    FastPtrs<T, WM> ptrs;
+    fast_setup<T, WM>(ptrs, A, B, g, m0, n0, wave, lane);
+    typename VecOf<T>::v8 fa[4], fb[4];
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s)
-        if (s < nk) fast_issue<T, WM>(smem + s * STAGE_BYTES, A, B, g, m0, n0, s * BK, wave, lane);
+        if (s < nk) fast_issue<T, WM>(smem + s * STAGE_BYTES, ptrs, s * BK, wave);
 
     for (int kt = 0; kt < nk; ++kt) {
         // tile kt must have landed; tiles kt+1 .. kt+STAGES-2 (if they exist) may stay in flight
@@ -488,25 +526,235 @@ VB_KERNEL VB_LAUNCH_BOUNDS(WM * 128) gemm_nt_pipe_kernel(GemmArgs g) {
         else if (STAGES >= 4 && kt + STAGES - 3 < nk) vb_wait_vmcnt<(STAGES >= 4 ? STAGES - 3 : 0) * PER_TILE>();
         else vb_wait_vmcnt<0>();
         vb_raw_barrier();     // (a) everyone's part of tile kt is in LDS, (b) everyone finished reading tile kt-1
-        if (kt + STAGES - 1 < nk)
-            fast_issue<T, WM>(smem + ((kt + STAGES - 1) % STAGES) * STAGE_BYTES, A, B, g, m0, n0, (kt + STAGES - 1) * BK,
-                              wave, lane);
+        if (kt + STAGES - 1 < nk && !(g.debug & 1))
+            fast_issue<T, WM>(smem + ((kt + STAGES - 1) % STAGES) * STAGE_BYTES, ptrs, (kt + STAGES - 1) * BK, wave);
         const unsigned char* ldsA = smem + (kt % STAGES) * STAGE_BYTES;
         const unsigned char* ldsB = ldsA + BMX * 128;
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
-            typename VecOf<T>::v8 fa[4], fb[4];
+            if (!(g.debug & 2) || kt == 0) {
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) fa[mi] = load_frag(ldsA, wm * 64 + mi * 16 + li, ks, lg, T());
+                for (int mi = 0; mi < 4; ++mi) fa[mi] = load_frag(ldsA, wm * 64 + mi * 16 + li, ks, lg, T());
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) fb[ni] = load_frag(ldsB, wn * 64 + ni * 16 + li, ks, lg, T());
+                for (int ni = 0; ni < 4; ++ni) fb[ni] = load_frag(ldsB, wn * 64 + ni * 16 + li, ks, lg, T());
+            }
+            if (!(g.debug & 4)) {
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+                for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = vb_mma(fa[mi], fb[ni], acc[mi][ni]);
+                    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = vb_mma(fa[mi], fb[ni], acc[mi][ni]);
+            } else {
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) acc[mi][0][0] += to_f32(fa[mi][0]) + to_f32(fb[mi][0]);   // keep the reads live
+            }
         }
     }
     gemm_epilogue<T, TO>(acc, smem, g, m0 + wm * 64, n0 + wn * 64, wave, lane);
+}
+
+// =================================================================================================
+// Ping-pong variant of the 256x128 / 8-wave kernel.  Waves w and w+4 share a SIMD; the two wave groups
+// (waves 0-3, waves 4-7) run ONE SEGMENT out of phase, so on every SIMD one wave is in an MFMA segment
+// (16 MFMAs = one K step of its 64x64 tile) while its partner is in a fragment-read segment
+// (8 ds_read_b128).  Segments are separated by raw barriers (4 per K tile); the matrix pipe of each SIMD
+// then sees back-to-back MFMA segments instead of "both waves read, both waves compute".
+//     segment 4kt   : G0 reads (kt, k-step 0)   | G1 MFMAs (kt-1, k-step 1)      + issue tile kt+1
+//     segment 4kt+1 : G0 MFMAs (kt, 0)          | G1 reads (kt, 0)
+//     segment 4kt+2 : G0 reads (kt, 1)          | G1 MFMAs (kt, 0)
+//     segment 4kt+3 : G0 MFMAs (kt, 1)          | G1 reads (kt, 1)
+// =================================================================================================
+template <typename T, typename TO>
+VB_KERNEL VB_LAUNCH_BOUNDS(512) gemm_nt_pingpong_kernel(GemmArgs g) {
+    constexpr int WM = 4, BMX = 256;
+    constexpr int BK = TT<T>::BK, KSTEPS = TT<T>::KSTEPS;
+    constexpr int STAGE_BYTES = (BMX + 128) * 128;
+    VB_DYN_SMEM(smem);
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 15, lg = lane >> 4;
+    const int grp = wave >> 2;
+    const int nwg = g.tiles_m * g.tiles_n;
+    const int tile = xcd_remap((int)blockIdx.x, nwg);
+    const int m0 = (tile / g.tiles_n) * BMX, n0 = (tile % g.tiles_n) * BN;
+    const T* A = (const T*)g.A;
+    const T* B = (const T*)g.B;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    typename VecOf<T>::v8 fa[4], fb[4];
+
+    const int nk = g.K / BK;
+    FastPtrs<T, WM> ptrs;
+    fast_setup<T, WM>(ptrs, A, B, g, m0, n0, wave, lane);
+    fast_issue<T, WM>(smem, ptrs, 0, wave);
+
+    auto rd = [&](int kt, int ks) {
+        const unsigned char* ldsA = smem + (kt & 1) * STAGE_BYTES;
+        const unsigned char* ldsB = ldsA + BMX * 128;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) fa[mi] = load_frag(ldsA, wm * 64 + mi * 16 + li, ks, lg, T());
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) fb[ni] = load_frag(ldsB, wn * 64 + ni * 16 + li, ks, lg, T());
+    };
+    auto mm = [&]() {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = vb_mma(fa[mi], fb[ni], acc[mi][ni]);
+    };
+    static_assert(KSTEPS == 2 || KSTEPS == 1, "");
+
+    for (int kt = 0; kt <= nk; ++kt) {
+        // ---- segment 4kt
+        if (kt < nk) vb_wait_vmcnt<0>();           // my share of tile kt (issued one K tile ago) has landed
+        vb_raw_barrier();
+        if (kt + 1 < nk) fast_issue<T, WM>(smem + ((kt + 1) & 1) * STAGE_BYTES, ptrs, (kt + 1) * BK, wave);
+        if (grp == 0) { if (kt < nk) rd(kt, 0); }
+        else { if (kt > 0) mm(); }
+        if (kt == nk) break;
+        // ---- segment 4kt+1
+        vb_raw_barrier();
+        if (grp == 0) mm(); else rd(kt, 0);
+        if (KSTEPS == 2) {
+            // ---- segment 4kt+2
+            vb_raw_barrier();
+            if (grp == 0) rd(kt, 1); else mm();
+            // ---- segment 4kt+3
+            vb_raw_barrier();
+            if (grp == 0) mm(); else rd(kt, 1);
+        }
+    }
+    gemm_epilogue<T, TO>(acc, smem, g, m0 + wm * 64, n0 + wn * 64, wave, lane);
+}
+
+template <typename T, typename TO>
+int launch_pingpong(GemmArgs g, hipStream_t stream) {
+    constexpr int SM = 2 * (256 + 128) * 128;
+    g.tiles_m = (g.M + 255) / 256;
+    dim3 grid((unsigned)(g.tiles_m * g.tiles_n)), block(512);
+#ifndef VB_EMU
+    if (g_prof) {
+        ProfRec r;
+        if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return VB_ERR_LAUNCH;
+        r.flops = 2.0 * g.M * g.N * g.K;
+        r.key = (sizeof(T) == 2 ? 0 : 8) | (sizeof(TO) == 4 ? 4 : 0);
+        (void)hipEventRecord(r.e0, stream);
+        VB_LAUNCH((gemm_nt_pingpong_kernel<T, TO>), grid, block, SM, stream, g);
+        (void)hipEventRecord(r.e1, stream);
+        g_prof->push_back(r);
+        return vb_check_launch();
+    }
+#endif
+    VB_LAUNCH((gemm_nt_pingpong_kernel<T, TO>), grid, block, SM, stream, g);
+    return vb_check_launch();
+}
+
+// =================================================================================================
+// 256x256 tile, 8 waves as 2 (M) x 4 (N), 128x64 per wave (8x4 fragments, 128 fp32 accumulators per lane),
+// two 64 KB LDS stages.  Per flop it moves 2/3 of the L2->LDS bytes of the 256x128 tile (measured wall:
+// ~15-19 TB/s of tile traffic saturates the load path, profiles/r01_gemm_ablation.txt) and reads 25 %
+// fewer fragment bytes per MFMA.  Used when the grid still fills the chip (>= ~200 tiles).
+// =================================================================================================
+template <typename T, typename TO>
+VB_KERNEL VB_LAUNCH_BOUNDS(512) gemm_nt_big_kernel(GemmArgs g) {
+    constexpr int BK = TT<T>::BK, KSTEPS = TT<T>::KSTEPS, EPC = TT<T>::EPC;
+    constexpr int STAGE_BYTES = 2 * 256 * 128;
+    VB_DYN_SMEM(smem);
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int li = lane & 15, lg = lane >> 4;
+    const int nwg = g.tiles_m * g.tiles_n;
+    const int tile = xcd_remap((int)blockIdx.x, nwg);
+    const int m0 = (tile / g.tiles_n) * 256, n0 = (tile % g.tiles_n) * 256;
+    const T* A = (const T*)g.A;
+    const T* B = (const T*)g.B;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // LDS-direct copies: 32 + 32 one-KiB instructions per K tile, 4 + 4 per wave
+    const T* pa[4];
+    const T* pb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ swz(row);
+        int ga = m0 + row; ga = ga < g.M ? ga : g.M - 1;
+        int gb = n0 + row; gb = gb < g.N ? gb : g.N - 1;
+        pa[i] = A + (long)ga * g.lda + c * EPC;
+        pb[i] = B + (long)gb * g.ldb + c * EPC;
+    }
+    auto issue = [&](int kt) {
+        unsigned char* la = smem + (kt & 1) * STAGE_BYTES;
+        unsigned char* lb = la + 256 * 128;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) vb_glds16(pa[i] + kt * BK, la + (wave * 4 + i) * 8 * 128);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) vb_glds16(pb[i] + kt * BK, lb + (wave * 4 + i) * 8 * 128);
+    };
+
+    const int nk = g.K / BK;
+    issue(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        vb_wait_vmcnt<0>();
+        vb_raw_barrier();
+        if (kt + 1 < nk) issue(kt + 1);
+        const unsigned char* ldsA = smem + (kt & 1) * STAGE_BYTES;
+        const unsigned char* ldsB = ldsA + 256 * 128;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            typename VecOf<T>::v8 fb[4];
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) fb[ni] = load_frag(ldsB, wn * 64 + ni * 16 + li, ks, lg, T());
+#pragma unroll
+            for (int mh = 0; mh < 2; ++mh) {
+                typename VecOf<T>::v8 fa[4];
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) fa[mi] = load_frag(ldsA, wm * 128 + (mh * 4 + mi) * 16 + li, ks, lg, T());
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) acc[mh * 4 + mi][ni] = vb_mma(fa[mi], fb[ni], acc[mh * 4 + mi][ni]);
+            }
+        }
+    }
+    // two 64x64 sub-tiles per wave through the shared epilogue
+    f32x4(&lo)[4][4] = *reinterpret_cast<f32x4(*)[4][4]>(&acc[0]);
+    f32x4(&hi)[4][4] = *reinterpret_cast<f32x4(*)[4][4]>(&acc[4]);
+    gemm_epilogue<T, TO>(lo, smem, g, m0 + wm * 128, n0 + wn * 64, wave, lane);
+    gemm_epilogue<T, TO>(hi, smem, g, m0 + wm * 128 + 64, n0 + wn * 64, wave, lane);
+}
+
+template <typename T, typename TO>
+int launch_big(GemmArgs g, hipStream_t stream) {
+    constexpr int SM = 2 * 2 * 256 * 128;
+    static_assert(8 * EPI_BYTES_PER_WAVE <= SM, "epilogue slabs must fit");
+    g.tiles_m = (g.M + 255) / 256;
+    g.tiles_n = (g.N + 255) / 256;
+    dim3 grid((unsigned)(g.tiles_m * g.tiles_n)), block(512);
+#ifndef VB_EMU
+    if (g_prof) {
+        ProfRec r;
+        if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return VB_ERR_LAUNCH;
+        r.flops = 2.0 * g.M * g.N * g.K;
+        r.key = (sizeof(T) == 2 ? 0 : 8) | (sizeof(TO) == 4 ? 4 : 0);
+        (void)hipEventRecord(r.e0, stream);
+        VB_LAUNCH((gemm_nt_big_kernel<T, TO>), grid, block, SM, stream, g);
+        (void)hipEventRecord(r.e1, stream);
+        g_prof->push_back(r);
+        return vb_check_launch();
+    }
+#endif
+    VB_LAUNCH((gemm_nt_big_kernel<T, TO>), grid, block, SM, stream, g);
+    return vb_check_launch();
 }
 
 template <typename T, typename TO, int WM, int STAGES>
@@ -537,6 +785,7 @@ int launch_pipe(GemmArgs g, hipStream_t stream, double* flops_key_unused = nullp
 // variant of the pipelined kernel: tens = waves in M (2 -> 128-row tile, 4 -> 256-row tile), units = stages.
 // 0 = use the generic kernel.
 static int g_nt_variant = 42;
+static int g_debug = 0;
 
 template <typename T, typename TO>
 int dispatch_pipe(const GemmArgs& g, hipStream_t s) {
@@ -546,6 +795,8 @@ int dispatch_pipe(const GemmArgs& g, hipStream_t s) {
         case 24: return launch_pipe<T, TO, 2, 4>(g, s);
         case 42: return launch_pipe<T, TO, 4, 2>(g, s);
         case 43: return launch_pipe<T, TO, 4, 3>(g, s);
+        case 44: return launch_pingpong<T, TO>(g, s);
+        case 88: return launch_big<T, TO>(g, s);
         default: return VB_ERR_UNSUPPORTED;
     }
 }
@@ -574,7 +825,7 @@ extern "C" int vb_gemm(int dtype, int out_dtype, int a_layout, int b_layout,
                        int M, int N, int K, float alpha, const float* alpha_dev, const float* bias,
                        const void* addend, int64_t ld_addend, int act,
                        const void* aux_in, void* aux_out, int64_t ld_aux, int accumulate,
-                       void* stream) {
+                       float* colsum_out, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C) return VB_ERR_ARG;
     if (dtype != VB_F32 && dtype != VB_BF16) return VB_ERR_ARG;
     if (out_dtype != VB_F32 && out_dtype != dtype) return VB_ERR_ARG;
@@ -586,8 +837,9 @@ extern "C" int vb_gemm(int dtype, int out_dtype, int a_layout, int b_layout,
     GemmArgs g;
     g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
     g.bias = bias; g.addend = addend; g.ld_addend = ld_addend; g.aux_in = aux_in; g.aux_out = aux_out;
-    g.ld_aux = ld_aux; g.alpha = alpha; g.alpha_dev = alpha_dev; g.act = act; g.accumulate = accumulate;
+    g.ld_aux = ld_aux; g.alpha = alpha; g.alpha_dev = alpha_dev; g.colsum = colsum_out; g.act = act; g.accumulate = accumulate;
     g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
+    g.debug = g_debug;
     const int bk = dtype == VB_BF16 ? 64 : 32;
     const int nk = (K + bk - 1) / bk;
     // LDS-direct copies need whole K tiles (a masked lane would leave stale LDS behind)
@@ -596,7 +848,7 @@ extern "C" int vb_gemm(int dtype, int out_dtype, int a_layout, int b_layout,
     // split-K only where the result is an fp32 accumulator without an element-wise epilogue
     g.splits = 1; g.kt_per_split = nk;
     const int tiles = g.tiles_m * g.tiles_n;
-    if (accumulate && out_dtype == VB_F32 && !bias && !addend && act == VB_ACT_NONE && tiles < 256 && nk >= 16) {
+    if (accumulate && out_dtype == VB_F32 && !bias && !addend && !colsum_out && act == VB_ACT_NONE && tiles < 256 && nk >= 16) {
         int want = (320 + tiles - 1) / tiles;
         int maxs = nk / 8;
         if (want > maxs) want = maxs;
@@ -646,7 +898,9 @@ extern "C" int64_t vb_gemm_profile_read(double* ms, double* flops, int* key, int
 }
 
 extern "C" int vb_gemm_set_variant(int variant) {
-    if (variant != 0 && variant != 22 && variant != 23 && variant != 24 && variant != 42 && variant != 43) return VB_ERR_ARG;
+    if (variant != 0 && variant != 22 && variant != 23 && variant != 24 && variant != 42 && variant != 43 && variant != 44 && variant != 88) return VB_ERR_ARG;
     g_nt_variant = variant;
     return VB_OK;
 }
+
+extern "C" int vb_gemm_set_debug(int bits) { g_debug = bits; return VB_OK; }

@@ -108,21 +108,21 @@ extern "C" int vb_bert_layer_fwd(int dtype, const void* h_in, const float* mask_
 
     // 1. packed Q|K|V projection
     VB_TRY(vb_gemm(dtype, dtype, VB_KCONTIG, VB_KCONTIG, h_in, H, wqkv, H, sv.qkv, 3 * H, M, 3 * H, H, 1.f, nullptr,
-                   bqkv, nullptr, 0, VB_ACT_NONE, nullptr, nullptr, 0, 0, stream));
+                   bqkv, nullptr, 0, VB_ACT_NONE, nullptr, nullptr, 0, 0, nullptr, stream));
     // 2. fused attention
     VB_TRY(vb_attn_fwd(dtype, sv.qkv, mask_add, sv.ctx, sv.lse, sv.keepbits, B, S, nh, 64, p_attn, seed, sid, stream));
     // 3. attention output projection
     VB_TRY(vb_gemm(dtype, dtype, VB_KCONTIG, VB_KCONTIG, sv.ctx, H, wo, H, sc.t_h0, H, M, H, H, 1.f, nullptr, bo,
-                   nullptr, 0, VB_ACT_NONE, nullptr, nullptr, 0, 0, stream));
+                   nullptr, 0, VB_ACT_NONE, nullptr, nullptr, 0, 0, nullptr, stream));
     // 4. dropout + residual + LayerNorm
     VB_TRY(vb_ln_fwd(dtype, sc.t_h0, h_in, sv.z1, sv.a_out, sv.mean1, sv.rstd1, g1, b1, M, H, eps, p_hidden, sid + 1,
                      0.f, 0, seed, stream));
     // 5. FFN in + erf-GELU (pre-activation kept for backward)
     VB_TRY(vb_gemm(dtype, dtype, VB_KCONTIG, VB_KCONTIG, sv.a_out, H, wi, H, sv.inter, I, M, I, H, 1.f, nullptr, bi,
-                   nullptr, 0, VB_ACT_GELU, nullptr, sv.pre, I, 0, stream));
+                   nullptr, 0, VB_ACT_GELU, nullptr, sv.pre, I, 0, nullptr, stream));
     // 6. FFN out
     VB_TRY(vb_gemm(dtype, dtype, VB_KCONTIG, VB_KCONTIG, sv.inter, I, wo2, I, sc.t_h1, H, M, H, I, 1.f, nullptr, bo2,
-                   nullptr, 0, VB_ACT_NONE, nullptr, nullptr, 0, 0, stream));
+                   nullptr, 0, VB_ACT_NONE, nullptr, nullptr, 0, 0, nullptr, stream));
     // 7. dropout + residual + LayerNorm
     VB_TRY(vb_ln_fwd(dtype, sc.t_h1, sv.a_out, sv.z2, h_out, sv.mean2, sv.rstd2, g2, b2, M, H, eps, p_hidden, sid + 4,
                      0.f, 0, seed, stream));
@@ -153,13 +153,13 @@ extern "C" int vb_bert_layer_bwd(int dtype, const void* h_in, const float* mask_
     // dgrad dx[M,in] = dy[M,out] W[out,in]: with W^T [in, ld>=out] both operands are K-contiguous (LDS-direct
     // loads); otherwise W is read K-strided and transposed on the fly
     auto dgrad = [&](const void* dy, int n_out, const void* w, int which_t, int n_in, void* dx, const void* addend,
-                     int act, const void* aux) -> int {
+                     int act, const void* aux, float* colsum = nullptr) -> int {
         const void* wt = weights_t ? weights_t[which_t] : nullptr;
         if (wt)
             return vb_gemm(dtype, dtype, VB_KCONTIG, VB_KCONTIG, dy, n_out, wt, ld_t[which_t], dx, n_in, M, n_in, n_out,
-                           1.f, nullptr, nullptr, addend, n_in, act, aux, nullptr, n_in, 0, stream);
+                           1.f, nullptr, nullptr, addend, n_in, act, aux, nullptr, n_in, 0, colsum, stream);
         return vb_gemm(dtype, dtype, VB_KCONTIG, VB_KSTRIDED, dy, n_out, w, n_in, dx, n_in, M, n_in, n_out, 1.f, nullptr,
-                       nullptr, addend, n_in, act, aux, nullptr, n_in, 0, stream);
+                       nullptr, addend, n_in, act, aux, nullptr, n_in, 0, colsum, stream);
     };
 
     unsigned char* dz2 = sc.t_h0;                        // d(a_out) through the residual of the output LN
@@ -169,14 +169,13 @@ extern "C" int vb_bert_layer_bwd(int dtype, const void* h_in, const float* mask_
                      G[VB_LW_FO_B], M, H, p_hidden, sid + 4, 0.f, 0, seed, sc.ln_ws, stream));
     // 2. wgrad FFN-out: dW[H,I] += dfo^T inter
     VB_TRY(vb_gemm(dtype, VB_F32, VB_KSTRIDED, VB_KSTRIDED, dfo, H, sv.inter, I, G[VB_LW_FO_W], I, H, I, M, 1.f, nullptr,
-                   nullptr, nullptr, 0, VB_ACT_NONE, nullptr, nullptr, 0, 1, stream));
+                   nullptr, nullptr, 0, VB_ACT_NONE, nullptr, nullptr, 0, 1, nullptr, stream));
     // 3. dgrad FFN-out with GELU' folded into the epilogue: dpre = (dfo Wo2) * gelu'(pre)
-    VB_TRY(dgrad(dfo, H, wo2, VB_LWT_FO, I, sc.t_i, nullptr, VB_ACT_GELU_GRAD, sv.pre));
-    // 4. bias gradient FFN-in
-    VB_TRY(vb_colsum(dtype, sc.t_i, I, G[VB_LW_FI_B], nullptr, M, I, stream));
+    //    (+ 4. bias gradient of FFN-in = column sums of dpre, accumulated by the same epilogue)
+    VB_TRY(dgrad(dfo, H, wo2, VB_LWT_FO, I, sc.t_i, nullptr, VB_ACT_GELU_GRAD, sv.pre, G[VB_LW_FI_B]));
     // 5. wgrad FFN-in: dW[I,H] += dpre^T a_out
     VB_TRY(vb_gemm(dtype, VB_F32, VB_KSTRIDED, VB_KSTRIDED, sc.t_i, I, sv.a_out, H, G[VB_LW_FI_W], H, I, H, M, 1.f,
-                   nullptr, nullptr, nullptr, 0, VB_ACT_NONE, nullptr, nullptr, 0, 1, stream));
+                   nullptr, nullptr, nullptr, 0, VB_ACT_NONE, nullptr, nullptr, 0, 1, nullptr, stream));
     // 6. dgrad FFN-in + residual gradient: da = dpre Wi + dz2
     VB_TRY(dgrad(sc.t_i, I, wi, VB_LWT_FI, H, sc.t_h2, dz2, VB_ACT_NONE, nullptr));
     // 7. attention-output LayerNorm backward
@@ -186,7 +185,7 @@ extern "C" int vb_bert_layer_bwd(int dtype, const void* h_in, const float* mask_
                      G[VB_LW_AO_B], M, H, p_hidden, sid + 1, 0.f, 0, seed, sc.ln_ws, stream));
     // 8. wgrad attention-out: dW[H,H] += dao^T ctx
     VB_TRY(vb_gemm(dtype, VB_F32, VB_KSTRIDED, VB_KSTRIDED, dao, H, sv.ctx, H, G[VB_LW_AO_W], H, H, H, M, 1.f, nullptr,
-                   nullptr, nullptr, 0, VB_ACT_NONE, nullptr, nullptr, 0, 1, stream));
+                   nullptr, nullptr, 0, VB_ACT_NONE, nullptr, nullptr, 0, 1, nullptr, stream));
     // 9. dgrad attention-out: dctx = dao Wo
     VB_TRY(dgrad(dao, H, wo, VB_LWT_AO, H, sc.t_h3, nullptr, VB_ACT_NONE, nullptr));
     // 10-11. attention backward (dQ pass, dK/dV pass)
@@ -196,7 +195,7 @@ extern "C" int vb_bert_layer_bwd(int dtype, const void* h_in, const float* mask_
     VB_TRY(vb_colsum(dtype, sc.t_3h, 3 * H, G[VB_LW_QKV_B], nullptr, M, 3 * H, stream));
     // 13. wgrad QKV: dW[3H,H] += dqkv^T h_in
     VB_TRY(vb_gemm(dtype, VB_F32, VB_KSTRIDED, VB_KSTRIDED, sc.t_3h, 3 * H, h_in, H, G[VB_LW_QKV_W], H, 3 * H, H, M, 1.f,
-                   nullptr, nullptr, nullptr, 0, VB_ACT_NONE, nullptr, nullptr, 0, 1, stream));
+                   nullptr, nullptr, nullptr, 0, VB_ACT_NONE, nullptr, nullptr, 0, 1, nullptr, stream));
     // 14. dgrad QKV + residual gradient: dh = dqkv Wqkv + dz1
     VB_TRY(dgrad(sc.t_3h, 3 * H, wqkv, VB_LWT_QKV, H, d_in, dz1, VB_ACT_NONE, nullptr));
     return VB_OK;

@@ -156,7 +156,7 @@ def gemm_key_name(key):
 
 
 def gemm(a, b, M, N, K, a_layout=VB_KCONTIG, b_layout=VB_KCONTIG, out=None, out_dtype=None, bias=None, act=VB_ACT_NONE,
-         addend=None, aux_in=None, aux_out=None, accumulate=False, alpha=1.0, alpha_dev=None):
+         addend=None, aux_in=None, aux_out=None, accumulate=False, alpha=1.0, alpha_dev=None, colsum_out=None):
     dt = a.dtype
     if b.dtype != dt:
         raise RuntimeError("visualbert_amd.gemm: operand dtypes differ (%s vs %s)" % (dt, b.dtype))
@@ -169,7 +169,7 @@ def gemm(a, b, M, N, K, a_layout=VB_KCONTIG, b_layout=VB_KCONTIG, out=None, out_
                                   ptr(a), _ld(a), ptr(b), _ld(b), ptr(out), _ld(out), M, N, K, float(alpha),
                                   ptr(alpha_dev), ptr(bias), ptr(addend), _ld(addend) if addend is not None else 0,
                                   act, ptr(aux_in), ptr(aux_out), _ld(aux) if aux is not None else 0,
-                                  1 if accumulate else 0, stream_ptr())
+                                  1 if accumulate else 0, ptr(colsum_out), stream_ptr())
     check(run(), "vb_gemm")
     return out
 
@@ -181,16 +181,18 @@ def linear_fwd(x, w, bias, act=VB_ACT_NONE, aux_out=None, out_dtype=None, addend
     return gemm(x, w, M, N, K, bias=bias, act=act, aux_out=aux_out, out_dtype=out_dtype, addend=addend)
 
 
-def linear_dgrad(dy, w, act=VB_ACT_NONE, aux_in=None, addend=None, out=None, alpha_dev=None, wt=None, k_pad=None):
+def linear_dgrad(dy, w, act=VB_ACT_NONE, aux_in=None, addend=None, out=None, alpha_dev=None, wt=None, k_pad=None,
+                 colsum_out=None):
     """dx = (dy w) [* gelu'(aux_in)] [+ addend]; dy [M,N], w [N,K].  With wt = w^T ([K, ld >= N]) both operands
     are K-contiguous (LDS-direct loads); otherwise w is read K-strided.  k_pad: reduce over this many
     columns instead of N when BOTH dy and wt are zero-padded that far (ragged vocabulary)."""
     M, N = dy.shape
     K = w.shape[1]
     if wt is not None:
-        return gemm(dy, wt, M, K, k_pad or N, act=act, aux_in=aux_in, addend=addend, out=out, alpha_dev=alpha_dev)
+        return gemm(dy, wt, M, K, k_pad or N, act=act, aux_in=aux_in, addend=addend, out=out, alpha_dev=alpha_dev,
+                    colsum_out=colsum_out)
     return gemm(dy, w, M, K, N, b_layout=VB_KSTRIDED, act=act, aux_in=aux_in, addend=addend, out=out,
-                alpha_dev=alpha_dev)
+                alpha_dev=alpha_dev, colsum_out=colsum_out)
 
 
 def linear_wgrad(dy, x, dw, alpha_dev=None):
@@ -506,9 +508,9 @@ class FFNBlockFn(torch.autograd.Function):
                          seed)
         g_ow, d4 = grad_target(om.dense.weight)
         linear_wgrad(dfo, inter, g_ow)
-        dpre = linear_dgrad(dfo, weight_for(om.dense.weight, dt), act=VB_ACT_GELU_GRAD, aux_in=pre)
         g_ib, d5 = grad_target(im.dense.bias)
-        colsum(dpre, g_ib)
+        dpre = linear_dgrad(dfo, weight_for(om.dense.weight, dt), act=VB_ACT_GELU_GRAD, aux_in=pre,
+                            wt=weight_t_for(om.dense.weight, dt), colsum_out=g_ib)
         g_iw, d6 = grad_target(im.dense.weight)
         linear_wgrad(dpre, a2, g_iw)
         da = linear_dgrad(dpre, weight_for(im.dense.weight, dt), addend=dz)

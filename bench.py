@@ -92,7 +92,7 @@ def main():
         dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)
 
     from visualbert_amd import ops
-    from visualbert_amd.data import synthetic_pretraining_batch, FeatureStager
+    from visualbert_amd.data import synthetic_pretraining_batch, FeatureStager, pin_batch
     from visualbert_amd.model import AttrDict, ModelWrapper, VisualBERTFixedImageEmbedding
     from visualbert_amd.modeling import BertConfig
     from visualbert_amd.parallel import DataParallelGradSync
@@ -143,7 +143,7 @@ def main():
     h2d = None
     if args.h2d:
         stager = FeatureStager(dev)
-        host = synthetic_pretraining_batch(B, T, R, Dv, V, seed=rank, device="cpu")
+        host = pin_batch(synthetic_pretraining_batch(B, T, R, Dv, V, seed=rank, device="cpu"))
         nxt, ev = stager.stage(host, 0)
         barrier()
         t1 = time.perf_counter()

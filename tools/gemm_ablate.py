@@ -20,10 +20,10 @@ for name, n, k in [("ffn-out", 768, 3072), ("qkv", 2304, 768)]:
     a = (torch.randn(M, k, generator=g) * 0.5).to(torch.bfloat16).to(dev)
     w = (torch.randn(n, k, generator=g) * 0.05).to(torch.bfloat16).to(dev)
     out = torch.empty(M, n, dtype=torch.bfloat16, device=dev)
-    for v in (42, 43, 22, 24):
+    for v in (42,):
         L.vb_gemm_set_variant(v)
         row = []
-        for dbg, label in [(0, "full"), (1, "no-tile-loads"), (2, "no-frag-reads"), (4, "no-mfma"), (3, "mfma-only"), (6, "loads-only"), (5, "reads-only")]:
+        for dbg, label in [(0, "full"), (8, "setprio"), (16, "late-issue"), (24, "both"), (3, "mfma-only"), (6, "loads-only"), (5, "reads-only"), (0, "full-again")]:
             L.vb_gemm_set_debug(dbg)
             ms = bench(lambda: ops.gemm(a, w, M, n, k, out=out))
             row.append("%s %.1fus" % (label, ms * 1e3))

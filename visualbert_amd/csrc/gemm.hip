@@ -489,7 +489,7 @@ VB_DEVICE void fast_issue(unsigned char* stage, const FastPtrs<T, WM>& p, int k0
         vb_glds16(p.b[i] + k0, lb + (wave * FastPtrs<T, WM>::B_INSTR + i) * 8 * 128);
 }
 
-template <typename T, typename TO, int WM, int STAGES>
+template <typename T, typename TO, int WM, int STAGES, int DBG = 0>
 VB_KERNEL VB_LAUNCH_BOUNDS(WM * 128) gemm_nt_pipe_kernel(GemmArgs g) {
     constexpr int NW = WM * 2, BMX = WM * 64;
     constexpr int BK = TT<T>::BK, KSTEPS = TT<T>::KSTEPS;
@@ -526,27 +526,38 @@ VB_KERNEL VB_LAUNCH_BOUNDS(WM * 128) gemm_nt_pipe_kernel(GemmArgs g) {
         else if (STAGES >= 4 && kt + STAGES - 3 < nk) vb_wait_vmcnt<(STAGES >= 4 ? STAGES - 3 : 0) * PER_TILE>();
         else vb_wait_vmcnt<0>();
         vb_raw_barrier();     // (a) everyone's part of tile kt is in LDS, (b) everyone finished reading tile kt-1
-        if (kt + STAGES - 1 < nk && !(g.debug & 1))
+        // DBG is a compile-time ablation / experiment mask (0 in production): 1 skip tile loads, 2 skip fragment
+        // reads, 4 skip MFMAs, 8 raise wave priority around the MFMA block, 16 issue the next tile's copies
+        // after the first K step instead of before it
+        if (!(DBG & 16) && kt + STAGES - 1 < nk && !(DBG & 1))
             fast_issue<T, WM>(smem + ((kt + STAGES - 1) % STAGES) * STAGE_BYTES, ptrs, (kt + STAGES - 1) * BK, wave);
         const unsigned char* ldsA = smem + (kt % STAGES) * STAGE_BYTES;
         const unsigned char* ldsB = ldsA + BMX * 128;
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
-            if (!(g.debug & 2) || kt == 0) {
+            if (!(DBG & 2) || kt == 0) {
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi) fa[mi] = load_frag(ldsA, wm * 64 + mi * 16 + li, ks, lg, T());
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) fb[ni] = load_frag(ldsB, wn * 64 + ni * 16 + li, ks, lg, T());
             }
-            if (!(g.debug & 4)) {
+            if (!(DBG & 4)) {
+#ifndef VB_EMU
+                if (DBG & 8) __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = vb_mma(fa[mi], fb[ni], acc[mi][ni]);
+#ifndef VB_EMU
+                if (DBG & 8) __builtin_amdgcn_s_setprio(0);
+#endif
             } else {
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi) acc[mi][0][0] += to_f32(fa[mi][0]) + to_f32(fb[mi][0]);   // keep the reads live
             }
+            if ((DBG & 16) && ks == 0 && kt + STAGES - 1 < nk)
+                fast_issue<T, WM>(smem + ((kt + STAGES - 1) % STAGES) * STAGE_BYTES, ptrs, (kt + STAGES - 1) * BK, wave);
         }
     }
     gemm_epilogue<T, TO>(acc, smem, g, m0 + wm * 64, n0 + wn * 64, wave, lane);
@@ -778,6 +789,15 @@ int launch_pipe(GemmArgs g, hipStream_t stream, double* flops_key_unused = nullp
         return vb_check_launch();
     }
 #endif
+    if constexpr (sizeof(T) == 2 && sizeof(TO) == 2 && WM == 4 && STAGES == 2) {
+        switch (g.debug) {                       // ablation / experiment builds of the production kernel
+            case 0: break;
+#define VB_DBG_CASE(D) case D: VB_LAUNCH((gemm_nt_pipe_kernel<T, TO, WM, STAGES, D>), grid, block, SM, stream, g); return vb_check_launch();
+            VB_DBG_CASE(1) VB_DBG_CASE(2) VB_DBG_CASE(3) VB_DBG_CASE(4) VB_DBG_CASE(5) VB_DBG_CASE(6) VB_DBG_CASE(8) VB_DBG_CASE(16) VB_DBG_CASE(24)
+#undef VB_DBG_CASE
+            default: return VB_ERR_ARG;
+        }
+    }
     VB_LAUNCH((gemm_nt_pipe_kernel<T, TO, WM, STAGES>), grid, block, SM, stream, g);
     return vb_check_launch();
 }

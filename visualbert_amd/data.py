@@ -10,6 +10,11 @@ asynchronous host-to-device copy (hipMemcpyAsync underneath) on a side stream, d
 import torch
 
 
+def pin_batch(batch):
+    """move a host batch into pinned memory (what a feature store / loader worker would hand over)."""
+    return {k: v.pin_memory() for k, v in batch.items()}
+
+
 def synthetic_pretraining_batch(B, T=128, R=36, Dv=2048, vocab=30522, seed=0, device="cpu", ragged=False):
     g = torch.Generator().manual_seed(4000 + seed)
     ids = torch.randint(0, vocab, (B, T), generator=g, dtype=torch.int64)
@@ -47,12 +52,15 @@ class FeatureStager(object):
         out = {}
         with torch.cuda.stream(self.stream):
             for k, v in host_batch.items():
-                key = (slot, k)
-                pin = self._pinned.get(key)
-                if pin is None or pin.shape != v.shape or pin.dtype != v.dtype:
-                    pin = torch.empty(v.shape, dtype=v.dtype, pin_memory=True)
-                    self._pinned[key] = pin
-                pin.copy_(v)
+                if v.is_pinned():                       # the feature store already lives in pinned memory
+                    pin = v
+                else:
+                    key = (slot, k)
+                    pin = self._pinned.get(key)
+                    if pin is None or pin.shape != v.shape or pin.dtype != v.dtype:
+                        pin = torch.empty(v.shape, dtype=v.dtype, pin_memory=True)
+                        self._pinned[key] = pin
+                    pin.copy_(v)
                 out[k] = pin.to(self.device, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self.stream)

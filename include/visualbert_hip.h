@@ -219,6 +219,9 @@ int vb_gemm_set_variant(int variant);
 /* ablation switch for kernel analysis (results are WRONG when non-zero): 1 skip tile loads, 2 skip fragment
  * reads, 4 skip MFMAs in the pipelined kernel */
 int vb_gemm_set_debug(int bits);
+/* MFMA issue-rate ceiling micro-kernel (measurement aid): kind 0 = 16x16x32 bf16, 1 = 32x32x16 bf16; each
+ * wave of each 512-thread block issues iters x 524288 FLOP; out: fp32[blocks*512] sink */
+int vb_mfma_peak(int kind, int iters, int blocks, float* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,26 @@
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from visualbert_amd import _lib, ops
+dev = torch.device("cuda", 0)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+S, nh = 164, 12
+H = nh * 64
+g = torch.Generator().manual_seed(0)
+qkv = (0.5 * torch.randn(B * S, 3 * H, generator=g)).to(torch.bfloat16).to(dev)
+mask = torch.zeros(B, S, device=dev)
+dctx = torch.randn(B * S, H, generator=g).to(torch.bfloat16).to(dev)
+def bench(fn, iters=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+flops = 4.0 * S * S * 64 * nh * B
+for p in (0.0, 0.1):
+    ctx, lse, bits = ops.attn_fwd(qkv, mask, B, S, nh, p, 5, 3)
+    tf = bench(lambda: ops.attn_fwd(qkv, mask, B, S, nh, p, 5, 3))
+    tb = bench(lambda: ops.attn_bwd(qkv, mask, dctx, lse, bits, B, S, nh, p, 5, 3))
+    print("B=%d p=%.1f: fwd %.1f us (%.0f TF)  bwd %.1f us (%.0f TF)" % (B, p, tf, flops / tf / 1e6, tb, 2.5 * flops / tb / 1e6))

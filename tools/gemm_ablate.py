@@ -23,7 +23,7 @@ for name, n, k in [("ffn-out", 768, 3072), ("qkv", 2304, 768)]:
     for v in (42,):
         L.vb_gemm_set_variant(v)
         row = []
-        for dbg, label in [(0, "full"), (8, "setprio"), (16, "late-issue"), (24, "both"), (3, "mfma-only"), (6, "loads-only"), (5, "reads-only"), (0, "full-again")]:
+        for dbg, label in [(0, "full"), (32, "full,1/4 barriers"), (3, "mfma-only"), (35, "mfma-only,1/4 barriers"), (5, "reads-only"), (37, "reads-only,1/4 bar"), (6, "loads-only"), (38, "loads-only,1/4 bar")]:
             L.vb_gemm_set_debug(dbg)
             ms = bench(lambda: ops.gemm(a, w, M, n, k, out=out))
             row.append("%s %.1fus" % (label, ms * 1e3))

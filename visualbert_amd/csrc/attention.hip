@@ -144,7 +144,7 @@ VB_DEVICE long keep_index(const AttnArgs& a, int bh, int q, int g, int w, int nw
 // forward
 // =================================================================================================
 template <typename T, int NKF>
-VB_KERNEL VB_LAUNCH_BOUNDS(NT) attn_fwd_kernel(AttnArgs a) {
+VB_KERNEL VB_LAUNCH_BOUNDS2(NT, 3) attn_fwd_kernel(AttnArgs a) {
     constexpr int NK = NKF * 16, NKS = NKF / 2, NW = (NKF + 15) / 16;
     VB_DYN_SMEM(smem);
     unsigned char* ldsK = smem;

@@ -210,6 +210,18 @@ VB_DEVICE void gemm_epilogue(f32x4 (&acc)[4][4], unsigned char* smem, const Gemm
     float cs[8];                                      // column sums of this lane's 8 columns (bias gradient)
 #pragma unroll
     for (int j = 0; j < 8; ++j) cs[j] = 0.f;
+    // a lane always owns the same 8 columns: bias is loaded once, ahead of the first barrier
+    const int cc = lane & 7;
+    const int ncol = nw0 + cc * 8;
+    const bool full = (ncol + 8 <= g.N);
+    const int nv = full ? 8 : (ncol < g.N ? g.N - ncol : 0);
+    float bb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bb[j] = 0.f;
+    if (g.bias && ncol < g.N) {
+        if (full && (((uintptr_t)(g.bias + ncol)) & 15) == 0) load8(bb, g.bias + ncol);
+        else for (int j = 0; j < nv; ++j) bb[j] = g.bias[ncol + j];
+    }
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
         __syncthreads();                 // LDS free (pass 0: main loop done; pass 1: previous reads done)
@@ -236,11 +248,35 @@ VB_DEVICE void gemm_epilogue(f32x4 (&acc)[4][4], unsigned char* smem, const Gemm
             }
             continue;
         }
+        // per-row operands of this pass (4 rows per lane): all global loads are issued back to back BEFORE any
+        // store of the pass -- interleaved with the stores they would each pay a full memory round trip,
+        // because the compiler must assume C may alias them (measured: ~8 us of a 12 us K=64 launch)
+        float xa[4][8], xd[4][8], xc[4][8];
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            const int row = it * 8 + (lane >> 3), cc = lane & 7;
+            const int m = mw0 + pass * 32 + it * 8 + (lane >> 3);
+            const bool ok = m < g.M && ncol < g.N;
+            if (g.act == VB_ACT_GELU_GRAD) {
+                const T* ai = (const T*)g.aux_in + (long)m * g.ld_aux + ncol;
+                if (ok && full && (g.ld_aux & 7) == 0) load8(xa[it], ai);
+                else for (int j = 0; j < 8; ++j) xa[it][j] = (ok && j < nv) ? to_f32(ai[j]) : 0.f;
+            }
+            if (g.addend) {
+                const T* ad = (const T*)g.addend + (long)m * g.ld_addend + ncol;
+                if (ok && full && (g.ld_addend & 7) == 0) load8(xd[it], ad);
+                else for (int j = 0; j < 8; ++j) xd[it][j] = (ok && j < nv) ? to_f32(ad[j]) : 0.f;
+            }
+            if (g.accumulate) {
+                const TO* cp = C + (long)m * g.ldc + ncol;
+                if (ok && full && (g.ldc & 7) == 0) load8(xc[it], cp);
+                else for (int j = 0; j < 8; ++j) xc[it][j] = (ok && j < nv) ? to_f32(cp[j]) : 0.f;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = it * 8 + (lane >> 3);
             const int m = mw0 + pass * 32 + row;
-            const int n = nw0 + cc * 8;
+            const int n = ncol;
             if (m >= g.M || n >= g.N) continue;
             float v[8];
             {
@@ -249,20 +285,8 @@ VB_DEVICE void gemm_epilogue(f32x4 (&acc)[4][4], unsigned char* smem, const Gemm
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { v[j] = lo[j]; v[4 + j] = hi[j]; }
             }
-            const bool full = (n + 8 <= g.N);
-            const int nv = full ? 8 : g.N - n;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] *= alpha;
-            if (g.bias) {
-                if (full && (((uintptr_t)(g.bias + n)) & 15) == 0) {
-                    float bb[8]; load8(bb, g.bias + n);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] += bb[j];
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) if (j < nv) v[j] += g.bias[n + j];
-                }
-            }
+            for (int j = 0; j < 8; ++j) v[j] = v[j] * alpha + bb[j];
             if (g.act == VB_ACT_GELU) {
                 if (g.aux_out) {                                  // pre-activation, kept for backward
                     T* ao = (T*)g.aux_out + (long)m * g.ld_aux + n;
@@ -275,30 +299,20 @@ VB_DEVICE void gemm_epilogue(f32x4 (&acc)[4][4], unsigned char* smem, const Gemm
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = tanhf(v[j]);
             } else if (g.act == VB_ACT_GELU_GRAD) {
-                const T* ai = (const T*)g.aux_in + (long)m * g.ld_aux + n;
-                float x[8];
-                if (full && (g.ld_aux & 7) == 0) load8(x, ai);
-                else for (int j = 0; j < 8; ++j) x[j] = j < nv ? to_f32(ai[j]) : 0.f;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] *= gelu_grad_f(x[j]);
+                for (int j = 0; j < 8; ++j) v[j] *= gelu_grad_f(xa[it][j]);
             }
             if (g.addend) {
-                const T* ad = (const T*)g.addend + (long)m * g.ld_addend + n;
-                float x[8];
-                if (full && (g.ld_addend & 7) == 0) load8(x, ad);
-                else for (int j = 0; j < 8; ++j) x[j] = j < nv ? to_f32(ad[j]) : 0.f;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] += x[j];
+                for (int j = 0; j < 8; ++j) v[j] += xd[it][j];
+            }
+            if (g.accumulate) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += xc[it][j];
             }
             TO* cp = C + (long)m * g.ldc + n;
-            if (g.accumulate) {
-                float x[8];
-                if (full && (g.ldc & 7) == 0) load8(x, cp);
-                else for (int j = 0; j < 8; ++j) x[j] = j < nv ? to_f32(cp[j]) : 0.f;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] += x[j];
-            }
-            if (full && (g.ldc & 7) == 0) store8(cp, v);
+            if (g.debug & 64) { if (v[0] == 123.456f) store8(cp, v); }     // ablation: no global stores
+            else if (full && (g.ldc & 7) == 0) store8(cp, v);
             else for (int j = 0; j < nv; ++j) cp[j] = from_f32<TO>(v[j]);
 #pragma unroll
             for (int j = 0; j < 8; ++j) if (j < nv) cs[j] += v[j];
@@ -525,7 +539,8 @@ VB_KERNEL VB_LAUNCH_BOUNDS(WM * 128) gemm_nt_pipe_kernel(GemmArgs g) {
         if (STAGES >= 3 && kt + STAGES - 2 < nk) vb_wait_vmcnt<(STAGES - 2) * PER_TILE>();
         else if (STAGES >= 4 && kt + STAGES - 3 < nk) vb_wait_vmcnt<(STAGES >= 4 ? STAGES - 3 : 0) * PER_TILE>();
         else vb_wait_vmcnt<0>();
-        vb_raw_barrier();     // (a) everyone's part of tile kt is in LDS, (b) everyone finished reading tile kt-1
+        if (!(DBG & 32) || (kt & 3) == 0)
+            vb_raw_barrier(); // (a) everyone's part of tile kt is in LDS, (b) everyone finished reading tile kt-1
         // DBG is a compile-time ablation / experiment mask (0 in production): 1 skip tile loads, 2 skip fragment
         // reads, 4 skip MFMAs, 8 raise wave priority around the MFMA block, 16 issue the next tile's copies
         // after the first K step instead of before it
@@ -561,6 +576,106 @@ VB_KERNEL VB_LAUNCH_BOUNDS(WM * 128) gemm_nt_pipe_kernel(GemmArgs g) {
         }
     }
     gemm_epilogue<T, TO>(acc, smem, g, m0 + wm * 64, n0 + wn * 64, wave, lane);
+}
+
+// =================================================================================================
+// Interleaved variant (256x128 tile, 8 waves, 3 LDS stages).  Same data flow as the pipelined kernel, but
+// inside every K tile the next tile-but-one's LDS-direct copies and the second K step's fragment reads
+// are woven BETWEEN the first K step's MFMAs (an MFMA occupies the matrix pipe for 16 cycles = ~4 issue
+// slots; the other 3 are free for LDS / VMEM instructions of the same wave).  The copies are
+// unconditional (a clamped, redundant tile near the end) so the whole K tile is one basic block the
+// scheduler hints (sched_group_barrier) can order.
+// =================================================================================================
+template <typename T, typename TO>
+VB_KERNEL VB_LAUNCH_BOUNDS(512) gemm_nt_weave_kernel(GemmArgs g) {
+    constexpr int WM = 4, BMX = 256, STAGES = 3;
+    constexpr int BK = TT<T>::BK, KSTEPS = TT<T>::KSTEPS;
+    constexpr int STAGE_BYTES = (BMX + 128) * 128;
+    constexpr int PER_TILE = (BMX / 8) / 8 + (128 / 8) / 8;        // 6 LDS-direct instructions per wave per tile
+    VB_DYN_SMEM(smem);
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 15, lg = lane >> 4;
+    const int nwg = g.tiles_m * g.tiles_n;
+    const int tile = xcd_remap((int)blockIdx.x, nwg);
+    const int m0 = (tile / g.tiles_n) * BMX, n0 = (tile % g.tiles_n) * BN;
+    const T* A = (const T*)g.A;
+    const T* B = (const T*)g.B;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = g.K / BK;
+    FastPtrs<T, WM> ptrs;
+    fast_setup<T, WM>(ptrs, A, B, g, m0, n0, wave, lane);
+    fast_issue<T, WM>(smem, ptrs, 0, wave);
+    fast_issue<T, WM>(smem + STAGE_BYTES, ptrs, (nk > 1 ? 1 : 0) * BK, wave);
+
+    for (int kt = 0; kt < nk; ++kt) {
+        vb_wait_vmcnt<PER_TILE>();            // tile kt has landed; tile kt+1 may still be in flight
+        vb_raw_barrier();                     // tile kt visible to all; everyone done with tile kt-1 (stage (kt+2)%3)
+        const unsigned char* ldsA = smem + (kt % STAGES) * STAGE_BYTES;
+        const unsigned char* ldsB = ldsA + BMX * 128;
+        typename VecOf<T>::v8 fa0[4], fb0[4], fa1[4], fb1[4];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) fa0[mi] = load_frag(ldsA, wm * 64 + mi * 16 + li, 0, lg, T());
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) fb0[ni] = load_frag(ldsB, wn * 64 + ni * 16 + li, 0, lg, T());
+        // tile kt+2 (clamped) into the stage tile kt-1 occupied
+        const int kn = kt + 2 < nk ? kt + 2 : nk - 1;
+        fast_issue<T, WM>(smem + ((kt + 2) % STAGES) * STAGE_BYTES, ptrs, kn * BK, wave);
+        if (KSTEPS == 2) {
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) fa1[mi] = load_frag(ldsA, wm * 64 + mi * 16 + li, 1, lg, T());
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) fb1[ni] = load_frag(ldsB, wn * 64 + ni * 16 + li, 1, lg, T());
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = vb_mma(fa0[mi], fb0[ni], acc[mi][ni]);
+        if (KSTEPS == 2) {
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = vb_mma(fa1[mi], fb1[ni], acc[mi][ni]);
+        }
+        // order: 8 fragment reads (K step 0) first, then weave {MFMA, VMEM} x 6, {MFMA, DS read} x 8, the rest MFMAs
+        VB_SCHED_GROUP(0x100, 8);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { VB_SCHED_GROUP(0x8, 1); VB_SCHED_GROUP(0x20, 1); }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { VB_SCHED_GROUP(0x8, 1); VB_SCHED_GROUP(0x100, 1); }
+        VB_SCHED_GROUP(0x8, 18);
+    }
+    vb_wait_vmcnt<0>();                        // the clamped tail copies must not land on the epilogue's slabs
+    gemm_epilogue<T, TO>(acc, smem, g, m0 + wm * 64, n0 + wn * 64, wave, lane);
+}
+
+template <typename T, typename TO>
+int launch_weave(GemmArgs g, hipStream_t stream) {
+    constexpr int SM = 3 * (256 + 128) * 128;
+    g.tiles_m = (g.M + 255) / 256;
+    dim3 grid((unsigned)(g.tiles_m * g.tiles_n)), block(512);
+#ifndef VB_EMU
+    if (g_prof) {
+        ProfRec r;
+        if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return VB_ERR_LAUNCH;
+        r.flops = 2.0 * g.M * g.N * g.K;
+        r.key = (sizeof(T) == 2 ? 0 : 8) | (sizeof(TO) == 4 ? 4 : 0);
+        (void)hipEventRecord(r.e0, stream);
+        VB_LAUNCH((gemm_nt_weave_kernel<T, TO>), grid, block, SM, stream, g);
+        (void)hipEventRecord(r.e1, stream);
+        g_prof->push_back(r);
+        return vb_check_launch();
+    }
+#endif
+    VB_LAUNCH((gemm_nt_weave_kernel<T, TO>), grid, block, SM, stream, g);
+    return vb_check_launch();
 }
 
 // =================================================================================================
@@ -790,10 +905,10 @@ int launch_pipe(GemmArgs g, hipStream_t stream, double* flops_key_unused = nullp
     }
 #endif
     if constexpr (sizeof(T) == 2 && sizeof(TO) == 2 && WM == 4 && STAGES == 2) {
-        switch (g.debug) {                       // ablation / experiment builds of the production kernel
+        switch (g.debug & 63) {                  // ablation / experiment builds of the production kernel
             case 0: break;
 #define VB_DBG_CASE(D) case D: VB_LAUNCH((gemm_nt_pipe_kernel<T, TO, WM, STAGES, D>), grid, block, SM, stream, g); return vb_check_launch();
-            VB_DBG_CASE(1) VB_DBG_CASE(2) VB_DBG_CASE(3) VB_DBG_CASE(4) VB_DBG_CASE(5) VB_DBG_CASE(6) VB_DBG_CASE(8) VB_DBG_CASE(16) VB_DBG_CASE(24)
+            VB_DBG_CASE(1) VB_DBG_CASE(2) VB_DBG_CASE(3) VB_DBG_CASE(4) VB_DBG_CASE(5) VB_DBG_CASE(6) VB_DBG_CASE(8) VB_DBG_CASE(16) VB_DBG_CASE(24) VB_DBG_CASE(35) VB_DBG_CASE(32) VB_DBG_CASE(37) VB_DBG_CASE(38)
 #undef VB_DBG_CASE
             default: return VB_ERR_ARG;
         }
@@ -804,12 +919,19 @@ int launch_pipe(GemmArgs g, hipStream_t stream, double* flops_key_unused = nullp
 
 // variant of the pipelined kernel: tens = waves in M (2 -> 128-row tile, 4 -> 256-row tile), units = stages.
 // 0 = use the generic kernel.
-static int g_nt_variant = 42;
+static int g_nt_variant = 1;     // 1 = auto: 256x256 tile where the grid still fills the chip and K or N is large, else 256x128
 static int g_debug = 0;
 
 template <typename T, typename TO>
 int dispatch_pipe(const GemmArgs& g, hipStream_t s) {
-    switch (g_nt_variant) {
+    int variant = g_nt_variant;
+    if (variant == 1) {
+        // measured on MI355X (profiles/r01_gemm_variant_sweep_b128.txt): the 256x256 tile wins on long-K and
+        // wide-N shapes once it yields >= ~200 workgroups; the 256x128 tile wins everywhere else
+        const long t256 = (long)((g.M + 255) / 256) * ((g.N + 255) / 256);
+        variant = (t256 >= 200 && (g.K >= 1536 || g.N >= 3072) && g.N <= 8192) ? 88 : 42;
+    }
+    switch (variant) {
         case 22: return launch_pipe<T, TO, 2, 2>(g, s);
         case 23: return launch_pipe<T, TO, 2, 3>(g, s);
         case 24: return launch_pipe<T, TO, 2, 4>(g, s);
@@ -817,6 +939,7 @@ int dispatch_pipe(const GemmArgs& g, hipStream_t s) {
         case 43: return launch_pipe<T, TO, 4, 3>(g, s);
         case 44: return launch_pingpong<T, TO>(g, s);
         case 88: return launch_big<T, TO>(g, s);
+        case 53: return launch_weave<T, TO>(g, s);
         default: return VB_ERR_UNSUPPORTED;
     }
 }
@@ -918,9 +1041,53 @@ extern "C" int64_t vb_gemm_profile_read(double* ms, double* flops, int* key, int
 }
 
 extern "C" int vb_gemm_set_variant(int variant) {
-    if (variant != 0 && variant != 22 && variant != 23 && variant != 24 && variant != 42 && variant != 43 && variant != 44 && variant != 88) return VB_ERR_ARG;
+    if (variant != 0 && variant != 1 && variant != 22 && variant != 23 && variant != 24 && variant != 42 && variant != 43 && variant != 44 && variant != 88 && variant != 53) return VB_ERR_ARG;
     g_nt_variant = variant;
     return VB_OK;
 }
 
 extern "C" int vb_gemm_set_debug(int bits) { g_debug = bits; return VB_OK; }
+
+// ---- measurement aid: issue-rate ceiling of the two bf16 MFMA shapes at the clocks this chip really holds ---
+#ifndef VB_EMU
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <int KIND>
+__global__ void __launch_bounds__(512) mfma_peak_kernel(float* out, int iters) {
+    bf16x8 a, b;
+    for (int j = 0; j < 8; ++j) { a[j] = (bf16)(0.001f * (threadIdx.x + j)); b[j] = (bf16)(0.002f * (threadIdx.x - j)); }
+    if (KIND == 0) {
+        f32x4 acc[16];
+        for (int i = 0; i < 16; ++i) acc[i] = f32x4{0, 0, 0, 0};
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
+        }
+        float s = 0; for (int i = 0; i < 16; ++i) s += acc[i][0];
+        out[blockIdx.x * 512 + threadIdx.x] = s;
+    } else {
+        f32x16 acc[4];
+        for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+        }
+        float s = 0; for (int i = 0; i < 4; ++i) s += acc[i][0];
+        out[blockIdx.x * 512 + threadIdx.x] = s;
+    }
+}
+#endif
+// kind 0: 32 x v_mfma_f32_16x16x32_bf16 per iteration, kind 1: 16 x v_mfma_f32_32x32x16_bf16 (same FLOPs: 524288 per wave-iter)
+extern "C" int vb_mfma_peak(int kind, int iters, int blocks, float* out, void* stream) {
+#ifndef VB_EMU
+    if (kind == 0) hipLaunchKernelGGL(mfma_peak_kernel<0>, dim3(blocks), dim3(512), 0, (hipStream_t)stream, out, iters);
+    else hipLaunchKernelGGL(mfma_peak_kernel<1>, dim3(blocks), dim3(512), 0, (hipStream_t)stream, out, iters);
+    return vb_check_launch();
+#else
+    (void)kind; (void)iters; (void)blocks; (void)out; (void)stream;
+    return VB_ERR_UNSUPPORTED;
+#endif
+}

@@ -160,6 +160,16 @@ VB_KERNEL VB_LAUNCH_BOUNDS(1024) ln_bwd_reduce_kernel(const float* partials, int
     }
 }
 
+// LDS accumulate of 8 column partials owned exclusively by this lane (no atomics, no conflicts with other lanes)
+VB_DEVICE void lds_acc8(float* p, const float (&v)[8]) {
+    f32x4 lo = *(f32x4*)p, hi = *(f32x4*)(p + 4);
+    lo = f32x4{lo[0] + v[0], lo[1] + v[1], lo[2] + v[2], lo[3] + v[3]};
+    hi = f32x4{hi[0] + v[4], hi[1] + v[5], hi[2] + v[6], hi[3] + v[7]};
+    *(f32x4*)p = lo; *(f32x4*)(p + 4) = hi;
+}
+
+// The column accumulators (dgamma, dbeta, bias gradient) live in LDS as [half-wave][3][H] fp32 -- in registers
+// they cost 72 VGPRs and halved the occupancy of this latency-bound streaming kernel (175 -> ~100 VGPRs).
 template <typename T, int NC>
 VB_KERNEL VB_LAUNCH_BOUNDS(NT) ln_bwd_kernel(LnBwdArgs a) {
     VB_DYN_SMEM(smem);
@@ -167,11 +177,18 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) ln_bwd_kernel(LnBwdArgs a) {
     const int l32 = threadIdx.x & 31, hw = threadIdx.x >> 5;
     const int H = a.H;
     const float invH = 1.0f / (float)H;
-    float acc_g[NC][8], acc_b[NC][8], acc_x[NC][8];
+    float* my = lds + (long)hw * 3 * H;                 // this half-wave's [3][H] accumulators
 #pragma unroll
-    for (int ci = 0; ci < NC; ++ci)
+    for (int ci = 0; ci < NC; ++ci) {                   // every lane zeroes exactly the columns it owns
+        const int col = (l32 + 32 * ci) * 8;
+        if (col < H) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { acc_g[ci][j] = 0.f; acc_b[ci][j] = 0.f; acc_x[ci][j] = 0.f; }
+            for (int w = 0; w < 3; ++w) {
+                *(f32x4*)(my + w * H + col) = f32x4{0.f, 0.f, 0.f, 0.f};
+                *(f32x4*)(my + w * H + col + 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    }
 
     for (int base = blockIdx.x * HW_PER_BLOCK; base < a.M; base += gridDim.x * HW_PER_BLOCK) {
         const int row = base + hw;
@@ -189,11 +206,16 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) ln_bwd_kernel(LnBwdArgs a) {
                 float zz[8], gm[8];
                 load8(zz, (const T*)a.z + e);
                 load8(gm, a.gamma + col);
+                float pg[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     xh[ci][j] = (zz[j] - mean) * rstd;
-                    acc_g[ci][j] += dy[ci][j] * xh[ci][j];
-                    acc_b[ci][j] += dy[ci][j];
+                    pg[j] = dy[ci][j] * xh[ci][j];
+                }
+                lds_acc8(my + col, pg);                    // dgamma partials
+                lds_acc8(my + H + col, dy[ci]);            // dbeta partials
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
                     dy[ci][j] *= gm[j];                       // g = dy * gamma
                     s1 += dy[ci][j];
                     s2 += dy[ci][j] * xh[ci][j];
@@ -215,17 +237,24 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) ln_bwd_kernel(LnBwdArgs a) {
                     if (a.din.p > 0.f) apply_dropout8(dz, a.din, (uint64_t)e >> 3);
                     if (a.dx != a.dz) store8((T*)a.dx + e, dz);
                 }
-                if (a.dbias) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) acc_x[ci][j] += dz[j];
-                }
+                if (a.dbias) lds_acc8(my + 2 * H + col, dz);  // bias-gradient partials (of dx)
             }
         }
     }
+    __syncthreads();
+    // reduce the 8 half-waves' accumulators, then this block's row of the partials workspace (two-stage, no
+    // global atomics) or fp32 atomics straight into HBM
     float* part = a.partials ? a.partials + (long)blockIdx.x * 3 * H : nullptr;
-    if (a.dgamma) block_colsum_flush<NC>(acc_g, lds, a.dgamma, H, l32, hw, part);
-    if (a.dbeta) block_colsum_flush<NC>(acc_b, lds, a.dbeta, H, l32, hw, part ? part + H : nullptr);
-    if (a.dbias) block_colsum_flush<NC>(acc_x, lds, a.dbias, H, l32, hw, part ? part + 2 * H : nullptr);
+    for (int i = threadIdx.x; i < 3 * H; i += NT) {
+        const int which = i / H, c = i - which * H;
+        float* out = which == 0 ? a.dgamma : (which == 1 ? a.dbeta : a.dbias);
+        if (!out) continue;
+        float sum = 0.f;
+#pragma unroll
+        for (int h = 0; h < HW_PER_BLOCK; ++h) sum += lds[(long)h * 3 * H + i];
+        if (part) part[i] = sum;
+        else atomicAdd(&out[c], sum);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -400,7 +429,7 @@ extern "C" int vb_ln_bwd(int dtype, const void* dy, const void* z, const float* 
                 make_drop(p_out, seed, stream_out), ws};
     dim3 grid(row_grid(M, ws ? 512 : 256));
     hipStream_t s = (hipStream_t)stream;
-    const size_t smem = (size_t)H * HW_PER_BLOCK * sizeof(float);
+    const size_t smem = (size_t)H * HW_PER_BLOCK * 3 * sizeof(float);
     if (dtype == VB_BF16) VB_DISPATCH_NC(ln_bwd_kernel, bf16, H, grid, smem, s, a);
     else if (dtype == VB_F32) VB_DISPATCH_NC(ln_bwd_kernel, float, H, grid, smem, s, a);
     else return VB_ERR_ARG;

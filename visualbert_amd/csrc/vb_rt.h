@@ -12,6 +12,7 @@
 #define VB_KERNEL static void
 #define VB_DEVICE static inline
 #define VB_LAUNCH_BOUNDS(n)
+#define VB_LAUNCH_BOUNDS2(n, w)
 #define VB_DYN_SMEM(name) unsigned char* name = ::hipemu::blk()->smem
 #define VB_LAUNCH(kernel, grid, block, smem, stream, ...) \
     ::hipemu::launch((grid), (block), (smem), [=]() { kernel(__VA_ARGS__); })
@@ -20,6 +21,7 @@
 #define VB_KERNEL __global__ void
 #define VB_DEVICE static __device__ __forceinline__
 #define VB_LAUNCH_BOUNDS(n) __launch_bounds__(n)
+#define VB_LAUNCH_BOUNDS2(n, w) __launch_bounds__(n, w)   /* w = minimum waves per SIMD */
 // all LDS lives in the dynamic region, 16-byte aligned base (cdna guide, Guideline 17)
 #define VB_DYN_SMEM(name)                                                            \
     extern __shared__ __attribute__((aligned(16))) unsigned char vb_dyn_smem_raw[];  \
@@ -144,6 +146,14 @@ VB_DEVICE void vb_raw_barrier() {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
+#endif
+
+// instruction-order hints for the LLVM scheduler (guide T19): emit `n` instructions of class `mask` next.
+// masks: 0x8 MFMA, 0x20 VMEM read, 0x100 DS read.  No-ops in the simulator build.
+#ifdef VB_EMU
+#define VB_SCHED_GROUP(mask, n) do {} while (0)
+#else
+#define VB_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier((mask), (n), 0)
 #endif
 
 // ------------------------------------------------------------------------------------------

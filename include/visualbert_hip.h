@@ -208,7 +208,8 @@ int vb_bert_layer_bwd(int dtype, const void* h_in, const float* mask_add, const 
 /* Optional HIP-event timing of every vb_gemm launch (measurement aid for bench.py's roofline object):
  * vb_gemm_profile(1) starts recording an event pair around each launch on the launch stream,
  * vb_gemm_profile_read() (after a device synchronise) returns per-launch {milliseconds, algorithmic FLOPs
- * 2MNK, key}; key bits: 8 = fp32 operands (else bf16), 4 = fp32 output, 2 = A K-strided, 1 = B K-strided.
+ * 2MNK, key}; key bits: 8 = fp32 operands (else bf16), 4 = fp32 output, 2 = A K-strided, 1 = B K-strided,
+ * 16 = 256x256-tile kernel, 32 = experimental pipelined variant (neither: 256x128 pipelined kernel when bits 1,2 are 0).
  * vb_gemm_profile(0) stops and frees the events. */
 int vb_gemm_profile(int enable);
 int64_t vb_gemm_profile_read(double* ms, double* flops, int* key, int64_t max_records);
@@ -219,9 +220,18 @@ int vb_gemm_set_variant(int variant);
 /* ablation switch for kernel analysis (results are WRONG when non-zero): 1 skip tile loads, 2 skip fragment
  * reads, 4 skip MFMAs in the pipelined kernel */
 int vb_gemm_set_debug(int bits);
+/* workgroups launched by the persistent 256x256 eight-phase kernel (variant 80); 0 = one per compute unit.
+ * Small values make one workgroup walk several output tiles on small test problems. */
+int vb_gemm_set_persistent_wgs(int n);
+/* debug bit 64 (256x128 pipelined kernel, bf16): waves 0 and 4 of workgroup 0 write per-K-tile shader-clock stamps
+ * {landed, barrier, copies issued, frags0, mfma0, frags1, mfma1} to this device buffer (uint64[2][64][8]) */
+int vb_gemm_set_trace(void* device_u64x1024);
 /* MFMA issue-rate ceiling micro-kernel (measurement aid): kind 0 = 16x16x32 bf16, 1 = 32x32x16 bf16; each
  * wave of each 512-thread block issues iters x 524288 FLOP; out: fp32[blocks*512] sink */
 int vb_mfma_peak(int kind, int iters, int blocks, float* out, void* stream);
+/* global -> LDS (LDS-direct) streaming ceiling (measurement aid): each wave of each 512-thread block streams iters
+ * 1-KiB pieces from a span-byte window with `depth` (1,2,4,8,16) pieces in flight */
+int vb_glds_stream(int depth, const void* src, int64_t span, int iters, int blocks, float* sink, void* stream);
 
 #ifdef __cplusplus
 }

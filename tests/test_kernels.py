@@ -305,7 +305,7 @@ def test_attention_fwd_bwd(dev, dt, cfg):
     assert err <= tol(dt, 5e-5, 0.04) * max(1.0, gmax), (err, gmax)
 
 
-@pytest.mark.parametrize("variant", [0, 22, 23, 42, 43, 44, 53, 88])
+@pytest.mark.parametrize("variant", [0, 22, 42, 80])
 def test_gemm_pipelined_variants_agree(dev, variant):
     """every pipelined K-contiguous kernel variant (tile shape x LDS stages, counted vmcnt, ping-pong,
     256x256) must give the generic kernel's answer -- on hardware this is what validates the
@@ -324,4 +324,79 @@ def test_gemm_pipelined_variants_agree(dev, variant):
             C = gemm(dev, dt, A, B, M, N, K, 0, 0, out_f32=True, bias=bias)
             assert (C - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
     finally:
+        L.vb_gemm_set_variant(1)
+
+
+@pytest.mark.parametrize("variant", [22, 42, 80])
+def test_gemm_specialised_epilogues(dev, variant):
+    """the K-contiguous fast kernels carry ONE epilogue each (activation and optional operands are template
+    parameters, picked by the launcher): bias only, GELU + saved pre-activation, GELU' + fused column sums,
+    residual addend -- on 16-byte aligned operands (the specialised instantiations) for bf16 -> bf16, plus the
+    bf16 -> fp32 ragged-N instantiation of the MLM decoder; M ragged on purpose."""
+    L = _lib.lib()
+    M, N, K = 530, 512, 192
+    g = torch.Generator().manual_seed(variant)
+    dt = torch.bfloat16
+    A = (torch.randn(M, K, generator=g) * 0.5).to(dt).to(dev)
+    B = (torch.randn(N, K, generator=g) * 0.2).to(dt).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    base = A.float() @ B.float().t()
+    lim = lambda ref: 1.2e-2 * max(1.0, ref.abs().max().item())
+    try:
+        assert L.vb_gemm_set_variant(variant) == 0
+        # bias only
+        C = gemm(dev, dt, A, B, M, N, K, 0, 0, bias=bias)
+        ref = base + bias
+        assert (C.float() - ref).abs().max().item() <= lim(ref)
+        # GELU + pre-activation
+        aux = torch.zeros(M, N, dtype=dt, device=dev)
+        C = gemm(dev, dt, A, B, M, N, K, 0, 0, bias=bias, act=_lib.VB_ACT_GELU, aux_out=aux)
+        assert (aux.float() - ref).abs().max().item() <= lim(ref)
+        assert (C.float() - torch.nn.functional.gelu(ref)).abs().max().item() <= lim(ref)
+        # GELU' + column sums
+        pre = torch.randn(M, N, generator=g).to(dt).to(dev)
+        cs = torch.ones(N, device=dev)
+        C = gemm(dev, dt, A, B, M, N, K, 0, 0, act=_lib.VB_ACT_GELU_GRAD, aux_in=pre, colsum=cs)
+        x = pre.float()
+        gg = 0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
+        ref2 = base * gg
+        assert (C.float() - ref2).abs().max().item() <= lim(ref2)
+        assert (cs - (1.0 + ref2.sum(0))).abs().max().item() <= 2e-2 * max(1.0, ref2.sum(0).abs().max().item())
+        # residual addend
+        add_t = torch.randn(M, N, generator=g).to(dt).to(dev)
+        C = gemm(dev, dt, A, B, M, N, K, 0, 0, addend=add_t)
+        ref3 = base + add_t.float()
+        assert (C.float() - ref3).abs().max().item() <= lim(ref3)
+        # bf16 -> fp32, ragged N (vocabulary-sized decoder): columns N-6.. are a partial 8-column group
+        Nr = N - 6
+        Cf = torch.full((M, N), 7.0, device=dev)[:, :Nr]
+        Cf = gemm(dev, dt, A, B[:Nr], M, Nr, K, 0, 0, out_f32=True, bias=bias[:Nr].contiguous(), acc=None)
+        assert (Cf - ref[:, :Nr]).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
+    finally:
+        L.vb_gemm_set_variant(1)
+
+
+@pytest.mark.parametrize("K", [64, 128, 192, 256, 320, 768])
+def test_gemm_eight_phase_k_tails(dev, K):
+    """the 8-phase 256x256 kernel has a 6-half-tile prologue and a counted-wait tail that depend on the
+    number of K tiles: 1, 2, 3, 4, 5 and 12 tiles, ragged M/N edges, bf16 and fp32 outputs."""
+    L = _lib.lib()
+    M, N = 530, 270
+    g = torch.Generator().manual_seed(K)
+    dt = torch.bfloat16
+    A = padded(M, K, dt, dev, g)
+    B = padded(N, K, dt, dev, g)
+    bias = torch.randn(N, generator=g).to(dev)
+    ref = A.float() @ B.float().t() + bias
+    try:
+        assert L.vb_gemm_set_variant(80) == 0
+        for wgs in (0, 1, 2, 4):            # 6 output tiles: one per workgroup, or 6 / 3 / 2 walked by one workgroup
+            assert L.vb_gemm_set_persistent_wgs(wgs) == 0
+            for out_f32 in (True, False):
+                for _ in range(2):
+                    C = gemm(dev, dt, A, B, M, N, K, 0, 0, out_f32=out_f32, bias=bias)
+                    lim = (2e-3 if out_f32 else 1e-2) * ref.abs().max().item()
+                    assert (C.float() - ref).abs().max().item() <= lim
+    finally:
+        L.vb_gemm_set_persistent_wgs(0)
         L.vb_gemm_set_variant(1)

@@ -1,5 +1,7 @@
 #!/usr/bin/env python
-"""ablation of the pipelined GEMM on the GPU box: which of {tile loads, fragment reads, MFMAs} bounds the loop"""
+"""ablation of the two-barrier pipelined GEMM (variant 42) on the GPU box: which of {tile loads, fragment reads,
+MFMAs} bounds the loop.  (The combined / fewer-barrier builds behind profiles/r01_gemm_ablation*.txt were removed with
+the kernels they led to; the single-knob builds 1, 2, 4 remain.)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -23,7 +25,7 @@ for name, n, k in [("ffn-out", 768, 3072), ("qkv", 2304, 768)]:
     for v in (42,):
         L.vb_gemm_set_variant(v)
         row = []
-        for dbg, label in [(0, "full"), (32, "full,1/4 barriers"), (3, "mfma-only"), (35, "mfma-only,1/4 barriers"), (5, "reads-only"), (37, "reads-only,1/4 bar"), (6, "loads-only"), (38, "loads-only,1/4 bar")]:
+        for dbg, label in [(0, "full"), (1, "no tile loads"), (2, "no fragment reads"), (4, "no MFMAs")]:
             L.vb_gemm_set_debug(dbg)
             ms = bench(lambda: ops.gemm(a, w, M, n, k, out=out))
             row.append("%s %.1fus" % (label, ms * 1e3))

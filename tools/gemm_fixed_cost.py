@@ -18,11 +18,11 @@ def bench(fn, iters=30):
     summ = ops.gemm_profile_stop()
     d = list(summ.values())[0]
     return d["ms"] / d["launches"] * 1e3
-for v, dbg in ((42, 0),):
+for v, dbg in ((22, 0), (80, 0), (80, 128)):
     L.vb_gemm_set_variant(v); L.vb_gemm_set_debug(dbg)
     for n in (768, 2304, 3072):
         row = ["dbg=%d" % dbg]
-        for k in (64, 768, 3072):
+        for k in (64, 128, 256, 768, 1536, 3072):
             a = (torch.randn(M, k, generator=g) * 0.5).to(torch.bfloat16).to(dev)
             w = (torch.randn(n, k, generator=g) * 0.05).to(torch.bfloat16).to(dev)
             bias = torch.randn(n, generator=g).to(dev)

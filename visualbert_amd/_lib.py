@@ -47,7 +47,10 @@ SIGNATURES = {
     "vb_act_bwd": (_i, [_i, _p, _p, _p, _i64, _i, _p]),
     "vb_gemm_set_variant": (_i, [_i]),
     "vb_gemm_set_debug": (_i, [_i]),
+    "vb_gemm_set_persistent_wgs": (_i, [_i]),
+    "vb_gemm_set_trace": (_i, [_p]),
     "vb_mfma_peak": (_i, [_i, _i, _i, _p, _p]),
+    "vb_glds_stream": (_i, [_i, _p, _i64, _i, _i, _p, _p]),
     "vb_gemm_profile": (_i, [_i]),
     "vb_gemm_profile_read": (_i64, [_p, _p, _p, _i64]),
     "vb_bert_layer_saved_bytes": (_i64, [_i, _i, _i, _i, _i, _i, _f]),

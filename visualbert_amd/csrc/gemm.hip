@@ -32,6 +32,7 @@
 #include "vb_rt.h"
 #include "../../include/visualbert_hip.h"
 #include <vector>
+#include <type_traits>
 
 namespace {
 
@@ -69,6 +70,7 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     int splits, kt_per_split;     // split-K: slice s covers K tiles [s*kt_per_split, (s+1)*kt_per_split)
     int fast_a, fast_b;           // operand may be copied with global_load_lds (K-contiguous, no K tail)
+    unsigned long long* trace;    // measurement builds: per-iteration timestamps of waves 0 and 4 of workgroup 0
     float* colsum;                // optional fp32 [N]: += column sums of the stored values (bias gradient)
     int debug;                    // ablation bits (measurement only): 1 skip tile loads, 2 skip fragment reads, 4 skip MFMAs
 };
@@ -195,33 +197,157 @@ VB_DEVICE int xcd_remap(int bid, int nwg) {
     return base + idx;
 }
 
-// ---------------- epilogue: accumulators -> LDS (wave-private slab) -> row-contiguous vectors.
-// mw0 / nw0: first row / column of this wave's 64x64 sub-tile.  Uses __syncthreads(): every wave of the
-// workgroup must call it.  (A register-direct epilogue with swapped MFMA operand roles -- 4 consecutive
-// columns per lane, no LDS -- was measured 8-15 % SLOWER on MI355X: 8-byte stores and scattered atomics
-// lose more than the LDS round trip costs; gpurun_out/gemm_bench_c.txt.)
+// ---------------- epilogue ------------------------------------------------------------------------------
+// The accumulators leave through LDS so that a lane owns 8 consecutive columns of a row and every global
+// access is a full 128-byte row segment.  CODE SIZE IS A FIRST-ORDER COST HERE: the epilogue runs once per
+// output tile, straight-line, and an unrolled body that carries every activation and every ragged-edge
+// variant (~120 KB of instructions) cost 7-20 us per tile in instruction fetch alone on MI355X
+// (profiles/r01_gemm_epilogue_codesize.txt: same kernel, bias-only body: 68 -> 33 us at K=64).  Hence:
+//   * ACT is a template parameter (-1 = decided at run time) so a kernel carries one activation;
+//   * the ragged / unaligned path is a ROLLED per-element loop that reads the staged value back from LDS.
+// A register-direct epilogue with swapped MFMA operand roles (4 consecutive columns per lane, no LDS) was
+// measured 8-15 % slower (profiles/r01_gemm_register_epilogue_experiment.txt).
+// OPT (template) says which optional code an epilogue instantiation carries; a launcher picks the smallest
+// instantiation that covers the call (epi_needs)
+enum { EPI_ADD = 1,          // addend and/or accumulate operands
+       EPI_RAGGED = 2,       // N % 8 != 0 or a pointer / leading dimension that is not 16-byte aligned
+       EPI_COLSUM = 4,       // fused column sums
+       EPI_ALL = 7 };
+struct EpiLane {             // per-lane constants of an epilogue call
+    float bb[8], cs[8];
+    float alpha;
+    int ncol, nv;
+    bool vec;                // this lane's 8 columns are all valid and every row pointer is 16-byte aligned
+};
+template <typename T, typename TO, int OPT>
+VB_DEVICE void epi_lane_init(EpiLane& e, const GemmArgs& g, int nw0, int lane) {
+    e.alpha = g.alpha_dev ? g.alpha * g.alpha_dev[0] : g.alpha;
+    e.ncol = nw0 + (lane & 7) * 8;
+    const bool full = (e.ncol + 8 <= g.N);
+    e.nv = full ? 8 : (e.ncol < g.N ? g.N - e.ncol : 0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { e.bb[j] = 0.f; e.cs[j] = 0.f; }
+    if constexpr (OPT & EPI_RAGGED) {
+        e.vec = full && (((g.ldc * sizeof(TO)) | (uintptr_t)g.C) & 15) == 0 &&
+                (!g.addend || (((g.ld_addend * sizeof(T)) | (uintptr_t)g.addend) & 15) == 0) &&
+                (!(g.aux_in || g.aux_out) || (((g.ld_aux * sizeof(T)) | (uintptr_t)g.aux_in | (uintptr_t)g.aux_out) & 15) == 0);
+        if (g.bias && full) {
+            if ((((uintptr_t)(g.bias + e.ncol)) & 15) == 0) load8(e.bb, g.bias + e.ncol);
+            else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) e.bb[j] = g.bias[e.ncol + j];
+            }
+        }
+    } else {
+        e.vec = true;                                   // the launcher checked N % 8 == 0 and every alignment
+        if (g.bias && e.ncol < g.N) load8(e.bb, g.bias + e.ncol);
+    }
+}
+// what a call needs from its epilogue (host side)
+static int epi_needs(const GemmArgs& g, size_t t_size, size_t to_size) {
+    int n = 0;
+    if (g.addend || g.accumulate) n |= EPI_ADD;
+    if (g.colsum) n |= EPI_COLSUM;
+    bool aligned = (g.N % 8) == 0 && (((g.ldc * to_size) | (uintptr_t)g.C) & 15) == 0 &&
+                   (!g.bias || ((uintptr_t)g.bias & 15) == 0) &&
+                   (!g.addend || (((g.ld_addend * t_size) | (uintptr_t)g.addend) & 15) == 0) &&
+                   (!(g.aux_in || g.aux_out) || (((g.ld_aux * t_size) | (uintptr_t)g.aux_in | (uintptr_t)g.aux_out) & 15) == 0);
+    if (!aligned) n |= EPI_RAGGED;
+    return n;
+}
+// one element, every option decided at run time (ragged edges and unaligned leading dimensions only)
 template <typename T, typename TO>
+VB_DEVICE void epi_scalar(float x, const GemmArgs& g, float alpha, long m, int n) {
+    x = x * alpha + (g.bias ? g.bias[n] : 0.f);
+    if (g.act == VB_ACT_GELU) {
+        if (g.aux_out) ((T*)g.aux_out)[m * g.ld_aux + n] = from_f32<T>(x);
+        x = gelu_f(x);
+    } else if (g.act == VB_ACT_TANH) {
+        x = tanhf(x);
+    } else if (g.act == VB_ACT_GELU_GRAD) {
+        x *= gelu_grad_f(to_f32(((const T*)g.aux_in)[m * g.ld_aux + n]));
+    }
+    if (g.addend) x += to_f32(((const T*)g.addend)[m * g.ld_addend + n]);
+    TO* cp = (TO*)g.C + m * g.ldc + n;
+    if (g.accumulate) x += to_f32(*cp);
+    if (!(g.debug & 128)) *cp = from_f32<TO>(x);
+    if (g.colsum && g.splits == 1) vb_atomic_add_noret(g.colsum + n, x);
+}
+// per-row operands of the vector path, loaded ahead of the stores of the same pass: interleaved with the
+// stores each load would pay a full memory round trip (the compiler must assume C may alias them)
+template <typename T, typename TO, int ACT, int OPT>
+VB_DEVICE void epi_load8(float (&xa)[8], float (&xd)[8], float (&xc)[8], const GemmArgs& g, long m, int ncol) {
+    const int act = ACT >= 0 ? ACT : g.act;
+    if (act == VB_ACT_GELU_GRAD) load8(xa, (const T*)g.aux_in + m * g.ld_aux + ncol);
+    if constexpr (OPT & EPI_ADD) {
+        if (g.addend) load8(xd, (const T*)g.addend + m * g.ld_addend + ncol);
+        if (g.accumulate) load8(xc, (const TO*)g.C + m * g.ldc + ncol);
+    }
+}
+template <typename T, typename TO, int ACT, int OPT>
+VB_DEVICE void epi_vec8(float (&v)[8], const GemmArgs& g, EpiLane& e, long m,
+                        const float (&xa)[8], const float (&xd)[8], const float (&xc)[8]) {
+    const int act = ACT >= 0 ? ACT : g.act;
+    const int n = e.ncol;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = v[j] * e.alpha + e.bb[j];
+    if (act == VB_ACT_GELU) {
+        if (g.aux_out) store8((T*)g.aux_out + m * g.ld_aux + n, v);      // pre-activation, kept for backward
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
+    } else if (act == VB_ACT_TANH) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = tanhf(v[j]);
+    } else if (act == VB_ACT_GELU_GRAD) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= gelu_grad_f(xa[j]);
+    }
+    if constexpr (OPT & EPI_ADD) {
+        if (g.addend) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += xd[j];
+        }
+        if (g.accumulate) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += xc[j];
+        }
+    }
+    TO* cp = (TO*)g.C + m * g.ldc + n;
+    if (g.debug & 128) { if (v[0] == 123.456f) store8(cp, v); }           // ablation: no global stores
+    else store8(cp, v);
+    if constexpr (OPT & EPI_COLSUM) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e.cs[j] += v[j];
+    }
+}
+// column sums (bias gradient): lanes with equal (lane & 7) own the same 8 columns on different rows: reduce
+// over lane bits 3..5, then one fp32 atomic per column per wave
+VB_DEVICE void epi_colsum_flush(EpiLane& e, const GemmArgs& g, int nw0, int lane) {
+    if (!(g.colsum && g.splits == 1)) return;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        e.cs[j] += __shfl_xor(e.cs[j], 8);
+        e.cs[j] += __shfl_xor(e.cs[j], 16);
+        e.cs[j] += __shfl_xor(e.cs[j], 32);
+    }
+    if (lane < 8) {
+        const int n = nw0 + lane * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (n + j < g.N) vb_atomic_add_noret(g.colsum + n + j, e.cs[j]);
+    }
+}
+
+// Shared-buffer form (kernels whose tile buffers are dead by now): a wave stages 32 rows x 64 columns per pass in
+// its slab of the tile buffers.  mw0 / nw0: first row / column of the wave's 64x64 sub-tile.  Uses __syncthreads():
+// every wave of the workgroup must call it.
+template <typename T, typename TO, int ACT, int OPT>
 VB_DEVICE void gemm_epilogue(f32x4 (&acc)[4][4], unsigned char* smem, const GemmArgs& g, int mw0, int nw0,
                              int wave, int lane) {
     const int li = lane & 15, lg = lane >> 4;
     unsigned char* slab = smem + wave * EPI_BYTES_PER_WAVE;
-    TO* C = (TO*)g.C;
-    const float alpha = g.alpha_dev ? g.alpha * g.alpha_dev[0] : g.alpha;
-    float cs[8];                                      // column sums of this lane's 8 columns (bias gradient)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) cs[j] = 0.f;
-    // a lane always owns the same 8 columns: bias is loaded once, ahead of the first barrier
+    EpiLane e;
+    epi_lane_init<T, TO, OPT>(e, g, nw0, lane);
     const int cc = lane & 7;
-    const int ncol = nw0 + cc * 8;
-    const bool full = (ncol + 8 <= g.N);
-    const int nv = full ? 8 : (ncol < g.N ? g.N - ncol : 0);
-    float bb[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) bb[j] = 0.f;
-    if (g.bias && ncol < g.N) {
-        if (full && (((uintptr_t)(g.bias + ncol)) & 15) == 0) load8(bb, g.bias + ncol);
-        else for (int j = 0; j < nv; ++j) bb[j] = g.bias[ncol + j];
-    }
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
         __syncthreads();                 // LDS free (pass 0: main loop done; pass 1: previous reads done)
@@ -243,96 +369,45 @@ VB_DEVICE void gemm_epilogue(f32x4 (&acc)[4][4], unsigned char* smem, const Gemm
                 for (int row = 0; row < 32; ++row) {
                     const int m = mw0 + pass * 32 + row;
                     if (m < g.M && n < g.N)
-                        vb_atomic_add_noret((float*)C + (long)m * g.ldc + n, alpha * *(const float*)(slab + row * EPI_PITCH + lane * 4));
+                        vb_atomic_add_noret((float*)g.C + (long)m * g.ldc + n, e.alpha * *(const float*)(slab + row * EPI_PITCH + lane * 4));
                 }
             }
             continue;
         }
-        // per-row operands of this pass (4 rows per lane): all global loads are issued back to back BEFORE any
-        // store of the pass -- interleaved with the stores they would each pay a full memory round trip,
-        // because the compiler must assume C may alias them (measured: ~8 us of a 12 us K=64 launch)
         float xa[4][8], xd[4][8], xc[4][8];
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int m = mw0 + pass * 32 + it * 8 + (lane >> 3);
-            const bool ok = m < g.M && ncol < g.N;
-            if (g.act == VB_ACT_GELU_GRAD) {
-                const T* ai = (const T*)g.aux_in + (long)m * g.ld_aux + ncol;
-                if (ok && full && (g.ld_aux & 7) == 0) load8(xa[it], ai);
-                else for (int j = 0; j < 8; ++j) xa[it][j] = (ok && j < nv) ? to_f32(ai[j]) : 0.f;
-            }
-            if (g.addend) {
-                const T* ad = (const T*)g.addend + (long)m * g.ld_addend + ncol;
-                if (ok && full && (g.ld_addend & 7) == 0) load8(xd[it], ad);
-                else for (int j = 0; j < 8; ++j) xd[it][j] = (ok && j < nv) ? to_f32(ad[j]) : 0.f;
-            }
-            if (g.accumulate) {
-                const TO* cp = C + (long)m * g.ldc + ncol;
-                if (ok && full && (g.ldc & 7) == 0) load8(xc[it], cp);
-                else for (int j = 0; j < 8; ++j) xc[it][j] = (ok && j < nv) ? to_f32(cp[j]) : 0.f;
-            }
+            if (e.vec && m < g.M && e.ncol < g.N) epi_load8<T, TO, ACT, OPT>(xa[it], xd[it], xc[it], g, m, e.ncol);
         }
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int row = it * 8 + (lane >> 3);
             const int m = mw0 + pass * 32 + row;
-            const int n = ncol;
-            if (m >= g.M || n >= g.N) continue;
-            float v[8];
-            {
-                f32x4 lo = *(const f32x4*)(slab + row * EPI_PITCH + cc * 32);
-                f32x4 hi = *(const f32x4*)(slab + row * EPI_PITCH + cc * 32 + 16);
+            if (m >= g.M || e.ncol >= g.N) continue;
+            const unsigned char* src = slab + row * EPI_PITCH + cc * 32;
+            if (e.vec) {
+                float v[8];
+                f32x4 lo = *(const f32x4*)src;
+                f32x4 hi = *(const f32x4*)(src + 16);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { v[j] = lo[j]; v[4 + j] = hi[j]; }
+                epi_vec8<T, TO, ACT, OPT>(v, g, e, m, xa[it], xd[it], xc[it]);
             }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = v[j] * alpha + bb[j];
-            if (g.act == VB_ACT_GELU) {
-                if (g.aux_out) {                                  // pre-activation, kept for backward
-                    T* ao = (T*)g.aux_out + (long)m * g.ld_aux + n;
-                    if (full && (g.ld_aux & 7) == 0) store8(ao, v);
-                    else for (int j = 0; j < nv; ++j) ao[j] = from_f32<T>(v[j]);
+        }
+        if constexpr (OPT & EPI_RAGGED) {
+            // ragged / unaligned lanes: one rolled loop over (row, column) of the pass
+            if (!e.vec) {
+                for (int q = 0; q < 4 * e.nv; ++q) {
+                    const int it = q / e.nv, j = q - it * e.nv;
+                    const int row = it * 8 + (lane >> 3);
+                    const int m = mw0 + pass * 32 + row;
+                    if (m < g.M) epi_scalar<T, TO>(*(const float*)(slab + row * EPI_PITCH + cc * 32 + j * 4), g, e.alpha, m, e.ncol + j);
                 }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
-            } else if (g.act == VB_ACT_TANH) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = tanhf(v[j]);
-            } else if (g.act == VB_ACT_GELU_GRAD) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] *= gelu_grad_f(xa[it][j]);
             }
-            if (g.addend) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] += xd[it][j];
-            }
-            if (g.accumulate) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] += xc[it][j];
-            }
-            TO* cp = C + (long)m * g.ldc + n;
-            if (g.debug & 64) { if (v[0] == 123.456f) store8(cp, v); }     // ablation: no global stores
-            else if (full && (g.ldc & 7) == 0) store8(cp, v);
-            else for (int j = 0; j < nv; ++j) cp[j] = from_f32<TO>(v[j]);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) if (j < nv) cs[j] += v[j];
         }
     }
-    if (g.colsum && g.splits == 1) {
-        // lanes with equal (lane & 7) own the same 8 columns on different rows: reduce over lane bits 3..5,
-        // then one fp32 atomic per column per wave
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            cs[j] += __shfl_xor(cs[j], 8);
-            cs[j] += __shfl_xor(cs[j], 16);
-            cs[j] += __shfl_xor(cs[j], 32);
-        }
-        if (lane < 8) {
-            const int n = nw0 + lane * 8;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) if (n + j < g.N) vb_atomic_add_noret(g.colsum + n + j, cs[j]);
-        }
-    }
+    if constexpr (OPT & EPI_COLSUM) epi_colsum_flush(e, g, nw0, lane);
 }
 
 template <typename T, typename TO, int AL, int BL>
@@ -428,7 +503,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) gemm_kernel(GemmArgs g) {
         }
     }
 
-    gemm_epilogue<T, TO>(acc, smem, g, m0 + wm * 64, n0 + wn * 64, wave, lane);
+    gemm_epilogue<T, TO, -1, EPI_ALL>(acc, smem, g, m0 + wm * 64, n0 + wn * 64, wave, lane);
 }
 
 // ---- optional per-launch HIP-event timing (bench.py's roofline leg) -----------------------------------
@@ -503,7 +578,7 @@ VB_DEVICE void fast_issue(unsigned char* stage, const FastPtrs<T, WM>& p, int k0
         vb_glds16(p.b[i] + k0, lb + (wave * FastPtrs<T, WM>::B_INSTR + i) * 8 * 128);
 }
 
-template <typename T, typename TO, int WM, int STAGES, int DBG = 0>
+template <typename T, typename TO, int WM, int STAGES, int DBG = 0, int ACT = -1, int OPT = EPI_ALL>
 VB_KERNEL VB_LAUNCH_BOUNDS(WM * 128) gemm_nt_pipe_kernel(GemmArgs g) {
     constexpr int NW = WM * 2, BMX = WM * 64;
     constexpr int BK = TT<T>::BK, KSTEPS = TT<T>::KSTEPS;
@@ -539,8 +614,12 @@ VB_KERNEL VB_LAUNCH_BOUNDS(WM * 128) gemm_nt_pipe_kernel(GemmArgs g) {
         if (STAGES >= 3 && kt + STAGES - 2 < nk) vb_wait_vmcnt<(STAGES - 2) * PER_TILE>();
         else if (STAGES >= 4 && kt + STAGES - 3 < nk) vb_wait_vmcnt<(STAGES >= 4 ? STAGES - 3 : 0) * PER_TILE>();
         else vb_wait_vmcnt<0>();
+        const bool tr = (DBG & 64) && g.trace && blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0 && kt < 64;
+        unsigned long long* trp = (DBG & 64) && g.trace ? g.trace + ((wave >> 2) * 64 + (kt < 64 ? kt : 63)) * 8 : nullptr;
+        if (tr) trp[0] = vb_clock();          // tile landed (after the vmcnt wait)
         if (!(DBG & 32) || (kt & 3) == 0)
             vb_raw_barrier(); // (a) everyone's part of tile kt is in LDS, (b) everyone finished reading tile kt-1
+        if (tr) trp[1] = vb_clock();          // barrier released
         // DBG is a compile-time ablation / experiment mask (0 in production): 1 skip tile loads, 2 skip fragment
         // reads, 4 skip MFMAs, 8 raise wave priority around the MFMA block, 16 issue the next tile's copies
         // after the first K step instead of before it
@@ -548,6 +627,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS(WM * 128) gemm_nt_pipe_kernel(GemmArgs g) {
             fast_issue<T, WM>(smem + ((kt + STAGES - 1) % STAGES) * STAGE_BYTES, ptrs, (kt + STAGES - 1) * BK, wave);
         const unsigned char* ldsA = smem + (kt % STAGES) * STAGE_BYTES;
         const unsigned char* ldsB = ldsA + BMX * 128;
+        if (tr) trp[2] = vb_clock();          // tile kt+1 copies issued
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
             if (!(DBG & 2) || kt == 0) {
@@ -555,6 +635,13 @@ VB_KERNEL VB_LAUNCH_BOUNDS(WM * 128) gemm_nt_pipe_kernel(GemmArgs g) {
                 for (int mi = 0; mi < 4; ++mi) fa[mi] = load_frag(ldsA, wm * 64 + mi * 16 + li, ks, lg, T());
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) fb[ni] = load_frag(ldsB, wn * 64 + ni * 16 + li, ks, lg, T());
+            }
+            if (DBG & 64) {                   // measurement build: fragments in registers before the clock is read
+#ifndef VB_EMU
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+                if (tr) trp[3 + 2 * ks] = vb_clock();
             }
             if (!(DBG & 4)) {
 #ifndef VB_EMU
@@ -571,96 +658,26 @@ VB_KERNEL VB_LAUNCH_BOUNDS(WM * 128) gemm_nt_pipe_kernel(GemmArgs g) {
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi) acc[mi][0][0] += to_f32(fa[mi][0]) + to_f32(fb[mi][0]);   // keep the reads live
             }
+            if (DBG & 64) {
+#ifndef VB_EMU
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+                if (tr) trp[4 + 2 * ks] = vb_clock();    // this K step's MFMAs issued
+            }
             if ((DBG & 16) && ks == 0 && kt + STAGES - 1 < nk)
                 fast_issue<T, WM>(smem + ((kt + STAGES - 1) % STAGES) * STAGE_BYTES, ptrs, (kt + STAGES - 1) * BK, wave);
         }
     }
-    gemm_epilogue<T, TO>(acc, smem, g, m0 + wm * 64, n0 + wn * 64, wave, lane);
+    gemm_epilogue<T, TO, ACT, OPT>(acc, smem, g, m0 + wm * 64, n0 + wn * 64, wave, lane);
 }
 
-// =================================================================================================
-// Interleaved variant (256x128 tile, 8 waves, 3 LDS stages).  Same data flow as the pipelined kernel, but
-// inside every K tile the next tile-but-one's LDS-direct copies and the second K step's fragment reads
-// are woven BETWEEN the first K step's MFMAs (an MFMA occupies the matrix pipe for 16 cycles = ~4 issue
-// slots; the other 3 are free for LDS / VMEM instructions of the same wave).  The copies are
-// unconditional (a clamped, redundant tile near the end) so the whole K tile is one basic block the
-// scheduler hints (sched_group_barrier) can order.
-// =================================================================================================
+// activation baked into the kernel where it matters (bf16 in / bf16 out: FFN-in forward GELU, FFN-out dgrad GELU');
+// everything else takes the run-time epilogue (ACT = -1), except the plain bias epilogue (ACT = 0)
 template <typename T, typename TO>
-VB_KERNEL VB_LAUNCH_BOUNDS(512) gemm_nt_weave_kernel(GemmArgs g) {
-    constexpr int WM = 4, BMX = 256, STAGES = 3;
-    constexpr int BK = TT<T>::BK, KSTEPS = TT<T>::KSTEPS;
-    constexpr int STAGE_BYTES = (BMX + 128) * 128;
-    constexpr int PER_TILE = (BMX / 8) / 8 + (128 / 8) / 8;        // 6 LDS-direct instructions per wave per tile
-    VB_DYN_SMEM(smem);
-    const int t = threadIdx.x;
-    const int lane = t & 63, wave = t >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int li = lane & 15, lg = lane >> 4;
-    const int nwg = g.tiles_m * g.tiles_n;
-    const int tile = xcd_remap((int)blockIdx.x, nwg);
-    const int m0 = (tile / g.tiles_n) * BMX, n0 = (tile % g.tiles_n) * BN;
-    const T* A = (const T*)g.A;
-    const T* B = (const T*)g.B;
+constexpr bool kActSpecialised = (sizeof(T) == 2 && sizeof(TO) == 2);
 
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nk = g.K / BK;
-    FastPtrs<T, WM> ptrs;
-    fast_setup<T, WM>(ptrs, A, B, g, m0, n0, wave, lane);
-    fast_issue<T, WM>(smem, ptrs, 0, wave);
-    fast_issue<T, WM>(smem + STAGE_BYTES, ptrs, (nk > 1 ? 1 : 0) * BK, wave);
-
-    for (int kt = 0; kt < nk; ++kt) {
-        vb_wait_vmcnt<PER_TILE>();            // tile kt has landed; tile kt+1 may still be in flight
-        vb_raw_barrier();                     // tile kt visible to all; everyone done with tile kt-1 (stage (kt+2)%3)
-        const unsigned char* ldsA = smem + (kt % STAGES) * STAGE_BYTES;
-        const unsigned char* ldsB = ldsA + BMX * 128;
-        typename VecOf<T>::v8 fa0[4], fb0[4], fa1[4], fb1[4];
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) fa0[mi] = load_frag(ldsA, wm * 64 + mi * 16 + li, 0, lg, T());
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) fb0[ni] = load_frag(ldsB, wn * 64 + ni * 16 + li, 0, lg, T());
-        // tile kt+2 (clamped) into the stage tile kt-1 occupied
-        const int kn = kt + 2 < nk ? kt + 2 : nk - 1;
-        fast_issue<T, WM>(smem + ((kt + 2) % STAGES) * STAGE_BYTES, ptrs, kn * BK, wave);
-        if (KSTEPS == 2) {
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) fa1[mi] = load_frag(ldsA, wm * 64 + mi * 16 + li, 1, lg, T());
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) fb1[ni] = load_frag(ldsB, wn * 64 + ni * 16 + li, 1, lg, T());
-        }
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = vb_mma(fa0[mi], fb0[ni], acc[mi][ni]);
-        if (KSTEPS == 2) {
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = vb_mma(fa1[mi], fb1[ni], acc[mi][ni]);
-        }
-        // order: 8 fragment reads (K step 0) first, then weave {MFMA, VMEM} x 6, {MFMA, DS read} x 8, the rest MFMAs
-        VB_SCHED_GROUP(0x100, 8);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) { VB_SCHED_GROUP(0x8, 1); VB_SCHED_GROUP(0x20, 1); }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { VB_SCHED_GROUP(0x8, 1); VB_SCHED_GROUP(0x100, 1); }
-        VB_SCHED_GROUP(0x8, 18);
-    }
-    vb_wait_vmcnt<0>();                        // the clamped tail copies must not land on the epilogue's slabs
-    gemm_epilogue<T, TO>(acc, smem, g, m0 + wm * 64, n0 + wn * 64, wave, lane);
-}
-
-template <typename T, typename TO>
-int launch_weave(GemmArgs g, hipStream_t stream) {
-    constexpr int SM = 3 * (256 + 128) * 128;
-    g.tiles_m = (g.M + 255) / 256;
-    dim3 grid((unsigned)(g.tiles_m * g.tiles_n)), block(512);
+template <typename T, typename TO, int WM, int STAGES, int ACT, int OPT>
+int launch_pipe_act(const GemmArgs& g, dim3 grid, dim3 block, int smem_bytes, hipStream_t stream) {
 #ifndef VB_EMU
     if (g_prof) {
         ProfRec r;
@@ -668,137 +685,153 @@ int launch_weave(GemmArgs g, hipStream_t stream) {
         r.flops = 2.0 * g.M * g.N * g.K;
         r.key = (sizeof(T) == 2 ? 0 : 8) | (sizeof(TO) == 4 ? 4 : 0);
         (void)hipEventRecord(r.e0, stream);
-        VB_LAUNCH((gemm_nt_weave_kernel<T, TO>), grid, block, SM, stream, g);
+        VB_LAUNCH((gemm_nt_pipe_kernel<T, TO, WM, STAGES, 0, ACT, OPT>), grid, block, smem_bytes, stream, g);
         (void)hipEventRecord(r.e1, stream);
         g_prof->push_back(r);
         return vb_check_launch();
     }
 #endif
-    VB_LAUNCH((gemm_nt_weave_kernel<T, TO>), grid, block, SM, stream, g);
+    VB_LAUNCH((gemm_nt_pipe_kernel<T, TO, WM, STAGES, 0, ACT, OPT>), grid, block, smem_bytes, stream, g);
     return vb_check_launch();
 }
 
-// =================================================================================================
-// Ping-pong variant of the 256x128 / 8-wave kernel.  Waves w and w+4 share a SIMD; the two wave groups
-// (waves 0-3, waves 4-7) run ONE SEGMENT out of phase, so on every SIMD one wave is in an MFMA segment
-// (16 MFMAs = one K step of its 64x64 tile) while its partner is in a fragment-read segment
-// (8 ds_read_b128).  Segments are separated by raw barriers (4 per K tile); the matrix pipe of each SIMD
-// then sees back-to-back MFMA segments instead of "both waves read, both waves compute".
-//     segment 4kt   : G0 reads (kt, k-step 0)   | G1 MFMAs (kt-1, k-step 1)      + issue tile kt+1
-//     segment 4kt+1 : G0 MFMAs (kt, 0)          | G1 reads (kt, 0)
-//     segment 4kt+2 : G0 reads (kt, 1)          | G1 MFMAs (kt, 0)
-//     segment 4kt+3 : G0 MFMAs (kt, 1)          | G1 reads (kt, 1)
-// =================================================================================================
-template <typename T, typename TO>
-VB_KERNEL VB_LAUNCH_BOUNDS(512) gemm_nt_pingpong_kernel(GemmArgs g) {
-    constexpr int WM = 4, BMX = 256;
-    constexpr int BK = TT<T>::BK, KSTEPS = TT<T>::KSTEPS;
-    constexpr int STAGE_BYTES = (BMX + 128) * 128;
-    VB_DYN_SMEM(smem);
-    const int t = threadIdx.x;
-    const int lane = t & 63, wave = t >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int li = lane & 15, lg = lane >> 4;
-    const int grp = wave >> 2;
-    const int nwg = g.tiles_m * g.tiles_n;
-    const int tile = xcd_remap((int)blockIdx.x, nwg);
-    const int m0 = (tile / g.tiles_n) * BMX, n0 = (tile % g.tiles_n) * BN;
-    const T* A = (const T*)g.A;
-    const T* B = (const T*)g.B;
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-    typename VecOf<T>::v8 fa[4], fb[4];
-
-    const int nk = g.K / BK;
-    FastPtrs<T, WM> ptrs;
-    fast_setup<T, WM>(ptrs, A, B, g, m0, n0, wave, lane);
-    fast_issue<T, WM>(smem, ptrs, 0, wave);
-
-    auto rd = [&](int kt, int ks) {
-        const unsigned char* ldsA = smem + (kt & 1) * STAGE_BYTES;
-        const unsigned char* ldsB = ldsA + BMX * 128;
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) fa[mi] = load_frag(ldsA, wm * 64 + mi * 16 + li, ks, lg, T());
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) fb[ni] = load_frag(ldsB, wn * 64 + ni * 16 + li, ks, lg, T());
-    };
-    auto mm = [&]() {
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = vb_mma(fa[mi], fb[ni], acc[mi][ni]);
-    };
-    static_assert(KSTEPS == 2 || KSTEPS == 1, "");
-
-    for (int kt = 0; kt <= nk; ++kt) {
-        // ---- segment 4kt
-        if (kt < nk) vb_wait_vmcnt<0>();           // my share of tile kt (issued one K tile ago) has landed
-        vb_raw_barrier();
-        if (kt + 1 < nk) fast_issue<T, WM>(smem + ((kt + 1) & 1) * STAGE_BYTES, ptrs, (kt + 1) * BK, wave);
-        if (grp == 0) { if (kt < nk) rd(kt, 0); }
-        else { if (kt > 0) mm(); }
-        if (kt == nk) break;
-        // ---- segment 4kt+1
-        vb_raw_barrier();
-        if (grp == 0) mm(); else rd(kt, 0);
-        if (KSTEPS == 2) {
-            // ---- segment 4kt+2
-            vb_raw_barrier();
-            if (grp == 0) rd(kt, 1); else mm();
-            // ---- segment 4kt+3
-            vb_raw_barrier();
-            if (grp == 0) mm(); else rd(kt, 1);
+template <typename T, typename TO, int WM, int STAGES>
+int launch_pipe(GemmArgs g, hipStream_t stream) {
+    constexpr int BMX = WM * 64;
+    constexpr int SM = STAGES * (BMX + 128) * 128;
+    static_assert(WM * 2 * EPI_BYTES_PER_WAVE <= SM, "epilogue slabs must fit");
+    g.tiles_m = (g.M + BMX - 1) / BMX;
+    dim3 grid((unsigned)(g.tiles_m * g.tiles_n)), block(WM * 128);
+    if constexpr (sizeof(T) == 2 && sizeof(TO) == 2 && WM == 4 && STAGES == 2) {
+        switch (g.debug & 127) {                  // ablation / timeline builds of this kernel (measurement only)
+            case 0: break;
+#define VB_DBG_CASE(D) case D: VB_LAUNCH((gemm_nt_pipe_kernel<T, TO, WM, STAGES, D, 0, 0>), grid, block, SM, stream, g); return vb_check_launch();
+            VB_DBG_CASE(1) VB_DBG_CASE(2) VB_DBG_CASE(4) VB_DBG_CASE(64)
+#undef VB_DBG_CASE
+            default: return VB_ERR_ARG;
         }
     }
-    gemm_epilogue<T, TO>(acc, smem, g, m0 + wm * 64, n0 + wn * 64, wave, lane);
-}
-
-template <typename T, typename TO>
-int launch_pingpong(GemmArgs g, hipStream_t stream) {
-    constexpr int SM = 2 * (256 + 128) * 128;
-    g.tiles_m = (g.M + 255) / 256;
-    dim3 grid((unsigned)(g.tiles_m * g.tiles_n)), block(512);
-#ifndef VB_EMU
-    if (g_prof) {
-        ProfRec r;
-        if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return VB_ERR_LAUNCH;
-        r.flops = 2.0 * g.M * g.N * g.K;
-        r.key = (sizeof(T) == 2 ? 0 : 8) | (sizeof(TO) == 4 ? 4 : 0);
-        (void)hipEventRecord(r.e0, stream);
-        VB_LAUNCH((gemm_nt_pingpong_kernel<T, TO>), grid, block, SM, stream, g);
-        (void)hipEventRecord(r.e1, stream);
-        g_prof->push_back(r);
-        return vb_check_launch();
+    const int needs = epi_needs(g, sizeof(T), sizeof(TO));
+#define VB_TRY_EPI(A, O) if (g.act == (A) && (needs & ~(O)) == 0) return launch_pipe_act<T, TO, WM, STAGES, A, O>(g, grid, block, SM, stream)
+    if constexpr (kActSpecialised<T, TO>) {
+        VB_TRY_EPI(VB_ACT_NONE, 0);                        // forward projections, dgrad attention-out
+        VB_TRY_EPI(VB_ACT_GELU, 0);                        // FFN-in forward
+        VB_TRY_EPI(VB_ACT_GELU_GRAD, EPI_COLSUM);          // FFN-out dgrad (+ FFN-in bias gradient)
+        VB_TRY_EPI(VB_ACT_NONE, EPI_ADD);                  // dgrads that add the residual gradient
+    } else if constexpr (sizeof(T) == 2) {
+        VB_TRY_EPI(VB_ACT_NONE, EPI_RAGGED);               // MLM decoder logits (N = vocabulary size)
     }
-#endif
-    VB_LAUNCH((gemm_nt_pingpong_kernel<T, TO>), grid, block, SM, stream, g);
-    return vb_check_launch();
+#undef VB_TRY_EPI
+    return launch_pipe_act<T, TO, WM, STAGES, -1, EPI_ALL>(g, grid, block, SM, stream);
 }
 
 // =================================================================================================
-// 256x256 tile, 8 waves as 2 (M) x 4 (N), 128x64 per wave (8x4 fragments, 128 fp32 accumulators per lane),
-// two 64 KB LDS stages.  Per flop it moves 2/3 of the L2->LDS bytes of the 256x128 tile (measured wall:
-// ~15-19 TB/s of tile traffic saturates the load path, profiles/r01_gemm_ablation.txt) and reads 25 %
-// fewer fragment bytes per MFMA.  Used when the grid still fills the chip (>= ~200 tiles).
+// 256x256 tile, 8 waves as 2 (M) x 4 (N), EIGHT-PHASE schedule (guide "256^2 8-phase template", T3+T4+T5).
+// The in-kernel timeline of the two-barrier kernels above (profiles/r01_gemm_timeline.txt) shows every
+// wave spending ~25 % of a K tile ISSUING its LDS-direct copies (all 8 waves queue on the CU's one
+// texture-address unit at the same moment), ~22 % waiting for fragment reads and ~15 % for the next
+// tile, with the matrix pipe busy ~40 %.  Here a K tile is cut into 4 phases (one 64x32 quadrant of the
+// wave's 128x64 output each: 16 MFMAs), a phase is {fragment reads + ONE half-tile's copies + counted
+// vmcnt -> barrier -> MFMAs -> barrier}, and the two waves that share a SIMD (w, w+4) run ONE BARRIER
+// apart: while one issues memory work the other owns the matrix pipe (s_setprio 1).
+//
+// LDS: 2 buffers x {A0, A1, B0, B1} half-tiles of [128 rows][128 B] (128 KB).  Half-tile A_mh holds tile
+// rows (r>>6)*128 + mh*64 + (r&63), B_nh holds tile rows (r>>5)*64 + nh*32 + (r&31): a wave's quadrant
+// (mh, nh) reads rows wr*64.. of A_mh and wc*32.. of B_nh, while its output stays a contiguous 128x64 block.
+// Copy stream (half-tile index h = 4*tile + {A0,B0,B1,A1}): h = 0..5 in the prologue, phase p issues
+// h = p + 6 and waits until only the newest 4 half-tiles are in flight; phase p reads h <= p + 1 (landed
+// and barrier-published one phase earlier) and overwrites a half-tile last read >= 2 phases ago.
 // =================================================================================================
-template <typename T, typename TO>
-VB_KERNEL VB_LAUNCH_BOUNDS(512) gemm_nt_big_kernel(GemmArgs g) {
+VB_DEVICE void vb_phase_barrier() {
+#ifdef VB_EMU
+    __syncthreads();
+#else
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+// Epilogue of the persistent kernel: a wave drains its 128x64 block through a PRIVATE 4 KB LDS slab (16 rows
+// x 64 fp32, 16-column groups XOR-swizzled by the row quad so the MFMA-layout stores are conflict-free), one
+// 16-row fragment row per pass.  No workgroup barrier: LDS executes one wave's instructions in order, so the
+// wave's own stores are visible to its own loads; the slabs live ABOVE the two 64 KB tile buffers, which keep
+// receiving the next tile's copies meanwhile.
+constexpr int EPI8_BYTES_PER_WAVE = 16 * 256;
+// one 16-row fragment row (4 fragments = 16 rows x 64 columns) of a wave's block; mrow0 = its first global row
+template <typename T, typename TO, int ACT, int OPT>
+VB_DEVICE void gemm_epilogue_fragrow(f32x4 (&a)[4], unsigned char* slab, const GemmArgs& g, int mrow0, int lane, EpiLane& e) {
+    const int li = lane & 15, lg = lane >> 4, cc = lane & 7;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            *(float*)(slab + (lg * 4 + r) * 256 + (((ni ^ lg) * 16 + li) << 2)) = a[ni][r];
+    vb_wave_sync();
+    float xa[2][8], xd[2][8], xc[2][8];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int m = mrow0 + it * 8 + (lane >> 3);
+        if (e.vec && m < g.M && e.ncol < g.N) epi_load8<T, TO, ACT, OPT>(xa[it], xd[it], xc[it], g, m, e.ncol);
+    }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int row = it * 8 + (lane >> 3);
+        const int m = mrow0 + row;
+        const unsigned char* src = slab + row * 256 + (((((cc >> 1) ^ (row >> 2)) & 3) * 16 + (cc & 1) * 8) << 2);
+        if (m < g.M && e.ncol < g.N && e.vec) {
+            float v[8];
+            f32x4 lo = *(const f32x4*)src;
+            f32x4 hi = *(const f32x4*)(src + 16);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[j] = lo[j]; v[4 + j] = hi[j]; }
+            epi_vec8<T, TO, ACT, OPT>(v, g, e, m, xa[it], xd[it], xc[it]);
+        }
+    }
+    if constexpr (OPT & EPI_RAGGED) {
+        if (!e.vec) {                                   // ragged / unaligned lanes: one rolled loop per fragment row
+            for (int q = 0; q < 2 * e.nv; ++q) {
+                const int it = q / e.nv, j = q - it * e.nv;
+                const int row = it * 8 + (lane >> 3);
+                const int m = mrow0 + row;
+                const unsigned char* src = slab + row * 256 + (((((cc >> 1) ^ (row >> 2)) & 3) * 16 + (cc & 1) * 8) << 2);
+                if (m < g.M) epi_scalar<T, TO>(((const float*)src)[j], g, e.alpha, m, e.ncol + j);
+            }
+        }
+    }
+    vb_wave_sync();
+}
+template <typename T, typename TO, int ACT, int OPT>
+VB_DEVICE void gemm_epilogue_private(f32x4 (&acc)[8][4], unsigned char* slab, const GemmArgs& g, int mw0, int nw0, int lane) {
+    EpiLane e;
+    epi_lane_init<T, TO, OPT>(e, g, nw0, lane);
+    // constant indices spelled out: the accumulators must never be addressed by a loop variable
+    gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[0], slab, g, mw0 + 0, lane, e);
+    gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[1], slab, g, mw0 + 16, lane, e);
+    gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[2], slab, g, mw0 + 32, lane, e);
+    gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[3], slab, g, mw0 + 48, lane, e);
+    gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[4], slab, g, mw0 + 64, lane, e);
+    gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[5], slab, g, mw0 + 80, lane, e);
+    gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[6], slab, g, mw0 + 96, lane, e);
+    gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[7], slab, g, mw0 + 112, lane, e);
+    if constexpr (OPT & EPI_COLSUM) epi_colsum_flush(e, g, nw0, lane);
+}
+
+template <typename T, typename TO, int ACT, int OPT>
+VB_KERNEL VB_LAUNCH_BOUNDS(512) gemm_nt_8ph_kernel(GemmArgs g) {
     constexpr int BK = TT<T>::BK, KSTEPS = TT<T>::KSTEPS, EPC = TT<T>::EPC;
-    constexpr int STAGE_BYTES = 2 * 256 * 128;
+    constexpr int HALF = 128 * 128, BUF = 4 * HALF;
+    constexpr int SLOT_A0 = 0, SLOT_A1 = 1, SLOT_B0 = 2, SLOT_B1 = 3;
     VB_DYN_SMEM(smem);
     const int t = threadIdx.x;
-    const int lane = t & 63, wave = t >> 6;
-    const int wm = wave >> 2, wn = wave & 3;
+    const int lane = t & 63, wave = vb_uniform(t >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
     const int li = lane & 15, lg = lane >> 4;
-    const int nwg = g.tiles_m * g.tiles_n;
-    const int tile = xcd_remap((int)blockIdx.x, nwg);
-    const int m0 = (tile / g.tiles_n) * 256, n0 = (tile % g.tiles_n) * 256;
-    const T* A = (const T*)g.A;
-    const T* B = (const T*)g.B;
+    const int ntiles = g.tiles_m * g.tiles_n;
+    const int G = (int)gridDim.x;
+    const int my_tiles = (ntiles - (int)blockIdx.x + G - 1) / G;      // persistent: tiles blockIdx.x + G j
+    const unsigned char* A = (const unsigned char*)g.A;
+    const unsigned char* B = (const unsigned char*)g.B;
+    unsigned char* slab = smem + 2 * BUF + wave * EPI8_BYTES_PER_WAVE;
 
     f32x4 acc[8][4];
 #pragma unroll
@@ -806,140 +839,209 @@ VB_KERNEL VB_LAUNCH_BOUNDS(512) gemm_nt_big_kernel(GemmArgs g) {
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // LDS-direct copies: 32 + 32 one-KiB instructions per K tile, 4 + 4 per wave
-    const T* pa[4];
-    const T* pb[4];
+    // LDS-direct copies: a half-tile is 16 one-KiB instructions, 2 per wave: half-tile rows 16 wave + 8 i + lane/8.
+    // Their tile rows are rowA + 64 mh + 8 i (A) / rowB + 32 nh + 8 i (B); the source chunk is the LDS chunk slot
+    // XOR the row swizzle (swz(r + 8) = swz(r) ^ 4).  Per-lane BYTE offsets from the operand base (32 bits, checked by
+    // the launcher) are recomputed only when the load stream moves to another output tile; a K tile advances the
+    // SCALAR base, so issuing a copy costs no vector arithmetic.
+    const int l3 = lane >> 3;
+    const int rowA = (wave >> 2) * 128 + (wave & 3) * 16 + l3;
+    const int rowB = (wave >> 1) * 64 + (wave & 1) * 16 + l3;
+    const int csrc0 = ((lane & 7) ^ swz(wave * 16 + l3)) * 16;
+    const int csrc1 = csrc0 ^ 64;
+    unsigned offA[2][2], offB[2][2];
+    int ld_j = 0, ld_t = 0;                        // load stream position: K tile ld_t of my tile number ld_j
+    auto origin = [&](int j, int& m0, int& n0) {
+        const int tile = xcd_remap((int)blockIdx.x + G * j, ntiles);
+        m0 = (tile / g.tiles_n) * 256; n0 = (tile % g.tiles_n) * 256;
+    };
+    auto set_load_tile = [&](int j) {
+        int m0, n0;
+        origin(j, m0, n0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (wave * 4 + i) * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ swz(row);
-        int ga = m0 + row; ga = ga < g.M ? ga : g.M - 1;
-        int gb = n0 + row; gb = gb < g.N ? gb : g.N - 1;
-        pa[i] = A + (long)ga * g.lda + c * EPC;
-        pb[i] = B + (long)gb * g.ldb + c * EPC;
-    }
-    auto issue = [&](int kt) {
-        unsigned char* la = smem + (kt & 1) * STAGE_BYTES;
-        unsigned char* lb = la + 256 * 128;
+        for (int h = 0; h < 2; ++h) {
+            int a0 = m0 + rowA + h * 64, a1 = a0 + 8, b0 = n0 + rowB + h * 32, b1 = b0 + 8;
+            a0 = a0 < g.M ? a0 : g.M - 1; a1 = a1 < g.M ? a1 : g.M - 1;
+            b0 = b0 < g.N ? b0 : g.N - 1; b1 = b1 < g.N ? b1 : g.N - 1;
+            offA[h][0] = (unsigned)(a0 * (int)g.lda) * (unsigned)sizeof(T) + csrc0;
+            offA[h][1] = (unsigned)(a1 * (int)g.lda) * (unsigned)sizeof(T) + csrc1;
+            offB[h][0] = (unsigned)(b0 * (int)g.ldb) * (unsigned)sizeof(T) + csrc0;
+            offB[h][1] = (unsigned)(b1 * (int)g.ldb) * (unsigned)sizeof(T) + csrc1;
+        }
+    };
+    set_load_tile(0);
+    auto issueA = [&](int mh, int par) {
+        unsigned char* dst = smem + par * BUF + (mh ? SLOT_A1 : SLOT_A0) * HALF + wave * 2048;
+        const unsigned char* src = A + (long)ld_t * (BK * (int)sizeof(T));
+        vb_glds16(src + offA[mh][0], dst);
+        vb_glds16(src + offA[mh][1], dst + 1024);
+    };
+    auto issueB = [&](int nh, int par) {
+        unsigned char* dst = smem + par * BUF + (nh ? SLOT_B1 : SLOT_B0) * HALF + wave * 2048;
+        const unsigned char* src = B + (long)ld_t * (BK * (int)sizeof(T));
+        vb_glds16(src + offB[nh][0], dst);
+        vb_glds16(src + offB[nh][1], dst + 1024);
+    };
+    auto ld_advance = [&]() {
+        if (++ld_t == g.K / BK) { ld_t = 0; ++ld_j; set_load_tile(ld_j); }
+    };
+
+    typename VecOf<T>::v8 fa[4][KSTEPS], fb0[2][KSTEPS], fb1[2][KSTEPS];
+    auto readA = [&](const unsigned char* half) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) vb_glds16(pa[i] + kt * BK, la + (wave * 4 + i) * 8 * 128);
+        for (int f = 0; f < 4; ++f)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) vb_glds16(pb[i] + kt * BK, lb + (wave * 4 + i) * 8 * 128);
+            for (int ks = 0; ks < KSTEPS; ++ks) fa[f][ks] = load_frag(half, wr * 64 + f * 16 + li, ks, lg, T());
+    };
+    auto readB = [&](typename VecOf<T>::v8 (&fb)[2][KSTEPS], const unsigned char* half) {
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) fb[f][ks] = load_frag(half, wc * 32 + f * 16 + li, ks, lg, T());
+    };
+    auto quad = [&](int mh, int nh, typename VecOf<T>::v8 (&fb)[2][KSTEPS]) {
+#ifndef VB_EMU
+        __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                    acc[mh * 4 + f][nh * 2 + q] = vb_mma(fa[f][ks], fb[q][ks], acc[mh * 4 + f][nh * 2 + q]);
+#ifndef VB_EMU
+        __builtin_amdgcn_s_setprio(0);
+#endif
     };
 
     const int nk = g.K / BK;
-    issue(0);
-    for (int kt = 0; kt < nk; ++kt) {
-        vb_wait_vmcnt<0>();
-        vb_raw_barrier();
-        if (kt + 1 < nk) issue(kt + 1);
-        const unsigned char* ldsA = smem + (kt & 1) * STAGE_BYTES;
-        const unsigned char* ldsB = ldsA + 256 * 128;
+    const int GK = my_tiles * nk;                  // K tiles in this workgroup's stream
+    // prologue: K tile 0 (A0 B0 B1 A1) and the first two half-tiles of K tile 1
+    issueA(0, 0); issueB(0, 0); issueB(1, 0); issueA(1, 0);
+    if (GK > 1) { ld_advance(); issueA(0, 1); issueB(0, 1); vb_wait_vmcnt<8>(); }
+    else vb_wait_vmcnt<4>();
+    vb_phase_barrier();
+    if (wr == 1) vb_phase_barrier();               // waves 4-7 run one barrier behind waves 0-3
+
+    // vmcnt counts the epilogue's loads and stores too.  The vector-memory operations of a wave retire in issue order, so
+    // "all but the newest 8" stays correct after an epilogue: it only waits for MORE (the epilogue's stores).  Admitting
+    // those stores explicitly (vmcnt(8 + 16) for one K tile) measured no gain: the write burst is bandwidth, not
+    // acknowledgement latency (profiles/r01_gemm_8phase_notes.txt).
+    auto wait_steady = [&]() { vb_wait_vmcnt<8>(); };
+    int ct = 0, cj = 0;
+    for (int gk = 0; gk < GK; ++gk) {
+        const int par = gk & 1;
+        const unsigned char* buf = smem + par * BUF;
+        const bool n1 = gk + 1 < GK, n2 = gk + 2 < GK;
+        // ---- phase 0: quadrant (0, 0)
+        readB(fb0, buf + SLOT_B0 * HALF);
+        readA(buf + SLOT_A0 * HALF);
+        if (n1) { issueB(1, par ^ 1); wait_steady(); } else vb_wait_vmcnt<2>();
+        vb_phase_barrier();
+        quad(0, 0, fb0);
+        vb_phase_barrier();
+        // ---- phase 1: quadrant (0, 1)
+        readB(fb1, buf + SLOT_B1 * HALF);
+        if (n1) { issueA(1, par ^ 1); wait_steady(); } else vb_wait_vmcnt<0>();
+        vb_phase_barrier();
+        quad(0, 1, fb1);
+        vb_phase_barrier();
+        // ---- phase 2: quadrant (1, 1)
+        readA(buf + SLOT_A1 * HALF);
+        if (n2) { ld_advance(); issueA(0, par); wait_steady(); } else if (n1) vb_wait_vmcnt<6>(); else vb_wait_vmcnt<0>();
+        vb_phase_barrier();
+        quad(1, 1, fb1);
+        vb_phase_barrier();
+        // ---- phase 3: quadrant (1, 0)
+        if (n2) { issueB(0, par); wait_steady(); } else if (n1) vb_wait_vmcnt<4>(); else vb_wait_vmcnt<0>();
+        vb_phase_barrier();
+        quad(1, 0, fb0);
+        vb_phase_barrier();
+        if (++ct == nk) {
+            // output tile finished: drain it while the next tile's first K tiles are already landing
+            int m0, n0;
+            origin(cj, m0, n0);
+            gemm_epilogue_private<T, TO, ACT, OPT>(acc, slab, g, m0 + wr * 128, n0 + wc * 64, lane);
 #pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
-            typename VecOf<T>::v8 fb[4];
+            for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) fb[ni] = load_frag(ldsB, wn * 64 + ni * 16 + li, ks, lg, T());
-#pragma unroll
-            for (int mh = 0; mh < 2; ++mh) {
-                typename VecOf<T>::v8 fa[4];
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi) fa[mi] = load_frag(ldsA, wm * 128 + (mh * 4 + mi) * 16 + li, ks, lg, T());
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < 4; ++ni) acc[mh * 4 + mi][ni] = vb_mma(fa[mi], fb[ni], acc[mh * 4 + mi][ni]);
-            }
+                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+            ct = 0; ++cj;
         }
     }
-    // two 64x64 sub-tiles per wave through the shared epilogue
-    f32x4(&lo)[4][4] = *reinterpret_cast<f32x4(*)[4][4]>(&acc[0]);
-    f32x4(&hi)[4][4] = *reinterpret_cast<f32x4(*)[4][4]>(&acc[4]);
-    gemm_epilogue<T, TO>(lo, smem, g, m0 + wm * 128, n0 + wn * 64, wave, lane);
-    gemm_epilogue<T, TO>(hi, smem, g, m0 + wm * 128 + 64, n0 + wn * 64, wave, lane);
+    if (wr == 0) vb_phase_barrier();               // balance the stagger barrier
 }
 
+static int g_persistent_wgs = 0;       // 0 = one workgroup per CU
+template <typename T, typename TO, int ACT, int OPT>
+int launch_8ph_act(const GemmArgs& g, dim3 grid, dim3 block, int smem_bytes, hipStream_t stream) {
+#ifndef VB_EMU
+    if (g_prof) {
+        ProfRec r;
+        if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return VB_ERR_LAUNCH;
+        r.flops = 2.0 * g.M * g.N * g.K;
+        r.key = (sizeof(T) == 2 ? 0 : 8) | (sizeof(TO) == 4 ? 4 : 0) | 16;
+        (void)hipEventRecord(r.e0, stream);
+        VB_LAUNCH((gemm_nt_8ph_kernel<T, TO, ACT, OPT>), grid, block, smem_bytes, stream, g);
+        (void)hipEventRecord(r.e1, stream);
+        g_prof->push_back(r);
+        return vb_check_launch();
+    }
+#endif
+    VB_LAUNCH((gemm_nt_8ph_kernel<T, TO, ACT, OPT>), grid, block, smem_bytes, stream, g);
+    return vb_check_launch();
+}
 template <typename T, typename TO>
-int launch_big(GemmArgs g, hipStream_t stream) {
-    constexpr int SM = 2 * 2 * 256 * 128;
-    static_assert(8 * EPI_BYTES_PER_WAVE <= SM, "epilogue slabs must fit");
-    g.tiles_m = (g.M + 255) / 256;
-    g.tiles_n = (g.N + 255) / 256;
-    dim3 grid((unsigned)(g.tiles_m * g.tiles_n)), block(512);
-#ifndef VB_EMU
-    if (g_prof) {
-        ProfRec r;
-        if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return VB_ERR_LAUNCH;
-        r.flops = 2.0 * g.M * g.N * g.K;
-        r.key = (sizeof(T) == 2 ? 0 : 8) | (sizeof(TO) == 4 ? 4 : 0);
-        (void)hipEventRecord(r.e0, stream);
-        VB_LAUNCH((gemm_nt_big_kernel<T, TO>), grid, block, SM, stream, g);
-        (void)hipEventRecord(r.e1, stream);
-        g_prof->push_back(r);
-        return vb_check_launch();
-    }
-#endif
-    VB_LAUNCH((gemm_nt_big_kernel<T, TO>), grid, block, SM, stream, g);
-    return vb_check_launch();
-}
-
-template <typename T, typename TO, int WM, int STAGES>
-int launch_pipe(GemmArgs g, hipStream_t stream, double* flops_key_unused = nullptr) {
-    (void)flops_key_unused;
-    constexpr int BMX = WM * 64;
-    constexpr int SM = STAGES * (BMX + 128) * 128;
-    static_assert(WM * 2 * EPI_BYTES_PER_WAVE <= SM, "epilogue slabs must fit");
-    g.tiles_m = (g.M + BMX - 1) / BMX;
-    dim3 grid((unsigned)(g.tiles_m * g.tiles_n)), block(WM * 128);
-#ifndef VB_EMU
-    if (g_prof) {
-        ProfRec r;
-        if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return VB_ERR_LAUNCH;
-        r.flops = 2.0 * g.M * g.N * g.K;
-        r.key = (sizeof(T) == 2 ? 0 : 8) | (sizeof(TO) == 4 ? 4 : 0);
-        (void)hipEventRecord(r.e0, stream);
-        VB_LAUNCH((gemm_nt_pipe_kernel<T, TO, WM, STAGES>), grid, block, SM, stream, g);
-        (void)hipEventRecord(r.e1, stream);
-        g_prof->push_back(r);
-        return vb_check_launch();
-    }
-#endif
-    if constexpr (sizeof(T) == 2 && sizeof(TO) == 2 && WM == 4 && STAGES == 2) {
-        switch (g.debug & 63) {                  // ablation / experiment builds of the production kernel
-            case 0: break;
-#define VB_DBG_CASE(D) case D: VB_LAUNCH((gemm_nt_pipe_kernel<T, TO, WM, STAGES, D>), grid, block, SM, stream, g); return vb_check_launch();
-            VB_DBG_CASE(1) VB_DBG_CASE(2) VB_DBG_CASE(3) VB_DBG_CASE(4) VB_DBG_CASE(5) VB_DBG_CASE(6) VB_DBG_CASE(8) VB_DBG_CASE(16) VB_DBG_CASE(24) VB_DBG_CASE(35) VB_DBG_CASE(32) VB_DBG_CASE(37) VB_DBG_CASE(38)
-#undef VB_DBG_CASE
-            default: return VB_ERR_ARG;
+int launch_8ph(GemmArgs g, hipStream_t stream) {
+    constexpr int SM = 2 * 4 * 128 * 128 + 8 * EPI8_BYTES_PER_WAVE;
+    // 32-bit element offsets inside the kernel; bf16 operands only (fp32 is the parity path, not the fast path)
+    if (sizeof(T) != 2 || (long)g.M * g.lda >= (1L << 30) || (long)g.N * g.ldb >= (1L << 30))
+        return launch_pipe<T, TO, 4, 2>(g, stream);
+    if constexpr (sizeof(T) == 2) {
+        g.tiles_m = (g.M + 255) / 256;
+        g.tiles_n = (g.N + 255) / 256;
+        const int ntiles = g.tiles_m * g.tiles_n;
+        // persistent: one workgroup per CU walks tiles b, b + wgs, ...; the XCD-aware tile remap assumes workgroups b and
+        // b + wgs share an XCD (wgs % 8 == 0), which only matters when a workgroup has more than one tile
+        int wgs = g_persistent_wgs > 0 ? g_persistent_wgs : vb_num_cus();
+        if (wgs >= ntiles) wgs = ntiles;
+        else if (wgs >= 8) wgs &= ~7;
+        dim3 grid((unsigned)wgs), block(512);
+        const int needs = epi_needs(g, sizeof(T), sizeof(TO));
+#define VB_TRY_EPI(A, O) if (g.act == (A) && (needs & ~(O)) == 0) return launch_8ph_act<T, TO, A, O>(g, grid, block, SM, stream)
+        if constexpr (kActSpecialised<T, TO>) {
+            VB_TRY_EPI(VB_ACT_NONE, 0);
+            VB_TRY_EPI(VB_ACT_GELU, 0);
+            VB_TRY_EPI(VB_ACT_GELU_GRAD, EPI_COLSUM);
+            VB_TRY_EPI(VB_ACT_NONE, EPI_ADD);
+        } else {
+            VB_TRY_EPI(VB_ACT_NONE, EPI_RAGGED);
         }
+#undef VB_TRY_EPI
+        return launch_8ph_act<T, TO, -1, EPI_ALL>(g, grid, block, SM, stream);
     }
-    VB_LAUNCH((gemm_nt_pipe_kernel<T, TO, WM, STAGES>), grid, block, SM, stream, g);
-    return vb_check_launch();
+    return VB_ERR_UNSUPPORTED;
 }
 
 // variant of the pipelined kernel: tens = waves in M (2 -> 128-row tile, 4 -> 256-row tile), units = stages.
 // 0 = use the generic kernel.
 static int g_nt_variant = 1;     // 1 = auto: 256x256 tile where the grid still fills the chip and K or N is large, else 256x128
 static int g_debug = 0;
+static unsigned long long* g_trace = nullptr;
 
 template <typename T, typename TO>
 int dispatch_pipe(const GemmArgs& g, hipStream_t s) {
     int variant = g_nt_variant;
     if (variant == 1) {
-        // measured on MI355X (profiles/r01_gemm_variant_sweep_b128.txt): the 256x256 tile wins on long-K and
-        // wide-N shapes once it yields >= ~200 workgroups; the 256x128 tile wins everywhere else
+        // measured on MI355X (profiles/r01_gemm_variant_sweep_b128.txt)
         const long t256 = (long)((g.M + 255) / 256) * ((g.N + 255) / 256);
-        variant = (t256 >= 200 && (g.K >= 1536 || g.N >= 3072) && g.N <= 8192) ? 88 : 42;
+        variant = (sizeof(T) == 2 && t256 >= 160) ? 80 : 42;
     }
     switch (variant) {
         case 22: return launch_pipe<T, TO, 2, 2>(g, s);
-        case 23: return launch_pipe<T, TO, 2, 3>(g, s);
-        case 24: return launch_pipe<T, TO, 2, 4>(g, s);
         case 42: return launch_pipe<T, TO, 4, 2>(g, s);
-        case 43: return launch_pipe<T, TO, 4, 3>(g, s);
-        case 44: return launch_pingpong<T, TO>(g, s);
-        case 88: return launch_big<T, TO>(g, s);
-        case 53: return launch_weave<T, TO>(g, s);
+        case 80: return launch_8ph<T, TO>(g, s);
         default: return VB_ERR_UNSUPPORTED;
     }
 }
@@ -982,7 +1084,7 @@ extern "C" int vb_gemm(int dtype, int out_dtype, int a_layout, int b_layout,
     g.bias = bias; g.addend = addend; g.ld_addend = ld_addend; g.aux_in = aux_in; g.aux_out = aux_out;
     g.ld_aux = ld_aux; g.alpha = alpha; g.alpha_dev = alpha_dev; g.colsum = colsum_out; g.act = act; g.accumulate = accumulate;
     g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
-    g.debug = g_debug;
+    g.debug = g_debug; g.trace = g_trace;
     const int bk = dtype == VB_BF16 ? 64 : 32;
     const int nk = (K + bk - 1) / bk;
     // LDS-direct copies need whole K tiles (a masked lane would leave stale LDS behind)
@@ -1041,12 +1143,13 @@ extern "C" int64_t vb_gemm_profile_read(double* ms, double* flops, int* key, int
 }
 
 extern "C" int vb_gemm_set_variant(int variant) {
-    if (variant != 0 && variant != 1 && variant != 22 && variant != 23 && variant != 24 && variant != 42 && variant != 43 && variant != 44 && variant != 88 && variant != 53) return VB_ERR_ARG;
+    if (variant != 0 && variant != 1 && variant != 22 && variant != 42 && variant != 80) return VB_ERR_ARG;
     g_nt_variant = variant;
     return VB_OK;
 }
 
 extern "C" int vb_gemm_set_debug(int bits) { g_debug = bits; return VB_OK; }
+extern "C" int vb_gemm_set_persistent_wgs(int n) { if (n < 0) return VB_ERR_ARG; g_persistent_wgs = n; return VB_OK; }
 
 // ---- measurement aid: issue-rate ceiling of the two bf16 MFMA shapes at the clocks this chip really holds ---
 #ifndef VB_EMU
@@ -1091,3 +1194,46 @@ extern "C" int vb_mfma_peak(int kind, int iters, int blocks, float* out, void* s
     return VB_ERR_UNSUPPORTED;
 #endif
 }
+
+// ---- measurement aid: ceiling of the global -> LDS (LDS-direct) path per CU ---------------------------------
+// every wave of every 512-thread block streams `iters` x 1 KiB pieces from an `span`-byte window of src (L2- or
+// HBM-resident depending on span) into an LDS ring, keeping DEPTH pieces in flight (counted vmcnt).
+#ifndef VB_EMU
+template <int DEPTH>
+__global__ void __launch_bounds__(512) glds_stream_kernel(const unsigned char* src, long span, int iters, float* sink) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ring[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned char* myring = ring + wave * DEPTH * 1024;
+    // each block owns a window; consecutive pieces walk through it (wraps), each lane 16 B
+    long off = ((long)blockIdx.x * 8 + wave) * 65536 % span;
+    for (int i = 0; i < iters; ++i) {
+        const unsigned char* g = src + (off + (long)i * 1024) % span + lane * 16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)(myring + (i % DEPTH) * 1024), 16, 0, 0);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DEPTH - 1) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (sink && threadIdx.x == 0) sink[blockIdx.x] = *(float*)ring;
+}
+#endif
+extern "C" int vb_glds_stream(int depth, const void* src, int64_t span, int iters, int blocks, float* sink, void* stream) {
+#ifndef VB_EMU
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned char* p = (const unsigned char*)src;
+    switch (depth) {
+        case 1: hipLaunchKernelGGL(glds_stream_kernel<1>, dim3(blocks), dim3(512), 8 * 1 * 1024, s, p, (long)span, iters, sink); break;
+        case 2: hipLaunchKernelGGL(glds_stream_kernel<2>, dim3(blocks), dim3(512), 8 * 2 * 1024, s, p, (long)span, iters, sink); break;
+        case 4: hipLaunchKernelGGL(glds_stream_kernel<4>, dim3(blocks), dim3(512), 8 * 4 * 1024, s, p, (long)span, iters, sink); break;
+        case 8: hipLaunchKernelGGL(glds_stream_kernel<8>, dim3(blocks), dim3(512), 8 * 8 * 1024, s, p, (long)span, iters, sink); break;
+        case 16: hipLaunchKernelGGL(glds_stream_kernel<16>, dim3(blocks), dim3(512), 8 * 16 * 1024, s, p, (long)span, iters, sink); break;
+        default: return VB_ERR_ARG;
+    }
+    return vb_check_launch();
+#else
+    (void)depth; (void)src; (void)span; (void)iters; (void)blocks; (void)sink; (void)stream;
+    return VB_ERR_UNSUPPORTED;
+#endif
+}
+
+extern "C" int vb_gemm_set_trace(void* device_u64x1024) { g_trace = (unsigned long long*)device_u64x1024; return VB_OK; }

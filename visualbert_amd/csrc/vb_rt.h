@@ -148,6 +148,41 @@ VB_DEVICE void vb_raw_barrier() {
 }
 #endif
 
+// value known to be identical in every lane of the wave: keep it in a scalar register (addresses built from it
+// become scalar arithmetic instead of per-lane VALU + v_readfirstlane at every use)
+#ifdef VB_EMU
+VB_DEVICE int vb_uniform(int v) { return v; }
+#else
+VB_DEVICE int vb_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+#endif
+
+// wave-level ordering point for data exchanged through LDS by the lanes of ONE wave (no workgroup barrier):
+// the LDS unit executes a wave's instructions in order, so only the compiler has to be held back.
+#ifdef VB_EMU
+VB_DEVICE void vb_wave_sync() { (void)::hipemu::shfl(0, 0); }
+VB_DEVICE int vb_num_cus() { return 4; }
+#else
+VB_DEVICE void vb_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+static inline int vb_num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    }
+    return n;
+}
+#endif
+
+// shader clock (cycles) for in-kernel timelines (measurement builds only)
+#ifdef VB_EMU
+VB_DEVICE unsigned long long vb_clock() { return 0ull; }
+#else
+VB_DEVICE unsigned long long vb_clock() { return __builtin_readcyclecounter(); }
+#endif
+
 // instruction-order hints for the LLVM scheduler (guide T19): emit `n` instructions of class `mask` next.
 // masks: 0x8 MFMA, 0x20 VMEM read, 0x100 DS read.  No-ops in the simulator build.
 #ifdef VB_EMU

@@ -147,8 +147,10 @@ def gemm_profile_stop():
 
 def gemm_key_name(key):
     if not (key & 3):
-        return "gemm_nt_pipe_kernel<%s->%s, 256x128 tile, 2-stage LDS-direct>" % (
-            "fp32" if key & 8 else "bf16", "fp32" if (key & 4 or key & 8) else "bf16")
+        kind = ("gemm_nt_8ph_kernel<%s->%s, persistent 256x256 tile, 8-phase LDS-direct>" if key & 16 else
+                "gemm_nt_experimental<%s->%s>" if key & 32 else
+                "gemm_nt_pipe_kernel<%s->%s, 256x128 tile, 2-stage LDS-direct>")
+        return kind % ("fp32" if key & 8 else "bf16", "fp32" if (key & 4 or key & 8) else "bf16")
     return "gemm_kernel<%s->%s, A %s, B %s>" % ("fp32" if key & 8 else "bf16",
                                                 "fp32" if (key & 4 or key & 8) else "bf16",
                                                 "Kstrided" if key & 2 else "Kcontig",

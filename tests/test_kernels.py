@@ -348,20 +348,25 @@ def test_gemm_specialised_epilogues(dev, variant):
         C = gemm(dev, dt, A, B, M, N, K, 0, 0, bias=bias)
         ref = base + bias
         assert (C.float() - ref).abs().max().item() <= lim(ref)
-        # GELU + pre-activation
+        # GELU + pre-activation (run-time epilogue), GELU + saved derivative (the encoder layer's forward form)
         aux = torch.zeros(M, N, dtype=dt, device=dev)
         C = gemm(dev, dt, A, B, M, N, K, 0, 0, bias=bias, act=_lib.VB_ACT_GELU, aux_out=aux)
         assert (aux.float() - ref).abs().max().item() <= lim(ref)
         assert (C.float() - torch.nn.functional.gelu(ref)).abs().max().item() <= lim(ref)
-        # GELU' + column sums
+        gprime = lambda x: 0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
+        aux.zero_()
+        C = gemm(dev, dt, A, B, M, N, K, 0, 0, bias=bias, act=_lib.VB_ACT_GELU_SAVE_GRAD, aux_out=aux)
+        assert (C.float() - torch.nn.functional.gelu(ref)).abs().max().item() <= lim(ref)
+        # gelu' has slope <= ~0.6: the bf16 rounding of the pre-activation it is evaluated at moves it by <= 0.6 * |ref| / 256
+        assert (aux.float() - gprime(ref)).abs().max().item() <= lim(ref)
+        # GELU' + column sums (run-time epilogue), multiply-by-saved-derivative + column sums (the layer's backward form)
         pre = torch.randn(M, N, generator=g).to(dt).to(dev)
-        cs = torch.ones(N, device=dev)
-        C = gemm(dev, dt, A, B, M, N, K, 0, 0, act=_lib.VB_ACT_GELU_GRAD, aux_in=pre, colsum=cs)
-        x = pre.float()
-        gg = 0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
-        ref2 = base * gg
-        assert (C.float() - ref2).abs().max().item() <= lim(ref2)
-        assert (cs - (1.0 + ref2.sum(0))).abs().max().item() <= 2e-2 * max(1.0, ref2.sum(0).abs().max().item())
+        for act, factor in ((_lib.VB_ACT_GELU_GRAD, gprime(pre.float())), (_lib.VB_ACT_MUL_AUX, pre.float())):
+            cs = torch.ones(N, device=dev)
+            C = gemm(dev, dt, A, B, M, N, K, 0, 0, act=act, aux_in=pre, colsum=cs)
+            ref2 = base * factor
+            assert (C.float() - ref2).abs().max().item() <= lim(ref2)
+            assert (cs - (1.0 + ref2.sum(0))).abs().max().item() <= 2e-2 * max(1.0, ref2.sum(0).abs().max().item())
         # residual addend
         add_t = torch.randn(M, N, generator=g).to(dt).to(dev)
         C = gemm(dev, dt, A, B, M, N, K, 0, 0, addend=add_t)

@@ -266,6 +266,13 @@ VB_DEVICE void epi_scalar(float x, const GemmArgs& g, float alpha, long m, int n
         x = tanhf(x);
     } else if (g.act == VB_ACT_GELU_GRAD) {
         x *= gelu_grad_f(to_f32(((const T*)g.aux_in)[m * g.ld_aux + n]));
+    } else if (g.act == VB_ACT_GELU_SAVE_GRAD) {
+        float y, dy;
+        gelu_and_grad_f(x, y, dy);
+        ((T*)g.aux_out)[m * g.ld_aux + n] = from_f32<T>(dy);
+        x = y;
+    } else if (g.act == VB_ACT_MUL_AUX) {
+        x *= to_f32(((const T*)g.aux_in)[m * g.ld_aux + n]);
     }
     if (g.addend) x += to_f32(((const T*)g.addend)[m * g.ld_addend + n]);
     TO* cp = (TO*)g.C + m * g.ldc + n;
@@ -278,7 +285,7 @@ VB_DEVICE void epi_scalar(float x, const GemmArgs& g, float alpha, long m, int n
 template <typename T, typename TO, int ACT, int OPT>
 VB_DEVICE void epi_load8(float (&xa)[8], float (&xd)[8], float (&xc)[8], const GemmArgs& g, long m, int ncol) {
     const int act = ACT >= 0 ? ACT : g.act;
-    if (act == VB_ACT_GELU_GRAD) load8(xa, (const T*)g.aux_in + m * g.ld_aux + ncol);
+    if (act == VB_ACT_GELU_GRAD || act == VB_ACT_MUL_AUX) load8(xa, (const T*)g.aux_in + m * g.ld_aux + ncol);
     if constexpr (OPT & EPI_ADD) {
         if (g.addend) load8(xd, (const T*)g.addend + m * g.ld_addend + ncol);
         if (g.accumulate) load8(xc, (const TO*)g.C + m * g.ldc + ncol);
@@ -301,6 +308,14 @@ VB_DEVICE void epi_vec8(float (&v)[8], const GemmArgs& g, EpiLane& e, long m,
     } else if (act == VB_ACT_GELU_GRAD) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] *= gelu_grad_f(xa[j]);
+    } else if (act == VB_ACT_GELU_SAVE_GRAD) {
+        float d[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gelu_and_grad_f(v[j], v[j], d[j]);
+        store8((T*)g.aux_out + m * g.ld_aux + n, d);                      // gelu'(pre), what backward multiplies by
+    } else if (act == VB_ACT_MUL_AUX) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= xa[j];
     }
     if constexpr (OPT & EPI_ADD) {
         if (g.addend) {
@@ -715,8 +730,8 @@ int launch_pipe(GemmArgs g, hipStream_t stream) {
 #define VB_TRY_EPI(A, O) if (g.act == (A) && (needs & ~(O)) == 0) return launch_pipe_act<T, TO, WM, STAGES, A, O>(g, grid, block, SM, stream)
     if constexpr (kActSpecialised<T, TO>) {
         VB_TRY_EPI(VB_ACT_NONE, 0);                        // forward projections, dgrad attention-out
-        VB_TRY_EPI(VB_ACT_GELU, 0);                        // FFN-in forward
-        VB_TRY_EPI(VB_ACT_GELU_GRAD, EPI_COLSUM);          // FFN-out dgrad (+ FFN-in bias gradient)
+        VB_TRY_EPI(VB_ACT_GELU_SAVE_GRAD, 0);              // FFN-in forward
+        VB_TRY_EPI(VB_ACT_MUL_AUX, EPI_COLSUM);            // FFN-out dgrad (+ FFN-in bias gradient)
         VB_TRY_EPI(VB_ACT_NONE, EPI_ADD);                  // dgrads that add the residual gradient
     } else if constexpr (sizeof(T) == 2) {
         VB_TRY_EPI(VB_ACT_NONE, EPI_RAGGED);               // MLM decoder logits (N = vocabulary size)
@@ -759,7 +774,8 @@ VB_DEVICE void vb_phase_barrier() {
 constexpr int EPI8_BYTES_PER_WAVE = 16 * 256;
 // one 16-row fragment row (4 fragments = 16 rows x 64 columns) of a wave's block; mrow0 = its first global row
 template <typename T, typename TO, int ACT, int OPT>
-VB_DEVICE void gemm_epilogue_fragrow(f32x4 (&a)[4], unsigned char* slab, const GemmArgs& g, int mrow0, int lane, EpiLane& e) {
+VB_DEVICE void gemm_epilogue_fragrow(f32x4 (&a)[4], unsigned char* slab, const GemmArgs& g, int mrow0, int lane, EpiLane& e,
+                                      const u32x4* pre, int pre_kind) {
     const int li = lane & 15, lg = lane >> 4, cc = lane & 7;
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni)
@@ -771,6 +787,14 @@ VB_DEVICE void gemm_epilogue_fragrow(f32x4 (&a)[4], unsigned char* slab, const G
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
         const int m = mrow0 + it * 8 + (lane >> 3);
+        if constexpr (sizeof(T) == 2) {
+            if (pre_kind) {                             // row operand already in registers (gemm_epilogue_private)
+                const bf16x8 x = *(const bf16x8*)&pre[it];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { if (pre_kind == 1) xa[it][j] = (float)x[j]; else xd[it][j] = (float)x[j]; }
+                continue;
+            }
+        }
         if (e.vec && m < g.M && e.ncol < g.N) epi_load8<T, TO, ACT, OPT>(xa[it], xd[it], xc[it], g, m, e.ncol);
     }
 #pragma unroll
@@ -804,15 +828,45 @@ template <typename T, typename TO, int ACT, int OPT>
 VB_DEVICE void gemm_epilogue_private(f32x4 (&acc)[8][4], unsigned char* slab, const GemmArgs& g, int mw0, int nw0, int lane) {
     EpiLane e;
     epi_lane_init<T, TO, OPT>(e, g, nw0, lane);
+    // The per-row operand of the specialised epilogues (saved GELU' / residual gradient) is fetched for the WHOLE 128x64
+    // block in two batches of 8 independent 16-byte loads per lane (the fragment registers are dead by now) instead of
+    // two per fragment row, each waiting out an HBM round trip before its multiply (8 round trips per tile).
+    constexpr bool PRE_AUX = sizeof(T) == 2 && !(OPT & EPI_RAGGED) && (ACT == VB_ACT_MUL_AUX || ACT == VB_ACT_GELU_GRAD);
+    constexpr bool PRE_ADD = sizeof(T) == 2 && !(OPT & EPI_RAGGED) && ACT >= 0 && !PRE_AUX && (OPT & EPI_ADD);
+    u32x4 pre[4][2];                                // two batches of 4 fragment rows (8 loads in flight, 32 VGPRs)
+    int pre_kind = 0;
+    const unsigned char* pbase = nullptr;
+    long pld = 0;
+    if constexpr (PRE_AUX || PRE_ADD) {
+        if (PRE_AUX) { pbase = (const unsigned char*)g.aux_in; pld = g.ld_aux; pre_kind = 1; }
+        else if (g.addend && !g.accumulate) { pbase = (const unsigned char*)g.addend; pld = g.ld_addend; pre_kind = 2; }
+    }
+    auto preload = [&](int mi0) {
+        if constexpr (PRE_AUX || PRE_ADD) {
+            if (pre_kind) {
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int it = 0; it < 2; ++it) {
+                        int m = mw0 + (mi0 + mi) * 16 + it * 8 + (lane >> 3);
+                        m = m < g.M ? m : g.M - 1;                  // clamped rows are loaded but never stored
+                        const int n = e.ncol < g.N ? e.ncol : 0;
+                        pre[mi][it] = *(const u32x4*)(pbase + ((long)m * pld + n) * 2);
+                    }
+            }
+        }
+    };
     // constant indices spelled out: the accumulators must never be addressed by a loop variable
-    gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[0], slab, g, mw0 + 0, lane, e);
-    gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[1], slab, g, mw0 + 16, lane, e);
-    gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[2], slab, g, mw0 + 32, lane, e);
-    gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[3], slab, g, mw0 + 48, lane, e);
-    gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[4], slab, g, mw0 + 64, lane, e);
-    gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[5], slab, g, mw0 + 80, lane, e);
-    gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[6], slab, g, mw0 + 96, lane, e);
-    gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[7], slab, g, mw0 + 112, lane, e);
+    preload(0);
+    gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[0], slab, g, mw0 + 0, lane, e, pre[0], pre_kind);
+    gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[1], slab, g, mw0 + 16, lane, e, pre[1], pre_kind);
+    gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[2], slab, g, mw0 + 32, lane, e, pre[2], pre_kind);
+    gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[3], slab, g, mw0 + 48, lane, e, pre[3], pre_kind);
+    preload(4);
+    gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[4], slab, g, mw0 + 64, lane, e, pre[0], pre_kind);
+    gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[5], slab, g, mw0 + 80, lane, e, pre[1], pre_kind);
+    gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[6], slab, g, mw0 + 96, lane, e, pre[2], pre_kind);
+    gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[7], slab, g, mw0 + 112, lane, e, pre[3], pre_kind);
     if constexpr (OPT & EPI_COLSUM) epi_colsum_flush(e, g, nw0, lane);
 }
 
@@ -1012,8 +1066,8 @@ int launch_8ph(GemmArgs g, hipStream_t stream) {
 #define VB_TRY_EPI(A, O) if (g.act == (A) && (needs & ~(O)) == 0) return launch_8ph_act<T, TO, A, O>(g, grid, block, SM, stream)
         if constexpr (kActSpecialised<T, TO>) {
             VB_TRY_EPI(VB_ACT_NONE, 0);
-            VB_TRY_EPI(VB_ACT_GELU, 0);
-            VB_TRY_EPI(VB_ACT_GELU_GRAD, EPI_COLSUM);
+            VB_TRY_EPI(VB_ACT_GELU_SAVE_GRAD, 0);
+            VB_TRY_EPI(VB_ACT_MUL_AUX, EPI_COLSUM);
             VB_TRY_EPI(VB_ACT_NONE, EPI_ADD);
         } else {
             VB_TRY_EPI(VB_ACT_NONE, EPI_RAGGED);
@@ -1078,7 +1132,9 @@ extern "C" int vb_gemm(int dtype, int out_dtype, int a_layout, int b_layout,
     // vector loads are 16 bytes: leading dimensions and base pointers must keep them aligned
     if ((lda % 8) || (ldb % 8) || (((uintptr_t)A | (uintptr_t)B) & 15)) return VB_ERR_ARG;
     (void)epc;
-    if (act == VB_ACT_GELU_GRAD && !aux_in) return VB_ERR_ARG;
+    if ((act == VB_ACT_GELU_GRAD || act == VB_ACT_MUL_AUX) && !aux_in) return VB_ERR_ARG;
+    if (act == VB_ACT_GELU_SAVE_GRAD && !aux_out) return VB_ERR_ARG;
+    if (act < VB_ACT_NONE || act > VB_ACT_MUL_AUX) return VB_ERR_ARG;
     GemmArgs g;
     g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
     g.bias = bias; g.addend = addend; g.ld_addend = ld_addend; g.aux_in = aux_in; g.aux_out = aux_out;

@@ -119,7 +119,7 @@ extern "C" int vb_bert_layer_fwd(int dtype, const void* h_in, const float* mask_
                      0.f, 0, seed, stream));
     // 5. FFN in + erf-GELU (pre-activation kept for backward)
     VB_TRY(vb_gemm(dtype, dtype, VB_KCONTIG, VB_KCONTIG, sv.a_out, H, wi, H, sv.inter, I, M, I, H, 1.f, nullptr, bi,
-                   nullptr, 0, VB_ACT_GELU, nullptr, sv.pre, I, 0, nullptr, stream));
+                   nullptr, 0, VB_ACT_GELU_SAVE_GRAD, nullptr, sv.pre, I, 0, nullptr, stream));
     // 6. FFN out
     VB_TRY(vb_gemm(dtype, dtype, VB_KCONTIG, VB_KCONTIG, sv.inter, I, wo2, I, sc.t_h1, H, M, H, I, 1.f, nullptr, bo2,
                    nullptr, 0, VB_ACT_NONE, nullptr, nullptr, 0, 0, nullptr, stream));
@@ -172,7 +172,7 @@ extern "C" int vb_bert_layer_bwd(int dtype, const void* h_in, const float* mask_
                    nullptr, nullptr, 0, VB_ACT_NONE, nullptr, nullptr, 0, 1, nullptr, stream));
     // 3. dgrad FFN-out with GELU' folded into the epilogue: dpre = (dfo Wo2) * gelu'(pre)
     //    (+ 4. bias gradient of FFN-in = column sums of dpre, accumulated by the same epilogue)
-    VB_TRY(dgrad(dfo, H, wo2, VB_LWT_FO, I, sc.t_i, nullptr, VB_ACT_GELU_GRAD, sv.pre, G[VB_LW_FI_B]));
+    VB_TRY(dgrad(dfo, H, wo2, VB_LWT_FO, I, sc.t_i, nullptr, VB_ACT_MUL_AUX, sv.pre, G[VB_LW_FI_B]));
     // 5. wgrad FFN-in: dW[I,H] += dpre^T a_out
     VB_TRY(vb_gemm(dtype, VB_F32, VB_KSTRIDED, VB_KSTRIDED, sc.t_i, I, sv.a_out, H, G[VB_LW_FI_W], H, I, H, M, 1.f,
                    nullptr, nullptr, nullptr, 0, VB_ACT_NONE, nullptr, nullptr, 0, 1, nullptr, stream));

@@ -261,13 +261,25 @@ VB_DEVICE float fast_erf(float x) {
     const float r = 1.0f - p * t * fast_exp(-ax * ax);
     return x < 0.f ? -r : r;
 }
-VB_DEVICE float gelu_f(float x) { return x * 0.5f * (1.0f + fast_erf(x * 0.70710678118654752440f)); }
-VB_DEVICE float gelu_grad_f(float x) {
-    // d/dx [x * Phi(x)] = Phi(x) + x * phi(x)
-    float cdf = 0.5f * (1.0f + fast_erf(x * 0.70710678118654752440f));
-    float pdf = 0.39894228040143267794f * fast_exp(-0.5f * x * x);
-    return cdf + x * pdf;
+// Phi(x) and phi(x) of the standard normal with ONE exponential: erf(x/sqrt2) = 1 - poly(t) exp(-x^2/2) and
+// phi(x) = exp(-x^2/2)/sqrt(2 pi) share it.
+VB_DEVICE void gelu_parts(float x, float& cdf, float& pdf) {
+    const float ax = fabsf(x) * 0.70710678118654752440f;
+    const float t = fast_rcp(1.0f + 0.3275911f * ax);
+    const float e = fast_exp(-0.5f * x * x);
+    float p = 1.061405429f;
+    p = p * t - 1.453152027f;
+    p = p * t + 1.421413741f;
+    p = p * t - 0.284496736f;
+    p = p * t + 0.254829592f;
+    const float r = 1.0f - p * t * e;                 // erf(|x| / sqrt 2)
+    cdf = 0.5f * (1.0f + (x < 0.f ? -r : r));
+    pdf = 0.39894228040143267794f * e;
 }
+VB_DEVICE float gelu_f(float x) { float c, d; gelu_parts(x, c, d); return x * c; }
+// d/dx [x * Phi(x)] = Phi(x) + x * phi(x)
+VB_DEVICE float gelu_grad_f(float x) { float c, d; gelu_parts(x, c, d); return c + x * d; }
+VB_DEVICE void gelu_and_grad_f(float x, float& y, float& dy) { float c, d; gelu_parts(x, c, d); y = x * c; dy = c + x * d; }
 
 #define VB_OK 0
 #define VB_ERR_ARG (-1)

@@ -18,7 +18,7 @@ Conventions
 import torch
 
 from . import _lib
-from ._lib import (VB_ACT_GELU, VB_ACT_GELU_GRAD, VB_ACT_NONE, VB_ACT_TANH, VB_KCONTIG, VB_KSTRIDED, check, ptr,
+from ._lib import (VB_ACT_GELU, VB_ACT_GELU_GRAD, VB_ACT_GELU_SAVE_GRAD, VB_ACT_MUL_AUX, VB_ACT_NONE, VB_ACT_TANH, VB_KCONTIG, VB_KSTRIDED, check, ptr,
                    stream_ptr)
 
 _ACT = {None: VB_ACT_NONE, "none": VB_ACT_NONE, "gelu": VB_ACT_GELU, "tanh": VB_ACT_TANH}
@@ -483,8 +483,8 @@ class FFNBlockFn(torch.autograd.Function):
         dt = a2.dtype
         I = inter_mod.dense.weight.size(0)
         pre = torch.empty((B * S, I), dtype=dt, device=a2.device)
-        inter = linear_fwd(a2, weight_for(inter_mod.dense.weight, dt), inter_mod.dense.bias.detach(), VB_ACT_GELU,
-                           aux_out=pre)
+        inter = linear_fwd(a2, weight_for(inter_mod.dense.weight, dt), inter_mod.dense.bias.detach(),
+                           VB_ACT_GELU_SAVE_GRAD, aux_out=pre)      # pre <- gelu'(pre-activation)
         fo = linear_fwd(inter, weight_for(out_mod.dense.weight, dt), out_mod.dense.bias.detach())
         seed = next_seed()
         y, z, mean, rstd = ln_fwd(fo, a2, out_mod.LayerNorm.weight.detach(), out_mod.LayerNorm.bias.detach(),
@@ -511,7 +511,7 @@ class FFNBlockFn(torch.autograd.Function):
         g_ow, d4 = grad_target(om.dense.weight)
         linear_wgrad(dfo, inter, g_ow)
         g_ib, d5 = grad_target(im.dense.bias)
-        dpre = linear_dgrad(dfo, weight_for(om.dense.weight, dt), act=VB_ACT_GELU_GRAD, aux_in=pre,
+        dpre = linear_dgrad(dfo, weight_for(om.dense.weight, dt), act=VB_ACT_MUL_AUX, aux_in=pre,
                             wt=weight_t_for(om.dense.weight, dt), colsum_out=g_ib)
         g_iw, d6 = grad_target(im.dense.weight)
         linear_wgrad(dpre, a2, g_iw)

@@ -219,6 +219,18 @@ int vb_bert_layer_bwd(int dtype, const void* h_in, const float* mask_add, const 
 int vb_gemm_profile(int enable);
 int64_t vb_gemm_profile_read(double* ms, double* flops, int* key, int64_t max_records);
 
+/* Weight gradients of a group of Linears that saw the same tokens (the four of an encoder layer), one launch:
+ *   dw[i][n_out[i], n_in[i]] (fp32, ld_dw[i]) += alpha * dy[i]^T x[i],   dy[i]: [tokens, n_out[i]] (T, ld_dy[i]),
+ *   x[i]: [tokens, n_in[i]] (T, ld_x[i]).  n <= 8.  alpha_dev: optional fp32 device scalar multiplying alpha.
+ * bf16 with tokens % 64 == 0 and every dimension / leading dimension a multiple of 8 runs as ONE persistent kernel
+ * (operands copied as stored, fragments gathered by transposing LDS reads, token slices added with fp32 atomics);
+ * anything else falls back to n vb_gemm calls.
+ * Replaces: the dW = dy^T x half of autograd for nn.Linear at pytorch_pretrained_bert/modeling.py:232-234 (Q,K,V),
+ * :271, :303, :316. */
+int vb_wgrad_grouped(int dtype, int n, const void* const* dy, const int64_t* ld_dy, const void* const* x,
+                     const int64_t* ld_x, void* const* dw, const int64_t* ld_dw, const int* n_out, const int* n_in,
+                     int tokens, float alpha, const float* alpha_dev, void* stream);
+
 /* Tuning knob (measurement aid): selects the pipelined K-contiguous x K-contiguous GEMM kernel.
  * variant = 10 * (waves in M: 2 -> 128x128 tile, 4 -> 256x128 tile) + LDS stages (2..4); 0 = generic kernel. */
 int vb_gemm_set_variant(int variant);

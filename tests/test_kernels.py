@@ -91,6 +91,50 @@ def test_gemm_dgrad_wgrad_layouts(dev, dt, shape):
     assert (C - ref).abs().max().item() <= 3e-4 * max(1.0, ref.abs().max().item())
 
 
+def _wgrad_grouped(dev, dys, xs, dws, tokens, alpha=1.0, alpha_dev=None):
+    L = _lib.lib()
+    n = len(dys)
+    PA = ctypes.c_void_p * n
+    I64 = ctypes.c_int64 * n
+    I32 = ctypes.c_int * n
+    rc = L.vb_wgrad_grouped(_lib.VB_BF16, n, PA(*[_lib.ptr(t) for t in dys]), I64(*[t.stride(0) for t in dys]),
+                            PA(*[_lib.ptr(t) for t in xs]), I64(*[t.stride(0) for t in xs]),
+                            PA(*[_lib.ptr(t) for t in dws]), I64(*[t.stride(0) for t in dws]),
+                            I32(*[t.size(1) for t in dys]), I32(*[t.size(1) for t in xs]), tokens, alpha,
+                            _lib.ptr(alpha_dev), _lib.stream_ptr())
+    _lib.check(rc, "vb_wgrad_grouped")
+
+
+@pytest.mark.parametrize("tokens", [64, 192, 704])
+@pytest.mark.parametrize("wgs", [0, 1, 3])
+def test_wgrad_grouped_transposing_reads(dev, tokens, wgs):
+    """dW += dY^T X for a group of Linears in one persistent launch: operands copied as stored ([token][feature]) and
+    gathered into MFMA fragments by ds_read_b64_tr_b16 (in the simulator: the measured lane map).  1, 3 and 11 K tiles
+    of 64 tokens, ragged 256x256 output tiles, token slices added atomically, one / three workgroups walking all
+    items; also the same shapes through vb_gemm's K-strided x K-strided entry (the per-op path)."""
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(tokens + wgs)
+    dt = torch.bfloat16
+    shapes = [(264, 520), (768, 256), (8, 72)]                  # (out, in)
+    dys = [(torch.randn(tokens, o, generator=g) * 0.5).to(dt).to(dev) for o, _ in shapes]
+    xs = [(torch.randn(tokens, i, generator=g) * 0.5).to(dt).to(dev) for _, i in shapes]
+    try:
+        assert L.vb_gemm_set_persistent_wgs(wgs) == 0
+        dws = [torch.full((o, i), 1.5, device=dev) for o, i in shapes]
+        sc = torch.tensor([0.5], device=dev)
+        _wgrad_grouped(dev, dys, xs, dws, tokens, alpha=2.0, alpha_dev=sc)
+        for dy, x, dw in zip(dys, xs, dws):
+            ref = 1.5 + dy.float().t() @ x.float()
+            assert (dw - ref).abs().max().item() <= 2e-4 * max(1.0, ref.abs().max().item())
+        # per-op entry: vb_gemm(K-strided, K-strided, fp32 accumulate)
+        acc = torch.full(shapes[0], -1.0, device=dev)
+        C = gemm(dev, dt, dys[0], xs[0], shapes[0][0], shapes[0][1], tokens, 1, 1, out_f32=True, acc=acc)
+        ref = -1.0 + dys[0].float().t() @ xs[0].float()
+        assert (C - ref).abs().max().item() <= 2e-4 * max(1.0, ref.abs().max().item())
+    finally:
+        L.vb_gemm_set_persistent_wgs(0)
+
+
 def ln_fwd(dev, dt, x, resid, gamma, beta, p_in=0.0, p_out=0.0, seed=5, want_z=True):
     M, H = x.shape
     L = _lib.lib()

@@ -45,6 +45,7 @@ SIGNATURES = {
     "vb_scatter_rows": (_i, [_i, _p, _p, _p, _i, _i, _i, _p]),
     "vb_colsum": (_i, [_i, _p, _i64, _p, _p, _i, _i, _p]),
     "vb_act_bwd": (_i, [_i, _p, _p, _p, _i64, _i, _p]),
+    "vb_wgrad_grouped": (_i, [_i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _f, _p, _p]),
     "vb_gemm_set_variant": (_i, [_i]),
     "vb_gemm_set_debug": (_i, [_i]),
     "vb_gemm_set_persistent_wgs": (_i, [_i]),

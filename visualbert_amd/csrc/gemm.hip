@@ -1078,6 +1078,287 @@ int launch_8ph(GemmArgs g, hipStream_t stream) {
     return VB_ERR_UNSUPPORTED;
 }
 
+// =================================================================================================
+// Weight gradients: dW_p[out_p, in_p] += alpha * dY_p^T X_p for a GROUP of problems that share the token count
+// (the four Linears of an encoder layer), one persistent launch.  Both operands are K-strided ([token][feature]):
+// tiles are copied AS STORED (LDS-direct, a [64 token][128 feature] half-tile per copy stream step) and the MFMA
+// operand fragments are gathered with ds_read_b64_tr_b16, so nothing is transposed in HBM, registers or LDS.
+// Same eight-phase schedule, half-tile ring, counted waits and private epilogue slab as the kernel above.
+//
+// LDS image of a half-tile (16 KB, rows r = 0..127 of the operand's feature range, k = 0..63 tokens), in 16-byte
+// pieces T[k][8 c .. 8 c + 7]:  chunk q = (((r>>6) 2 + (k>>5)) 2 + ((k>>2)&1)) 2 + ((k>>4)&1)   (1 KB = one copy)
+//                                piece  i = ((r>>4)&3) 16 + (((k>>3)&1) 4 + (k&3)) 2 + ((r>>3)&1)
+// so that (a) one copy instruction fetches 8 token rows x 128 contiguous bytes (full cache lines) and (b) the 32
+// lanes of a ds_read_b64_tr_b16 half-wave read 256 CONSECUTIVE bytes: conflict-free by construction.
+//
+// Work: item = (problem, 256x256 output tile, token slice); workgroup b walks items b, b + G, ... (XCD-aware remap:
+// an XCD gets consecutive items = the tiles of one problem and token slice, which share operand panels in its L2).
+// Partial tiles are added with fp32 atomics (the output is an accumulator anyway).
+// =================================================================================================
+constexpr int VB_TN_MAX = 8;
+struct TnProblem {
+    const void* A; const void* B; float* C;      // dY [tokens][out], X [tokens][in], dW [out][in]
+    long lda, ldb, ldc;
+    int Mo, Ni;                                   // out, in
+    int tiles_n, tiles;                           // 256x256 tiles: columns, total
+    int item0;                                    // first item of this problem
+};
+struct TnArgs {
+    TnProblem p[VB_TN_MAX];
+    int nprob, KT, splits, kps, nitems;           // K tiles of 64 tokens; token slices; K tiles per slice; items
+    float alpha;
+    const float* alpha_dev;
+};
+
+VB_KERNEL VB_LAUNCH_BOUNDS(512) gemm_tn_8ph_kernel(TnArgs g) {
+    typedef bf16 T;
+    constexpr int HALF = 128 * 128, BUF = 4 * HALF;
+    constexpr int SLOT_A0 = 0, SLOT_A1 = 1, SLOT_B0 = 2, SLOT_B1 = 3;
+    VB_DYN_SMEM(smem);
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = vb_uniform(t >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int G = (int)gridDim.x;
+    const int my_items = (g.nitems - (int)blockIdx.x + G - 1) / G;
+    unsigned char* slab = smem + 2 * BUF + wave * EPI8_BYTES_PER_WAVE;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    struct Item { int p, m0, n0, kt0, nk; };
+    auto decode = [&](int j) {
+        Item it;
+        const int v = xcd_remap((int)blockIdx.x + G * j, g.nitems);
+        int p = 0;
+        for (int q = 1; q < g.nprob; ++q) if (v >= g.p[q].item0) p = q;
+        const int local = v - g.p[p].item0;
+        const int s = local / g.p[p].tiles, tl = local - s * g.p[p].tiles;
+        it.p = p;
+        it.m0 = (tl / g.p[p].tiles_n) * 256; it.n0 = (tl % g.p[p].tiles_n) * 256;
+        it.kt0 = s * g.kps;
+        it.nk = g.KT - it.kt0 < g.kps ? g.KT - it.kt0 : g.kps;
+        return it;
+    };
+
+    // ---- copy stream: wave w, instruction i fills chunk q = 2 w + i of a half-tile; lane -> piece (see header)
+    const int ck = ((wave >> 1) & 1) * 32 + ((lane >> 3) & 1) * 8 + (wave & 1) * 4 + ((lane >> 1) & 3);   // + 16 i
+    const int cr = (wave >> 2) * 64 + (lane >> 4) * 16 + (lane & 1) * 8;
+    unsigned offA[2][2], offB[2][2];
+    const unsigned char* srcA = nullptr;           // operand base of the load stream's K tile (uniform)
+    const unsigned char* srcB = nullptr;
+    long stepA = 0, stepB = 0;
+    int ld_j = 0, ld_t = 0, ld_nk = 0;
+    auto set_load_item = [&](int j) {
+        const Item it = decode(j);
+        const TnProblem& P = g.p[it.p];
+        ld_nk = it.nk;
+        stepA = 64 * P.lda * 2; stepB = 64 * P.ldb * 2;
+        srcA = (const unsigned char*)P.A + (long)it.kt0 * stepA;
+        srcB = (const unsigned char*)P.B + (long)it.kt0 * stepB;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                int ca = it.m0 + (cr >> 6) * 128 + h * 64 + (cr & 63);
+                int cb = it.n0 + (cr >> 5) * 64 + h * 32 + (cr & 31);
+                ca = ca <= P.Mo - 8 ? ca : P.Mo - 8;          // clamped pieces land in rows the epilogue masks
+                cb = cb <= P.Ni - 8 ? cb : P.Ni - 8;
+                offA[h][i] = (unsigned)(((ck + 16 * i) * (int)P.lda + ca) * 2);
+                offB[h][i] = (unsigned)(((ck + 16 * i) * (int)P.ldb + cb) * 2);
+            }
+    };
+    auto issueA = [&](int mh, int par) {
+        unsigned char* dst = smem + par * BUF + (mh ? SLOT_A1 : SLOT_A0) * HALF + wave * 2048;
+        vb_glds16(srcA + offA[mh][0], dst);
+        vb_glds16(srcA + offA[mh][1], dst + 1024);
+    };
+    auto issueB = [&](int nh, int par) {
+        unsigned char* dst = smem + par * BUF + (nh ? SLOT_B1 : SLOT_B0) * HALF + wave * 2048;
+        vb_glds16(srcB + offB[nh][0], dst);
+        vb_glds16(srcB + offB[nh][1], dst + 1024);
+    };
+    auto ld_advance = [&]() {
+        if (++ld_t == ld_nk) { ld_t = 0; ++ld_j; set_load_item(ld_j); }
+        else { srcA += stepA; srcB += stepB; }
+    };
+
+    // ---- fragment gathers: lane (s = lane & 15, kg = lane >> 4) of a transposing read
+    const int s16 = lane & 15, kg = lane >> 4;
+    const int lane_off = (kg >> 1) * 1024 + ((kg & 1) * 4 + (s16 >> 2)) * 32 + ((s16 >> 1) & 1) * 16 + (s16 & 1) * 8;
+    const int offa_w = wr * 8192 + lane_off;                                   // F = wr
+    const int offb_w = (wc >> 1) * 8192 + (wc & 1) * 512 + lane_off;           // F = wc >> 1, f16l = (wc & 1) 2 + g
+    bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+    auto gather = [&](const unsigned char* p) {
+        const bf16x4 lo = vb_lds_read_tr(p), hi = vb_lds_read_tr(p + 2048);     // k + 0..3, k + 4..7  (h = 0, 1)
+        return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+    auto readA = [&](const unsigned char* half) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fa[f][ks] = gather(half + offa_w + ks * 4096 + f * 256);
+    };
+    auto readB = [&](bf16x8 (&fb)[2][2], const unsigned char* half) {
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fb[f][ks] = gather(half + offb_w + ks * 4096 + f * 256);
+    };
+    auto quad = [&](int mh, int nh, bf16x8 (&fb)[2][2]) {
+#ifndef VB_EMU
+        __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                    acc[mh * 4 + f][nh * 2 + q] = vb_mma(fa[f][ks], fb[q][ks], acc[mh * 4 + f][nh * 2 + q]);
+#ifndef VB_EMU
+        __builtin_amdgcn_s_setprio(0);
+#endif
+    };
+    // partial tile -> fp32 atomics, a wave covering 64 consecutive columns of one row per instruction
+    auto drain = [&](const Item& it) {
+        const TnProblem& P = g.p[it.p];
+        const float alpha = g.alpha_dev ? g.alpha * g.alpha_dev[0] : g.alpha;
+        const int li = lane & 15, lg = lane >> 4;
+        const int n = it.n0 + wc * 64 + lane;
+        auto fragrow = [&](f32x4 (&a)[4], int mrow0) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    *(float*)(slab + (lg * 4 + r) * 256 + (((ni ^ lg) * 16 + li) << 2)) = a[ni][r];
+            vb_wave_sync();
+            for (int row = 0; row < 16; ++row) {
+                const int m = mrow0 + row;
+                const float v = *(const float*)(slab + row * 256 + (((((lane >> 4) ^ (row >> 2)) & 3) * 16 + (lane & 15)) << 2));
+                if (m < P.Mo && n < P.Ni) vb_atomic_add_noret(P.C + (long)m * P.ldc + n, alpha * v);
+            }
+            vb_wave_sync();
+        };
+        const int mw0 = it.m0 + wr * 128;
+        fragrow(acc[0], mw0 + 0);  fragrow(acc[1], mw0 + 16); fragrow(acc[2], mw0 + 32); fragrow(acc[3], mw0 + 48);
+        fragrow(acc[4], mw0 + 64); fragrow(acc[5], mw0 + 80); fragrow(acc[6], mw0 + 96); fragrow(acc[7], mw0 + 112);
+    };
+
+    int GK = 0;
+    for (int j = 0; j < my_items; ++j) GK += decode(j).nk;
+    set_load_item(0);
+    // prologue: K tile 0 (A0 B0 B1 A1) and the first two half-tiles of K tile 1
+    issueA(0, 0); issueB(0, 0); issueB(1, 0); issueA(1, 0);
+    if (GK > 1) { ld_advance(); issueA(0, 1); issueB(0, 1); vb_wait_vmcnt<8>(); }
+    else vb_wait_vmcnt<4>();
+    vb_phase_barrier();
+    if (wr == 1) vb_phase_barrier();               // waves 4-7 run one barrier behind waves 0-3
+
+    int ct = 0, cj = 0;
+    Item cur = decode(0);
+    for (int gk = 0; gk < GK; ++gk) {
+        const int par = gk & 1;
+        const unsigned char* buf = smem + par * BUF;
+        const bool n1 = gk + 1 < GK, n2 = gk + 2 < GK;
+        // ---- phase 0: quadrant (0, 0)
+        readB(fb0, buf + SLOT_B0 * HALF);
+        readA(buf + SLOT_A0 * HALF);
+        if (n1) { issueB(1, par ^ 1); vb_wait_vmcnt<8>(); } else vb_wait_vmcnt<2>();
+        vb_phase_barrier();
+        quad(0, 0, fb0);
+        vb_phase_barrier();
+        // ---- phase 1: quadrant (0, 1)
+        readB(fb1, buf + SLOT_B1 * HALF);
+        if (n1) { issueA(1, par ^ 1); vb_wait_vmcnt<8>(); } else vb_wait_vmcnt<0>();
+        vb_phase_barrier();
+        quad(0, 1, fb1);
+        vb_phase_barrier();
+        // ---- phase 2: quadrant (1, 1)
+        readA(buf + SLOT_A1 * HALF);
+        if (n2) { ld_advance(); issueA(0, par); vb_wait_vmcnt<8>(); } else if (n1) vb_wait_vmcnt<6>(); else vb_wait_vmcnt<0>();
+        vb_phase_barrier();
+        quad(1, 1, fb1);
+        vb_phase_barrier();
+        // ---- phase 3: quadrant (1, 0)
+        if (n2) { issueB(0, par); vb_wait_vmcnt<8>(); } else if (n1) vb_wait_vmcnt<4>(); else vb_wait_vmcnt<0>();
+        vb_phase_barrier();
+        quad(1, 0, fb0);
+        vb_phase_barrier();
+        if (++ct == cur.nk) {
+            drain(cur);
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+            ct = 0; ++cj;
+            if (cj < my_items) cur = decode(cj);
+        }
+    }
+    if (wr == 0) vb_phase_barrier();               // balance the stagger barrier
+}
+
+// token slices: few enough to keep the atomic traffic (items x 256 KB) low, many enough to fill the chip
+static int tn_pick_splits(int tiles, int KT, int wgs) {
+    int best = 1;
+    double best_cost = 1e30;
+    for (int s = 1; s <= 32 && s <= KT; ++s) {
+        const int kps = (KT + s - 1) / s;
+        const int real = (KT + kps - 1) / kps;
+        if (real != s) continue;
+        const long items = (long)tiles * s;
+        const long rounds = (items + wgs - 1) / wgs;
+        const double cost = rounds * (kps + 8.0);            // epilogue ~ 8 K tiles' worth of time per item
+        if (cost < best_cost * 0.97) { best_cost = cost; best = s; }
+    }
+    return best;
+}
+
+// problems must share K (tokens, a multiple of 64); every dimension a multiple of 8; bf16 operands
+static int launch_tn_group(TnArgs& g, int K, hipStream_t stream) {
+    constexpr int SM = 2 * 4 * 128 * 128 + 8 * EPI8_BYTES_PER_WAVE;
+    g.KT = K / 64;
+    int tiles = 0;
+    for (int i = 0; i < g.nprob; ++i) {
+        TnProblem& P = g.p[i];
+        P.tiles_n = (P.Ni + 255) / 256;
+        P.tiles = ((P.Mo + 255) / 256) * P.tiles_n;
+        tiles += P.tiles;
+    }
+    int wgs = g_persistent_wgs > 0 ? g_persistent_wgs : vb_num_cus();
+    g.splits = tn_pick_splits(tiles, g.KT, wgs);
+    g.kps = (g.KT + g.splits - 1) / g.splits;
+    int item0 = 0;
+    for (int i = 0; i < g.nprob; ++i) { g.p[i].item0 = item0; item0 += g.p[i].tiles * g.splits; }
+    g.nitems = item0;
+    if (wgs >= g.nitems) wgs = g.nitems;
+    else if (wgs >= 8) wgs &= ~7;
+    dim3 grid((unsigned)wgs), block(512);
+#ifndef VB_EMU
+    if (g_prof) {
+        ProfRec r;
+        if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return VB_ERR_LAUNCH;
+        r.flops = 0;
+        for (int i = 0; i < g.nprob; ++i) r.flops += 2.0 * g.p[i].Mo * g.p[i].Ni * K;
+        r.key = 4 | 2 | 1 | 16;
+        (void)hipEventRecord(r.e0, stream);
+        VB_LAUNCH(gemm_tn_8ph_kernel, grid, block, SM, stream, g);
+        (void)hipEventRecord(r.e1, stream);
+        g_prof->push_back(r);
+        return vb_check_launch();
+    }
+#endif
+    VB_LAUNCH(gemm_tn_8ph_kernel, grid, block, SM, stream, g);
+    return vb_check_launch();
+}
+static bool tn_eligible(const void* A, long lda, const void* B, long ldb, const float* C, long ldc, int Mo, int Ni, int K) {
+    return K >= 64 && (K % 64) == 0 && Mo >= 8 && Ni >= 8 && (Mo % 8) == 0 && (Ni % 8) == 0 && (lda % 8) == 0 && (ldb % 8) == 0 &&
+           ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0 && C != nullptr && ldc >= Ni &&
+           64L * lda * 2 + 2L * Mo < (1L << 31) && 64L * ldb * 2 + 2L * Ni < (1L << 31);
+}
+
 // variant of the pipelined kernel: tens = waves in M (2 -> 128-row tile, 4 -> 256-row tile), units = stages.
 // 0 = use the generic kernel.
 static int g_nt_variant = 1;     // 1 = auto: 256x256 tile where the grid still fills the chip and K or N is large, else 256x128
@@ -1160,8 +1441,44 @@ extern "C" int vb_gemm(int dtype, int out_dtype, int a_layout, int b_layout,
     }
     hipStream_t s = (hipStream_t)stream;
     const int of32 = (out_dtype == VB_F32) ? 1 : 0;
+    if (dtype == VB_BF16 && of32 && a_layout == VB_KSTRIDED && b_layout == VB_KSTRIDED && accumulate && !bias && !addend &&
+        !colsum_out && act == VB_ACT_NONE && g_nt_variant != 0 && tn_eligible(A, lda, B, ldb, (const float*)C, ldc, M, N, K)) {
+        TnArgs tg;
+        tg.nprob = 1; tg.alpha = alpha; tg.alpha_dev = alpha_dev;
+        tg.p[0].A = A; tg.p[0].B = B; tg.p[0].C = (float*)C; tg.p[0].lda = lda; tg.p[0].ldb = ldb; tg.p[0].ldc = ldc;
+        tg.p[0].Mo = M; tg.p[0].Ni = N;
+        return launch_tn_group(tg, K, s);
+    }
     if (dtype == VB_BF16) return dispatch<bf16>(of32 && true, a_layout, b_layout, g, s);
     return dispatch<float>(1, a_layout, b_layout, g, s);
+}
+
+extern "C" int vb_wgrad_grouped(int dtype, int n, const void* const* dy, const int64_t* ld_dy, const void* const* x,
+                                const int64_t* ld_x, void* const* dw, const int64_t* ld_dw, const int* n_out,
+                                const int* n_in, int tokens, float alpha, const float* alpha_dev, void* stream) {
+    if (n <= 0 || n > VB_TN_MAX || !dy || !ld_dy || !x || !ld_x || !dw || !ld_dw || !n_out || !n_in || tokens <= 0)
+        return VB_ERR_ARG;
+    if (dtype != VB_F32 && dtype != VB_BF16) return VB_ERR_ARG;
+    bool fast = dtype == VB_BF16 && g_nt_variant != 0;
+    for (int i = 0; i < n && fast; ++i)
+        fast = tn_eligible(dy[i], ld_dy[i], x[i], ld_x[i], (const float*)dw[i], ld_dw[i], n_out[i], n_in[i], tokens);
+    if (fast) {
+        TnArgs tg;
+        tg.nprob = n; tg.alpha = alpha; tg.alpha_dev = alpha_dev;
+        for (int i = 0; i < n; ++i) {
+            tg.p[i].A = dy[i]; tg.p[i].B = x[i]; tg.p[i].C = (float*)dw[i];
+            tg.p[i].lda = ld_dy[i]; tg.p[i].ldb = ld_x[i]; tg.p[i].ldc = ld_dw[i];
+            tg.p[i].Mo = n_out[i]; tg.p[i].Ni = n_in[i];
+        }
+        return launch_tn_group(tg, tokens, (hipStream_t)stream);
+    }
+    for (int i = 0; i < n; ++i) {
+        int rc = vb_gemm(dtype, VB_F32, VB_KSTRIDED, VB_KSTRIDED, dy[i], ld_dy[i], x[i], ld_x[i], dw[i], ld_dw[i],
+                         n_out[i], n_in[i], tokens, alpha, alpha_dev, nullptr, nullptr, 0, VB_ACT_NONE, nullptr, nullptr, 0,
+                         1, nullptr, stream);
+        if (rc != VB_OK) return rc;
+    }
+    return VB_OK;
 }
 
 extern "C" int vb_gemm_profile(int enable) {

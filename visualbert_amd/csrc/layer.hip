@@ -45,7 +45,7 @@ Saved carve_saved(unsigned char* base, const Dims& d, bool attn_dropout) {
 
 // scratch (temporaries, reusable by every layer on the same stream)
 struct Scratch {
-    unsigned char *t_h0, *t_h1, *t_h2, *t_h3, *t_i, *t_3h;
+    unsigned char *t_h0, *t_h1, *t_h2, *t_h3, *t_h4, *t_h5, *t_i, *t_3h;
     float* dsum;
     float* ln_ws;
     size_t total;
@@ -58,6 +58,8 @@ Scratch carve_scratch(unsigned char* base, const Dims& d) {
     s.t_h1 = take((size_t)d.M * d.H * d.es);
     s.t_h2 = take((size_t)d.M * d.H * d.es);
     s.t_h3 = take((size_t)d.M * d.H * d.es);
+    s.t_h4 = take((size_t)d.M * d.H * d.es);
+    s.t_h5 = take((size_t)d.M * d.H * d.es);
     s.t_i = take((size_t)d.M * d.I * d.es);
     s.t_3h = take((size_t)d.M * 3 * d.H * d.es);
     s.dsum = (float*)take((size_t)d.B * d.nh * d.S * 4);
@@ -162,41 +164,45 @@ extern "C" int vb_bert_layer_bwd(int dtype, const void* h_in, const float* mask_
                        nullptr, addend, n_in, act, aux, nullptr, n_in, 0, colsum, stream);
     };
 
+    // Every output gradient (dfo, dpre, dao, dqkv) stays alive to the end of the layer so that the four weight
+    // gradients run as ONE grouped launch (vb_wgrad_grouped): 108 output tiles x 2 token slices fill the chip with
+    // 164-K-tile items, where four separate launches had 9..36 tiles each and needed 7..28 slices (atomic traffic x4).
     unsigned char* dz2 = sc.t_h0;                        // d(a_out) through the residual of the output LN
     unsigned char* dfo = p_hidden > 0.f ? sc.t_h1 : dz2; // d(FFN-out dense output)
     // 1. output LayerNorm backward (+ bias gradient of the FFN-out dense as a by-product)
     VB_TRY(vb_ln_bwd(dtype, d_out, sv.z2, sv.mean2, sv.rstd2, g2, dz2, dfo, G[VB_LW_LN2_G], G[VB_LW_LN2_B],
                      G[VB_LW_FO_B], M, H, p_hidden, sid + 4, 0.f, 0, seed, sc.ln_ws, stream));
-    // 2. wgrad FFN-out: dW[H,I] += dfo^T inter
-    VB_TRY(vb_gemm(dtype, VB_F32, VB_KSTRIDED, VB_KSTRIDED, dfo, H, sv.inter, I, G[VB_LW_FO_W], I, H, I, M, 1.f, nullptr,
-                   nullptr, nullptr, 0, VB_ACT_NONE, nullptr, nullptr, 0, 1, nullptr, stream));
-    // 3. dgrad FFN-out with GELU' folded into the epilogue: dpre = (dfo Wo2) * gelu'(pre)
-    //    (+ 4. bias gradient of FFN-in = column sums of dpre, accumulated by the same epilogue)
+    // 2. dgrad FFN-out with the saved GELU' folded into the epilogue: dpre = (dfo Wo2) * gelu'(pre)
+    //    (+ bias gradient of FFN-in = column sums of dpre, accumulated by the same epilogue)
     VB_TRY(dgrad(dfo, H, wo2, VB_LWT_FO, I, sc.t_i, nullptr, VB_ACT_MUL_AUX, sv.pre, G[VB_LW_FI_B]));
-    // 5. wgrad FFN-in: dW[I,H] += dpre^T a_out
-    VB_TRY(vb_gemm(dtype, VB_F32, VB_KSTRIDED, VB_KSTRIDED, sc.t_i, I, sv.a_out, H, G[VB_LW_FI_W], H, I, H, M, 1.f,
-                   nullptr, nullptr, nullptr, 0, VB_ACT_NONE, nullptr, nullptr, 0, 1, nullptr, stream));
-    // 6. dgrad FFN-in + residual gradient: da = dpre Wi + dz2
+    // 3. dgrad FFN-in + residual gradient: da = dpre Wi + dz2
     VB_TRY(dgrad(sc.t_i, I, wi, VB_LWT_FI, H, sc.t_h2, dz2, VB_ACT_NONE, nullptr));
-    // 7. attention-output LayerNorm backward
-    unsigned char* dz1 = sc.t_h0;
-    unsigned char* dao = p_hidden > 0.f ? sc.t_h1 : dz1;
+    // 4. attention-output LayerNorm backward
+    unsigned char* dz1 = sc.t_h5;
+    unsigned char* dao = p_hidden > 0.f ? sc.t_h4 : dz1;
     VB_TRY(vb_ln_bwd(dtype, sc.t_h2, sv.z1, sv.mean1, sv.rstd1, g1, dz1, dao, G[VB_LW_LN1_G], G[VB_LW_LN1_B],
                      G[VB_LW_AO_B], M, H, p_hidden, sid + 1, 0.f, 0, seed, sc.ln_ws, stream));
-    // 8. wgrad attention-out: dW[H,H] += dao^T ctx
-    VB_TRY(vb_gemm(dtype, VB_F32, VB_KSTRIDED, VB_KSTRIDED, dao, H, sv.ctx, H, G[VB_LW_AO_W], H, H, H, M, 1.f, nullptr,
-                   nullptr, nullptr, 0, VB_ACT_NONE, nullptr, nullptr, 0, 1, nullptr, stream));
-    // 9. dgrad attention-out: dctx = dao Wo
+    // 5. dgrad attention-out: dctx = dao Wo
     VB_TRY(dgrad(dao, H, wo, VB_LWT_AO, H, sc.t_h3, nullptr, VB_ACT_NONE, nullptr));
-    // 10-11. attention backward (dQ pass, dK/dV pass)
+    // 6-7. attention backward (dQ pass, dK/dV pass)
     VB_TRY(vb_attn_bwd(dtype, sv.qkv, mask_add, sc.t_h3, sv.lse, sv.keepbits, sc.dsum, sc.t_3h, B, S, nh, 64, p_attn,
                        seed, sid, stream));
-    // 12. bias gradient QKV
+    // 8. bias gradient QKV
     VB_TRY(vb_colsum(dtype, sc.t_3h, 3 * H, G[VB_LW_QKV_B], nullptr, M, 3 * H, stream));
-    // 13. wgrad QKV: dW[3H,H] += dqkv^T h_in
-    VB_TRY(vb_gemm(dtype, VB_F32, VB_KSTRIDED, VB_KSTRIDED, sc.t_3h, 3 * H, h_in, H, G[VB_LW_QKV_W], H, 3 * H, H, M, 1.f,
-                   nullptr, nullptr, nullptr, 0, VB_ACT_NONE, nullptr, nullptr, 0, 1, nullptr, stream));
-    // 14. dgrad QKV + residual gradient: dh = dqkv Wqkv + dz1
+    // 9. dgrad QKV + residual gradient: dh = dqkv Wqkv + dz1
     VB_TRY(dgrad(sc.t_3h, 3 * H, wqkv, VB_LWT_QKV, H, d_in, dz1, VB_ACT_NONE, nullptr));
+    // 10. the four weight gradients: dW_fo[H,I] += dfo^T inter, dW_fi[I,H] += dpre^T a_out, dW_ao[H,H] += dao^T ctx,
+    //     dW_qkv[3H,H] += dqkv^T h_in
+    {
+        const void* dys[4] = {dfo, sc.t_i, dao, sc.t_3h};
+        const int64_t ld_dy[4] = {H, I, H, 3 * H};
+        const void* xs[4] = {sv.inter, sv.a_out, sv.ctx, h_in};
+        const int64_t ld_x[4] = {I, H, H, H};
+        void* dws[4] = {G[VB_LW_FO_W], G[VB_LW_FI_W], G[VB_LW_AO_W], G[VB_LW_QKV_W]};
+        const int64_t ld_dw[4] = {I, H, H, H};
+        const int n_out[4] = {H, I, H, 3 * H};
+        const int n_in[4] = {I, H, H, H};
+        VB_TRY(vb_wgrad_grouped(dtype, 4, dys, ld_dy, xs, ld_x, dws, ld_dw, n_out, n_in, M, 1.f, nullptr, stream));
+    }
     return VB_OK;
 }

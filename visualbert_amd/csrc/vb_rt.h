@@ -148,6 +148,27 @@ VB_DEVICE void vb_raw_barrier() {
 }
 #endif
 
+// ds_read_b64_tr_b16 (gfx950): within each 16-lane group, lane s passes the address of 4 contiguous 16-bit values
+// M[s][0..3]; lane l receives { M[(l>>2) + 4 j][l & 3] : j = 0..3 }  (measured: profiles/r01_ds_read_tr_probe.txt).
+// With lane s pointing at T[k0 + (s>>2)][r0 + 4 (s&3) ..] of a K-major tile T[k][row] -- a [4 k][16 row] block --
+// lane l gets T[k0 + j][r0 + l], j = 0..3: four consecutive k of ONE row, i.e. half of a 16x16x32 MFMA operand
+// fragment, from a tile that was never transposed in memory.
+#ifdef VB_EMU
+VB_DEVICE bf16x4 vb_lds_read_tr(const unsigned char* p) {
+    uint64_t mine;
+    memcpy(&mine, p, 8);
+    auto slots = ::hipemu::wave_exchange(&mine, 8);
+    const int l = ::hipemu::cur()->lane, g16 = l & ~15, d = (l & 15) >> 2, c = l & 3;
+    bf16x4 out;
+    for (int j = 0; j < 4; ++j) { bf16 v; memcpy(&v, slots[g16 + d + 4 * j] + c * 2, 2); out[j] = v; }
+    return out;
+}
+#else
+VB_DEVICE bf16x4 vb_lds_read_tr(const unsigned char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p);
+}
+#endif
+
 // value known to be identical in every lane of the wave: keep it in a scalar register (addresses built from it
 // become scalar arithmetic instead of per-lane VALU + v_readfirstlane at every use)
 #ifdef VB_EMU

@@ -115,9 +115,9 @@ def test_wgrad_grouped_transposing_reads(dev, tokens, wgs):
     L = _lib.lib()
     g = torch.Generator().manual_seed(tokens + wgs)
     dt = torch.bfloat16
-    shapes = [(264, 520), (768, 256), (8, 72)]                  # (out, in)
-    dys = [(torch.randn(tokens, o, generator=g) * 0.5).to(dt).to(dev) for o, _ in shapes]
-    xs = [(torch.randn(tokens, i, generator=g) * 0.5).to(dt).to(dev) for _, i in shapes]
+    shapes = [(264, 520), (768, 256), (8, 72), (282, 45)]       # (out, in); the last: neither a multiple of 8
+    dys = [padded(tokens, o, dt, dev, g) for o, _ in shapes]
+    xs = [padded(tokens, i, dt, dev, g) for _, i in shapes]
     try:
         assert L.vb_gemm_set_persistent_wgs(wgs) == 0
         dws = [torch.full((o, i), 1.5, device=dev) for o, i in shapes]
@@ -349,7 +349,7 @@ def test_attention_fwd_bwd(dev, dt, cfg):
     assert err <= tol(dt, 5e-5, 0.04) * max(1.0, gmax), (err, gmax)
 
 
-@pytest.mark.parametrize("variant", [0, 22, 42, 80])
+@pytest.mark.parametrize("variant", [0, 22, 42, 80, 81])
 def test_gemm_pipelined_variants_agree(dev, variant):
     """every pipelined K-contiguous kernel variant (tile shape x LDS stages, counted vmcnt, ping-pong,
     256x256) must give the generic kernel's answer -- on hardware this is what validates the
@@ -371,7 +371,7 @@ def test_gemm_pipelined_variants_agree(dev, variant):
         L.vb_gemm_set_variant(1)
 
 
-@pytest.mark.parametrize("variant", [22, 42, 80])
+@pytest.mark.parametrize("variant", [22, 42, 80, 81])
 def test_gemm_specialised_epilogues(dev, variant):
     """the K-contiguous fast kernels carry ONE epilogue each (activation and optional operands are template
     parameters, picked by the launcher): bias only, GELU + saved pre-activation, GELU' + fused column sums,
@@ -438,7 +438,8 @@ def test_gemm_eight_phase_k_tails(dev, K):
     bias = torch.randn(N, generator=g).to(dev)
     ref = A.float() @ B.float().t() + bias
     try:
-        assert L.vb_gemm_set_variant(80) == 0
+      for variant in (80, 81):              # eight-slot and four-slot schedules of the persistent kernel
+        assert L.vb_gemm_set_variant(variant) == 0
         for wgs in (0, 1, 2, 4):            # 6 output tiles: one per workgroup, or 6 / 3 / 2 walked by one workgroup
             assert L.vb_gemm_set_persistent_wgs(wgs) == 0
             for out_f32 in (True, False):

@@ -18,7 +18,7 @@ def bench(fn, iters=30):
     summ = ops.gemm_profile_stop()
     d = list(summ.values())[0]
     return d["ms"] / d["launches"] * 1e3
-for v, dbg in ((22, 0), (80, 0), (80, 128)):
+for v, dbg in ((80, 0), (81, 0)):
     L.vb_gemm_set_variant(v); L.vb_gemm_set_debug(dbg)
     for n in (768, 2304, 3072):
         row = ["dbg=%d" % dbg]

@@ -757,6 +757,11 @@ int launch_pipe(GemmArgs g, hipStream_t stream) {
 // h = p + 6 and waits until only the newest 4 half-tiles are in flight; phase p reads h <= p + 1 (landed
 // and barrier-published one phase earlier) and overwrites a half-tile last read >= 2 phases ago.
 // =================================================================================================
+VB_DEVICE void vb_sched_fence() {
+#ifndef VB_EMU
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
 VB_DEVICE void vb_phase_barrier() {
 #ifdef VB_EMU
     __syncthreads();
@@ -870,7 +875,7 @@ VB_DEVICE void gemm_epilogue_private(f32x4 (&acc)[8][4], unsigned char* slab, co
     if constexpr (OPT & EPI_COLSUM) epi_colsum_flush(e, g, nw0, lane);
 }
 
-template <typename T, typename TO, int ACT, int OPT>
+template <typename T, typename TO, int ACT, int OPT, int SCHED>
 VB_KERNEL VB_LAUNCH_BOUNDS(512) gemm_nt_8ph_kernel(GemmArgs g) {
     constexpr int BK = TT<T>::BK, KSTEPS = TT<T>::KSTEPS, EPC = TT<T>::EPC;
     constexpr int HALF = 128 * 128, BUF = 4 * HALF;
@@ -971,6 +976,57 @@ VB_KERNEL VB_LAUNCH_BOUNDS(512) gemm_nt_8ph_kernel(GemmArgs g) {
 
     const int nk = g.K / BK;
     const int GK = my_tiles * nk;                  // K tiles in this workgroup's stream
+    if constexpr (SCHED == 1) {
+        // ---- FOUR-SLOT schedule: two quadrants (32 MFMAs) per slot, half the barriers.  Per K tile g (buffer g & 1):
+        //   E(g): reads A0 B0 B1 | issues A1 of tile g+1 | MFMAs (0,0) (0,1)
+        //   O(g): reads A1       | issues A0 B0 B1 of tile g+2 (into the buffer E(g) just drained) | MFMAs (1,1) (1,0)
+        // A wave waits for its own fragment reads BEFORE the barrier that ends its memory slot, so a half-tile may be
+        // refilled one phase after its last read; every counted wait is "all but the newest 8".
+        issueA(0, 0); issueB(0, 0); issueB(1, 0); issueA(1, 0);
+        if (GK > 1) { ld_advance(); issueA(0, 1); issueB(0, 1); issueB(1, 1); vb_wait_vmcnt<6>(); }
+        else vb_wait_vmcnt<0>();
+        vb_phase_barrier();
+        if (wr == 1) vb_phase_barrier();           // waves 4-7 run one barrier behind waves 0-3
+        int ct = 0, cj = 0;
+        for (int gk = 0; gk < GK; ++gk) {
+            const int par = gk & 1;
+            const unsigned char* buf = smem + par * BUF;
+            const bool n1 = gk + 1 < GK, n2 = gk + 2 < GK;
+            // ---- E
+            readB(fb0, buf + SLOT_B0 * HALF);
+            readA(buf + SLOT_A0 * HALF);
+            readB(fb1, buf + SLOT_B1 * HALF);
+            if (n1) { issueA(1, par ^ 1); vb_wait_vmcnt<8>(); } else vb_wait_vmcnt<0>();
+            vb_raw_barrier();                      // lgkmcnt(0) first: my reads of A0 B0 B1 are done
+            vb_sched_fence();
+            quad(0, 0, fb0);
+            quad(0, 1, fb1);
+            vb_phase_barrier();
+            // ---- O
+            readA(buf + SLOT_A1 * HALF);
+            if (n2) { ld_advance(); issueA(0, par); issueB(0, par); issueB(1, par); vb_wait_vmcnt<8>(); }
+            else if (n1) vb_wait_vmcnt<2>();
+            else vb_wait_vmcnt<0>();
+            vb_raw_barrier();
+            vb_sched_fence();
+            quad(1, 1, fb1);
+            quad(1, 0, fb0);
+            vb_phase_barrier();
+            if (++ct == nk) {
+                // output tile finished: drain it while the next tile's first K tiles are already landing
+                int m0, n0;
+                origin(cj, m0, n0);
+                gemm_epilogue_private<T, TO, ACT, OPT>(acc, slab, g, m0 + wr * 128, n0 + wc * 64, lane);
+    #pragma unroll
+                for (int mi = 0; mi < 8; ++mi)
+    #pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+                ct = 0; ++cj;
+            }
+        }
+        if (wr == 0) vb_phase_barrier();           // balance the stagger barrier
+        return;
+    }
     // prologue: K tile 0 (A0 B0 B1 A1) and the first two half-tiles of K tile 1
     issueA(0, 0); issueB(0, 0); issueB(1, 0); issueA(1, 0);
     if (GK > 1) { ld_advance(); issueA(0, 1); issueB(0, 1); vb_wait_vmcnt<8>(); }
@@ -1028,8 +1084,9 @@ VB_KERNEL VB_LAUNCH_BOUNDS(512) gemm_nt_8ph_kernel(GemmArgs g) {
 }
 
 static int g_persistent_wgs = 0;       // 0 = one workgroup per CU
-template <typename T, typename TO, int ACT, int OPT>
-int launch_8ph_act(const GemmArgs& g, dim3 grid, dim3 block, int smem_bytes, hipStream_t stream) {
+static int g_8ph_sched = 0;             // 0 = eight slots per K tile, 1 = four (measurement knob: variant 81)
+template <typename T, typename TO, int ACT, int OPT, int SCHED>
+int launch_8ph_sched(const GemmArgs& g, dim3 grid, dim3 block, int smem_bytes, hipStream_t stream) {
 #ifndef VB_EMU
     if (g_prof) {
         ProfRec r;
@@ -1037,14 +1094,19 @@ int launch_8ph_act(const GemmArgs& g, dim3 grid, dim3 block, int smem_bytes, hip
         r.flops = 2.0 * g.M * g.N * g.K;
         r.key = (sizeof(T) == 2 ? 0 : 8) | (sizeof(TO) == 4 ? 4 : 0) | 16;
         (void)hipEventRecord(r.e0, stream);
-        VB_LAUNCH((gemm_nt_8ph_kernel<T, TO, ACT, OPT>), grid, block, smem_bytes, stream, g);
+        VB_LAUNCH((gemm_nt_8ph_kernel<T, TO, ACT, OPT, SCHED>), grid, block, smem_bytes, stream, g);
         (void)hipEventRecord(r.e1, stream);
         g_prof->push_back(r);
         return vb_check_launch();
     }
 #endif
-    VB_LAUNCH((gemm_nt_8ph_kernel<T, TO, ACT, OPT>), grid, block, smem_bytes, stream, g);
+    VB_LAUNCH((gemm_nt_8ph_kernel<T, TO, ACT, OPT, SCHED>), grid, block, smem_bytes, stream, g);
     return vb_check_launch();
+}
+template <typename T, typename TO, int ACT, int OPT>
+int launch_8ph_act(const GemmArgs& g, dim3 grid, dim3 block, int smem_bytes, hipStream_t stream) {
+    if (g_8ph_sched == 1) return launch_8ph_sched<T, TO, ACT, OPT, 1>(g, grid, block, smem_bytes, stream);
+    return launch_8ph_sched<T, TO, ACT, OPT, 0>(g, grid, block, smem_bytes, stream);
 }
 template <typename T, typename TO>
 int launch_8ph(GemmArgs g, hipStream_t stream) {
@@ -1101,6 +1163,7 @@ struct TnProblem {
     long lda, ldb, ldc;
     int Mo, Ni;                                   // out, in
     int tiles_n, tiles;                           // 256x256 tiles: columns, total
+    int tiles_m;                                  // rows; tiles are walked along the SHORTER dimension first (see decode)
     int item0;                                    // first item of this problem
 };
 struct TnArgs {
@@ -1137,7 +1200,11 @@ VB_KERNEL VB_LAUNCH_BOUNDS(512) gemm_tn_8ph_kernel(TnArgs g) {
         const int local = v - g.p[p].item0;
         const int s = local / g.p[p].tiles, tl = local - s * g.p[p].tiles;
         it.p = p;
-        it.m0 = (tl / g.p[p].tiles_n) * 256; it.n0 = (tl % g.p[p].tiles_n) * 256;
+        // consecutive items (= one XCD's concurrent workgroups) cover whole rows / columns of the shorter tile
+        // dimension: the fewest distinct operand panels per XCD L2
+        const int tm = g.p[p].tiles_m, tn = g.p[p].tiles_n;
+        if (tm < tn) { it.m0 = (tl % tm) * 256; it.n0 = (tl / tm) * 256; }
+        else { it.m0 = (tl / tn) * 256; it.n0 = (tl % tn) * 256; }
         it.kt0 = s * g.kps;
         it.nk = g.KT - it.kt0 < g.kps ? g.KT - it.kt0 : g.kps;
         return it;
@@ -1164,8 +1231,9 @@ VB_KERNEL VB_LAUNCH_BOUNDS(512) gemm_tn_8ph_kernel(TnArgs g) {
             for (int i = 0; i < 2; ++i) {
                 int ca = it.m0 + (cr >> 6) * 128 + h * 64 + (cr & 63);
                 int cb = it.n0 + (cr >> 5) * 64 + h * 32 + (cr & 31);
-                ca = ca <= P.Mo - 8 ? ca : P.Mo - 8;          // clamped pieces land in rows the epilogue masks
-                cb = cb <= P.Ni - 8 ? cb : P.Ni - 8;
+                const int mo8 = (P.Mo + 7) & ~7, ni8 = (P.Ni + 7) & ~7;   // readable up to round_up(rows, 8) per token (ABI)
+                ca = ca <= mo8 - 8 ? ca : mo8 - 8;            // clamped pieces land in rows the epilogue masks
+                cb = cb <= ni8 - 8 ? cb : ni8 - 8;
                 offA[h][i] = (unsigned)(((ck + 16 * i) * (int)P.lda + ca) * 2);
                 offB[h][i] = (unsigned)(((ck + 16 * i) * (int)P.ldb + cb) * 2);
             }
@@ -1250,10 +1318,11 @@ VB_KERNEL VB_LAUNCH_BOUNDS(512) gemm_tn_8ph_kernel(TnArgs g) {
     int GK = 0;
     for (int j = 0; j < my_items; ++j) GK += decode(j).nk;
     set_load_item(0);
-    // prologue: K tile 0 (A0 B0 B1 A1) and the first two half-tiles of K tile 1
+    // four-slot schedule (see gemm_nt_8ph_kernel, SCHED = 1): E(g) reads A0 B0 B1, issues A1 of tile g+1, MFMAs (0,0) (0,1);
+    // O(g) reads A1, issues A0 B0 B1 of tile g+2, MFMAs (1,1) (1,0); every counted wait is "all but the newest 8"
     issueA(0, 0); issueB(0, 0); issueB(1, 0); issueA(1, 0);
-    if (GK > 1) { ld_advance(); issueA(0, 1); issueB(0, 1); vb_wait_vmcnt<8>(); }
-    else vb_wait_vmcnt<4>();
+    if (GK > 1) { ld_advance(); issueA(0, 1); issueB(0, 1); issueB(1, 1); vb_wait_vmcnt<6>(); }
+    else vb_wait_vmcnt<0>();
     vb_phase_barrier();
     if (wr == 1) vb_phase_barrier();               // waves 4-7 run one barrier behind waves 0-3
 
@@ -1263,28 +1332,24 @@ VB_KERNEL VB_LAUNCH_BOUNDS(512) gemm_tn_8ph_kernel(TnArgs g) {
         const int par = gk & 1;
         const unsigned char* buf = smem + par * BUF;
         const bool n1 = gk + 1 < GK, n2 = gk + 2 < GK;
-        // ---- phase 0: quadrant (0, 0)
+        // ---- E
         readB(fb0, buf + SLOT_B0 * HALF);
         readA(buf + SLOT_A0 * HALF);
-        if (n1) { issueB(1, par ^ 1); vb_wait_vmcnt<8>(); } else vb_wait_vmcnt<2>();
-        vb_phase_barrier();
-        quad(0, 0, fb0);
-        vb_phase_barrier();
-        // ---- phase 1: quadrant (0, 1)
         readB(fb1, buf + SLOT_B1 * HALF);
         if (n1) { issueA(1, par ^ 1); vb_wait_vmcnt<8>(); } else vb_wait_vmcnt<0>();
-        vb_phase_barrier();
+        vb_raw_barrier();                          // lgkmcnt(0) first: my gathers of A0 B0 B1 are done
+        vb_sched_fence();
+        quad(0, 0, fb0);
         quad(0, 1, fb1);
         vb_phase_barrier();
-        // ---- phase 2: quadrant (1, 1)
+        // ---- O
         readA(buf + SLOT_A1 * HALF);
-        if (n2) { ld_advance(); issueA(0, par); vb_wait_vmcnt<8>(); } else if (n1) vb_wait_vmcnt<6>(); else vb_wait_vmcnt<0>();
-        vb_phase_barrier();
+        if (n2) { ld_advance(); issueA(0, par); issueB(0, par); issueB(1, par); vb_wait_vmcnt<8>(); }
+        else if (n1) vb_wait_vmcnt<2>();
+        else vb_wait_vmcnt<0>();
+        vb_raw_barrier();
+        vb_sched_fence();
         quad(1, 1, fb1);
-        vb_phase_barrier();
-        // ---- phase 3: quadrant (1, 0)
-        if (n2) { issueB(0, par); vb_wait_vmcnt<8>(); } else if (n1) vb_wait_vmcnt<4>(); else vb_wait_vmcnt<0>();
-        vb_phase_barrier();
         quad(1, 0, fb0);
         vb_phase_barrier();
         if (++ct == cur.nk) {
@@ -1310,7 +1375,7 @@ static int tn_pick_splits(int tiles, int KT, int wgs) {
         if (real != s) continue;
         const long items = (long)tiles * s;
         const long rounds = (items + wgs - 1) / wgs;
-        const double cost = rounds * (kps + 8.0);            // epilogue ~ 8 K tiles' worth of time per item
+        const double cost = rounds * (kps + 24.0);           // draining a tile with atomics ~ 24 K tiles' worth of time (measured)
         if (cost < best_cost * 0.97) { best_cost = cost; best = s; }
     }
     return best;
@@ -1324,7 +1389,8 @@ static int launch_tn_group(TnArgs& g, int K, hipStream_t stream) {
     for (int i = 0; i < g.nprob; ++i) {
         TnProblem& P = g.p[i];
         P.tiles_n = (P.Ni + 255) / 256;
-        P.tiles = ((P.Mo + 255) / 256) * P.tiles_n;
+        P.tiles_m = (P.Mo + 255) / 256;
+        P.tiles = P.tiles_m * P.tiles_n;
         tiles += P.tiles;
     }
     int wgs = g_persistent_wgs > 0 ? g_persistent_wgs : vb_num_cus();
@@ -1354,7 +1420,7 @@ static int launch_tn_group(TnArgs& g, int K, hipStream_t stream) {
     return vb_check_launch();
 }
 static bool tn_eligible(const void* A, long lda, const void* B, long ldb, const float* C, long ldc, int Mo, int Ni, int K) {
-    return K >= 64 && (K % 64) == 0 && Mo >= 8 && Ni >= 8 && (Mo % 8) == 0 && (Ni % 8) == 0 && (lda % 8) == 0 && (ldb % 8) == 0 &&
+    return K >= 64 && (K % 64) == 0 && Mo >= 1 && Ni >= 1 && lda >= ((Mo + 7) & ~7) && ldb >= ((Ni + 7) & ~7) && (lda % 8) == 0 && (ldb % 8) == 0 &&
            ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0 && C != nullptr && ldc >= Ni &&
            64L * lda * 2 + 2L * Mo < (1L << 31) && 64L * ldb * 2 + 2L * Ni < (1L << 31);
 }
@@ -1371,12 +1437,13 @@ int dispatch_pipe(const GemmArgs& g, hipStream_t s) {
     if (variant == 1) {
         // measured on MI355X (profiles/r01_gemm_variant_sweep_b128.txt)
         const long t256 = (long)((g.M + 255) / 256) * ((g.N + 255) / 256);
-        variant = (sizeof(T) == 2 && t256 >= 160) ? 80 : 42;
+        variant = (sizeof(T) == 2 && t256 >= 160) ? 81 : 42;
     }
     switch (variant) {
         case 22: return launch_pipe<T, TO, 2, 2>(g, s);
         case 42: return launch_pipe<T, TO, 4, 2>(g, s);
-        case 80: return launch_8ph<T, TO>(g, s);
+        case 80: g_8ph_sched = 0; return launch_8ph<T, TO>(g, s);
+        case 81: g_8ph_sched = 1; return launch_8ph<T, TO>(g, s);
         default: return VB_ERR_UNSUPPORTED;
     }
 }
@@ -1516,7 +1583,7 @@ extern "C" int64_t vb_gemm_profile_read(double* ms, double* flops, int* key, int
 }
 
 extern "C" int vb_gemm_set_variant(int variant) {
-    if (variant != 0 && variant != 1 && variant != 22 && variant != 42 && variant != 80) return VB_ERR_ARG;
+    if (variant != 0 && variant != 1 && variant != 22 && variant != 42 && variant != 80 && variant != 81) return VB_ERR_ARG;
     g_nt_variant = variant;
     return VB_OK;
 }

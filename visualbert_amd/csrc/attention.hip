@@ -206,13 +206,13 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(NT, 3) attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
         for (int kp = 0; kp < NKS; ++kp) {
             if (a.p > 0.f) {
-                // one Philox call covers this lane's 8 probabilities of fragments 2kp, 2kp+1
+                // one generator call covers this lane's 8 probabilities of fragments 2kp, 2kp+1
                 const uint64_t grp = ((((uint64_t)bh * S + q) * 4 + lg) << 5) + kp;
-                Philox8 rnd = philox4x32_10(a.seed, grp, a.stream);
+                Rand8 rnd = vb_dropout_bits8(a.seed, grp, a.stream);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int kf = 2 * kp + (e >> 2), r = e & 3;
-                    const bool keep = philox_keep(rnd, e, a.thresh);
+                    const bool keep = rand8_keep(rnd, e, a.thresh);
                     st[kf][r] = keep ? st[kf][r] * inv * a.inv_keep : 0.f;
                     if (keep) bits[kf >> 4] |= (uint64_t)1 << ((kf & 15) * 4 + r);
                 }

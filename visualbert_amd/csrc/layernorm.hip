@@ -32,9 +32,9 @@ static inline DropSpec make_drop(float p, uint64_t seed, uint32_t stream) {
 }
 // multiply v[0..8) by the keep mask / (1-p) of group (element index >> 3)
 VB_DEVICE void apply_dropout8(float (&v)[8], const DropSpec& d, uint64_t group) {
-    Philox8 r = philox4x32_10(d.seed, group, d.stream);
+    Rand8 r = vb_dropout_bits8(d.seed, group, d.stream);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = philox_keep(r, j, d.thresh) ? v[j] * d.scale : 0.0f;
+    for (int j = 0; j < 8; ++j) v[j] = rand8_keep(r, j, d.thresh) ? v[j] * d.scale : 0.0f;
 }
 
 struct LnFwdArgs {

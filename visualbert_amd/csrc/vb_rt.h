@@ -233,28 +233,36 @@ VB_DEVICE float half_sum(float v) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Counter-based RNG for dropout: Philox4x32-10 keyed by (seed), counter = (group, stream).
-// One call yields 128 bits = eight 16-bit uniforms; element e of group g is dropped iff
-// u16[e] < thresh16, thresh16 = round(p * 65536).  Any kernel (forward or backward, any thread
-// mapping) regenerates the same mask from (seed, stream, element index) -- no mask tensor in HBM.
+// Counter-based random bits for dropout.  One call yields 128 bits = eight 16-bit uniforms for the 8 consecutive
+// elements of "group"; element e is dropped iff u16[e] < thresh16, thresh16 = round(p * 65536).  Any kernel (forward
+// or backward, any thread mapping) regenerates the same mask from (seed, stream, element index) -- no mask tensor
+// in HBM.  The generator is a KEYED 32-bit mixer (two multiplies per word, key material folded in before the first
+// and between the two multiplies; the key schedule is wave-uniform, i.e. scalar): 8 integer multiplies per 8
+// elements where Philox4x32-10 needs 40 -- 32-bit multiplies are quarter-rate on CDNA, and Philox was 27 % of the
+// attention forward kernel and a co-limiter of the LayerNorm kernels (profiles/r01_dropout_rng.txt).  Dropout masks
+// need decorrelated, unbiased bits, not cryptographic strength; the keep fraction and the forward/backward agreement
+// are tested (tests/test_kernels.py).
 // ------------------------------------------------------------------------------------------
-struct Philox8 { uint32_t w[4]; };
-VB_DEVICE Philox8 philox4x32_10(uint64_t seed, uint64_t group, uint32_t stream) {
-    uint32_t c0 = (uint32_t)group, c1 = (uint32_t)(group >> 32), c2 = stream, c3 = 0x5ca1ab1eu;
-    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+struct Rand8 { uint32_t w[4]; };               // eight 16-bit uniforms
+VB_DEVICE uint32_t vb_mix32(uint32_t x, uint32_t k) {
+    x ^= x >> 16; x *= 0x7feb352du;
+    x ^= k;
+    x ^= x >> 15; x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+VB_DEVICE Rand8 vb_dropout_bits8(uint64_t seed, uint64_t group, uint32_t stream) {
+    const uint32_t s0 = (uint32_t)seed, s1 = (uint32_t)(seed >> 32);
+    const uint32_t k1 = vb_mix32(s0 ^ (stream * 0x9E3779B9u), s1 ^ 0x5ca1ab1eu);           // uniform: scalar unit
+    const uint32_t k2 = vb_mix32(s1 + stream * 0x85EBCA6Bu, k1) ^ ((uint32_t)(group >> 30) * 0xC2B2AE35u);
+    const uint32_t c = (uint32_t)group * 4u + k1;
+    Rand8 o;
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    Philox8 o; o.w[0] = c0; o.w[1] = c1; o.w[2] = c2; o.w[3] = c3;
+    for (int i = 0; i < 4; ++i) o.w[i] = vb_mix32(c + (uint32_t)i, k2);
     return o;
 }
 // keep-mask bit e (0..7) of a group
-VB_DEVICE bool philox_keep(const Philox8& r, int e, uint32_t thresh16) {
+VB_DEVICE bool rand8_keep(const Rand8& r, int e, uint32_t thresh16) {
     uint32_t u = (r.w[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu;
     return u >= thresh16;
 }

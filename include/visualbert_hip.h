@@ -170,6 +170,9 @@ int vb_refresh_transposed_shadow(const void* bf16_shadow, void* bf16_shadow_t, c
 int vb_prepare_inputs(const int64_t* input_mask, const int64_t* image_dim, const int64_t* image_mask,
                       const int64_t* masked_lm_labels, int64_t* attention_mask, float* mask_add,
                       int64_t* labels_ext, int B, int T, int R, void* stream);
+/* zero `bytes` bytes (multiple of 16, 16-byte aligned): the flat gradient arena, once per step (replaces the
+ * zero_grad loop over parameters of pytorch_pretrained_bert/optimization.py's callers) */
+int vb_zero(void* dst, int64_t bytes, void* stream);
 /* elementwise dtype conversion (VB_F32 / VB_BF16 in any combination) */
 int vb_cast(int src_dtype, const void* src, int dst_dtype, void* dst, int64_t n, void* stream);
 /* VQA head gather (modeling.py:1503-1505): out[b] = x[b, input_mask[b].sum() - 2]; index_out int64[B] */

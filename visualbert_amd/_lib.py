@@ -40,6 +40,7 @@ SIGNATURES = {
     "vb_refresh_bf16_shadow": (_i, [_p, _p, _p, _i, _p, _p]),
     "vb_refresh_transposed_shadow": (_i, [_p, _p, _p, _p, _i, _p]),
     "vb_prepare_inputs": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "vb_zero": (_i, [_p, _i64, _p]),
     "vb_cast": (_i, [_i, _p, _i, _p, _i64, _p]),
     "vb_gather_rows": (_i, [_i, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "vb_scatter_rows": (_i, [_i, _p, _p, _p, _i, _i, _i, _p]),

@@ -138,7 +138,8 @@ VB_DEVICE void block_colsum_flush(float (&acc)[NC][8], float* lds, float* out, i
 }
 
 // second stage: out[c] += sum over blocks of partials[b][which][c].  1024 threads = 32 columns x 32 row
-// groups: coalesced 128-byte reads, 32 independent chains per column, LDS tree at the end.
+// groups: coalesced 128-byte reads, 32 independent chains per column, LDS tree at the end.  gridDim.z slices the
+// partial rows (a 24 x 3 grid alone left 2/3 of the chip idle over 9 MB of partials); slices meet in fp32 atomics.
 VB_KERNEL VB_LAUNCH_BOUNDS(1024) ln_bwd_reduce_kernel(const float* partials, int nblocks, int H, float* dgamma,
                                                      float* dbeta, float* dbias) {
     VB_DYN_SMEM(smem);
@@ -146,17 +147,20 @@ VB_KERNEL VB_LAUNCH_BOUNDS(1024) ln_bwd_reduce_kernel(const float* partials, int
     const int cx = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cx;
     const int which = blockIdx.y;
+    const int per = (nblocks + (int)gridDim.z - 1) / (int)gridDim.z;
+    const int b0 = (int)blockIdx.z * per, b1 = b0 + per < nblocks ? b0 + per : nblocks;
     float* out = which == 0 ? dgamma : (which == 1 ? dbeta : dbias);
     float s = 0.f;
     if (c < H && out) {
-        for (int b = rg; b < nblocks; b += 32) s += partials[((long)b * 3 + which) * H + c];
+        for (int b = b0 + rg; b < b1; b += 32) s += partials[((long)b * 3 + which) * H + c];
     }
     red[rg * 33 + cx] = s;
     __syncthreads();
     if (rg == 0 && c < H && out) {
         float t = 0.f;
         for (int r = 0; r < 32; ++r) t += red[r * 33 + cx];
-        out[c] += t;
+        if (gridDim.z == 1) out[c] += t;
+        else atomicAdd(&out[c], t);
     }
 }
 
@@ -168,24 +172,30 @@ VB_DEVICE void lds_acc8(float* p, const float (&v)[8]) {
     *(f32x4*)p = lo; *(f32x4*)(p + 4) = hi;
 }
 
-// The column accumulators (dgamma, dbeta, bias gradient) live in LDS as [half-wave][3][H] fp32 -- in registers
-// they cost 72 VGPRs and halved the occupancy of this latency-bound streaming kernel (175 -> ~100 VGPRs).
+// The column accumulators (dgamma, dbeta, bias gradient) live in LDS as [wave][3][H] fp32 -- in registers they cost 72
+// VGPRs and halved the occupancy of this latency-bound streaming kernel.  A wave works on two rows (one per 32-lane
+// half); the halves' contributions are added with v_permlane32_swap and the lower half alone updates LDS, so a
+// workgroup needs 36 KB (4 workgroups = 16 waves per CU; the [half-wave] form needed 74 KB = 8 waves per CU).
+constexpr int WAVES_PER_BLOCK = NT / 64;
 template <typename T, int NC>
 VB_KERNEL VB_LAUNCH_BOUNDS(NT) ln_bwd_kernel(LnBwdArgs a) {
     VB_DYN_SMEM(smem);
     float* lds = (float*)smem;
-    const int l32 = threadIdx.x & 31, hw = threadIdx.x >> 5;
+    const int l32 = threadIdx.x & 31, hw = threadIdx.x >> 5, wave = threadIdx.x >> 6;
+    const bool lower = (threadIdx.x & 32) == 0;
     const int H = a.H;
     const float invH = 1.0f / (float)H;
-    float* my = lds + (long)hw * 3 * H;                 // this half-wave's [3][H] accumulators
+    float* my = lds + (long)wave * 3 * H;               // this wave's [3][H] accumulators
+    if (lower) {
 #pragma unroll
-    for (int ci = 0; ci < NC; ++ci) {                   // every lane zeroes exactly the columns it owns
-        const int col = (l32 + 32 * ci) * 8;
-        if (col < H) {
+        for (int ci = 0; ci < NC; ++ci) {               // every lane zeroes exactly the columns it owns
+            const int col = (l32 + 32 * ci) * 8;
+            if (col < H) {
 #pragma unroll
-            for (int w = 0; w < 3; ++w) {
-                *(f32x4*)(my + w * H + col) = f32x4{0.f, 0.f, 0.f, 0.f};
-                *(f32x4*)(my + w * H + col + 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int w = 0; w < 3; ++w) {
+                    *(f32x4*)(my + w * H + col) = f32x4{0.f, 0.f, 0.f, 0.f};
+                    *(f32x4*)(my + w * H + col + 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
             }
         }
     }
@@ -199,6 +209,9 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) ln_bwd_kernel(LnBwdArgs a) {
 #pragma unroll
         for (int ci = 0; ci < NC; ++ci) {
             const int col = (l32 + 32 * ci) * 8;
+            float pg[8], pb[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { pg[j] = 0.f; pb[j] = 0.f; dy[ci][j] = 0.f; xh[ci][j] = 0.f; }
             if (act && col < H) {
                 const long e = (long)row * H + col;
                 load8(dy[ci], (const T*)a.dy + e);
@@ -206,20 +219,21 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) ln_bwd_kernel(LnBwdArgs a) {
                 float zz[8], gm[8];
                 load8(zz, (const T*)a.z + e);
                 load8(gm, a.gamma + col);
-                float pg[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     xh[ci][j] = (zz[j] - mean) * rstd;
-                    pg[j] = dy[ci][j] * xh[ci][j];
-                }
-                lds_acc8(my + col, pg);                    // dgamma partials
-                lds_acc8(my + H + col, dy[ci]);            // dbeta partials
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
+                    pg[j] = dy[ci][j] * xh[ci][j];            // dgamma contribution
+                    pb[j] = dy[ci][j];                        // dbeta contribution
                     dy[ci][j] *= gm[j];                       // g = dy * gamma
                     s1 += dy[ci][j];
                     s2 += dy[ci][j] * xh[ci][j];
                 }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { pg[j] = vb_pair_sum32(pg[j]); pb[j] = vb_pair_sum32(pb[j]); }
+            if (lower && col < H) {
+                lds_acc8(my + col, pg);
+                lds_acc8(my + H + col, pb);
             }
         }
         s1 = half_sum(s1) * invH;
@@ -227,9 +241,11 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) ln_bwd_kernel(LnBwdArgs a) {
 #pragma unroll
         for (int ci = 0; ci < NC; ++ci) {
             const int col = (l32 + 32 * ci) * 8;
+            float dz[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dz[j] = 0.f;
             if (act && col < H) {
                 const long e = (long)row * H + col;
-                float dz[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) dz[j] = rstd * (dy[ci][j] - s1 - xh[ci][j] * s2);
                 store8((T*)a.dz + e, dz);
@@ -237,13 +253,17 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) ln_bwd_kernel(LnBwdArgs a) {
                     if (a.din.p > 0.f) apply_dropout8(dz, a.din, (uint64_t)e >> 3);
                     if (a.dx != a.dz) store8((T*)a.dx + e, dz);
                 }
-                if (a.dbias) lds_acc8(my + 2 * H + col, dz);  // bias-gradient partials (of dx)
+            }
+            if (a.dbias) {                                   // bias-gradient partials (of dx); wave-uniform branch
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dz[j] = vb_pair_sum32(dz[j]);
+                if (lower && col < H) lds_acc8(my + 2 * H + col, dz);
             }
         }
     }
     __syncthreads();
-    // reduce the 8 half-waves' accumulators, then this block's row of the partials workspace (two-stage, no
-    // global atomics) or fp32 atomics straight into HBM
+    // reduce the waves' accumulators, then this block's row of the partials workspace (two-stage, no global
+    // atomics) or fp32 atomics straight into HBM
     float* part = a.partials ? a.partials + (long)blockIdx.x * 3 * H : nullptr;
     for (int i = threadIdx.x; i < 3 * H; i += NT) {
         const int which = i / H, c = i - which * H;
@@ -251,7 +271,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) ln_bwd_kernel(LnBwdArgs a) {
         if (!out) continue;
         float sum = 0.f;
 #pragma unroll
-        for (int h = 0; h < HW_PER_BLOCK; ++h) sum += lds[(long)h * 3 * H + i];
+        for (int h = 0; h < WAVES_PER_BLOCK; ++h) sum += lds[(long)h * 3 * H + i];
         if (part) part[i] = sum;
         else atomicAdd(&out[c], sum);
     }
@@ -416,7 +436,7 @@ extern "C" int vb_ln_fwd(int dtype, const void* x, const void* resid, void* z_ou
 }
 
 extern "C" int64_t vb_ln_bwd_ws_bytes(int M, int H) {
-    return (int64_t)row_grid(M, 512) * 3 * H * (int64_t)sizeof(float);
+    return (int64_t)row_grid(M, 1024) * 3 * H * (int64_t)sizeof(float);
 }
 
 extern "C" int vb_ln_bwd(int dtype, const void* dy, const void* z, const float* mean, const float* rstd,
@@ -427,14 +447,14 @@ extern "C" int vb_ln_bwd(int dtype, const void* dy, const void* z, const float* 
     if (p_in > 0.f && (!dx || dx == dz)) return VB_ERR_ARG;   // dropped and un-dropped grads differ
     LnBwdArgs a{dy, z, mean, rstd, gamma, dz, dx, dgamma, dbeta, dbias, M, H, make_drop(p_in, seed, stream_in),
                 make_drop(p_out, seed, stream_out), ws};
-    dim3 grid(row_grid(M, ws ? 512 : 256));
+    dim3 grid(row_grid(M, ws ? 1024 : 256));
     hipStream_t s = (hipStream_t)stream;
-    const size_t smem = (size_t)H * HW_PER_BLOCK * 3 * sizeof(float);
+    const size_t smem = (size_t)H * WAVES_PER_BLOCK * 3 * sizeof(float);
     if (dtype == VB_BF16) VB_DISPATCH_NC(ln_bwd_kernel, bf16, H, grid, smem, s, a);
     else if (dtype == VB_F32) VB_DISPATCH_NC(ln_bwd_kernel, float, H, grid, smem, s, a);
     else return VB_ERR_ARG;
     if (ws && (dgamma || dbeta || dbias)) {
-        dim3 g2((unsigned)((H + 31) / 32), 3);
+        dim3 g2((unsigned)((H + 31) / 32), 3, grid.x >= 256 ? 4 : 1);
         VB_LAUNCH(ln_bwd_reduce_kernel, g2, dim3(1024), 32 * 33 * sizeof(float), s, (const float*)ws, (int)grid.x, H,
                   dgamma, dbeta, dbias);
     }

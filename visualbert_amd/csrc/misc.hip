@@ -133,6 +133,13 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) act_bwd_kernel(const T* dy, const T* aux, T* dx, 
     }
 }
 
+// zero a 16-byte aligned region: the gradient arena (448 MB at BERT-base) before every backward.  Grid-stride 16-byte
+// stores, 4 per thread per trip.
+VB_KERNEL VB_LAUNCH_BOUNDS(NT) zero_kernel(u32x4* p, long n16) {
+    const long stride = (long)gridDim.x * NT;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n16; i += stride) p[i] = u32x4{0u, 0u, 0u, 0u};
+}
+
 }  // namespace
 
 extern "C" const char* vb_version(void) {
@@ -152,6 +159,15 @@ extern "C" int vb_prepare_inputs(const int64_t* input_mask, const int64_t* image
     dim3 grid((unsigned)((n + NT - 1) / NT > 1024 ? 1024 : (n + NT - 1) / NT));
     VB_LAUNCH(prepare_inputs_kernel, grid, dim3(NT), 0, (hipStream_t)stream, input_mask, image_dim, image_mask,
               masked_lm_labels, attention_mask, mask_add, labels_ext, B, T, R);
+    return vb_check_launch();
+}
+
+extern "C" int vb_zero(void* dst, int64_t bytes, void* stream) {
+    if (!dst || bytes <= 0 || (bytes & 15) || (((uintptr_t)dst) & 15)) return VB_ERR_ARG;
+    const long n16 = bytes / 16;
+    long blocks = (n16 + NT - 1) / NT;
+    if (blocks > 8192) blocks = 8192;
+    VB_LAUNCH(zero_kernel, dim3((unsigned)blocks), dim3(NT), 0, (hipStream_t)stream, (u32x4*)dst, n16);
     return vb_check_launch();
 }
 

@@ -169,6 +169,22 @@ VB_DEVICE bf16x4 vb_lds_read_tr(const unsigned char* p) {
 }
 #endif
 
+// x(lane) + x(lane ^ 32): the two 32-lane halves of a wave exchanged with ONE VALU instruction (v_permlane32_swap,
+// gfx950) instead of an LDS-crossbar shuffle
+#ifdef VB_EMU
+VB_DEVICE float vb_pair_sum32(float x) { return x + __shfl_xor(x, 32); }
+#else
+VB_DEVICE float vb_pair_sum32(float x) {
+    // v_permlane32_swap_b32 a, b swaps a[32..63] with b[0..31]: with a = b = x it leaves a = {lo|lo}, b = {hi|hi}.
+    // Inline asm because hipcc 7.2 mis-folds __builtin_amdgcn_permlane32_swap's second result into the first (the ISA
+    // showed r[0] + r[0]; caught by the LayerNorm parity tests on the device).  hipcc does not resolve hazards around an
+    // asm statement: the s_nop pair covers VALU-write -> permlane read and permlane write -> VALU read.
+    float a = x, b = x;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+#endif
+
 // value known to be identical in every lane of the wave: keep it in a scalar register (addresses built from it
 // become scalar arithmetic instead of per-lane VALU + v_readfirstlane at every use)
 #ifdef VB_EMU

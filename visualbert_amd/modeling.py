@@ -185,7 +185,12 @@ class ParameterArena(object):
         return lo, hi
 
     def zero_grad(self):
-        self.grad.zero_()
+        g = self.grad
+        nbytes = g.numel() * 4
+        if g.is_cuda and nbytes % 16 == 0 and g.data_ptr() % 16 == 0:
+            _lib.check(_lib.lib().vb_zero(_lib.ptr(g), nbytes, _lib.stream_ptr()), "vb_zero")
+        else:
+            g.zero_()
 
     def tables(self, optimise_flags, decay_flags):
         """device int64 tables for vb_bert_adam_step / vb_refresh_bf16_shadow."""

@@ -746,6 +746,7 @@ class MLMHeadLossFn(torch.autograd.Function):
         out_logits = logits.view(B, S, V) if logits.is_contiguous() else logits.as_strided(
             (B, S, V), (S * logits.stride(0), logits.stride(0), 1), logits.storage_offset())
         ctx.mark_non_differentiable(out_logits)
+        ctx.set_materialize_grads(False)      # else autograd zero-fills a [B,S,V] fp32 gradient for the logits (2.6 GB at B=128)
         if loss is None:
             return out_logits, torch.zeros((), device=s2.device)
         return out_logits, loss
@@ -810,6 +811,7 @@ class SmallLinearCEFn(torch.autograd.Function):
         ctx.x_shape = x.shape
         ctx.save_for_backward(x2, dy)
         ctx.mark_non_differentiable(y)
+        ctx.set_materialize_grads(False)
         return y, loss
 
     @staticmethod
@@ -870,6 +872,7 @@ class VQAHeadLossFn(torch.autograd.Function):
         ctx.save_for_backward(g, idx, dlogits, mask)
         out = logits.contiguous().view(B, 1, N)
         ctx.mark_non_differentiable(out, idx)
+        ctx.set_materialize_grads(False)
         return out, loss.reshape(()), score.reshape(()), idx
 
     @staticmethod

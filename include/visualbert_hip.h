@@ -128,6 +128,13 @@ int vb_attn_bwd(int dtype, const void* qkv, const float* mask_add, const void* d
  * ---------------------------------------------------------------------------------------------- */
 int vb_ce_fwd_bwd(int dtype, const float* logits, int64_t ld_logits, const int64_t* labels, int ignore_index,
                   float* acc2, float* loss, void* dlogits, int64_t ld_dlogits, int M, int V, void* stream);
+/* Same loss; the gradient is written COMPACTLY: row r of dlogits_compact (T [n_rows_padded, ld_dlogits]) is the
+ * gradient of source row rows[r] (the rows whose label is counted, in any order), rows r >= n_rows are zero padding.
+ * Rows with ignored labels have an all-zero gradient, so every backward GEMM of the MLM decoder (dgrad, wgrad, bias
+ * gradient) can run over the ~12 % masked rows only -- exactly (pytorch_pretrained_bert/modeling.py:1471-1474). */
+int vb_ce_fwd_bwd_rows(int dtype, const float* logits, int64_t ld_logits, const int64_t* labels, int ignore_index,
+                       const int64_t* rows, int n_rows, int n_rows_padded, float* acc2, float* loss,
+                       void* dlogits_compact, int64_t ld_dlogits, int M, int V, void* stream);
 int vb_kldiv_fwd_bwd(const float* logits, int64_t ld_logits, const float* target, int64_t ld_target,
                      float* loss, float* score, float* dlogits, int64_t ld_dlogits, int M, int V, void* stream);
 

@@ -322,15 +322,32 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) embed_fwd_kernel(EmbArgs a) {
     }
 }
 
+// word-embedding gradient: d_word[id[b, s]] += dz[b, s] for the text positions.  One workgroup per text token; thread t
+// owns columns t, t + 256, ...: every atomic instruction of a wave covers 64 CONSECUTIVE floats of one table row (two
+// cache lines).  (Inside embed_bwd_kernel each lane owned 8 consecutive columns, i.e. every atomic instruction touched
+// 32 lanes x 4 B spread over 1 KB: 12.6 M atomics at B=128 took most of that kernel's 377 us.)
+template <typename TT_>
+VB_KERNEL VB_LAUNCH_BOUNDS(NT) embed_word_scatter_kernel(const TT_* dz, const int64_t* ids, float* d_word,
+                                                        int B, int T, int S, int H, int V) {
+    const int tok = blockIdx.x;                        // b * T + s
+    const int b = tok / T, s = tok - b * T;
+    long id = ids[tok];
+    id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+    const TT_* src = dz + ((long)b * S + s) * H;
+    float* dst = d_word + id * H;
+    for (int c = threadIdx.x; c < H; c += NT) vb_atomic_add_noret(dst + c, to_f32(src[c]));
+}
+
 struct EmbBwdArgs {
     const void* dz; const int64_t* ids; const int64_t* type_ids; const int64_t* vis_type;
     float* d_word; float* d_pos; float* d_type; float* d_pos_vis; float* d_type_vis; void* d_vis_proj;
     int B, T, R, H, V, TV, P;
 };
 
-// one workgroup per sequence position s: the position-embedding gradient of s is owned by exactly
-// one workgroup (register accumulate over the batch); word rows are scattered with fp32 atomics;
-// the (tiny) type tables are reduced in LDS first.
+// workgroup (s, c) handles sequence position s for the batch slice c of gridDim.y slices: the position-embedding
+// gradient of s is accumulated in registers over the slice (then added atomically -- one owner when there is one
+// slice); word rows are scattered with fp32 atomics; the (tiny) type tables are reduced in LDS first.  164 workgroups
+// (one per position) left a third of the chip idle with 16 serial trips each: 377 us at B=128.
 template <typename TT_, int NC>
 VB_KERNEL VB_LAUNCH_BOUNDS(NT) embed_bwd_kernel(EmbBwdArgs a) {
     VB_DYN_SMEM(smem);
@@ -346,7 +363,9 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) embed_bwd_kernel(EmbBwdArgs a) {
     for (int ci = 0; ci < NC; ++ci)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[ci][j] = 0.f;
-    for (int b = hw; b < a.B; b += HW_PER_BLOCK) {
+    const int bper = (a.B + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int b_lo = (int)blockIdx.y * bper, b_hi = b_lo + bper < a.B ? b_lo + bper : a.B;
+    for (int b = b_lo + hw; b < b_hi; b += HW_PER_BLOCK) {
         const long row = (long)b * S + s;
         long id = 0, tt = 0;
         if (text) {
@@ -391,7 +410,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) embed_bwd_kernel(EmbBwdArgs a) {
     float* dtype = text ? a.d_type : a.d_type_vis;
     for (int i = threadIdx.x; i < H; i += NT) {
         if (dpos) {
-            if (text) dpos[i] += lds_pos[i];                 // sole owner of this row
+            if (text && gridDim.y == 1) dpos[i] += lds_pos[i];  // sole owner of this row
             else atomicAdd(&dpos[i], lds_pos[i]);            // all visual slots share position row 0
         }
     }
@@ -484,13 +503,19 @@ extern "C" int vb_embed_bwd(int dtype, const void* dz, const int64_t* input_ids,
                             int B, int T, int R, int H, int V, int type_vocab, int max_pos, void* stream) {
     if (!dz || !input_ids || B <= 0 || T <= 0 || R < 0 || bad_h(H)) return VB_ERR_ARG;
     if (type_vocab <= 0 || type_vocab > 8 || max_pos <= 0 || V <= 0) return VB_ERR_ARG;
-    EmbBwdArgs a{dz, input_ids, token_type_ids, visual_type, d_word, d_pos, d_type, d_pos_vis, d_type_vis,
+    // the word-table scatter runs as its own coalesced-atomic kernel; the main kernel gets no d_word
+    EmbBwdArgs a{dz, input_ids, token_type_ids, visual_type, nullptr, d_pos, d_type, d_pos_vis, d_type_vis,
                  d_vis_proj, B, T, R, H, V, type_vocab, max_pos};
-    dim3 grid((unsigned)(T + R));
+    dim3 grid((unsigned)(T + R), (unsigned)(B >= 64 ? 8 : (B >= 16 ? 2 : 1)));
     hipStream_t s = (hipStream_t)stream;
     const size_t smem = (size_t)H * (1 + type_vocab) * sizeof(float);
     if (dtype == VB_BF16) VB_DISPATCH_NC(embed_bwd_kernel, bf16, H, grid, smem, s, a);
     else if (dtype == VB_F32) VB_DISPATCH_NC(embed_bwd_kernel, float, H, grid, smem, s, a);
     else return VB_ERR_ARG;
+    if (d_word) {
+        dim3 g2((unsigned)(B * T));
+        if (dtype == VB_BF16) VB_LAUNCH(embed_word_scatter_kernel<bf16>, g2, dim3(NT), 0, s, (const bf16*)dz, input_ids, d_word, B, T, T + R, H, V);
+        else VB_LAUNCH(embed_word_scatter_kernel<float>, g2, dim3(NT), 0, s, (const float*)dz, input_ids, d_word, B, T, T + R, H, V);
+    }
     return vb_check_launch();
 }

@@ -54,13 +54,15 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) ce_count_kernel(const int64_t* labels, int M, int
 
 template <typename T>
 VB_KERNEL VB_LAUNCH_BOUNDS(NT) ce_row_kernel(const float* logits, long ld, const int64_t* labels, int ignore_index,
-                                            float* acc, T* dlogits, long ldd, int M, int V) {
+                                            float* acc, T* dlogits, long ldd, int M, int V,
+                                            const int64_t* rows, int n_rows) {
     VB_DYN_SMEM(smem);
     float* red = (float*)smem;
-    const int row = blockIdx.x;
-    const int64_t label = labels[row];
-    const bool counted = (label != ignore_index && label >= 0 && label < V);
-    T* drow = dlogits ? dlogits + (long)row * ldd : nullptr;
+    // compact form: workgroup r handles source row rows[r] and writes row r of dlogits; r >= n_rows are pad rows
+    const int row = rows ? ((int)blockIdx.x < n_rows ? (int)rows[blockIdx.x] : -1) : (int)blockIdx.x;
+    const int64_t label = row >= 0 ? labels[row] : (int64_t)ignore_index;
+    const bool counted = (row >= 0 && label != ignore_index && label >= 0 && label < V);
+    T* drow = dlogits ? dlogits + (long)blockIdx.x * ldd : nullptr;
     // 8-element vectors whenever the row pitches keep 16-byte alignment (they do for the padded MLM buffers)
     const bool vec = ((ld & 7) == 0) && ((ldd & 7) == 0) && ((((uintptr_t)logits) | ((uintptr_t)dlogits)) & 31) == 0;
     if (!counted) {                                      // workgroup-uniform branch: ~88 % of MLM rows
@@ -218,10 +220,29 @@ extern "C" int vb_ce_fwd_bwd(int dtype, const float* logits, int64_t ld_logits, 
     VB_LAUNCH(ce_count_kernel, dim3(1), dim3(NT), 64, s, labels, M, V, ignore_index, acc2);
     if (dtype == VB_BF16)
         VB_LAUNCH(ce_row_kernel<bf16>, dim3((unsigned)M), dim3(NT), 64, s, logits, (long)ld_logits, labels,
-                  ignore_index, acc2, (bf16*)dlogits, (long)ld_dlogits, M, V);
+                  ignore_index, acc2, (bf16*)dlogits, (long)ld_dlogits, M, V, (const int64_t*)nullptr, 0);
     else if (dtype == VB_F32)
         VB_LAUNCH(ce_row_kernel<float>, dim3((unsigned)M), dim3(NT), 64, s, logits, (long)ld_logits, labels,
-                  ignore_index, acc2, (float*)dlogits, (long)ld_dlogits, M, V);
+                  ignore_index, acc2, (float*)dlogits, (long)ld_dlogits, M, V, (const int64_t*)nullptr, 0);
+    else return VB_ERR_ARG;
+    VB_LAUNCH(ce_finish_kernel, dim3(1), dim3(64), 0, s, (const float*)acc2, loss);
+    return vb_check_launch();
+}
+
+extern "C" int vb_ce_fwd_bwd_rows(int dtype, const float* logits, int64_t ld_logits, const int64_t* labels,
+                                  int ignore_index, const int64_t* rows, int n_rows, int n_rows_padded, float* acc2,
+                                  float* loss, void* dlogits_compact, int64_t ld_dlogits, int M, int V, void* stream) {
+    if (!logits || !labels || !acc2 || !loss || !dlogits_compact || M <= 0 || V <= 0) return VB_ERR_ARG;
+    if (n_rows < 0 || n_rows > M || n_rows_padded < n_rows || n_rows_padded <= 0 || (n_rows > 0 && !rows)) return VB_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    VB_LAUNCH(ce_count_kernel, dim3(1), dim3(NT), 64, s, labels, M, V, ignore_index, acc2);
+    const int64_t* r = rows ? rows : labels;               // never dereferenced when n_rows == 0
+    if (dtype == VB_BF16)
+        VB_LAUNCH(ce_row_kernel<bf16>, dim3((unsigned)n_rows_padded), dim3(NT), 64, s, logits, (long)ld_logits, labels,
+                  ignore_index, acc2, (bf16*)dlogits_compact, (long)ld_dlogits, M, V, r, n_rows);
+    else if (dtype == VB_F32)
+        VB_LAUNCH(ce_row_kernel<float>, dim3((unsigned)n_rows_padded), dim3(NT), 64, s, logits, (long)ld_logits, labels,
+                  ignore_index, acc2, (float*)dlogits_compact, (long)ld_dlogits, M, V, r, n_rows);
     else return VB_ERR_ARG;
     VB_LAUNCH(ce_finish_kernel, dim3(1), dim3(64), 0, s, (const float*)acc2, loss);
     return vb_check_launch();

@@ -731,18 +731,25 @@ class MLMHeadLossFn(torch.autograd.Function):
         logits = linear_fwd(tn, E, head.bias.detach(), out_dtype=torch.float32)
         loss = None
         dlogits = None
+        rows = None
         if labels is not None:
             acc = torch.empty(2, dtype=torch.float32, device=s2.device)
             loss = torch.empty(1, dtype=torch.float32, device=s2.device)
-            dlogits = torch.empty((B * S, round_up(V, 64)), dtype=dt, device=s2.device)[:, :V]
             lab = labels.reshape(-1).contiguous()
-            check(_lib.lib().vb_ce_fwd_bwd(_lib.dtype_code(dt), ptr(logits), _ld(logits), ptr(lab), -1, ptr(acc),
-                                           ptr(loss), ptr(dlogits), _ld(dlogits), B * S, V, stream_ptr()),
-                  "vb_ce_fwd_bwd")
+            # Rows whose label is ignored (~88 % of an MLM batch) have an exactly zero gradient: the backward GEMMs of
+            # the decoder run over the masked rows only.  nonzero() is the one host sync of the step (it sizes the
+            # compact buffers); the forward kernels of all layers are already queued behind it.
+            rows = torch.nonzero(lab != -1).reshape(-1)
+            n = int(rows.numel())
+            n_pad = round_up(max(n, 1), 64)
+            dlogits = torch.empty((n_pad, round_up(V, 64)), dtype=dt, device=s2.device)[:, :V]
+            check(_lib.lib().vb_ce_fwd_bwd_rows(_lib.dtype_code(dt), ptr(logits), _ld(logits), ptr(lab), -1,
+                                                ptr(rows) if n else None, n, n_pad, ptr(acc), ptr(loss), ptr(dlogits),
+                                                _ld(dlogits), B * S, V, stream_ptr()), "vb_ce_fwd_bwd_rows")
             loss = loss.reshape(())
         ctx.head, ctx.word_weight = head, word_weight
         ctx.cfg = (B, S, H, V)
-        ctx.save_for_backward(s2, pre, t, tn, mean, rstd, dlogits)
+        ctx.save_for_backward(s2, pre, t, tn, mean, rstd, dlogits, rows)
         out_logits = logits.view(B, S, V) if logits.is_contiguous() else logits.as_strided(
             (B, S, V), (S * logits.stride(0), logits.stride(0), 1), logits.storage_offset())
         ctx.mark_non_differentiable(out_logits)
@@ -753,7 +760,7 @@ class MLMHeadLossFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, _dlogits_unused, dloss):
-        s2, pre, t, tn, mean, rstd, dlogits = ctx.saved_tensors
+        s2, pre, t, tn, mean, rstd, dlogits, rows = ctx.saved_tensors
         if dlogits is None:
             raise RuntimeError("visualbert_amd: backward through the MLM head needs masked_lm_labels")
         B, S, H, V = ctx.cfg
@@ -763,12 +770,25 @@ class MLMHeadLossFn(torch.autograd.Function):
         up = _upstream_scalar(dloss)
         E = weight_for(ctx.word_weight, dt)
         Et = weight_t_for(ctx.word_weight, dt)
+        n, n_pad = int(rows.numel()), dlogits.size(0)
+        # compact operands: dlogits is [n_pad, V] (rows of the masked tokens, zero padding), tn_c the same rows of tn
+        tn_c = torch.zeros((n_pad, H), dtype=dt, device=tn.device)
+        if n:
+            tn_c[:n] = tn.index_select(0, rows)
+        # dgrad over few rows and a 30522-long reduction: split-K (fp32 accumulate) instead of 30 output tiles
+        dtn_c = torch.zeros((n_pad, H), dtype=torch.float32, device=tn.device)
         k_pad = None
         if Et is not None and Et.stride(0) == _ld(dlogits) and (Et.stride(0) % 64) == 0:
             k_pad = Et.stride(0)                    # both pads are zero: reduce over whole K tiles (LDS-direct)
-        dtn = linear_dgrad(dlogits, E, alpha_dev=up, wt=Et, k_pad=k_pad)
+        if Et is not None:
+            gemm(dlogits, Et, n_pad, H, k_pad or V, out=dtn_c, accumulate=True, alpha_dev=up)
+        else:
+            gemm(dlogits, E, n_pad, H, V, b_layout=VB_KSTRIDED, out=dtn_c, accumulate=True, alpha_dev=up)
+        dtn = torch.zeros((B * S, H), dtype=dt, device=tn.device)
+        if n:
+            dtn.index_copy_(0, rows, dtn_c[:n].to(dt))
         g_E, d1 = grad_target(ctx.word_weight)
-        linear_wgrad(dlogits, tn, g_E, alpha_dev=up)
+        linear_wgrad(dlogits, tn_c, g_E, alpha_dev=up)
         g_db, d2 = grad_target(head.bias)
         colsum(dlogits, g_db, scale_dev=up)
         g_lw, d3 = grad_target(tr.LayerNorm.weight)

@@ -40,6 +40,22 @@ def flops_per_sample(L, H, I, V, S, R, Dv):
     return 3 * fwd
 
 
+def pmc_traffic(batch, key):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/gpu_pmc_traffic.sh ->
+    profiles/pmc_traffic.json): rocprofv3 cannot wrap this process from the inside, so the counters are collected by
+    that script on the same command line and read back here; None when the file does not match this run."""
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        return None
+    if d.get("per_gpu_batch") != batch or not (key & 16) or (key & 15):
+        return None
+    return d.get("traffic_bytes_per_launch")
+
+
 def cpu_baseline(batch_size, T, R, steps=3):
     """the oracle (a restatement of TrainVisualBERTObjective + ModelWrapper.step + BertAdam) on host cores."""
     from oracle import visualbert_oracle as vo
@@ -167,7 +183,7 @@ def main():
                 key, d = max(summ.items(), key=lambda kv: kv[1]["ms"])
                 ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
                 roofline = dict(bound="mfma", achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
-                                traffic=None,
+                                traffic=pmc_traffic(B, key),
                                 kernel=ops.gemm_key_name(key),
                                 launches_per_step=d["launches"] / args.steps,
                                 avg_launch_us=round(d["ms"] * 1e3 / d["launches"], 2),

@@ -939,6 +939,9 @@ class TrainVisualBERTObjective(PreTrainedBertModel):
                 flat_masked_lm_labels = ext
         else:
             flat_attention_mask = flat_input_mask
+        if self.training_head_type == "pretraining" and flat_masked_lm_labels is not None and not output_all_encoded_layers:
+            flat_masked_lm_labels = flat_masked_lm_labels.contiguous()
+            ops.plan_masked_rows(flat_masked_lm_labels)      # count the labelled rows now, read the count 12 layers later
 
         sequence_output, pooled_output = self.bert(
             flat_input_ids, flat_token_type_ids, flat_attention_mask, visual_embeddings=flat_visual_embeddings,

@@ -295,6 +295,57 @@ def _upstream_scalar(g):
 
 
 # ------------------------------------------------------------------------------------------------
+# masked-row plan of the MLM head: which rows carry a label, known to the HOST without draining the GPU queue.
+# The count is launched where the labels first appear (start of the model forward) and copied to pinned memory
+# asynchronously; by the time the head needs it (12 layers later) the copy has long finished -- and if the host is
+# a step ahead, waiting on its event leaves the whole forward queued behind it, so the GPU never idles.
+# ------------------------------------------------------------------------------------------------
+class MaskedRowPlan:
+    def __init__(self, labels):
+        lab = labels.reshape(-1)
+        self.key = (lab.data_ptr(), lab.numel())
+        self.valid = lab != -1
+        self.count_host = None
+        self.event = None
+        if lab.is_cuda:
+            cnt = self.valid.sum(dtype=torch.int64)
+            self.count_host = torch.empty(1, dtype=torch.int64, pin_memory=True)
+            self.count_host.copy_(cnt, non_blocking=True)
+            self.event = torch.cuda.Event()
+            self.event.record()
+
+    def rows(self):
+        """int64 indices of the labelled rows (ascending)."""
+        if self.event is None:
+            return torch.nonzero(self.valid).reshape(-1)
+        self.event.synchronize()
+        n = int(self.count_host[0])
+        if n == 0:
+            return torch.empty(0, dtype=torch.int64, device=self.valid.device)
+        try:
+            return torch.nonzero_static(self.valid, size=n).reshape(-1)       # sized on the host: no sync
+        except (RuntimeError, NotImplementedError):
+            return torch.nonzero(self.valid).reshape(-1)
+
+
+_row_plan = None
+
+
+def plan_masked_rows(labels):
+    """call as early as the (extended) MLM labels exist; MLMHeadLossFn picks the plan up by tensor identity."""
+    global _row_plan
+    _row_plan = MaskedRowPlan(labels) if labels is not None else None
+
+
+def _rows_for(lab):
+    global _row_plan
+    plan, _row_plan = _row_plan, None
+    if plan is not None and plan.key == (lab.data_ptr(), lab.numel()):
+        return plan.rows()
+    return torch.nonzero(lab != -1).reshape(-1)           # no plan: one host sync
+
+
+# ------------------------------------------------------------------------------------------------
 # autograd Functions
 # ------------------------------------------------------------------------------------------------
 class LinearFn(torch.autograd.Function):
@@ -737,9 +788,9 @@ class MLMHeadLossFn(torch.autograd.Function):
             loss = torch.empty(1, dtype=torch.float32, device=s2.device)
             lab = labels.reshape(-1).contiguous()
             # Rows whose label is ignored (~88 % of an MLM batch) have an exactly zero gradient: the backward GEMMs of
-            # the decoder run over the masked rows only.  nonzero() is the one host sync of the step (it sizes the
-            # compact buffers); the forward kernels of all layers are already queued behind it.
-            rows = torch.nonzero(lab != -1).reshape(-1)
+            # the decoder run over the masked rows only.  Their number sizes the compact buffers; it comes from the
+            # plan made at the start of the forward (MaskedRowPlan), not from a queue-draining sync here.
+            rows = _rows_for(lab)
             n = int(rows.numel())
             n_pad = round_up(max(n, 1), 64)
             dlogits = torch.empty((n_pad, round_up(V, 64)), dtype=dt, device=s2.device)[:, :V]

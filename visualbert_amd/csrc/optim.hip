@@ -106,6 +106,26 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) shadow_transpose_kernel(const bf16* src, bf16* ds
     const int64_t* te = tensors + tl[0] * 5;
     const long soff = te[0], R = te[1], C = te[2], doff = te[3], dld = te[4];
     const long r0 = tl[1] * 64, c0 = tl[2] * 64;
+    // interior tiles of 16-byte aligned tensors move whole 16-byte vectors on both sides (the element-wise form below
+    // took 232 us per step for 85 M weights: 1.4 TB/s)
+    const bool fast = r0 + 64 <= R && c0 + 64 <= C && (C & 7) == 0 && (dld & 7) == 0 && (soff & 7) == 0 && (doff & 7) == 0;
+    if (fast) {
+        for (int i = threadIdx.x; i < 64 * 8; i += NT) {
+            const int r = i >> 3, cc = (i & 7) * 8;
+            const u32x4 v = *(const u32x4*)(src + soff + (r0 + r) * C + c0 + cc);
+            uint32_t* t32 = (uint32_t*)(tile + r * 66 + cc);
+            t32[0] = v[0]; t32[1] = v[1]; t32[2] = v[2]; t32[3] = v[3];
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 64 * 8; i += NT) {
+            const int c = i >> 3, rr = (i & 7) * 8;      // output row = source column
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = tile[(rr + j) * 66 + c];
+            *(bf16x8*)(dst + doff + (c0 + c) * dld + r0 + rr) = o;
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < 64 * 8; i += NT) {
         const int r = i >> 3, cc = (i & 7) * 8;
         const long gr = r0 + r, gc = c0 + cc;

@@ -372,22 +372,80 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) attn_bwd_dkv_kernel(AttnArgs a) {
 #pragma unroll
     for (int df = 0; df < 4; ++df) { dkT[df] = f32x4{0.f, 0.f, 0.f, 0.f}; dvT[df] = dkT[df]; }
 
+    // A query chunk's global data (Q, dO rows, lse, D, keep-bits) is fetched into REGISTERS one chunk ahead and written to
+    // LDS in both layouts (row-major + transposed) from the same registers: the HBM trip of chunk c+1 runs under the
+    // MFMAs of chunk c, and Q / dO are read once instead of twice (bf16; the fp32 parity path stages as before).
+    constexpr bool PIPE = sizeof(T) == 2;
+    constexpr int BPT = (QC * 4 * NW + NT - 1) / NT;       // keep-bit words per thread per chunk
+    u32x4 cq0 = u32x4{0u, 0u, 0u, 0u}, cq1 = cq0, cd0 = cq0, cd1 = cq0;
+    float c_lse = INFINITY, c_d = 0.f;
+    uint64_t c_bits[BPT];
+    auto load_chunk = [&](int q0) {
+        const int dc = t & 7, r = (t >> 3) * 2;             // rows q0 + r, q0 + r + 1; 16-byte column chunk dc
+        const u32x4 z = u32x4{0u, 0u, 0u, 0u};
+        const bool ok0 = q0 + r < S, ok1 = q0 + r + 1 < S;
+        cq0 = ok0 ? *(const u32x4*)(qkv + (row0 + q0 + r) * ldx + h * D + dc * 8) : z;
+        cq1 = ok1 ? *(const u32x4*)(qkv + (row0 + q0 + r + 1) * ldx + h * D + dc * 8) : z;
+        cd0 = ok0 ? *(const u32x4*)(dctx + (row0 + q0 + r) * (long)H + h * D + dc * 8) : z;
+        cd1 = ok1 ? *(const u32x4*)(dctx + (row0 + q0 + r + 1) * (long)H + h * D + dc * 8) : z;
+        if (t < QC) {
+            const int q = q0 + t;
+            c_lse = q < S ? a.lse[(long)bh * S + q] : INFINITY;     // exp(x - inf) = 0 for padded queries
+            c_d = q < S ? a.dsum[(long)bh * S + q] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < BPT; ++j) {
+            const int i = t + j * NT;
+            const int q = q0 + i / (4 * NW);
+            c_bits[j] = (a.p > 0.f && i < QC * 4 * NW && q < S) ? a.keepbits[((long)bh * S + q0) * 4 * NW + i] : ~(uint64_t)0;
+        }
+    };
+    auto store_tr2 = [&](unsigned char* lds, const u32x4& x0, const u32x4& x1) {
+        const int dc = t & 7, r = (t >> 3) * 2;
+        const int pitch = tr_pitch<bf16>(QC);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const uint32_t a0 = x0[w], b0 = x1[w];
+            *(uint32_t*)(lds + (dc * 8 + 2 * w) * pitch + r * 2) = (a0 & 0xFFFFu) | (b0 << 16);
+            *(uint32_t*)(lds + (dc * 8 + 2 * w + 1) * pitch + r * 2) = (a0 >> 16) | (b0 & 0xFFFF0000u);
+        }
+    };
+    auto store_chunk = [&]() {
+        const int dc = t & 7, r = (t >> 3) * 2;
+        *(u32x4*)(ldsQ + rm_off<T>(r, dc)) = cq0;
+        *(u32x4*)(ldsQ + rm_off<T>(r + 1, dc)) = cq1;
+        *(u32x4*)(ldsDO + rm_off<T>(r, dc)) = cd0;
+        *(u32x4*)(ldsDO + rm_off<T>(r + 1, dc)) = cd1;
+        store_tr2(ldsQT, cq0, cq1);
+        store_tr2(ldsDOT, cd0, cd1);
+        if (t < QC) { ldsLse[t] = c_lse; ldsD[t] = c_d; }
+#pragma unroll
+        for (int j = 0; j < BPT; ++j) if (t + j * NT < QC * 4 * NW) ldsBits[t + j * NT] = c_bits[j];
+    };
+    if constexpr (PIPE) load_chunk(0);
+
     for (int q0 = 0; q0 < S; q0 += QC) {
         __syncthreads();                                   // previous chunk fully consumed
-        stage_rm<T>(ldsQ, qkv, ldx, row0 + q0, h * D, S - q0, QC, t);
-        stage_rm<T>(ldsDO, dctx, (long)H, row0 + q0, h * D, S - q0, QC, t);
-        stage_tr(ldsQT, qkv, ldx, row0 + q0, h * D, S - q0, QC, t);
-        stage_tr(ldsDOT, dctx, (long)H, row0 + q0, h * D, S - q0, QC, t);
-        for (int k = t; k < QC; k += NT) {
-            const int q = q0 + k;
-            ldsLse[k] = q < S ? a.lse[(long)bh * S + q] : INFINITY;   // exp(x - inf) = 0 for padded queries
-            ldsD[k] = q < S ? a.dsum[(long)bh * S + q] : 0.f;
+        if constexpr (PIPE) {
+            store_chunk();
+            __syncthreads();
+            if (q0 + QC < S) load_chunk(q0 + QC);
+        } else {
+            stage_rm<T>(ldsQ, qkv, ldx, row0 + q0, h * D, S - q0, QC, t);
+            stage_rm<T>(ldsDO, dctx, (long)H, row0 + q0, h * D, S - q0, QC, t);
+            stage_tr(ldsQT, qkv, ldx, row0 + q0, h * D, S - q0, QC, t);
+            stage_tr(ldsDOT, dctx, (long)H, row0 + q0, h * D, S - q0, QC, t);
+            for (int k = t; k < QC; k += NT) {
+                const int q = q0 + k;
+                ldsLse[k] = q < S ? a.lse[(long)bh * S + q] : INFINITY;   // exp(x - inf) = 0 for padded queries
+                ldsD[k] = q < S ? a.dsum[(long)bh * S + q] : 0.f;
+            }
+            for (int i = t; i < QC * 4 * NW; i += NT) {
+                const int q = q0 + i / (4 * NW);
+                ldsBits[i] = (a.p > 0.f && q < S) ? a.keepbits[((long)bh * S + q0) * 4 * NW + i] : ~(uint64_t)0;
+            }
+            __syncthreads();
         }
-        for (int i = t; i < QC * 4 * NW; i += NT) {
-            const int q = q0 + i / (4 * NW);
-            ldsBits[i] = (a.p > 0.f && q < S) ? a.keepbits[((long)bh * S + q0) * 4 * NW + i] : ~(uint64_t)0;
-        }
-        __syncthreads();
         if (!wave_on) continue;
 #pragma unroll
         for (int qc = 0; qc < QC / 32; ++qc) {

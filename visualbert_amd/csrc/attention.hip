@@ -86,6 +86,56 @@ VB_DEVICE void stage_tr(unsigned char* lds, const float* X, long ldx, long row0,
     }
 }
 
+// ---- batched staging (bf16) -------------------------------------------------------------------------------------
+// The loops above wait for every global load before its LDS store (the compiler keeps them rolled: one HBM round trip
+// per trip, 9 serial round trips per workgroup in the forward kernel).  Here a thread first issues ALL its loads of a
+// [NROWS][64] tile -- pair-item i = rows (2j, 2j+1) x 16-byte chunk dc -- and only then stores, row-major and / or
+// transposed, from the same registers.
+template <int NROWS>
+struct PairTile {
+    static constexpr int ITEMS = (NROWS / 2) * 8, PER = (ITEMS + NT - 1) / NT;
+    u32x4 x0[PER], x1[PER];
+};
+template <int NROWS>
+VB_DEVICE void pair_load(PairTile<NROWS>& p, const bf16* X, long ldx, long row0, int c0, int S, int t) {
+#pragma unroll
+    for (int k = 0; k < PairTile<NROWS>::PER; ++k) {
+        const int idx = t + k * NT;
+        const int dc = idx & 7, r = (idx >> 3) * 2;
+        const u32x4 z = u32x4{0u, 0u, 0u, 0u};
+        const bool in = idx < PairTile<NROWS>::ITEMS;
+        p.x0[k] = (in && r < S) ? *(const u32x4*)(X + (row0 + r) * ldx + c0 + dc * 8) : z;
+        p.x1[k] = (in && r + 1 < S) ? *(const u32x4*)(X + (row0 + r + 1) * ldx + c0 + dc * 8) : z;
+    }
+}
+template <int NROWS>
+VB_DEVICE void pair_store_rm(const PairTile<NROWS>& p, unsigned char* lds, int t) {
+#pragma unroll
+    for (int k = 0; k < PairTile<NROWS>::PER; ++k) {
+        const int idx = t + k * NT;
+        if (idx >= PairTile<NROWS>::ITEMS) continue;
+        const int dc = idx & 7, r = (idx >> 3) * 2;
+        *(u32x4*)(lds + rm_off<bf16>(r, dc)) = p.x0[k];
+        *(u32x4*)(lds + rm_off<bf16>(r + 1, dc)) = p.x1[k];
+    }
+}
+template <int NROWS>
+VB_DEVICE void pair_store_tr(const PairTile<NROWS>& p, unsigned char* lds, int t) {
+    const int pitch = tr_pitch<bf16>(NROWS);
+#pragma unroll
+    for (int k = 0; k < PairTile<NROWS>::PER; ++k) {
+        const int idx = t + k * NT;
+        if (idx >= PairTile<NROWS>::ITEMS) continue;
+        const int dc = idx & 7, r = (idx >> 3) * 2;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const uint32_t a = p.x0[k][w], b = p.x1[k][w];
+            *(uint32_t*)(lds + (dc * 8 + 2 * w) * pitch + r * 2) = (a & 0xFFFFu) | (b << 16);
+            *(uint32_t*)(lds + (dc * 8 + 2 * w + 1) * pitch + r * 2) = (a >> 16) | (b & 0xFFFF0000u);
+        }
+    }
+}
+
 // ---- fragments -------------------------------------------------------------------------------
 // 8 consecutive d (d0 = ks*32 + g*8) of row `row` of a row-major LDS tile
 VB_DEVICE bf16x8 frag_rm(const unsigned char* lds, int row, int ks, int g, bf16) {
@@ -156,8 +206,16 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(NT, 3) attn_fwd_kernel(AttnArgs a) {
     const long ldx = 3L * H, row0 = (long)b * S;
     const T* qkv = (const T*)a.qkv;
 
-    stage_rm<T>(ldsK, qkv, ldx, row0, H + h * D, S, NK, t);
-    stage_tr(ldsVT, qkv, ldx, row0, 2 * H + h * D, S, NK, t);
+    if constexpr (sizeof(T) == 2) {
+        PairTile<NK> tk, tv;
+        pair_load<NK>(tk, qkv, ldx, row0, H + h * D, S, t);
+        pair_load<NK>(tv, qkv, ldx, row0, 2 * H + h * D, S, t);
+        pair_store_rm<NK>(tk, ldsK, t);
+        pair_store_tr<NK>(tv, ldsVT, t);
+    } else {
+        stage_rm<T>(ldsK, qkv, ldx, row0, H + h * D, S, NK, t);
+        stage_tr(ldsVT, qkv, ldx, row0, 2 * H + h * D, S, NK, t);
+    }
     for (int k = t; k < NK; k += NT) ldsMask[k] = k < S ? a.mask_add[(long)b * S + k] : -INFINITY;
     __syncthreads();
 
@@ -260,9 +318,18 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) attn_bwd_dq_kernel(AttnArgs a) {
     const long ldx = 3L * H, row0 = (long)b * S;
     const T* qkv = (const T*)a.qkv;
 
-    stage_rm<T>(ldsK, qkv, ldx, row0, H + h * D, S, NK, t);
-    stage_rm<T>(ldsV, qkv, ldx, row0, 2 * H + h * D, S, NK, t);
-    stage_tr(ldsKT, qkv, ldx, row0, H + h * D, S, NK, t);
+    if constexpr (sizeof(T) == 2) {
+        PairTile<NK> tk, tv;                               // K is fetched once for both of its LDS images
+        pair_load<NK>(tk, qkv, ldx, row0, H + h * D, S, t);
+        pair_load<NK>(tv, qkv, ldx, row0, 2 * H + h * D, S, t);
+        pair_store_rm<NK>(tk, ldsK, t);
+        pair_store_tr<NK>(tk, ldsKT, t);
+        pair_store_rm<NK>(tv, ldsV, t);
+    } else {
+        stage_rm<T>(ldsK, qkv, ldx, row0, H + h * D, S, NK, t);
+        stage_rm<T>(ldsV, qkv, ldx, row0, 2 * H + h * D, S, NK, t);
+        stage_tr(ldsKT, qkv, ldx, row0, H + h * D, S, NK, t);
+    }
     for (int k = t; k < NK; k += NT) ldsMask[k] = k < S ? a.mask_add[(long)b * S + k] : -INFINITY;
     __syncthreads();
 

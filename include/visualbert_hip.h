@@ -118,8 +118,8 @@ int vb_attn_bwd(int dtype, const void* qkv, const float* mask_add, const void* d
 
 /* ------------------------------------------------------------------------------------------------
  * Losses.  logits are fp32 with leading dimension ld_logits (pad columns are ignored).
- * vb_ce_fwd_bwd: CrossEntropyLoss(ignore_index) mean over counted rows -> loss[0]; acc2 is an fp32[2]
- *   scratch {sum, count}; dlogits (T, may be NULL) receives d loss / d logits for an upstream gradient
+ * vb_ce_fwd_bwd: CrossEntropyLoss(ignore_index) mean over counted rows -> loss[0]; acc2 is an fp32[66]
+ *   scratch {sum, count, 64 partial sums}; dlogits (T, may be NULL) receives d loss / d logits for an upstream gradient
  *   of 1, INCLUDING zeroed pad columns up to ld_dlogits and all-zero rows for ignored labels.
  *   Replaces modeling.py:1471-1477 (masked LM, image-text match), :1563-1565 (NLVR2) and autograd.
  * vb_kldiv_fwd_bwd: KLDivLoss(batchmean)(log_softmax(logits), target) -> loss[0]; score[0] (may be NULL)

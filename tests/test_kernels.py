@@ -135,6 +135,43 @@ def test_wgrad_grouped_transposing_reads(dev, tokens, wgs):
         L.vb_gemm_set_persistent_wgs(0)
 
 
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("V", [1000, 33000])        # register-cached single pass (V <= 32768) / rolled two-pass rows
+def test_cross_entropy_dense_and_compact_rows(dev, dt, V):
+    """CrossEntropyLoss(ignore_index=-1) + gradient, dense rows (vb_ce_fwd_bwd) and the compact form the MLM head uses
+    (vb_ce_fwd_bwd_rows: gradient of the labelled rows only, zero padding rows) against torch."""
+    L = _lib.lib()
+    M = 37
+    g = torch.Generator().manual_seed(V)
+    ld = (V + 63) // 64 * 64
+    logits = torch.zeros(M, ld, device=dev)
+    logits[:, :V] = (torch.randn(M, V, generator=g) * 3).to(dev)
+    lab = torch.randint(0, V, (M,), generator=g)
+    lab[torch.rand(M, generator=g) < 0.6] = -1
+    lab[3] = V - 1                                   # last valid column
+    lab = lab.to(dev)
+    ref_in = logits[:, :V].detach().clone().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(ref_in, lab, ignore_index=-1)
+    ref.backward()
+    acc = torch.empty(66, device=dev); loss = torch.empty(1, device=dev)
+    dl = torch.full((M, ld), 7.0, dtype=dt, device=dev)
+    _lib.check(L.vb_ce_fwd_bwd(_lib.dtype_code(dt), _lib.ptr(logits), ld, _lib.ptr(lab), -1, _lib.ptr(acc), _lib.ptr(loss),
+                               _lib.ptr(dl), ld, M, V, _lib.stream_ptr()), "vb_ce_fwd_bwd")
+    assert abs(loss.item() - ref.item()) <= 2e-5 * max(1.0, abs(ref.item()))
+    t = tol(dt, 2e-6, 2e-3)
+    assert (dl[:, :V].float() - ref_in.grad).abs().max().item() <= t
+    assert (dl[:, V:].float() == 0).all()                                   # pad columns are written as zeros
+    rows = torch.nonzero(lab != -1).reshape(-1)
+    n = rows.numel(); n_pad = (n + 63) // 64 * 64
+    dlc = torch.full((n_pad, ld), 7.0, dtype=dt, device=dev)
+    _lib.check(L.vb_ce_fwd_bwd_rows(_lib.dtype_code(dt), _lib.ptr(logits), ld, _lib.ptr(lab), -1, _lib.ptr(rows), n, n_pad,
+                                    _lib.ptr(acc), _lib.ptr(loss), _lib.ptr(dlc), ld, M, V, _lib.stream_ptr()),
+               "vb_ce_fwd_bwd_rows")
+    assert abs(loss.item() - ref.item()) <= 2e-5 * max(1.0, abs(ref.item()))
+    assert (dlc[:n, :V].float() - ref_in.grad[rows]).abs().max().item() <= t
+    assert (dlc[n:].float() == 0).all() and (dlc[:, V:].float() == 0).all()
+
+
 def ln_fwd(dev, dt, x, resid, gamma, beta, p_in=0.0, p_out=0.0, seed=5, want_z=True):
     M, H = x.shape
     L = _lib.lib()

@@ -39,17 +39,22 @@ VB_DEVICE float block_reduce_max(float v, float* red) {
     return r;
 }
 
-// acc[0] = sum of row losses, acc[1] = number of counted rows (as float)
+// acc[0] = sum of row losses, acc[1] = number of counted rows (as float), acc[2 .. 2 + CE_SLOTS) = partial sums:
+// a row adds its loss to slot (row & 63) -- thousands of workgroups adding to ONE address serialise in L2 at ~100 ns
+// per atomic (2492 labelled rows: 247 us, the whole kernel); 64 addresses take that off the critical path.
+constexpr int CE_SLOTS = 64;
 VB_KERNEL VB_LAUNCH_BOUNDS(NT) ce_count_kernel(const int64_t* labels, int M, int V, int ignore_index, float* acc) {
     VB_DYN_SMEM(smem);
     float* red = (float*)smem;
+    // acc[] was zeroed by the launcher; every workgroup adds the count of its slice (a single workgroup walking 20992
+    // labels with one load in flight took 40 us)
     float c = 0.f;
-    for (int i = threadIdx.x; i < M; i += NT) {
+    for (int i = blockIdx.x * NT + threadIdx.x; i < M; i += gridDim.x * NT) {
         const int64_t l = labels[i];
         c += (l != ignore_index && l >= 0 && l < V) ? 1.f : 0.f;
     }
     c = block_reduce_sum(c, red);
-    if (threadIdx.x == 0) { acc[0] = 0.f; acc[1] = c; }
+    if (threadIdx.x == 0 && c != 0.f) atomicAdd(&acc[1], c);
 }
 
 template <typename T>
@@ -77,6 +82,62 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) ce_row_kernel(const float* logits, long ld, const
         return;
     }
     const float* x = logits + (long)row * ld;
+    // Rows of up to 32768 columns live in registers (16 x 8 floats per thread): every load of the row is issued before
+    // the first use (the rolled online-softmax loop below pays one HBM round trip per trip, twice over), the logits are
+    // read once, and the gradient is written from the registers.
+    constexpr int CACHE_IT = 16;
+    if (vec && V <= CACHE_IT * NT * 8) {
+        const float x_label = x[label];                  // issued with the row, not after the reductions
+        const float count = acc[1];
+        float v[CACHE_IT][8];
+#pragma unroll
+        for (int k = 0; k < CACHE_IT; ++k) {
+            const int j = (k * NT + (int)threadIdx.x) * 8;
+            if (j < V) load8(v[k], x + j);               // pad columns (j + e >= V) are readable; masked below
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[k][e] = -INFINITY;
+            }
+        }
+        float m = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < CACHE_IT; ++k) {
+            const int j = (k * NT + (int)threadIdx.x) * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (j + e >= V) v[k][e] = -INFINITY;
+                m = fmaxf(m, v[k][e]);
+            }
+        }
+        const float gm = block_reduce_max(m, red);
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < CACHE_IT; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += fast_exp(v[k][e] - gm);      // exp(-inf) = 0 for the masked tail
+        const float gs = block_reduce_sum(s, red);
+        const float lse = gm + logf(gs);
+        if (threadIdx.x == 0) atomicAdd(&acc[2 + (blockIdx.x & (CE_SLOTS - 1))], lse - x_label);
+        if (drow) {
+            const float invc = 1.0f / count;
+#pragma unroll
+            for (int k = 0; k < CACHE_IT; ++k) {
+                const long j = ((long)k * NT + threadIdx.x) * 8;
+                if (j < ldd) {
+                    float o[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        o[e] = (j + e < V) ? (fast_exp(v[k][e] - lse) - ((j + e) == label ? 1.f : 0.f)) * invc : 0.f;
+                    store8(drow + j, o);
+                }
+            }
+            for (long j = ((long)CACHE_IT * NT + threadIdx.x) * 8; j < ldd; j += NT * 8) {   // pad beyond the cached span
+                float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                store8(drow + j, z);
+            }
+        }
+        return;
+    }
     float m = -INFINITY, s = 0.f;                        // online max / sum-exp
     if (vec) {
         for (int j = threadIdx.x * 8; j < V; j += NT * 8) {
@@ -99,7 +160,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) ce_row_kernel(const float* logits, long ld, const
     s = (m == -INFINITY) ? 0.f : s * expf(m - gm);
     const float gs = block_reduce_sum(s, red);
     const float lse = gm + logf(gs);
-    if (threadIdx.x == 0) atomicAdd(&acc[0], lse - x[label]);
+    if (threadIdx.x == 0) atomicAdd(&acc[2 + (blockIdx.x & (CE_SLOTS - 1))], lse - x[label]);
     if (drow) {
         const float invc = 1.0f / acc[1];
         if (vec) {
@@ -121,9 +182,12 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) ce_row_kernel(const float* logits, long ld, const
     }
 }
 
-// loss[0] = acc[0] / acc[1]   (NaN when nothing is counted, like the reference)
-VB_KERNEL ce_finish_kernel(const float* acc, float* loss) {
-    if (threadIdx.x == 0) loss[0] = acc[0] / acc[1];
+// loss[0] = sum(partials) / acc[1]   (NaN when nothing is counted, like the reference); acc[0] = the sum
+VB_KERNEL ce_finish_kernel(float* acc, float* loss) {
+    float v = threadIdx.x < CE_SLOTS ? acc[2 + threadIdx.x] : 0.f;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    if (threadIdx.x == 0) { acc[0] = v; loss[0] = v / acc[1]; }
 }
 
 // KLDivLoss(reduction=batchmean)(log_softmax(logits), target) + gradient + VQA score, one block per row
@@ -217,7 +281,8 @@ extern "C" int vb_ce_fwd_bwd(int dtype, const float* logits, int64_t ld_logits, 
     if (!logits || !labels || !acc2 || !loss || M <= 0 || V <= 0) return VB_ERR_ARG;
     if (dlogits && ld_dlogits < V) return VB_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    VB_LAUNCH(ce_count_kernel, dim3(1), dim3(NT), 64, s, labels, M, V, ignore_index, acc2);
+    if (hipMemsetAsync(acc2, 0, sizeof(float) * (2 + CE_SLOTS), s) != hipSuccess) return VB_ERR_LAUNCH;
+    VB_LAUNCH(ce_count_kernel, dim3((unsigned)((M + NT - 1) / NT > 128 ? 128 : (M + NT - 1) / NT)), dim3(NT), 64, s, labels, M, V, ignore_index, acc2);
     if (dtype == VB_BF16)
         VB_LAUNCH(ce_row_kernel<bf16>, dim3((unsigned)M), dim3(NT), 64, s, logits, (long)ld_logits, labels,
                   ignore_index, acc2, (bf16*)dlogits, (long)ld_dlogits, M, V, (const int64_t*)nullptr, 0);
@@ -225,7 +290,7 @@ extern "C" int vb_ce_fwd_bwd(int dtype, const float* logits, int64_t ld_logits, 
         VB_LAUNCH(ce_row_kernel<float>, dim3((unsigned)M), dim3(NT), 64, s, logits, (long)ld_logits, labels,
                   ignore_index, acc2, (float*)dlogits, (long)ld_dlogits, M, V, (const int64_t*)nullptr, 0);
     else return VB_ERR_ARG;
-    VB_LAUNCH(ce_finish_kernel, dim3(1), dim3(64), 0, s, (const float*)acc2, loss);
+    VB_LAUNCH(ce_finish_kernel, dim3(1), dim3(64), 0, s, acc2, loss);
     return vb_check_launch();
 }
 
@@ -235,7 +300,8 @@ extern "C" int vb_ce_fwd_bwd_rows(int dtype, const float* logits, int64_t ld_log
     if (!logits || !labels || !acc2 || !loss || !dlogits_compact || M <= 0 || V <= 0) return VB_ERR_ARG;
     if (n_rows < 0 || n_rows > M || n_rows_padded < n_rows || n_rows_padded <= 0 || (n_rows > 0 && !rows)) return VB_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    VB_LAUNCH(ce_count_kernel, dim3(1), dim3(NT), 64, s, labels, M, V, ignore_index, acc2);
+    if (hipMemsetAsync(acc2, 0, sizeof(float) * (2 + CE_SLOTS), s) != hipSuccess) return VB_ERR_LAUNCH;
+    VB_LAUNCH(ce_count_kernel, dim3((unsigned)((M + NT - 1) / NT > 128 ? 128 : (M + NT - 1) / NT)), dim3(NT), 64, s, labels, M, V, ignore_index, acc2);
     const int64_t* r = rows ? rows : labels;               // never dereferenced when n_rows == 0
     if (dtype == VB_BF16)
         VB_LAUNCH(ce_row_kernel<bf16>, dim3((unsigned)n_rows_padded), dim3(NT), 64, s, logits, (long)ld_logits, labels,
@@ -244,7 +310,7 @@ extern "C" int vb_ce_fwd_bwd_rows(int dtype, const float* logits, int64_t ld_log
         VB_LAUNCH(ce_row_kernel<float>, dim3((unsigned)n_rows_padded), dim3(NT), 64, s, logits, (long)ld_logits, labels,
                   ignore_index, acc2, (float*)dlogits_compact, (long)ld_dlogits, M, V, r, n_rows);
     else return VB_ERR_ARG;
-    VB_LAUNCH(ce_finish_kernel, dim3(1), dim3(64), 0, s, (const float*)acc2, loss);
+    VB_LAUNCH(ce_finish_kernel, dim3(1), dim3(64), 0, s, acc2, loss);
     return vb_check_launch();
 }
 

@@ -784,7 +784,7 @@ class MLMHeadLossFn(torch.autograd.Function):
         dlogits = None
         rows = None
         if labels is not None:
-            acc = torch.empty(2, dtype=torch.float32, device=s2.device)
+            acc = torch.empty(66, dtype=torch.float32, device=s2.device)
             loss = torch.empty(1, dtype=torch.float32, device=s2.device)
             lab = labels.reshape(-1).contiguous()
             # Rows whose label is ignored (~88 % of an MLM batch) have an exactly zero gradient: the backward GEMMs of
@@ -872,7 +872,7 @@ class SmallLinearCEFn(torch.autograd.Function):
         loss = torch.zeros((), dtype=torch.float32, device=x2.device)
         dy = None
         if labels is not None:
-            acc = torch.empty(2, dtype=torch.float32, device=x2.device)
+            acc = torch.empty(66, dtype=torch.float32, device=x2.device)
             l1 = torch.empty(1, dtype=torch.float32, device=x2.device)
             dy = torch.empty((M, N), dtype=torch.float32, device=x2.device)
             check(_lib.lib().vb_ce_fwd_bwd(_lib.VB_F32, ptr(y), N, ptr(labels.reshape(-1).contiguous()), ignore_index,

@@ -33,7 +33,21 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) adam_norm_kernel(const float* grads, const int64_
     const int64_t* c = chunks + (long)blockIdx.x * 4;
     const long off = c[1], len = c[2];
     float s = 0.f;
-    for (long i = threadIdx.x; i < len; i += NT) { const float g = grads[off + i]; s += g * g; }
+    if (((off | len) & 3) == 0) {
+        // 16-byte loads, four independent ones in flight per trip (the scalar rolled loop paid a memory round trip per
+        // element: 145 us for 448 MB)
+        const f32x4* g4 = (const f32x4*)(grads + off);
+        const long n4 = len >> 2;
+        long i = threadIdx.x;
+        for (; i + 3 * NT < n4; i += 4 * NT) {
+            const f32x4 a = g4[i], b = g4[i + NT], c2 = g4[i + 2 * NT], d = g4[i + 3 * NT];
+            s += (a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3]) + (b[0] * b[0] + b[1] * b[1] + b[2] * b[2] + b[3] * b[3]) +
+                 (c2[0] * c2[0] + c2[1] * c2[1] + c2[2] * c2[2] + c2[3] * c2[3]) + (d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]);
+        }
+        for (; i < n4; i += NT) { const f32x4 a = g4[i]; s += a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3]; }
+    } else {
+        for (long i = threadIdx.x; i < len; i += NT) { const float g = grads[off + i]; s += g * g; }
+    }
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();

@@ -105,6 +105,8 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
+        from visualbert_amd.parallel import configure_rccl_env
+        configure_rccl_env()
         dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)
 
     from visualbert_amd import ops

@@ -15,9 +15,30 @@ stream behind an event, so it overlaps the remaining backward compute.  xGMI is 
 (7 links x ~153 GB/s per GPU): a ring all-reduce moves 2(N-1)/N x payload per GPU and is per-link
 bound, so buckets are whole layers (28 MB fp32 at BERT-base) -- large enough to run at link speed,
 small enough that the last one (embeddings, 94 MB + heads) is the only exposed tail.
+
+Compute units for the collective.  The persistent GEMM kernels launch one 160-KB-LDS workgroup per CU, and such a
+workgroup cannot share a CU with an RCCL workgroup: while the collective is resident on c CUs, c workgroups of a GEMM
+launch wait for a free CU.  Reserving CUs up front (VB_COMM_CUS=c: GEMMs use CUs - c workgroups while buckets are in
+flight, RCCL capped to c channels via NCCL_MAX_NCHANNELS) was measured on one GPU and is OFF by default: the N=768 GEMMs
+have 246 output tiles, so ANY grid below 246 workgroups costs them a second round (30 -> 47 us, 78 -> 128 us at 224
+workgroups) -- the same price the un-reserved launch pays only while the collective really is resident.
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+from . import _lib
+
+
+def comm_cus():
+    return int(os.environ.get("VB_COMM_CUS", "0"))
+
+
+def configure_rccl_env():
+    """call before init_process_group: with VB_COMM_CUS=c keep the collective on at most c channels (= CUs)."""
+    if comm_cus() > 0:
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", str(comm_cus()))
 
 
 class DataParallelGradSync(object):
@@ -32,6 +53,7 @@ class DataParallelGradSync(object):
         self.backend = dist.get_backend(process_group)
         self._works = []
         self._done = set()
+        self._reserved = False
         self._install()
 
     def _install(self):
@@ -61,11 +83,23 @@ class DataParallelGradSync(object):
         if lo is None:
             return
         view = self.obj.arena.grad[lo:hi]
+        self._reserve_cus(True)
         if self.backend == "nccl":
             w = dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.pg, async_op=True)
         else:                                                 # gloo (CPU tests): SUM then scale
             w = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
         self._works.append((w, view))
+
+    def _reserve_cus(self, on):
+        """leave comm_cus() CUs to RCCL while buckets are in flight (see the module docstring)."""
+        if self.backend != "nccl" or self.world == 1 or comm_cus() <= 0 or on == self._reserved:
+            return
+        self._reserved = on
+        wgs = 0
+        if on:
+            cus = torch.cuda.get_device_properties(self.obj.arena.grad.device).multi_processor_count
+            wgs = max(8, (cus - comm_cus()) // 8 * 8)
+        _lib.check(_lib.lib().vb_gemm_set_persistent_wgs(wgs), "vb_gemm_set_persistent_wgs")
 
     def _layer_ready(self, layer_index):
         # everything above this layer in the graph has finished enqueuing its backward
@@ -80,3 +114,4 @@ class DataParallelGradSync(object):
             if self.backend != "nccl":
                 view.div_(self.world)
         self._works = []
+        self._reserve_cus(False)

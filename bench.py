@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed/RCCL even with one rank")
     ap.add_argument("--h2d", action="store_true", help="also time a run that streams each batch from pinned host memory")
+    ap.add_argument("--sparse-mlm-head", action="store_true",
+                    help="also time the opt-in MLM head over the labelled positions only (SURVEY 8f/N1); reported as an extra field")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -173,6 +175,19 @@ def main():
         barrier()
         h2d = B * world * args.steps / (time.perf_counter() - t1)
 
+    sparse = None
+    if args.sparse_mlm_head:
+        mw.model.bert.sparse_mlm_head = True
+        for _ in range(2):
+            mw.step(batch)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            mw.step(batch)
+        barrier()
+        sparse = B * world * args.steps / (time.perf_counter() - t1)
+        mw.model.bert.sparse_mlm_head = False
+
     ms_per_step = elapsed / args.steps * 1e3
     value = B * world * args.steps / elapsed
     fps = flops_per_sample(L, H, I, V, S, R, Dv)
@@ -219,6 +234,8 @@ def main():
         }
         if h2d is not None:
             out["samples_per_s_with_pinned_h2d"] = round(h2d, 2)
+        if sparse is not None:
+            out["samples_per_s_sparse_mlm_head_optin"] = round(sparse, 2)
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()

@@ -195,3 +195,28 @@ def test_bert_base_config2_logits_vs_oracle(dev):
     err16 = float((lg16 - ref16["logits"]).abs().max())
     print("BERT-base bf16: max|dlogit| vs fp32 reference %.3e, vs bf16-emulating oracle %.3e" % (gap, err16))
     assert err16 < 5e-2 and gap < 0.2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_sparse_mlm_head_matches_dense_head(dev, dtype):
+    """the MLM head over the labelled positions only gives the dense head's loss, the dense
+    head's logits at those positions and the dense head's parameter gradients."""
+    cfg, head, sd, batch, g = load_case("micro_pretraining")
+    outs = []
+    for sparse in (False, True):
+        model = build_model(cfg, head, sd, dev, dtype=dtype, dropout=0.0)
+        model.train()
+        model.bert.sparse_mlm_head = sparse
+        model.bert.arena.zero_grad()
+        out = model(**to_dev(batch, dev))
+        out["loss"].backward()
+        outs.append((out, model.bert.arena.grad.detach().float().cpu().clone()))
+    (od, gd), (os_, gs) = outs
+    assert abs(float(od["loss"].detach()) - float(os_["loss"].detach())) <= (1e-5 if dtype == torch.float32 else 2e-3)
+    rows = os_["logits_rows"].cpu()
+    V = od["logits"].size(-1)
+    dense_rows = od["logits"].reshape(-1, V).float().cpu()[rows]
+    lerr = (os_["logits"].float().cpu() - dense_rows).abs().max().item()
+    assert lerr <= (1e-4 if dtype == torch.float32 else 5e-2), lerr
+    gerr = (gd - gs).abs().max().item()
+    assert gerr <= (2e-5 if dtype == torch.float32 else 2e-2) * max(1.0, gd.abs().max().item()), gerr

@@ -813,6 +813,7 @@ class TrainVisualBERTObjective(PreTrainedBertModel):
         self.hard_cap_seq_len = hard_cap_seq_len
         self.bert = BertVisualModel(config)
         self.training_head_type = training_head_type
+        self.sparse_mlm_head = False       # opt-in: MLM head over the labelled positions only (changes `logits` to [n, V])
         if training_head_type == "pretraining":
             self.cls = BertPreTrainingHeads(config, self.bert.embeddings.word_embeddings.weight)
         elif training_head_type == "vqa":
@@ -958,9 +959,17 @@ class TrainVisualBERTObjective(PreTrainedBertModel):
         if self.training_head_type == "pretraining":
             pred = self.cls.predictions
             tr = pred.transform
-            logits, mlm_loss = ops.MLMHeadLossFn.apply(
-                sequence_output, flat_masked_lm_labels, pred, pred.decoder.weight, pred.bias, tr.dense.weight,
-                tr.dense.bias, tr.LayerNorm.weight, tr.LayerNorm.bias)
+            if self.sparse_mlm_head and flat_masked_lm_labels is not None:
+                # opt-in: the head runs over the labelled positions only; `logits` is [n, V] and
+                # `logits_rows` says which of the B*S positions they are -- the reference returns [B, S, V]
+                logits, logit_rows, mlm_loss = ops.SparseMLMHeadLossFn.apply(
+                    sequence_output, flat_masked_lm_labels, pred, pred.decoder.weight, pred.bias, tr.dense.weight,
+                    tr.dense.bias, tr.LayerNorm.weight, tr.LayerNorm.bias)
+                output_dict["logits_rows"] = logit_rows
+            else:
+                logits, mlm_loss = ops.MLMHeadLossFn.apply(
+                    sequence_output, flat_masked_lm_labels, pred, pred.decoder.weight, pred.bias, tr.dense.weight,
+                    tr.dense.bias, tr.LayerNorm.weight, tr.LayerNorm.bias)
             rel, nsp_loss = ops.SmallLinearCEFn.apply(pooled_output, is_random_next, -1,
                                                       self.cls.seq_relationship.weight, self.cls.seq_relationship.bias)
             output_dict["logits"] = logits

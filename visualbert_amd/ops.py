@@ -855,6 +855,88 @@ class MLMHeadLossFn(torch.autograd.Function):
                 grad_result(g_tb, d6), grad_result(g_lw, d3), grad_result(g_lb, d4))
 
 
+class SparseMLMHeadLossFn(torch.autograd.Function):
+    """Opt-in MLM head over the LABELLED positions only: gather the rows whose label is counted, then
+    transform GEMM+GELU -> LayerNorm -> tied-decoder GEMM -> CrossEntropyLoss on those rows.  Same loss and gradients as
+    MLMHeadLossFn (rows with an ignored label contribute nothing to either), without the ~88 % of the decoder forward and
+    the [B,S,V] logits tensor.  Returns (logits [n, V] fp32 of the labelled rows, row indices [n] into B*S, loss).
+    pytorch_pretrained_bert/modeling.py:397-401, 417-420, 1466-1473."""
+
+    @staticmethod
+    def forward(ctx, seq, labels, head, word_weight, *params):
+        B, S, H = seq.shape
+        s2 = seq.reshape(B * S, H)
+        dt = s2.dtype
+        tr = head.transform
+        lab = labels.reshape(-1).contiguous()
+        rows = _rows_for(lab)
+        n = int(rows.numel())
+        n_pad = round_up(max(n, 1), 64)
+        s_c = torch.zeros((n_pad, H), dtype=dt, device=s2.device)
+        lab_c = torch.full((n_pad,), -1, dtype=torch.int64, device=s2.device)
+        if n:
+            s_c[:n] = s2.index_select(0, rows)
+            lab_c[:n] = lab.index_select(0, rows)
+        pre = torch.empty((n_pad, H), dtype=dt, device=s2.device)
+        t = linear_fwd(s_c, weight_for(tr.dense.weight, dt), tr.dense.bias.detach(), VB_ACT_GELU, aux_out=pre)
+        tn, _, mean, rstd = ln_fwd(t, None, tr.LayerNorm.weight.detach(), tr.LayerNorm.bias.detach(),
+                                   tr.LayerNorm.variance_epsilon, save_z=False)
+        E = weight_for(word_weight, dt)
+        V = E.size(0)
+        logits = linear_fwd(tn, E, head.bias.detach(), out_dtype=torch.float32)
+        acc = torch.empty(66, dtype=torch.float32, device=s2.device)
+        loss = torch.empty(1, dtype=torch.float32, device=s2.device)
+        dlogits = torch.empty((n_pad, round_up(V, 64)), dtype=dt, device=s2.device)[:, :V]
+        check(_lib.lib().vb_ce_fwd_bwd(_lib.dtype_code(dt), ptr(logits), _ld(logits), ptr(lab_c), -1, ptr(acc), ptr(loss),
+                                       ptr(dlogits), _ld(dlogits), n_pad, V, stream_ptr()), "vb_ce_fwd_bwd")
+        ctx.head, ctx.word_weight = head, word_weight
+        ctx.cfg = (B, S, H, V, n)
+        ctx.save_for_backward(s_c, pre, t, tn, mean, rstd, dlogits, rows)
+        out_logits = logits[:n]
+        ctx.mark_non_differentiable(out_logits, rows)
+        ctx.set_materialize_grads(False)
+        return out_logits, rows, loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, _dl, _dr, dloss):
+        s_c, pre, t, tn, mean, rstd, dlogits, rows = ctx.saved_tensors
+        B, S, H, V, n = ctx.cfg
+        head = ctx.head
+        tr = head.transform
+        dt = s_c.dtype
+        n_pad = s_c.size(0)
+        up = _upstream_scalar(dloss)
+        E = weight_for(ctx.word_weight, dt)
+        Et = weight_t_for(ctx.word_weight, dt)
+        dtn32 = torch.zeros((n_pad, H), dtype=torch.float32, device=s_c.device)
+        k_pad = None
+        if Et is not None and Et.stride(0) == _ld(dlogits) and (Et.stride(0) % 64) == 0:
+            k_pad = Et.stride(0)
+        if Et is not None:
+            gemm(dlogits, Et, n_pad, H, k_pad or V, out=dtn32, accumulate=True, alpha_dev=up)
+        else:
+            gemm(dlogits, E, n_pad, H, V, b_layout=VB_KSTRIDED, out=dtn32, accumulate=True, alpha_dev=up)
+        dtn = dtn32.to(dt)
+        g_E, d1 = grad_target(ctx.word_weight)
+        linear_wgrad(dlogits, tn, g_E, alpha_dev=up)
+        g_db, d2 = grad_target(head.bias)
+        colsum(dlogits, g_db, scale_dev=up)
+        g_lw, d3 = grad_target(tr.LayerNorm.weight)
+        g_lb, d4 = grad_target(tr.LayerNorm.bias)
+        dt_, _ = ln_bwd(dtn, t, mean, rstd, tr.LayerNorm.weight.detach(), g_lw, g_lb)
+        dpre = act_bwd(dt_, pre, VB_ACT_GELU)
+        g_tw, d5 = grad_target(tr.dense.weight)
+        g_tb, d6 = grad_target(tr.dense.bias)
+        linear_wgrad(dpre, s_c, g_tw)
+        colsum(dpre, g_tb)
+        dseq_c = linear_dgrad(dpre, weight_for(tr.dense.weight, dt), wt=weight_t_for(tr.dense.weight, dt))
+        dseq = torch.zeros((B * S, H), dtype=dt, device=s_c.device)
+        if n:
+            dseq.index_copy_(0, rows, dseq_c[:n])
+        return (dseq.view(B, S, H), None, None, grad_result(g_E, d1), grad_result(g_db, d2), grad_result(g_tw, d5),
+                grad_result(g_tb, d6), grad_result(g_lw, d3), grad_result(g_lb, d4))
+
+
 class SmallLinearCEFn(torch.autograd.Function):
     """Linear with a tiny output width + CrossEntropyLoss: seq_relationship / image-text-match
     (modeling.py:451, 1474) and the NLVR2 classifier (modeling.py:1558-1565).  Returns (logits fp32, loss)."""

@@ -39,6 +39,34 @@ def synthetic_pretraining_batch(B, T=128, R=36, Dv=2048, vocab=30522, seed=0, de
     return {k: v.to(device) for k, v in batch.items()}
 
 
+def mask_tokens(input_ids, maskable, vocab_size, mask_id, probability=0.15, generator=None, uniforms=None,
+                random_ids=None):
+    """Vectorised BERT masking of a whole batch on the host.
+
+    Replaces the per-token Python loop `random_word` (pytorch_pretrained_bert/fine_tuning.py:272-308), which also rebuilds
+    `list(tokenizer.vocab.items())` for every replaced token: a token is selected with `probability`; of the selected ones
+    80 % become [MASK], 10 % a uniformly random vocabulary id, 10 % stay; the label is the ORIGINAL id at selected
+    positions and -1 elsewhere.  The reference draws one uniform per token and reuses it (prob /= probability) to pick
+    among the three outcomes -- so does this function, which makes it element-for-element identical to the loop when
+    given the same uniforms (`uniforms`, `random_ids`: injected draws for tests; otherwise from `generator`).
+
+    input_ids: int64 [B, T]; maskable: bool [B, T] (False for [CLS]/[SEP]/padding, which the reference never passes to
+    random_word).  Returns (masked_ids, labels)."""
+    ids = input_ids
+    if uniforms is None:
+        uniforms = torch.rand(ids.shape, generator=generator, dtype=torch.float64)
+    if random_ids is None:
+        random_ids = torch.randint(0, vocab_size, ids.shape, generator=generator, dtype=torch.int64)
+    sel = (uniforms < probability) & maskable
+    u2 = uniforms / probability
+    to_mask = sel & (u2 < 0.8)
+    to_rand = sel & (u2 >= 0.8) & (u2 < 0.9)
+    out = torch.where(to_mask, torch.full_like(ids, mask_id), ids)
+    out = torch.where(to_rand, random_ids, out)
+    labels = torch.where(sel, ids, torch.full_like(ids, -1))
+    return out, labels
+
+
 class FeatureStager(object):
     """Double-buffered pinned-host -> HBM streaming of a batch dict (the features are 295 KB/sample)."""
 

@@ -8,7 +8,7 @@ n, k, v = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 dbg = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 dev = torch.device("cuda", 0)
 L = _lib.lib()
-M = 64 * 164
+M = 128 * 164
 g = torch.Generator().manual_seed(0)
 a = (torch.randn(M, k, generator=g) * 0.5).to(torch.bfloat16).to(dev)
 w = (torch.randn(n, k, generator=g) * 0.05).to(torch.bfloat16).to(dev)

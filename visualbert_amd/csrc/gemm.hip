@@ -10,25 +10,23 @@
 //   wgrad    dW += dy^T x        autograd of the same lines (fp32 accumulate straight into the grad arena)
 //
 // Operand layouts (per operand, independent):
-//   VB_KCONTIG : stored [rows][K], K contiguous   (x, dy as A; W as B in forward)
-//   VB_KSTRIDED: stored [K][rows], rows contiguous (W as B in dgrad; dy and x in wgrad)
-// K-strided tiles are transposed in registers on their way into LDS, so no transposed copies of
-// weights or activations ever exist in HBM.
+//   VB_KCONTIG : stored [rows][K], K contiguous   (x, dy as A; W as B in forward; W^T shadows as B in dgrad)
+//   VB_KSTRIDED: stored [K][rows], rows contiguous (dy and x in wgrad; W as B in dgrad when no W^T shadow exists)
 //
-// Tile: 128x128 per workgroup of 4 waves (2x2, 64x64 per wave = 4x4 MFMA 16x16 fragments, 64 fp32
-// accumulators per lane).  LDS rows are always 128 B (64 bf16 / 32 fp32 of K) with a 16-byte-chunk XOR
-// swizzle; fragments are read with ds_read_b128.  LDS is double-buffered (2 x 32 KB): one barrier
-// per K tile, the next tile's loads fly under the current tile's MFMAs.
-//   * K-contiguous operand, K a multiple of the tile: global_load_lds_dwordx4 straight into LDS (no
-//     VGPR staging, no ds_write); the swizzle is applied to the per-lane SOURCE address because the
-//     LDS image of such a load is lane-linear (guide rule 21).
-//   * K-strided operand (or a ragged K tail): staged through registers, transposed 8x8 on the way.
-// Split-K (wgrad only, fp32 accumulate): the token dimension is the reduction, the output is only
-// [out,in] -- 36..144 tiles for BERT-base -- so the reduction is cut into `splits` slices that add
-// their partial tile with fire-and-forget fp32 atomics (the output is an accumulator anyway).
-// The accumulators leave through LDS so that the epilogue (bias, GELU, GELU', residual addend, fp32
-// accumulate) works on 8 consecutive columns per lane and every global store is a full 128-byte row
-// segment.
+// Kernels in this file (details next to each):
+//   gemm_nt_8ph_kernel   persistent 256x256-tile kernel for K-contiguous x K-contiguous bf16 GEMMs (every forward and
+//                        dgrad GEMM of the training step): LDS-direct copy stream of half-tiles that runs across output
+//                        tiles, four-slot schedule with the two wave groups one barrier apart, counted vmcnt waits,
+//                        wave-private epilogue slabs, epilogue specialised by template (ACT, OPT).
+//   gemm_tn_8ph_kernel   grouped weight gradients: both operands token-major, copied as stored, MFMA fragments gathered
+//                        with ds_read_b64_tr_b16; (problem, tile, token slice) work items, fp32 atomics.
+//   gemm_nt_pipe_kernel  two-barrier 128x128 / 256x128 kernels: small or odd problems (fewer than ~160 big tiles), fp32.
+//   gemm_kernel          generic 128x128 kernel for any layout / dtype / ragged K, register-staged transposes, split-K:
+//                        the strict-fp32 parity mode and the fallbacks.
+// Common: 128-byte LDS rows (64 bf16 / 32 fp32 of K) with a 16-byte-chunk XOR swizzle so fragment reads (ds_read_b128) are
+// conflict-free; K-contiguous operands with whole K tiles go global -> LDS directly (global_load_lds_dwordx4), the swizzle
+// applied to the per-lane SOURCE address because the LDS image of such a copy is lane-linear; accumulators leave through LDS
+// so every global access of the epilogue is a full 128-byte row segment.
 #include "vb_rt.h"
 #include "../../include/visualbert_hip.h"
 #include <vector>

@@ -1435,7 +1435,10 @@ int dispatch_pipe(const GemmArgs& g, hipStream_t s) {
     if (variant == 1) {
         // measured on MI355X (profiles/r01_gemm_variant_sweep_b128.txt)
         const long t256 = (long)((g.M + 255) / 256) * ((g.N + 255) / 256);
-        variant = (sizeof(T) == 2 && t256 >= 160) ? 81 : 42;
+        const long t128 = (long)((g.M + 255) / 256) * ((g.N + 127) / 128);
+        // big persistent tiles when they fill most of the chip; otherwise the two-barrier kernels, with the 128x128 tile
+        // when even 256x128 tiles would leave CUs idle (small batches)
+        variant = (sizeof(T) == 2 && t256 >= 160) ? 81 : (t128 >= 256 ? 42 : 22);
     }
     switch (variant) {
         case 22: return launch_pipe<T, TO, 2, 2>(g, s);

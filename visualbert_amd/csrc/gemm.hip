@@ -557,18 +557,24 @@ template <typename T, int WM>
 struct FastPtrs {
     static constexpr int NW = WM * 2, BMX = WM * 64;
     static constexpr int A_INSTR = (BMX / 8) / NW, B_INSTR = (128 / 8) / NW;
-    const T* a[A_INSTR];
-    const T* b[B_INSTR];
+    // per-lane BYTE offsets from the (wave-uniform) operand bases: 32 bits, checked by the launcher.  A K tile advances
+    // the scalar base, so issuing a copy costs no vector arithmetic (same as the persistent kernel).
+    unsigned a[A_INSTR];
+    unsigned b[B_INSTR];
+    const unsigned char* A;
+    const unsigned char* B;
 };
 template <typename T, int WM>
 VB_DEVICE void fast_setup(FastPtrs<T, WM>& p, const T* A, const T* B, const GemmArgs& g, int m0, int n0, int wave, int lane) {
+    p.A = (const unsigned char*)A;
+    p.B = (const unsigned char*)B;
 #pragma unroll
     for (int i = 0; i < FastPtrs<T, WM>::A_INSTR; ++i) {
         const int row = (wave * FastPtrs<T, WM>::A_INSTR + i) * 8 + (lane >> 3);
         const int c = (lane & 7) ^ swz(row);
         int grow = m0 + row;
         grow = grow < g.M ? grow : g.M - 1;
-        p.a[i] = A + (long)grow * g.lda + c * TT<T>::EPC;
+        p.a[i] = (unsigned)(((long)grow * g.lda + c * TT<T>::EPC) * (long)sizeof(T));
     }
 #pragma unroll
     for (int i = 0; i < FastPtrs<T, WM>::B_INSTR; ++i) {
@@ -576,19 +582,21 @@ VB_DEVICE void fast_setup(FastPtrs<T, WM>& p, const T* A, const T* B, const Gemm
         const int c = (lane & 7) ^ swz(row);
         int grow = n0 + row;
         grow = grow < g.N ? grow : g.N - 1;
-        p.b[i] = B + (long)grow * g.ldb + c * TT<T>::EPC;
+        p.b[i] = (unsigned)(((long)grow * g.ldb + c * TT<T>::EPC) * (long)sizeof(T));
     }
 }
 template <typename T, int WM>
 VB_DEVICE void fast_issue(unsigned char* stage, const FastPtrs<T, WM>& p, int k0, int wave) {
     unsigned char* la = stage;
     unsigned char* lb = stage + FastPtrs<T, WM>::BMX * 128;
+    const unsigned char* sa = p.A + (long)k0 * (long)sizeof(T);
+    const unsigned char* sb = p.B + (long)k0 * (long)sizeof(T);
 #pragma unroll
     for (int i = 0; i < FastPtrs<T, WM>::A_INSTR; ++i)
-        vb_glds16(p.a[i] + k0, la + (wave * FastPtrs<T, WM>::A_INSTR + i) * 8 * 128);
+        vb_glds16(sa + p.a[i], la + (wave * FastPtrs<T, WM>::A_INSTR + i) * 8 * 128);
 #pragma unroll
     for (int i = 0; i < FastPtrs<T, WM>::B_INSTR; ++i)
-        vb_glds16(p.b[i] + k0, lb + (wave * FastPtrs<T, WM>::B_INSTR + i) * 8 * 128);
+        vb_glds16(sb + p.b[i], lb + (wave * FastPtrs<T, WM>::B_INSTR + i) * 8 * 128);
 }
 
 template <typename T, typename TO, int WM, int STAGES, int DBG = 0, int ACT = -1, int OPT = EPI_ALL>
@@ -599,7 +607,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS(WM * 128) gemm_nt_pipe_kernel(GemmArgs g) {
     constexpr int PER_TILE = (BMX / 8) / NW + (128 / 8) / NW;       // LDS-direct instructions per wave per tile
     VB_DYN_SMEM(smem);
     const int t = threadIdx.x;
-    const int lane = t & 63, wave = t >> 6;
+    const int lane = t & 63, wave = vb_uniform(t >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 15, lg = lane >> 4;
     const int nwg = g.tiles_m * g.tiles_n;
@@ -713,6 +721,9 @@ int launch_pipe(GemmArgs g, hipStream_t stream) {
     constexpr int BMX = WM * 64;
     constexpr int SM = STAGES * (BMX + 128) * 128;
     static_assert(WM * 2 * EPI_BYTES_PER_WAVE <= SM, "epilogue slabs must fit");
+    // 32-bit byte offsets inside the kernel: larger operands take the generic kernel
+    if ((long)g.M * g.lda * (long)sizeof(T) >= (1L << 32) || (long)g.N * g.ldb * (long)sizeof(T) >= (1L << 32))
+        return launch_gemm<T, TO, VB_KCONTIG, VB_KCONTIG>(g, stream);
     g.tiles_m = (g.M + BMX - 1) / BMX;
     dim3 grid((unsigned)(g.tiles_m * g.tiles_n)), block(WM * 128);
     if constexpr (sizeof(T) == 2 && sizeof(TO) == 2 && WM == 4 && STAGES == 2) {

@@ -32,12 +32,19 @@ from oracle.reference_shim import load_reference, cpu_cuda_noop  # noqa: E402
 
 GOLDEN_DIR = os.path.join(os.path.dirname(HERE), "tests", "golden")
 
-# (file stem, config name, head, B, T, R, seed)
+# (file stem, config name, head, B, T, R, seed[, options]); options: bypass=True -> bypass_transformer
+# (modeling.py:1299-1314), alignment=A -> image_text_alignment [B,R,A] (modeling.py:1223-1245)
 CASES = [
     ("tiny_pretraining", "tiny", "pretraining", 2, 32, 8, 0),     # BASELINE.json configs[0]
     ("micro_pretraining", "micro", "pretraining", 3, 12, 5, 1),   # odd sizes: ragged tiles everywhere
     ("micro_vqa", "micro", "vqa", 3, 10, 6, 2),
     ("micro_nlvr", "micro", "nlvr", 2, 12, 8, 3),
+    # the branches and heads outside BASELINE.json's configs
+    ("micro_bypass", "micro", "pretraining", 3, 12, 5, 4, dict(bypass=True)),
+    ("micro_align", "micro", "pretraining", 3, 12, 5, 5, dict(alignment=3)),
+    ("micro_multichoice", "micro", "multichoice", 2, 10, 6, 6),
+    ("micro_vqa_advanced", "micro", "vqa_advanced", 3, 12, 5, 7),
+    ("micro_flickr", "micro", "flickr", 3, 12, 6, 8),
 ]
 
 LR, WARMUP, T_TOTAL = 5e-5, 0.1, 100
@@ -45,19 +52,20 @@ LOGIT_STRIDE = 509
 N_STEPS = 3
 
 
-def build_reference_model(cfg_kwargs, head, sd):
+def build_reference_model(cfg_kwargs, head, sd, bypass=False):
     ref_modeling, _ = load_reference()
     kw = dict(cfg_kwargs)
     vdim = kw.pop("visual_embedding_dim")
     V = kw.pop("vocab_size")
     config = ref_modeling.BertConfig(V, **kw)
-    model = ref_modeling.TrainVisualBERTObjective(config, head, visual_embedding_dim=vdim)
+    model = ref_modeling.TrainVisualBERTObjective(config, head, visual_embedding_dim=vdim,
+                                                  bypass_transformer=bypass)
     model.bert.embeddings.special_intialize()
     missing = model.load_state_dict(sd, strict=False)
     # the only key we do not supply is the tied decoder weight alias
     assert set(missing.missing_keys) <= {"cls.predictions.decoder.weight"}, missing
     assert not missing.unexpected_keys, missing
-    if head == "pretraining":
+    if head in ("pretraining", "vqa_advanced", "flickr"):
         assert model.cls.predictions.decoder.weight is model.bert.embeddings.word_embeddings.weight
     return model
 
@@ -69,8 +77,9 @@ def reference_forward(model, batch):
         return model(input_ids=batch["bert_input_ids"], token_type_ids=batch["bert_input_type_ids"],
                      input_mask=batch["bert_input_mask"], visual_embeddings=batch["image_feat_variable"],
                      position_embeddings_visual=None, image_mask=image_mask,
-                     visual_embeddings_type=batch.get("visual_embeddings_type"), image_text_alignment=None,
-                     label=batch.get("label"), flickr_position=None,
+                     visual_embeddings_type=batch.get("visual_embeddings_type"),
+                     image_text_alignment=batch.get("image_text_alignment"),
+                     label=batch.get("label"), flickr_position=batch.get("flickr_position"),
                      masked_lm_labels=batch.get("masked_lm_labels"), is_random_next=batch.get("is_random_next"),
                      output_all_encoded_layers=False)
 
@@ -91,31 +100,38 @@ def head16(t):
     return t.detach().reshape(-1)[:16].double().numpy().copy()
 
 
-def make_case(stem, cfg_name, head, B, T, R, seed):
+def make_case(stem, cfg_name, head, B, T, R, seed, options=None):
+    options = options or {}
     cfg_kwargs = vo.CONFIGS[cfg_name]
-    cfg = vo.OracleConfig(**cfg_kwargs)
+    cfg = vo.OracleConfig(bypass_transformer=bool(options.get("bypass")), **cfg_kwargs)
     sd = vo.synth_state_dict(cfg, head, seed)
-    batch = vo.synth_batch(cfg, B, T, R, seed, head)
-    model = build_reference_model(cfg_kwargs, head, sd)
+    batch = vo.synth_batch(cfg, B, T, R, seed, head, alignment=int(options.get("alignment", 0)))
+    model = build_reference_model(cfg_kwargs, head, sd, bypass=cfg.bypass_transformer)
     rec = OrderedDict()
     rec["meta"] = np.array([B, T, R, seed], dtype=np.int64)
 
-    # ---- eval-mode forward (dropout off): the logits parity target
+    # ---- eval-mode forward (dropout off): the logits parity target.  The encoder outputs are captured at the
+    # BertVisualModel boundary (the bypass branch refuses output_all_encoded_layers=True, modeling.py:1300)
     model.eval()
+    captured = []
+    hook = model.bert.register_forward_hook(lambda m, i, o: captured.append(o))
     with torch.no_grad():
         out = reference_forward(model, batch)
-        enc = None
-        with cpu_cuda_noop():
-            image_mask = vo.build_image_mask(batch["image_feat_variable"], batch["image_dim_variable"])
-            enc = model(input_ids=batch["bert_input_ids"], token_type_ids=batch["bert_input_type_ids"],
-                        input_mask=batch["bert_input_mask"], visual_embeddings=batch["image_feat_variable"],
-                        position_embeddings_visual=None, image_mask=image_mask,
-                        visual_embeddings_type=batch.get("visual_embeddings_type"),
-                        output_all_encoded_layers=True)
-    rec["sequence_output"] = enc["sequence_output"][-1].numpy()
-    rec["pooled_output"] = enc["pooled_output"].numpy()
+    hook.remove()
+    rec["sequence_output"] = captured[0][0].numpy()
+    rec["pooled_output"] = captured[0][1].numpy()
     rec["loss"] = out["loss"].double().numpy()
-    if head == "pretraining":
+    if head == "vqa_advanced":
+        rec["masked_lm_loss"] = out["masked_lm_loss"].double().numpy()
+        rec["accuracy"] = np.float64(out["accuracy"])
+        lg = out["logits"]
+        rec["logits_strided"] = lg[:, :, ::LOGIT_STRIDE].numpy()
+        rec["logits_argmax"] = lg.argmax(-1).numpy()
+    elif head == "flickr":
+        rec["accuracy"] = out["accuracy"].double().numpy()
+        rec["upperbound_accuracy"] = out["upperbound_accuracy"].double().numpy()
+        rec["entity_num"] = out["entity_num"].numpy()
+    elif head == "pretraining":
         rec["masked_lm_loss"] = out["masked_lm_loss"].double().numpy()
         rec["next_sentence_loss"] = out["next_sentence_loss"].double().numpy()
         rec["seq_relationship_score"] = out["seq_relationship_score"].numpy()
@@ -172,5 +188,7 @@ def make_case(stem, cfg_name, head, B, T, R, seed):
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    only = set(sys.argv[1:])                     # optional: the stems to (re)generate
     for case in CASES:
-        make_case(*case)
+        if not only or case[0] in only:
+            make_case(*case)

@@ -12,6 +12,12 @@ CASES = {
     "micro_pretraining": ("micro", "pretraining"),
     "micro_vqa": ("micro", "vqa"),
     "micro_nlvr": ("micro", "nlvr"),
+    # SURVEY 8f / N4 (options as in oracle/make_golden.py)
+    "micro_bypass": ("micro", "pretraining", dict(bypass=True)),
+    "micro_align": ("micro", "pretraining", dict(alignment=3)),
+    "micro_multichoice": ("micro", "multichoice"),
+    "micro_vqa_advanced": ("micro", "vqa_advanced"),
+    "micro_flickr": ("micro", "flickr"),
 }
 LR, WARMUP, T_TOTAL = 5e-5, 0.1, 100
 LOGIT_STRIDE = 509
@@ -19,12 +25,13 @@ N_STEPS = 3
 
 
 def load_case(stem):
-    cfg_name, head = CASES[stem]
+    cfg_name, head = CASES[stem][:2]
+    options = CASES[stem][2] if len(CASES[stem]) > 2 else {}
     g = np.load(os.path.join(GOLDEN_DIR, stem + ".npz"), allow_pickle=False)
     B, T, R, seed = [int(x) for x in g["meta"]]
-    cfg = vo.OracleConfig(**vo.CONFIGS[cfg_name])
+    cfg = vo.OracleConfig(bypass_transformer=bool(options.get("bypass")), **vo.CONFIGS[cfg_name])
     sd = vo.synth_state_dict(cfg, head, seed)
-    batch = vo.synth_batch(cfg, B, T, R, seed, head)
+    batch = vo.synth_batch(cfg, B, T, R, seed, head, alignment=int(options.get("alignment", 0)))
     return cfg, head, sd, batch, g
 
 

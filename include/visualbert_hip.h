@@ -85,21 +85,36 @@ int vb_ln_bwd(int dtype, const void* dy, const void* z, const float* mean, const
 int64_t vb_ln_bwd_ws_bytes(int M, int H);
 
 /* ------------------------------------------------------------------------------------------------
- * BertEmbeddingsWithVisualEmbedding gather-add (image_text_alignment == None branch).
+ * BertEmbeddingsWithVisualEmbedding gather-add.
  *   z[b, s<T]  = word[ids[b,s]] + pos[s] + type[type_ids[b,s]]
- *   z[b, T+r]  = vis_proj[b,r] + pos_vis[0] + type_vis[visual_type[b,r]]      (visual position id is 0)
- * Tables are the fp32 master parameters; vis_proj is the projection GEMM's output (T [B*R,H]).
+ *   z[b, T+r]  = vis_proj[b,r] + pos_vis[0] + type_vis[visual_type[b,r]] [+ pos_align[b,r]]   (visual position id is 0)
+ * Tables are the fp32 master parameters; vis_proj is the projection GEMM's output (T [B*R,H]); pos_align
+ * (fp32 [B*R,H], NULL when image_text_alignment is None) is vb_align_pos_fwd's output.
  * Backward scatters dz into the fp32 table gradients (ACCUMULATED) and copies the visual rows to
  * d_vis_proj (T [B*R,H]).   Replaces: modeling.py:1213-1253 and its autograd.
  * ---------------------------------------------------------------------------------------------- */
 int vb_embed_fwd(int dtype, const int64_t* input_ids, const int64_t* token_type_ids, const int64_t* visual_type,
                  const void* vis_proj, const float* word, const float* pos, const float* type,
-                 const float* pos_vis, const float* type_vis, void* z,
+                 const float* pos_vis, const float* type_vis, const float* pos_align, void* z,
                  int B, int T, int R, int H, int V, int type_vocab, int max_pos, void* stream);
 int vb_embed_bwd(int dtype, const void* dz, const int64_t* input_ids, const int64_t* token_type_ids,
                  const int64_t* visual_type, float* d_word, float* d_pos, float* d_type,
                  float* d_pos_vis, float* d_type_vis, void* d_vis_proj,
                  int B, int T, int R, int H, int V, int type_vocab, int max_pos, void* stream);
+
+/* output_attention_weights (modeling.py:241-261, :259-260): the softmax(QK^T/sqrt(d) + mask) probabilities the training
+ * kernels never materialise, written as fp32 [B, nh, S, S] from the packed qkv (T [B*S, 3H]) -- forward only, any S. */
+int vb_attn_probs(int dtype, const void* qkv, const float* mask_add, float* probs, int B, int S, int nh, int head_dim,
+                  void* stream);
+
+/* image_text_alignment branch (modeling.py:1223-1245): alignment int64 [B, Ra, A] holds, per region, the text
+ * positions of the words it is aligned with, -1 padded; only the first R <= Ra regions of a sample are used
+ * (:1241-1243).  fwd: out[b*R+r] = mean of pos[alignment[b,r,a]] over the entries != -1 (zeros when there is none).
+ * bwd: d_pos[alignment[b,r,a]] += dz[b, T+r] / count, dz being the T [B*(T+R), H] gradient of the summed embedding. */
+int vb_align_pos_fwd(const int64_t* alignment, const float* pos, float* out, int B, int R, int Ra, int A,
+                     int H, int max_pos, void* stream);
+int vb_align_pos_bwd(int dtype, const void* dz, const int64_t* alignment, float* d_pos, int B, int T, int R,
+                     int Ra, int A, int H, int max_pos, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused multi-head self-attention (head size 64).  qkv: T [B*S, 3H] (Q | K | V column blocks),
@@ -186,6 +201,28 @@ int vb_cast(int src_dtype, const void* src, int dst_dtype, void* dst, int64_t n,
 int vb_gather_rows(int dtype, const void* x, const int64_t* input_mask, void* out, int64_t* index_out,
                    int B, int S, int T, int H, void* stream);
 int vb_scatter_rows(int dtype, const void* dout, const int64_t* index, void* dx, int B, int S, int H, void* stream);
+
+/* Flickr30k grounding head (modeling.py:1568-1598).
+ * vb_gather_index_rows: batched_index_select (:1713-1716), out[b*E+e] = x[b, index[b,e]] with the -1 padding read as
+ *   position 0 (:1574); vb_scatter_index_rows is its adjoint, dx[b,s] = addend[b,s] + sum_{e: index[b,e]==s} dsel[b*E+e]
+ *   (addend may be NULL; dx is written completely).
+ * vb_flickr_scores_fwd: FlickrAttention.forward (:1624-1648) after its two projections -- q: T [B*E, ldq] (entity
+ *   queries), k: T [B*S, ldk] (keys of EVERY position; the regions are rows T..S-1 of a sample):
+ *   scores[b,e,r] = q[b,e].k[b,T+r] / sqrt(d) + (1 - image_mask[b,r]) * -10000 (fp32 [B*E, R]); stats fp32[3] =
+ *   {entities whose best-scoring region has a non-zero label, sum of the labels, entities with position != -1},
+ *   i.e. compute_score_with_logits_flickr (:1650-1673, recall 1) and entities_num (:1570).
+ * vb_flickr_scores_bwd: dq (T [B*E, ldq]) and dk (T [B*S, ldk], text rows zeroed) from dscores (fp32 [B*E, R]),
+ *   scaled by alpha * scale_dev[0] (scale_dev may be NULL). */
+int vb_gather_index_rows(int dtype, const void* x, const int64_t* index, void* out, int B, int S, int E, int H,
+                         void* stream);
+int vb_scatter_index_rows(int dtype, const void* dsel, const int64_t* index, const void* addend, void* dx,
+                          int B, int S, int E, int H, void* stream);
+int vb_flickr_scores_fwd(int dtype, const void* q, int64_t ldq, const void* k, int64_t ldk, const int64_t* image_mask,
+                         const float* label, const int64_t* position, float* scores, float* stats,
+                         int B, int E, int R, int S, int T, int d, void* stream);
+int vb_flickr_scores_bwd(int dtype, const float* dscores, const void* q, int64_t ldq, const void* k, int64_t ldk,
+                         void* dq, void* dk, const float* scale_dev, float alpha,
+                         int B, int E, int R, int S, int T, int d, void* stream);
 
 /* bias gradients: out[n] += scale * sum_m x[m,n]  (x: T [M,N], out fp32, scale_dev optional device scalar) */
 int vb_colsum(int dtype, const void* x, int64_t ld, float* out, const float* scale_dev, int M, int N, void* stream);

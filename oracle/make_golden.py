@@ -186,9 +186,37 @@ def make_case(stem, cfg_name, head, B, T, R, seed, options=None):
     print("wrote %s (%d KB)" % (path, os.path.getsize(path) // 1024))
 
 
+def make_attention_case(stem="micro_attention_weights", cfg_name="micro", B=2, T=12, R=5, seed=9):
+    """output_attention_weights=True (modeling.py:1428-1442): the forward returns only the per-layer attention
+    probabilities [B, nh, S, S] (eval mode -> no dropout on them) and loss None."""
+    ref_modeling, _ = load_reference()
+    cfg_kwargs = vo.CONFIGS[cfg_name]
+    cfg = vo.OracleConfig(**cfg_kwargs)
+    sd = vo.synth_state_dict(cfg, "pretraining", seed)
+    batch = vo.synth_batch(cfg, B, T, R, seed, "pretraining")
+    kw = dict(cfg_kwargs)
+    vdim = kw.pop("visual_embedding_dim")
+    V = kw.pop("vocab_size")
+    model = ref_modeling.TrainVisualBERTObjective(ref_modeling.BertConfig(V, **kw), "pretraining",
+                                                  visual_embedding_dim=vdim, output_attention_weights=True)
+    model.load_state_dict(sd, strict=False)
+    model.eval()
+    with torch.no_grad():
+        out = reference_forward(model, batch)
+    assert out["loss"] is None
+    rec = OrderedDict(meta=np.array([B, T, R, seed], dtype=np.int64))
+    for i, w in enumerate(out["attention_weights"]):
+        rec["attention_weights/%d" % i] = w.numpy()
+    path = os.path.join(GOLDEN_DIR, stem + ".npz")
+    np.savez_compressed(path, **rec)
+    print("wrote %s (%d KB)" % (path, os.path.getsize(path) // 1024))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     only = set(sys.argv[1:])                     # optional: the stems to (re)generate
     for case in CASES:
         if not only or case[0] in only:
             make_case(*case)
+    if not only or "micro_attention_weights" in only:
+        make_attention_case()

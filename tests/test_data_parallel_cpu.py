@@ -95,3 +95,16 @@ def test_two_rank_gradient_sync_matches_mean_of_replica_means():
     assert set(res) == {0, 1}
     for r, worst in res.items():
         assert worst < 1e-6, (r, worst)
+
+
+@pytest.mark.parametrize("head,bypass", [("pretraining", False), ("pretraining", True), ("vqa", False), ("nlvr", False),
+                                         ("multichoice", False), ("vqa_advanced", True), ("flickr", False)])
+def test_allreduce_buckets_tile_the_gradient_arena(head, bypass):
+    """every head (and the bypass_transformer variant with its extra layer): the L+2 buckets are contiguous, disjoint and
+    cover the whole flat gradient arena, so the per-bucket all-reduces average every gradient exactly once."""
+    from visualbert_amd.modeling import BertConfig, TrainVisualBERTObjective
+    bc = BertConfig(1000, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=512)
+    m = TrainVisualBERTObjective(bc, head, visual_embedding_dim=256, bypass_transformer=bypass)
+    r = sorted((lo, hi) for _, lo, hi in m.bucket_ranges())
+    assert r[0][0] == 0 and r[-1][1] == m.arena.grad.numel()
+    assert all(r[i][1] == r[i + 1][0] for i in range(len(r) - 1))

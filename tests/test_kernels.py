@@ -291,15 +291,19 @@ def test_embedding_fwd_bwd(dev, dt, B):
     typv = torch.randn(TV, H, generator=g).to(dev)
     vp = torch.randn(B * R, H, generator=g).to(dt).to(dev)
     z = torch.empty(B, T + R, H, dtype=dt, device=dev)
+    pal = torch.randn(B * R, H, generator=g).to(dev)           # vb_align_pos_fwd's output (image_text_alignment branch)
     L = _lib.lib()
-    rc = L.vb_embed_fwd(_lib.dtype_code(dt), _lib.ptr(ids), _lib.ptr(tt), _lib.ptr(vt), _lib.ptr(vp), _lib.ptr(word),
-                        _lib.ptr(pos), _lib.ptr(typ), _lib.ptr(posv), _lib.ptr(typv), _lib.ptr(z), B, T, R, H, V, TV, P,
-                        _lib.stream_ptr())
-    _lib.check(rc, "vb_embed_fwd")
     text = word[ids] + pos[:T].unsqueeze(0) + typ[tt]
-    vis = vp.float().view(B, R, H) + posv[0] + typv[vt]
-    ref = torch.cat((text, vis), 1)
-    assert (z.float() - ref).abs().max().item() <= tol(dt, 1e-6, 0.04)
+    for pos_align in (None, pal):
+        rc = L.vb_embed_fwd(_lib.dtype_code(dt), _lib.ptr(ids), _lib.ptr(tt), _lib.ptr(vt), _lib.ptr(vp), _lib.ptr(word),
+                            _lib.ptr(pos), _lib.ptr(typ), _lib.ptr(posv), _lib.ptr(typv), _lib.ptr(pos_align), _lib.ptr(z),
+                            B, T, R, H, V, TV, P, _lib.stream_ptr())
+        _lib.check(rc, "vb_embed_fwd")
+        vis = vp.float().view(B, R, H) + posv[0] + typv[vt]
+        if pos_align is not None:
+            vis = vis + pos_align.view(B, R, H)
+        ref = torch.cat((text, vis), 1)
+        assert (z.float() - ref).abs().max().item() <= tol(dt, 2e-6, 0.04)
     dz = torch.randn(B, T + R, H, generator=g).to(dt).to(dev)
     dw = torch.ones(V, H, device=dev); dp = torch.ones(P, H, device=dev); dty = torch.ones(TV, H, device=dev)
     dpv = torch.ones(P, H, device=dev); dtv = torch.ones(TV, H, device=dev)
@@ -488,3 +492,133 @@ def test_gemm_eight_phase_k_tails(dev, K):
     finally:
         L.vb_gemm_set_persistent_wgs(0)
         L.vb_gemm_set_variant(1)
+
+
+# ---- SURVEY 8f / N4 kernels ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", DTYPES)
+def test_alignment_position_means(dev, dt):
+    """vb_align_pos_fwd / _bwd against modeling.py:1223-1245 restated with torch ops: -1 padding, regions without any
+    aligned word, an alignment tensor padded past the region count, repeated words."""
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(5)
+    B, T, R, Ra, A, H, P = 3, 9, 5, 7, 4, 128, 16
+    al = torch.randint(0, T, (B, Ra, A), generator=g)
+    al[torch.rand(B, Ra, A, generator=g) < 0.4] = -1
+    al[0, 1] = -1                                   # no aligned word at all
+    al[1, 2] = 3                                    # the same word four times
+    pos = torch.randn(P, H, generator=g)
+    al_d, pos_d = al.to(dev), pos.to(dev)
+    out = torch.empty(B * R, H, dtype=torch.float32, device=dev)
+    _lib.check(L.vb_align_pos_fwd(_lib.ptr(al_d), _lib.ptr(pos_d), _lib.ptr(out), B, R, Ra, A, H, P, _lib.stream_ptr()),
+               "vb_align_pos_fwd")
+    pos_r = pos.clone().requires_grad_(True)
+    m = (al != -1).long()
+    pe = torch.nn.functional.embedding(m * al, pos_r) * m.float().unsqueeze(-1)
+    cnt = m.float().sum(2)
+    cnt[cnt == 0] = 1
+    ref = (pe.sum(2) / cnt.unsqueeze(-1))[:, :R]
+    assert (out.cpu().view(B, R, H) - ref.detach()).abs().max().item() < 1e-6
+    dz = torch.randn(B, T + R, H, generator=g).to(dt)
+    ref.backward(dz[:, T:].float())
+    d_pos = torch.zeros(P, H, dtype=torch.float32, device=dev)
+    dz_d = dz.to(dev).contiguous()
+    _lib.check(L.vb_align_pos_bwd(_lib.dtype_code(dt), _lib.ptr(dz_d), _lib.ptr(al_d), _lib.ptr(d_pos), B, T, R, Ra, A, H,
+                                  P, _lib.stream_ptr()), "vb_align_pos_bwd")
+    assert (d_pos.cpu() - pos_r.grad).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_index_gather_and_scatter_rows(dev, dt):
+    """batched_index_select (modeling.py:1713-1716) and its adjoint: -1 padding reads position 0, two entities on the
+    same word add up, untouched rows come from the addend."""
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(6)
+    B, S, E, H = 3, 11, 5, 128
+    x = torch.randn(B, S, H, generator=g).to(dt)
+    idx = torch.randint(0, S, (B, E), generator=g)
+    idx[0, 3:] = -1
+    idx[1, 1] = idx[1, 0]
+    x_d, idx_d = x.to(dev), idx.to(dev)
+    out = torch.empty(B * E, H, dtype=dt, device=dev)
+    _lib.check(L.vb_gather_index_rows(_lib.dtype_code(dt), _lib.ptr(x_d), _lib.ptr(idx_d), _lib.ptr(out), B, S, E, H,
+                                      _lib.stream_ptr()), "vb_gather_index_rows")
+    pos = idx.clamp(min=0)
+    ref = x.gather(1, pos.unsqueeze(2).expand(B, E, H))
+    assert torch.equal(out.cpu().view(B, E, H), ref)                     # pure data movement: bit-exact
+    dsel = torch.randn(B * E, H, generator=g).to(dt)
+    add = torch.randn(B * S, H, generator=g).to(dt)
+    dx = torch.empty(B * S, H, dtype=dt, device=dev)
+    _lib.check(L.vb_scatter_index_rows(_lib.dtype_code(dt), _lib.ptr(dsel.to(dev)), _lib.ptr(idx_d), _lib.ptr(add.to(dev)),
+                                       _lib.ptr(dx), B, S, E, H, _lib.stream_ptr()), "vb_scatter_index_rows")
+    refx = add.float().view(B, S, H).clone()
+    refx.scatter_add_(1, pos.unsqueeze(2).expand(B, E, H), dsel.float().view(B, E, H))
+    assert (dx.float().cpu().view(B, S, H) - refx).abs().max().item() <= tol(dt, 1e-6, 0.02 * refx.abs().max().item())
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_flickr_scores_and_gradients(dev, dt):
+    """vb_flickr_scores_fwd / _bwd against FlickrAttention.forward (modeling.py:1624-1648) and
+    compute_score_with_logits_flickr (:1650-1673) written with torch ops."""
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(7)
+    B, E, R, T, d = 3, 4, 7, 6, 64
+    S = T + R
+    q = torch.randn(B * E, d, generator=g).to(dt)
+    k = torch.randn(B * S, d, generator=g).to(dt)
+    im = (torch.arange(R).unsqueeze(0) < torch.tensor([[7], [4], [5]])).long()
+    lab = (torch.rand(B, E, R, generator=g) < 0.3).float() * im.unsqueeze(1).float()
+    lab = lab / lab.sum(-1, keepdim=True).clamp(min=1)
+    position = torch.randint(0, T, (B, E), generator=g)
+    position[2, 2:] = -1
+    lab[2, 2:] = 0
+    scores = torch.empty(B * E, R, dtype=torch.float32, device=dev)
+    stats = torch.empty(3, dtype=torch.float32, device=dev)
+    q_d, k_d = q.to(dev), k.to(dev)
+    _lib.check(L.vb_flickr_scores_fwd(_lib.dtype_code(dt), _lib.ptr(q_d), d, _lib.ptr(k_d), d, _lib.ptr(im.to(dev)),
+                                      _lib.ptr(lab.to(dev)), _lib.ptr(position.to(dev)), _lib.ptr(scores), _lib.ptr(stats),
+                                      B, E, R, S, T, d, _lib.stream_ptr()), "vb_flickr_scores_fwd")
+    qr = q.float().view(B, E, d).requires_grad_(True)
+    kr = k.float().view(B, S, d).requires_grad_(True)
+    ref = torch.matmul(qr, kr[:, T:].transpose(-1, -2)) / math.sqrt(d) + ((1.0 - im.float()) * -10000.0).unsqueeze(1)
+    assert (scores.cpu().view(B, E, R) - ref.detach()).abs().max().item() < 1e-4
+    am = ref.argmax(-1, keepdim=True)
+    hits = torch.gather((lab != 0).float(), 2, am).sum()
+    assert stats.cpu().tolist() == [float(hits), pytest.approx(float(lab.sum()), abs=1e-5),
+                                   float((position != -1).sum())]
+    ds = torch.randn(B, E, R, generator=g)
+    ref.backward(ds * 0.5 * 3.0)
+    up = torch.tensor([0.5], device=dev)
+    dq = torch.empty_like(q_d)
+    dk = torch.empty_like(k_d)
+    _lib.check(L.vb_flickr_scores_bwd(_lib.dtype_code(dt), _lib.ptr(ds.to(dev).contiguous()), _lib.ptr(q_d), d,
+                                      _lib.ptr(k_d), d, _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(up), 3.0,
+                                      B, E, R, S, T, d, _lib.stream_ptr()), "vb_flickr_scores_bwd")
+    eq = (dq.float().cpu().view(B, E, d) - qr.grad).abs().max().item()
+    ek = (dk.float().cpu().view(B, S, d) - kr.grad).abs().max().item()
+    assert eq <= tol(dt, 1e-4, 0.02 * qr.grad.abs().max().item()), eq
+    assert ek <= tol(dt, 1e-4, 0.02 * kr.grad.abs().max().item()), ek
+    assert float(dk.float().cpu().view(B, S, d)[:, :T].abs().max()) == 0.0     # no key gradient on the text rows
+
+
+def test_small_linear_ce_over_choice_groups(dev):
+    """multichoice head (modeling.py:1488-1500): Linear H -> 1 per choice, CrossEntropyLoss over logits.view(-1, 4)."""
+    from visualbert_amd import ops
+    g = torch.Generator().manual_seed(8)
+    Bq, H = 5, 128
+    x = torch.randn(Bq * 4, H, generator=g)
+    w = torch.nn.Parameter(torch.randn(1, H, generator=g).to(dev))
+    b = torch.nn.Parameter(torch.randn(1, generator=g).to(dev))
+    lab = torch.randint(0, 4, (Bq,), generator=g)
+    xd = x.to(dev).detach().requires_grad_(True)
+    logits, loss = ops.SmallLinearCEFn.apply(xd, lab.to(dev), -100, w, b, 4)
+    loss.backward()
+    xr = x.clone().requires_grad_(True)
+    wr, br = w.detach().cpu().clone().requires_grad_(True), b.detach().cpu().clone().requires_grad_(True)
+    lr = torch.nn.functional.linear(xr, wr, br).view(-1, 4)
+    lossr = torch.nn.functional.cross_entropy(lr, lab)
+    lossr.backward()
+    assert logits.shape == (Bq, 4)
+    assert (logits.cpu() - lr.detach()).abs().max().item() < 1e-4
+    assert abs(float(loss.detach()) - float(lossr.detach())) < 1e-5
+    assert (xd.grad.cpu() - xr.grad).abs().max().item() < 1e-5
+    assert (w.grad.cpu() - wr.grad).abs().max().item() < 1e-4

@@ -23,7 +23,8 @@ def build_model(cfg, head, sd, dev, dtype=torch.float32, dropout=None):
                     hidden_dropout_prob=hd, attention_probs_dropout_prob=ad,
                     max_position_embeddings=cfg.max_position_embeddings, type_vocab_size=cfg.type_vocab_size)
     model = VisualBERTFixedImageEmbedding(config=bc, training_head_type=head,
-                                          visual_embedding_dim=cfg.visual_embedding_dim, compute_dtype=dtype)
+                                          visual_embedding_dim=cfg.visual_embedding_dim, compute_dtype=dtype,
+                                          bypass_transformer=getattr(cfg, "bypass_transformer", False))
     model = model.to(dev)
     own = model.bert.state_dict()
     with torch.no_grad():
@@ -41,13 +42,24 @@ def test_fp32_forward_matches_reference_golden(dev, stem):
     cfg, head, sd, batch, g = load_case(stem)
     model = build_model(cfg, head, sd, dev)
     model.eval()
+    captured = []           # encoder outputs at the BertVisualModel boundary (as oracle/make_golden.py captures them)
+    hook = model.bert.bert.register_forward_hook(lambda m, i, o: captured.append(o))
     with torch.no_grad():
         out = model(**to_dev(batch, dev))
-        enc = model(**to_dev(batch, dev), output_all_encoded_layers=True)
-    assert maxdiff(enc["sequence_output"][-1].float().cpu(), g["sequence_output"]) < 1e-3
-    assert maxdiff(enc["pooled_output"].float().cpu(), g["pooled_output"]) < 1e-3
+    hook.remove()
+    assert maxdiff(captured[0][0].float().cpu(), g["sequence_output"]) < 1e-3
+    assert maxdiff(captured[0][1].float().cpu(), g["pooled_output"]) < 1e-3
     assert abs(float(out["loss"]) - float(g["loss"])) < 1e-3
-    if head == "pretraining":
+    if head == "vqa_advanced":
+        lg = out["logits"].float().cpu()
+        assert maxdiff(lg[:, :, ::LOGIT_STRIDE], g["logits_strided"]) < 1e-4
+        assert abs(float(out["masked_lm_loss"]) - float(g["masked_lm_loss"])) < 1e-4
+        assert np.array_equal(lg.argmax(-1).numpy(), g["logits_argmax"])
+        assert abs(float(out["accuracy"]) - float(g["accuracy"])) < 1e-9
+    elif head == "flickr":
+        for k in ("accuracy", "upperbound_accuracy", "entity_num"):     # integer counts: exact
+            assert abs(float(out[k]) - float(g[k])) < 1e-6, k
+    elif head == "pretraining":
         lg = out["logits"].float().cpu()
         err = maxdiff(lg[:, :, ::LOGIT_STRIDE], g["logits_strided"])
         assert err < 1e-3, err                                           # north_star: logits within 1e-3
@@ -93,10 +105,13 @@ def test_fp32_train_steps_match_reference_golden(dev, stem):
     for n, p in named.items():
         assert maxdiff(p.detach().cpu().reshape(-1)[:16], g["post_head/" + n]) < 2e-6, n
         d = float((p.detach().cpu() - sd[n]).double().norm())
+        if n in gnames and float(g["grad_norm/" + n]) < 1e-6:
+            continue        # a gradient that is 0 in exact arithmetic (e.g. the shared bias of the 4 choices): Adam
+                            # normalises its rounding noise into a +-lr step, the direction of which is noise too
         assert abs(d - float(g["delta_norm/" + n])) <= 5e-3 * float(g["delta_norm/" + n]) + 1e-7, n
 
 
-@pytest.mark.parametrize("stem", ["micro_pretraining", "tiny_pretraining"])
+@pytest.mark.parametrize("stem", ["micro_pretraining", "tiny_pretraining", "micro_bypass", "micro_align"])
 def test_bf16_matches_bf16_oracle(dev, stem):
     """bf16 kernels against the oracle with bf16 rounding at the same storage points (DESIGN.md numeric
     contract); the bf16-vs-fp32-reference gap is printed, not asserted."""
@@ -133,7 +148,60 @@ def test_dropout_training_step_runs_and_is_seed_deterministic(dev):
     assert abs(losses[0] - float(g["loss"])) > 1e-6      # dropout really changed the forward
 
 
-@pytest.mark.parametrize("stem", ["micro_pretraining", "tiny_pretraining"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_attention_weights_match_reference_golden(dev, dtype):
+    """output_attention_weights=True (modeling.py:1428-1442): the forward returns the per-layer attention probabilities
+    [B, nh, S, S] and loss None; fp32 kernels against the real reference's tensors, bf16 at bf16 tolerance."""
+    import os
+    from golden_util import GOLDEN_DIR
+    from visualbert_amd.modeling import BertConfig
+    from visualbert_amd.model import VisualBERTFixedImageEmbedding
+    g = np.load(os.path.join(GOLDEN_DIR, "micro_attention_weights.npz"))
+    B, T, R, seed = [int(x) for x in g["meta"]]
+    cfg = vo.OracleConfig(**vo.CONFIGS["micro"])
+    sd = vo.synth_state_dict(cfg, "pretraining", seed)
+    batch = vo.synth_batch(cfg, B, T, R, seed, "pretraining")
+    bc = BertConfig(cfg.vocab_size, hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers,
+                    num_attention_heads=cfg.num_attention_heads, intermediate_size=cfg.intermediate_size,
+                    max_position_embeddings=cfg.max_position_embeddings, type_vocab_size=cfg.type_vocab_size)
+    model = VisualBERTFixedImageEmbedding(config=bc, training_head_type="pretraining", compute_dtype=dtype,
+                                          visual_embedding_dim=cfg.visual_embedding_dim,
+                                          output_attention_weights=True).to(dev)
+    own = model.bert.state_dict()
+    with torch.no_grad():
+        for k, v in sd.items():
+            own[k].copy_(v)
+    model.eval()
+    with torch.no_grad():
+        out = model(**to_dev(batch, dev))
+    assert out["loss"] is None
+    assert len(out["attention_weights"]) == cfg.num_hidden_layers
+    for i, w in enumerate(out["attention_weights"]):
+        ref = g["attention_weights/%d" % i]
+        assert tuple(w.shape) == ref.shape
+        assert maxdiff(w.cpu(), ref) < (1e-5 if dtype == torch.float32 else 2e-2)
+        assert float((w.sum(-1) - 1).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("stem", ["micro_multichoice", "micro_flickr"])
+def test_bf16_small_heads_match_bf16_oracle(dev, stem):
+    """the N4 heads with bf16 kernels: loss against the bf16-emulating oracle; the flickr counts stay exact unless two
+    regions score within bf16 noise of each other (not the case for the fixture)."""
+    cfg, head, sd, batch, g = load_case(stem)
+    model = build_model(cfg, head, sd, dev, dtype=torch.bfloat16)
+    model.eval()
+    with torch.no_grad():
+        out = model(**to_dev(batch, dev))
+        ref = vo.objective_forward(sd, cfg, head, mode="bf16", **batch)
+    assert abs(float(out["loss"]) - float(ref["loss"])) < 2e-2
+    if head == "flickr":
+        assert float(out["entity_num"]) == float(ref["entity_num"])
+        assert abs(float(out["upperbound_accuracy"]) - float(ref["upperbound_accuracy"])) < 1e-6
+    else:
+        assert maxdiff(out["logits"].float().cpu(), ref["logits"]) < 2e-2
+
+
+@pytest.mark.parametrize("stem", ["micro_pretraining", "tiny_pretraining", "micro_bypass", "micro_align", "micro_flickr"])
 def test_bf16_gradients_track_bf16_oracle(dev, stem):
     """bf16 backward (W^T shadows + LDS-direct dgrad, split-K wgrad, fused layer call): every parameter's
     gradient must point the same way as the bf16-emulating oracle's (cosine >= 0.99, norm within 5 %)."""

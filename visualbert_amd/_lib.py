@@ -27,7 +27,10 @@ SIGNATURES = {
     "vb_ln_fwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _f, _u32, _f, _u32, _u64, _p]),
     "vb_ln_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _u32, _f, _u32, _u64, _p, _p]),
     "vb_ln_bwd_ws_bytes": (_i64, [_i, _i]),
-    "vb_embed_fwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "vb_embed_fwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "vb_attn_probs": (_i, [_i, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "vb_align_pos_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "vb_align_pos_bwd": (_i, [_i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "vb_embed_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "vb_attn_keepbits_words": (_i64, [_i]),
     "vb_attn_fwd": (_i, [_i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _u64, _u32, _p]),
@@ -45,6 +48,10 @@ SIGNATURES = {
     "vb_cast": (_i, [_i, _p, _i, _p, _i64, _p]),
     "vb_gather_rows": (_i, [_i, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "vb_scatter_rows": (_i, [_i, _p, _p, _p, _i, _i, _i, _p]),
+    "vb_gather_index_rows": (_i, [_i, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "vb_scatter_index_rows": (_i, [_i, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "vb_flickr_scores_fwd": (_i, [_i, _p, _i64, _p, _i64, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "vb_flickr_scores_bwd": (_i, [_i, _p, _p, _i64, _p, _i64, _p, _p, _p, _f, _i, _i, _i, _i, _i, _i, _p]),
     "vb_colsum": (_i, [_i, _p, _i64, _p, _p, _i, _i, _p]),
     "vb_act_bwd": (_i, [_i, _p, _p, _p, _i64, _i, _p]),
     "vb_wgrad_grouped": (_i, [_i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _f, _p, _p]),

@@ -281,7 +281,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) ln_bwd_kernel(LnBwdArgs a) {
 struct EmbArgs {
     const int64_t* ids; const int64_t* type_ids; const int64_t* vis_type;
     const void* vis_proj; const float* word; const float* pos; const float* type;
-    const float* pos_vis; const float* type_vis; void* z;
+    const float* pos_vis; const float* type_vis; const float* pos_align; void* z;
     int B, T, R, H, V, TV, P;
 };
 
@@ -292,7 +292,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) embed_fwd_kernel(EmbArgs a) {
     const long rows = (long)a.B * S;
     for (long row = (long)blockIdx.x * HW_PER_BLOCK + hw; row < rows; row += (long)gridDim.x * HW_PER_BLOCK) {
         const int b = (int)(row / S), s = (int)(row % S);
-        const float *t0, *t1, *t2;
+        const float *t0, *t1, *t2, *t3 = nullptr;
         const TT_* vp = nullptr;
         if (s < a.T) {
             long id = a.ids[(long)b * a.T + s]; id = id < 0 ? 0 : (id >= a.V ? a.V - 1 : id);
@@ -303,6 +303,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) embed_fwd_kernel(EmbArgs a) {
             long vt = a.vis_type ? a.vis_type[(long)b * a.R + r] : 0; vt = vt < 0 ? 0 : (vt >= a.TV ? a.TV - 1 : vt);
             vp = (const TT_*)a.vis_proj + ((long)b * a.R + r) * H;
             t0 = nullptr; t1 = a.pos_vis; t2 = a.type_vis + vt * H;      // visual position id is always 0
+            if (a.pos_align) t3 = a.pos_align + ((long)b * a.R + r) * H;   // + mean position of the aligned words
         }
 #pragma unroll
         for (int ci = 0; ci < NC; ++ci) {
@@ -311,6 +312,12 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) embed_fwd_kernel(EmbArgs a) {
                 float v[8], x[8];
                 if (t0) load8(v, t0 + col); else load8(v, vp + col);
                 load8(x, t1 + col);
+                if (t3) {                                    // reference order: vis + ((align + pos_vis) + type_vis)
+                    float y[8];
+                    load8(y, t3 + col);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x[j] += y[j];
+                }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] += x[j];
                 load8(x, t2 + col);
@@ -482,13 +489,13 @@ extern "C" int vb_ln_bwd(int dtype, const void* dy, const void* z, const float* 
 
 extern "C" int vb_embed_fwd(int dtype, const int64_t* input_ids, const int64_t* token_type_ids,
                             const int64_t* visual_type, const void* vis_proj, const float* word, const float* pos,
-                            const float* type, const float* pos_vis, const float* type_vis, void* z,
-                            int B, int T, int R, int H, int V, int type_vocab, int max_pos, void* stream) {
+                            const float* type, const float* pos_vis, const float* type_vis, const float* pos_align,
+                            void* z, int B, int T, int R, int H, int V, int type_vocab, int max_pos, void* stream) {
     if (!input_ids || !word || !pos || !type || !z || B <= 0 || T <= 0 || R < 0 || bad_h(H)) return VB_ERR_ARG;
     if (R > 0 && (!vis_proj || !pos_vis || !type_vis)) return VB_ERR_ARG;
     if (type_vocab <= 0 || type_vocab > 8 || max_pos <= 0 || V <= 0) return VB_ERR_ARG;
-    EmbArgs a{input_ids, token_type_ids, visual_type, vis_proj, word, pos, type, pos_vis, type_vis, z,
-              B, T, R, H, V, type_vocab, max_pos};
+    EmbArgs a{input_ids, token_type_ids, visual_type, vis_proj, word, pos, type, pos_vis, type_vis,
+              R > 0 ? pos_align : nullptr, z, B, T, R, H, V, type_vocab, max_pos};
     dim3 grid(row_grid((long)B * (T + R), 4096));
     hipStream_t s = (hipStream_t)stream;
     if (dtype == VB_BF16) VB_DISPATCH_NC(embed_fwd_kernel, bf16, H, grid, 0, s, a);

@@ -12,9 +12,10 @@ visualbert/models/model.py:213-223,272-288 work unchanged.  What differs is unde
     and a bf16 shadow arena feeds the MFMA GEMMs in bf16 mode;
   * compute dtype is selectable: torch.float32 (strict parity) or torch.bfloat16 (throughput).
 
-Branches of the reference that BASELINE.json's configs never take (image_text_alignment,
-bypass_transformer, output_attention_weights, multichoice / vqa_advanced / flickr heads) raise
-NotImplementedError: they are SURVEY.md section 8f row N4 ("next"), not silently approximated.
+The branches BASELINE.json's configs never take run on the same kernels:
+image_text_alignment, bypass_transformer, output_attention_weights, the multichoice / vqa_advanced / flickr heads.  What is left of
+that row raises NotImplementedError (the `confidence` / `position_embeddings_visual` inputs, which the reference's
+embeddings accept and ignore; attention weights under training-mode dropout) -- never silently approximated.
 """
 import copy
 import json
@@ -527,8 +528,17 @@ class BertLayer(nn.Module):
         self.output._sid = base + 4
 
     def forward(self, hidden_states, attention_mask):
-        if self.output_attention_weights:
-            raise NotImplementedError("output_attention_weights")
+        if self.output_attention_weights:                   # modeling.py:331-336: (layer_output, attention_probs)
+            if self.training and self.attention.self.dropout.p > 0.0:
+                raise NotImplementedError("output_attention_weights in training mode would return the probabilities "
+                                          "after dropout (modeling.py:251); only eval / p = 0 is provided")
+            mask_add = attention_mask.reshape(hidden_states.size(0), hidden_states.size(1)).to(torch.float32).contiguous()
+            with torch.no_grad():
+                probs = ops.attention_probs(hidden_states, self.attention.self, mask_add)
+            return self._forward_fused(hidden_states, attention_mask), probs
+        return self._forward_fused(hidden_states, attention_mask)
+
+    def _forward_fused(self, hidden_states, attention_mask):
         if self.grad_ready_hook is not None and torch.is_grad_enabled() and hidden_states.requires_grad:
             hidden_states = _GradReadyFn.apply(hidden_states, self)
         at, im, om = self.attention, self.intermediate, self.output
@@ -581,15 +591,20 @@ class BertEncoder(nn.Module):
         self.output_attention_weights = getattr(config, "output_attention_weights", False)
 
     def forward(self, hidden_states, attention_mask, output_all_encoded_layers=True):
-        if self.output_attention_weights:
-            raise NotImplementedError("output_attention_weights")
+        attn_data_list = []
         all_encoder_layers = []
         for layer_module in self.layer:
-            hidden_states = layer_module(hidden_states, attention_mask)
+            if self.output_attention_weights:               # modeling.py:352-362
+                hidden_states, attention_weights = layer_module(hidden_states, attention_mask)
+                attn_data_list.append(attention_weights)
+            else:
+                hidden_states = layer_module(hidden_states, attention_mask)
             if output_all_encoded_layers:
                 all_encoder_layers.append(hidden_states)
         if not output_all_encoded_layers:
             all_encoder_layers.append(hidden_states)
+        if self.output_attention_weights:
+            return all_encoder_layers, attn_data_list
         return all_encoder_layers
 
 
@@ -722,15 +737,15 @@ class BertEmbeddingsWithVisualEmbedding(nn.Module):
 
     def forward(self, input_ids, token_type_ids=None, visual_embeddings=None, visual_embeddings_type=None,
                 position_embeddings_visual=None, image_text_alignment=None, confidence=None):
-        if image_text_alignment is not None:
-            raise NotImplementedError("image_text_alignment branch (modeling.py:1223-1245) is SURVEY 8f/N4")
+        if visual_embeddings is None:
+            image_text_alignment = None
         if visual_embeddings is not None and visual_embeddings_type is None:
             visual_embeddings_type = torch.zeros(visual_embeddings.shape[:2], dtype=torch.long,
                                                  device=input_ids.device)
         m = self
         return ops.EmbeddingsFn.apply(
-            m, input_ids, token_type_ids, visual_embeddings, visual_embeddings_type, self.compute_dtype,
-            _drop_p(self.dropout, self.training), 8,
+            m, input_ids, token_type_ids, visual_embeddings, visual_embeddings_type, image_text_alignment,
+            self.compute_dtype, _drop_p(self.dropout, self.training), 8,
             m.word_embeddings.weight, m.position_embeddings.weight, m.token_type_embeddings.weight,
             m.LayerNorm.weight, m.LayerNorm.bias, m.token_type_embeddings_visual.weight,
             m.position_embeddings_visual.weight, m.projection.weight, m.projection.bias)
@@ -746,8 +761,12 @@ class BertVisualModel(PreTrainedBertModel):
         self.pooler = BertPooler(config)
         self.bypass_transformer = getattr(config, "bypass_transformer", False)
         if self.bypass_transformer:
-            raise NotImplementedError("bypass_transformer (modeling.py:1299-1314) is SURVEY 8f/N4")
+            self.additional_layer = BertLayer(config)           # modeling.py:1268-1269
+            self.additional_layer.set_index(config.num_hidden_layers)
         self.output_attention_weights = getattr(config, "output_attention_weights", False)
+        if self.bypass_transformer and self.output_attention_weights:
+            raise NotImplementedError("bypass_transformer with output_attention_weights: the reference's bypass branch "
+                                      "indexes the encoder's (layers, weights) tuple as a layer list (modeling.py:1306-1312)")
         self.apply(self.init_bert_weights)
 
     def forward(self, input_ids, token_type_ids, attention_mask, visual_embeddings, position_embeddings_visual,
@@ -763,12 +782,33 @@ class BertVisualModel(PreTrainedBertModel):
                                            position_embeddings_visual=position_embeddings_visual,
                                            visual_embeddings_type=visual_embeddings_type,
                                            image_text_alignment=image_text_alignment, confidence=confidence)
-        encoded_layers = self.encoder(embedding_output, extended_attention_mask,
-                                      output_all_encoded_layers=output_all_encoded_layers)
+        if self.bypass_transformer and visual_embeddings is not None:
+            # modeling.py:1299-1314: the encoder sees the text only; one more BertLayer sees text + regions
+            assert not output_all_encoded_layers
+            text_length = input_ids.size(1)
+            text_embedding_output = embedding_output[:, :text_length, :].contiguous()
+            visual_part = embedding_output[:, text_length:, :]
+            text_extended_attention_mask = extended_attention_mask[:, :, :text_length, :text_length]
+            encoded_layers = self.encoder(text_embedding_output, text_extended_attention_mask,
+                                          output_all_encoded_layers=output_all_encoded_layers)
+            sequence_output = encoded_layers[-1]
+            new_input = torch.cat((sequence_output, visual_part), dim=1)
+            final_sequence_output = self.additional_layer(new_input, extended_attention_mask)
+            pooled_output = self.pooler(final_sequence_output)
+            return final_sequence_output, pooled_output
+        attn_data_list = None
+        if self.output_attention_weights:                   # modeling.py:1316-1324
+            encoded_layers, attn_data_list = self.encoder(embedding_output, extended_attention_mask,
+                                                          output_all_encoded_layers=output_all_encoded_layers)
+        else:
+            encoded_layers = self.encoder(embedding_output, extended_attention_mask,
+                                          output_all_encoded_layers=output_all_encoded_layers)
         sequence_output = encoded_layers[-1]
         pooled_output = self.pooler(sequence_output)
         if not output_all_encoded_layers:
             encoded_layers = encoded_layers[-1]
+        if self.output_attention_weights:
+            return encoded_layers, pooled_output, attn_data_list
         return encoded_layers, pooled_output
 
 
@@ -796,7 +836,7 @@ class TrainVisualBERTObjective(PreTrainedBertModel):
     """modeling.py:1335-1598 -- same constructor / forward signature / output dict.  Extra keyword
     `compute_dtype` selects fp32 (parity) or bf16 (throughput) kernels; `.half()` maps to bf16."""
 
-    SUPPORTED_HEADS = ("pretraining", "vqa", "nlvr")
+    SUPPORTED_HEADS = ("pretraining", "vqa", "nlvr", "multichoice", "vqa_advanced", "flickr")
 
     def __init__(self, config, training_head_type, visual_embedding_dim=512, hard_cap_seq_len=None, cut_first="text",
                  embedding_strategy="plain", bypass_transformer=False, output_attention_weights=False,
@@ -806,8 +846,6 @@ class TrainVisualBERTObjective(PreTrainedBertModel):
         config.embedding_strategy = embedding_strategy
         config.bypass_transformer = bypass_transformer
         config.output_attention_weights = output_attention_weights
-        if output_attention_weights:
-            raise NotImplementedError("output_attention_weights is SURVEY 8f/N4")
         self.output_attention_weights = output_attention_weights
         self.cut_first = cut_first
         self.hard_cap_seq_len = hard_cap_seq_len
@@ -816,6 +854,16 @@ class TrainVisualBERTObjective(PreTrainedBertModel):
         self.sparse_mlm_head = False       # opt-in: MLM head over the labelled positions only (changes `logits` to [n, V])
         if training_head_type == "pretraining":
             self.cls = BertPreTrainingHeads(config, self.bert.embeddings.word_embeddings.weight)
+        elif training_head_type == "multichoice":           # modeling.py:1353-1356
+            self.dropout = nn.Dropout(config.hidden_dropout_prob)
+            self.classifier = nn.Linear(config.hidden_size, 1)
+            self.num_choices = 4                            # For VCR
+        elif training_head_type == "vqa_advanced":          # modeling.py:1361-1362
+            self.cls = BertPreTrainingHeads(config, self.bert.embeddings.word_embeddings.weight)
+        elif training_head_type == "flickr":                # modeling.py:1366-1369
+            self.dropout = nn.Dropout(config.hidden_dropout_prob)
+            self.cls = BertPreTrainingHeads(config, self.bert.embeddings.word_embeddings.weight)
+            self.flickr_attention = FlickrAttention(config)
         elif training_head_type == "vqa":
             self.dropout = nn.Dropout(config.hidden_dropout_prob)
             self.classifier = nn.Linear(config.hidden_size, 3129)
@@ -823,12 +871,28 @@ class TrainVisualBERTObjective(PreTrainedBertModel):
             self.dropout = nn.Dropout(config.hidden_dropout_prob)
             self.classifier = nn.Linear(config.hidden_size, 2)
         else:
-            raise NotImplementedError("training_head_type %r: heads outside BASELINE.json's configs "
-                                      "(multichoice, vqa_advanced, flickr) are SURVEY 8f/N4" % (training_head_type,))
+            raise NotImplementedError("training_head_type %r: the reference has %s"
+                                      % (training_head_type, ", ".join(self.SUPPORTED_HEADS)))
         self.apply(self.init_bert_weights)
+        self._mark_untouched_parameters()
         self.arena = None
         self.set_compute_dtype(compute_dtype)
         self.build_arena()
+
+    def _mark_untouched_parameters(self):
+        """parameters this head's loss never reaches.  In the reference their .grad stays None and BertAdam skips
+        them -- no moment update, no weight decay (optimization.py:254-255); here gradients are views into one
+        flat arena (always present, zero), so the fused optimizer is told which tensors to leave alone."""
+        head = self.training_head_type
+        untouched = []
+        if head == "vqa_advanced":                          # seq_relationship_score is returned, not trained on
+            untouched = ["cls.seq_relationship."]
+        elif head == "flickr":                              # cls is constructed but never called; no value projection
+            untouched = ["cls.predictions.bias", "cls.predictions.transform.", "cls.seq_relationship.",
+                         "flickr_attention.value."]
+        for n, p in self.named_parameters():
+            if any(n.startswith(u) for u in untouched):
+                p._vb_untouched = True
 
     # -- storage ---------------------------------------------------------------------------------
     def set_compute_dtype(self, dtype):
@@ -900,7 +964,7 @@ class TrainVisualBERTObjective(PreTrainedBertModel):
         a = self.arena
         L = len(self.bert.encoder.layer)
         r = []
-        head_pref = ["bert.pooler.", "cls.", "classifier."]
+        head_pref = ["bert.pooler.", "bert.additional_layer.", "cls.", "classifier.", "flickr_attention."]
         lo, hi = a.range_of(head_pref)
         r.append(("heads", lo, hi))
         for i in reversed(range(L)):
@@ -915,14 +979,16 @@ class TrainVisualBERTObjective(PreTrainedBertModel):
                 image_text_alignment=None, confidence=None, visual_embeddings_type=None, label=None,
                 flickr_position=None, masked_lm_labels=None, image_lm_lables=None, is_random_next=None,
                 output_all_encoded_layers=False):
-        if image_text_alignment is not None or flickr_position is not None or confidence is not None:
-            raise NotImplementedError("image_text_alignment / flickr / confidence inputs are SURVEY 8f/N4")
+        if confidence is not None or position_embeddings_visual is not None:
+            raise NotImplementedError("confidence / position_embeddings_visual: the reference's embeddings ignore "
+                                      "both (modeling.py:1198-1257); refusing rather than dropping them silently")
         flat_input_ids = transform_to_batch_sequence(input_ids)
         flat_token_type_ids = transform_to_batch_sequence(token_type_ids)
         flat_input_mask = transform_to_batch_sequence(input_mask)
         flat_image_mask = transform_to_batch_sequence(image_mask)
         flat_masked_lm_labels = transform_to_batch_sequence(masked_lm_labels)
         flat_visual_embeddings = transform_to_batch_sequence_dim(visual_embeddings)
+        flat_image_text_alignment = transform_to_batch_sequence_dim(image_text_alignment)
         if visual_embeddings_type is not None:
             visual_embeddings_type = transform_to_batch_sequence(visual_embeddings_type)
         elif flat_image_mask is not None:
@@ -940,14 +1006,24 @@ class TrainVisualBERTObjective(PreTrainedBertModel):
                 flat_masked_lm_labels = ext
         else:
             flat_attention_mask = flat_input_mask
-        if self.training_head_type == "pretraining" and flat_masked_lm_labels is not None and not output_all_encoded_layers:
+        if self.training_head_type in ("pretraining", "vqa_advanced") and flat_masked_lm_labels is not None \
+                and not output_all_encoded_layers:
             flat_masked_lm_labels = flat_masked_lm_labels.contiguous()
             ops.plan_masked_rows(flat_masked_lm_labels)      # count the labelled rows now, read the count 12 layers later
+
+        if self.output_attention_weights:                    # modeling.py:1428-1442
+            _, _, attention_weights = self.bert(
+                flat_input_ids, flat_token_type_ids, flat_attention_mask, visual_embeddings=flat_visual_embeddings,
+                position_embeddings_visual=None, visual_embeddings_type=visual_embeddings_type,
+                image_text_alignment=flat_image_text_alignment, confidence=None,
+                output_all_encoded_layers=output_all_encoded_layers)
+            return {"attention_weights": attention_weights, "loss": None}
 
         sequence_output, pooled_output = self.bert(
             flat_input_ids, flat_token_type_ids, flat_attention_mask, visual_embeddings=flat_visual_embeddings,
             position_embeddings_visual=None, visual_embeddings_type=visual_embeddings_type,
-            image_text_alignment=None, confidence=None, output_all_encoded_layers=output_all_encoded_layers)
+            image_text_alignment=flat_image_text_alignment, confidence=None,
+            output_all_encoded_layers=output_all_encoded_layers)
 
         output_dict = {}
         if output_all_encoded_layers:
@@ -984,6 +1060,46 @@ class TrainVisualBERTObjective(PreTrainedBertModel):
                 output_dict["loss"] = mlm_loss
             return output_dict
 
+        if self.training_head_type == "multichoice":         # modeling.py:1488-1500
+            p = _drop_p(self.dropout, self.training)
+            po = _small_dropout(pooled_output, p) if p > 0.0 else pooled_output
+            logits, loss = ops.SmallLinearCEFn.apply(po, label, -100, self.classifier.weight, self.classifier.bias,
+                                                     self.num_choices)
+            output_dict["logits"] = logits
+            output_dict["loss"] = loss if label is not None else None
+            return output_dict
+
+        if self.training_head_type == "vqa_advanced":        # modeling.py:1527-1554
+            pred = self.cls.predictions
+            tr = pred.transform
+            logits, mlm_loss = ops.MLMHeadLossFn.apply(
+                sequence_output, flat_masked_lm_labels, pred, pred.decoder.weight, pred.bias, tr.dense.weight,
+                tr.dense.bias, tr.LayerNorm.weight, tr.LayerNorm.bias)
+            rel, _ = ops.SmallLinearCEFn.apply(pooled_output, None, -1, self.cls.seq_relationship.weight,
+                                               self.cls.seq_relationship.bias)
+            output_dict["logits"] = logits
+            output_dict["seq_relationship_score"] = rel
+            output_dict["masked_lm_loss"] = mlm_loss
+            output_dict["loss"] = mlm_loss
+            # a sample counts when every labelled token is predicted (the reference loops over a numpy copy)
+            lab = flat_masked_lm_labels.view(flat_input_ids.size(0), -1)
+            hit = ((lab == -1) | (logits.argmax(-1).view(lab.shape) == lab)).all(dim=1)
+            output_dict["accuracy"] = float(hit.sum()) / lab.size(0)
+            return output_dict
+
+        if self.training_head_type == "flickr":              # modeling.py:1568-1598
+            if flickr_position is not None:
+                loss, acc, upper, entities_num = ops.FlickrHeadLossFn.apply(
+                    sequence_output, flickr_position, flat_image_mask, label, flat_input_mask.size(1),
+                    self.flickr_attention.attention_head_size, self.flickr_attention.query.weight,
+                    self.flickr_attention.query.bias, self.flickr_attention.key.weight,
+                    self.flickr_attention.key.bias)
+                output_dict["loss"] = loss
+                output_dict["accuracy"] = acc / entities_num
+                output_dict["upperbound_accuracy"] = upper / entities_num
+                output_dict["entity_num"] = entities_num
+            return output_dict
+
         if self.training_head_type == "vqa":
             logits, loss, acc, _ = ops.VQAHeadLossFn.apply(
                 sequence_output, flat_input_mask, label, _drop_p(self.dropout, self.training), 9,
@@ -1006,6 +1122,24 @@ class TrainVisualBERTObjective(PreTrainedBertModel):
             output_dict["loss"] = loss if label is not None else None
             return output_dict
         raise NotImplementedError(self.training_head_type)
+
+
+class FlickrAttention(nn.Module):
+    """modeling.py:1602-1648: ONE attention head of size H / num_attention_heads; only its query and key
+    projections are used (no value, no softmax) -- the scores feed the grounding loss."""
+
+    def __init__(self, config):
+        super(FlickrAttention, self).__init__()
+        if config.hidden_size % config.num_attention_heads != 0:
+            raise ValueError("The hidden size (%d) is not a multiple of the number of attention heads (%d)"
+                             % (config.hidden_size, config.num_attention_heads))
+        self.num_attention_heads = 1
+        self.attention_head_size = int(config.hidden_size / config.num_attention_heads)
+        self.all_head_size = self.num_attention_heads * self.attention_head_size
+        self.query = nn.Linear(config.hidden_size, self.all_head_size)
+        self.key = nn.Linear(config.hidden_size, self.all_head_size)
+        self.value = nn.Linear(config.hidden_size, self.all_head_size)
+        self.dropout = nn.Dropout(config.attention_probs_dropout_prob)
 
 
 def _small_dropout(x, p):

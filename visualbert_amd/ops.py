@@ -274,6 +274,23 @@ def attn_bwd(qkv, mask_add, dctx, lse, bits, B, S, nh, p, seed, sid):
     return dqkv
 
 
+def attention_probs(h, attn_self, mask_add):
+    """softmax(QK^T / sqrt(d) + mask) as fp32 [B, nh, S, S] -- what BertSelfAttention returns next to the context
+    under output_attention_weights (modeling.py:241-261).  Forward only: the packed QKV projection is recomputed
+    here because the training path never materialises the probabilities."""
+    B, S, H = h.shape
+    h2 = h.detach().reshape(B * S, H)
+    if not h2.is_contiguous():
+        h2 = h2.contiguous()
+    wqkv, bqkv = _packed_qkv(attn_self, h2.dtype)
+    qkv = linear_fwd(h2, wqkv, bqkv)
+    nh = attn_self.num_attention_heads
+    probs = torch.empty((B, nh, S, S), dtype=torch.float32, device=h.device)
+    check(_lib.lib().vb_attn_probs(_lib.dtype_code(qkv.dtype), ptr(qkv), ptr(mask_add), ptr(probs), B, S, nh, H // nh,
+                                   stream_ptr()), "vb_attn_probs")
+    return probs
+
+
 def prepare_inputs(input_mask, image_dim, image_mask, lm_labels, R):
     B, T = input_mask.shape
     dev = input_mask.device
@@ -681,11 +698,13 @@ class BertLayerFn(torch.autograd.Function):
 
 
 class EmbeddingsFn(torch.autograd.Function):
-    """BertEmbeddingsWithVisualEmbedding.forward (modeling.py:1198-1257, image_text_alignment=None):
-    region projection GEMM, gather-add of the five tables, concat, LayerNorm, dropout."""
+    """BertEmbeddingsWithVisualEmbedding.forward (modeling.py:1198-1257): region projection GEMM, gather-add of
+    the five tables (+ the mean text-position embedding of the aligned words when image_text_alignment is given,
+    :1223-1245), concat, LayerNorm, dropout."""
 
     @staticmethod
-    def forward(ctx, module, input_ids, token_type_ids, visual_embeddings, visual_type, dtype, p_hidden, sid, *params):
+    def forward(ctx, module, input_ids, token_type_ids, visual_embeddings, visual_type, alignment, dtype, p_hidden,
+                sid, *params):
         m = module
         B, T = input_ids.shape
         dev = input_ids.device
@@ -704,6 +723,15 @@ class EmbeddingsFn(torch.autograd.Function):
             else:
                 feats = f2
             vp = linear_fwd(feats, weight_for(m.projection.weight, dtype), m.projection.bias.detach())
+        pos_align = al = None
+        if R > 0 and alignment is not None:
+            al = alignment.contiguous()
+            if al.dim() != 3 or al.size(0) != B or al.size(1) < R:             # modeling.py:1241-1243
+                raise AssertionError("image_text_alignment must be [batch, >= regions, alignment_number]")
+            pos_align = torch.empty((B * R, H), dtype=torch.float32, device=dev)
+            check(_lib.lib().vb_align_pos_fwd(ptr(al), ptr(m.position_embeddings.weight.detach()), ptr(pos_align),
+                                              B, R, al.size(1), al.size(2), H, m.position_embeddings.weight.size(0),
+                                              stream_ptr()), "vb_align_pos_fwd")
         z = torch.empty((B * (T + R), H), dtype=dtype, device=dev)
         ids = input_ids.contiguous()
         tt = token_type_ids.contiguous() if token_type_ids is not None else None
@@ -713,14 +741,14 @@ class EmbeddingsFn(torch.autograd.Function):
             _lib.dtype_code(dtype), ptr(ids), ptr(tt), ptr(vt), ptr(vp), ptr(W.detach()),
             ptr(m.position_embeddings.weight.detach()), ptr(m.token_type_embeddings.weight.detach()),
             ptr(m.position_embeddings_visual.weight.detach()), ptr(m.token_type_embeddings_visual.weight.detach()),
-            ptr(z), B, T, R, H, W.size(0), m.token_type_embeddings.weight.size(0),
+            ptr(pos_align), ptr(z), B, T, R, H, W.size(0), m.token_type_embeddings.weight.size(0),
             m.position_embeddings.weight.size(0), stream_ptr()), "vb_embed_fwd")
         seed = next_seed()
         y, _, mean, rstd = ln_fwd(z, None, m.LayerNorm.weight.detach(), m.LayerNorm.bias.detach(),
                                   m.LayerNorm.variance_epsilon, 0.0, 0, p_hidden, sid, seed, save_z=False)
         ctx.module = m
         ctx.cfg = (B, T, R, H, dtype, p_hidden, sid, seed)
-        ctx.ids = (ids, tt, vt)
+        ctx.ids = (ids, tt, vt, al)
         ctx.save_for_backward(z, mean, rstd, feats)
         return y.view(B, T + R, H)
 
@@ -729,7 +757,7 @@ class EmbeddingsFn(torch.autograd.Function):
         z, mean, rstd, feats = ctx.saved_tensors
         m = ctx.module
         B, T, R, H, dtype, p_hidden, sid, seed = ctx.cfg
-        ids, tt, vt = ctx.ids
+        ids, tt, vt, al = ctx.ids
         dy2 = dy.reshape(B * (T + R), H)
         if dy2.dtype != dtype:
             dy2 = dy2.to(dtype)
@@ -747,6 +775,10 @@ class EmbeddingsFn(torch.autograd.Function):
             _lib.dtype_code(dtype), ptr(dz), ptr(ids), ptr(tt), ptr(vt), ptr(g_word), ptr(g_pos), ptr(g_type),
             ptr(g_posv), ptr(g_typev), ptr(dvp), B, T, R, H, W.size(0), m.token_type_embeddings.weight.size(0),
             m.position_embeddings.weight.size(0), stream_ptr()), "vb_embed_bwd")
+        if al is not None:
+            check(_lib.lib().vb_align_pos_bwd(_lib.dtype_code(dtype), ptr(dz), ptr(al), ptr(g_pos), B, T, R, al.size(1),
+                                              al.size(2), H, m.position_embeddings.weight.size(0), stream_ptr()),
+                  "vb_align_pos_bwd")
         g_pw = g_pb = None
         d8 = d9 = True
         if R > 0:
@@ -754,7 +786,7 @@ class EmbeddingsFn(torch.autograd.Function):
             g_pb, d9 = grad_target(m.projection.bias)
             linear_wgrad(dvp, feats, g_pw)
             colsum(dvp, g_pb)
-        return (None, None, None, None, None, None, None, None,
+        return (None, None, None, None, None, None, None, None, None,
                 grad_result(g_word, d3), grad_result(g_pos, d4), grad_result(g_type, d5),
                 grad_result(g_lw, d1), grad_result(g_lb, d2), grad_result(g_typev, d7), grad_result(g_posv, d6),
                 grad_result(g_pw, d8), grad_result(g_pb, d9))
@@ -939,10 +971,12 @@ class SparseMLMHeadLossFn(torch.autograd.Function):
 
 class SmallLinearCEFn(torch.autograd.Function):
     """Linear with a tiny output width + CrossEntropyLoss: seq_relationship / image-text-match
-    (modeling.py:451, 1474) and the NLVR2 classifier (modeling.py:1558-1565).  Returns (logits fp32, loss)."""
+    (modeling.py:451, 1474), the NLVR2 classifier (modeling.py:1558-1565) and, with choices = 4, the VCR
+    multiple-choice head (modeling.py:1488-1500: Linear H -> 1 per choice, the loss over logits.view(-1, 4)).
+    Returns (logits fp32 [M / choices, N * choices], loss)."""
 
     @staticmethod
-    def forward(ctx, x, labels, ignore_index, weight, bias):
+    def forward(ctx, x, labels, ignore_index, weight, bias, choices=1):
         x2 = as2d(x)
         if not x2.is_contiguous():
             x2 = x2.contiguous()
@@ -957,12 +991,17 @@ class SmallLinearCEFn(torch.autograd.Function):
             acc = torch.empty(66, dtype=torch.float32, device=x2.device)
             l1 = torch.empty(1, dtype=torch.float32, device=x2.device)
             dy = torch.empty((M, N), dtype=torch.float32, device=x2.device)
-            check(_lib.lib().vb_ce_fwd_bwd(_lib.VB_F32, ptr(y), N, ptr(labels.reshape(-1).contiguous()), ignore_index,
-                                           ptr(acc), ptr(l1), ptr(dy), N, M, N, stream_ptr()), "vb_ce_fwd_bwd")
+            if M % choices != 0:
+                raise RuntimeError("visualbert_amd: %d rows do not divide into groups of %d choices" % (M, choices))
+            cm, cv = M // choices, N * choices            # the loss sees y as [M / choices, N * choices] (same memory)
+            check(_lib.lib().vb_ce_fwd_bwd(_lib.VB_F32, ptr(y), cv, ptr(labels.reshape(-1).contiguous()), ignore_index,
+                                           ptr(acc), ptr(l1), ptr(dy), cv, cm, cv, stream_ptr()), "vb_ce_fwd_bwd")
             loss = l1.reshape(())
         ctx.wb = (weight, bias)
         ctx.x_shape = x.shape
         ctx.save_for_backward(x2, dy)
+        if choices != 1:
+            y = y.view(M // choices, N * choices)
         ctx.mark_non_differentiable(y)
         ctx.set_materialize_grads(False)
         return y, loss
@@ -982,7 +1021,8 @@ class SmallLinearCEFn(torch.autograd.Function):
         check(_lib.lib().vb_small_linear_bwd(_lib.dtype_code(x2.dtype), ptr(dy), ptr(x2), K, ptr(weight.detach()),
                                              ptr(dx), K, ptr(gw), ptr(gb), ptr(up), M, N, K, stream_ptr()),
               "vb_small_linear_bwd")
-        return (dx.view(ctx.x_shape) if dx is not None else None, None, None, grad_result(gw, d1), grad_result(gb, d2))
+        return (dx.view(ctx.x_shape) if dx is not None else None, None, None, grad_result(gw, d1), grad_result(gb, d2),
+                None)
 
 
 class VQAHeadLossFn(torch.autograd.Function):
@@ -1050,3 +1090,73 @@ class VQAHeadLossFn(torch.autograd.Function):
         check(_lib.lib().vb_scatter_rows(_lib.dtype_code(dt), ptr(dg.contiguous()), ptr(idx), ptr(dseq), B, S, H,
                                          stream_ptr()), "vb_scatter_rows")
         return dseq.view(B, S, H), None, None, None, None, grad_result(gw, d1), grad_result(gb, d2)
+
+
+class FlickrHeadLossFn(torch.autograd.Function):
+    """Flickr30k grounding head (modeling.py:1568-1598): batched_index_select of the entity positions, the query / key
+    projections of FlickrAttention (:1624-1648; one head, no value, no softmax), masked scores over the regions,
+    KLDivLoss(batchmean) on their log-softmax, compute_score_with_logits_flickr (:1650-1673).
+    Returns (loss, hits, label mass, entities_num) -- the caller forms accuracy = hits / entities_num."""
+
+    @staticmethod
+    def forward(ctx, seq, position, image_mask, label, T, d, wq, bq, wk, bk):
+        B, S, H = seq.shape
+        R = S - T
+        E = position.size(1)
+        s2 = seq.reshape(B * S, H)
+        if not s2.is_contiguous():
+            s2 = s2.contiguous()
+        dt, dev = s2.dtype, s2.device
+        L = _lib.lib()
+        pos = position.contiguous()
+        sel = torch.empty((B * E, H), dtype=dt, device=dev)
+        check(L.vb_gather_index_rows(_lib.dtype_code(dt), ptr(s2), ptr(pos), ptr(sel), B, S, E, H, stream_ptr()),
+              "vb_gather_index_rows")
+        q = linear_fwd(sel, weight_for(wq, dt), bq.detach())
+        k = linear_fwd(s2, weight_for(wk, dt), bk.detach())        # keys of every position; the regions are rows T..S-1
+        scores = torch.empty((B * E, R), dtype=torch.float32, device=dev)
+        stats = torch.empty(3, dtype=torch.float32, device=dev)
+        lab = label.contiguous().to(torch.float32).view(B * E, R)
+        im = image_mask.contiguous()
+        check(L.vb_flickr_scores_fwd(_lib.dtype_code(dt), ptr(q), _ld(q), ptr(k), _ld(k), ptr(im), ptr(lab), ptr(pos),
+                                     ptr(scores), ptr(stats), B, E, R, S, T, d, stream_ptr()), "vb_flickr_scores_fwd")
+        loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        ds = torch.empty((B * E, R), dtype=torch.float32, device=dev)
+        check(L.vb_kldiv_fwd_bwd(ptr(scores), R, ptr(lab), R, ptr(loss), None, ptr(ds), R, B * E, R, stream_ptr()),
+              "vb_kldiv_fwd_bwd")
+        # the kernel averages over its B*E rows; KLDivLoss(batchmean) on a [B, E, R] input divides by B
+        ctx.wb = (wq, bq, wk, bk)
+        ctx.cfg = (B, S, H, T, R, E, d)
+        ctx.save_for_backward(s2, pos, sel, q, k, ds)
+        ctx.set_materialize_grads(False)
+        hits, upper, n_ent = stats[0], stats[1], stats[2]
+        ctx.mark_non_differentiable(hits, upper, n_ent)
+        return loss.reshape(()) * float(E), hits, upper, n_ent
+
+    @staticmethod
+    def backward(ctx, dloss, _a, _b, _c):
+        s2, pos, sel, q, k, ds = ctx.saved_tensors
+        wq, bq, wk, bk = ctx.wb
+        B, S, H, T, R, E, d = ctx.cfg
+        dt = s2.dtype
+        L = _lib.lib()
+        up = _upstream_scalar(dloss)
+        dq = torch.empty_like(q)
+        dk = torch.empty_like(k)
+        check(L.vb_flickr_scores_bwd(_lib.dtype_code(dt), ptr(ds), ptr(q), _ld(q), ptr(k), _ld(k), ptr(dq), ptr(dk),
+                                     ptr(up), float(E), B, E, R, S, T, d, stream_ptr()), "vb_flickr_scores_bwd")
+        gwq, d1 = grad_target(wq)
+        gbq, d2 = grad_target(bq)
+        gwk, d3 = grad_target(wk)
+        gbk, d4 = grad_target(bk)
+        linear_wgrad(dq, sel, gwq)
+        colsum(dq, gbq)
+        linear_wgrad(dk, s2, gwk)
+        colsum(dk, gbk)
+        dsel = linear_dgrad(dq, weight_for(wq, dt))
+        dseq_k = linear_dgrad(dk, weight_for(wk, dt))
+        dseq = torch.empty((B * S, H), dtype=dt, device=s2.device)
+        check(L.vb_scatter_index_rows(_lib.dtype_code(dt), ptr(dsel.contiguous()), ptr(pos), ptr(dseq_k.contiguous()),
+                                      ptr(dseq), B, S, E, H, stream_ptr()), "vb_scatter_index_rows")
+        return (dseq.view(B, S, H), None, None, None, None, None, grad_result(gwq, d1), grad_result(gbq, d2),
+                grad_result(gwk, d3), grad_result(gbk, d4))

@@ -133,7 +133,9 @@ class BertAdam(Optimizer):
             code = 0
         else:
             raise NotImplementedError("fused BertAdam: schedule %s has no device kernel" % type(sch).__name__)
-        opt_flags = [id(p) in member for p in arena.params]
+        # parameters the model's loss never reaches keep .grad = None in the reference and BertAdam skips them
+        # (optimization.py:254-255): no moments, no weight decay.  The models mark those tensors (_vb_untouched).
+        opt_flags = [id(p) in member and not getattr(p, "_vb_untouched", False) for p in arena.params]
         dec_flags = [member.get(id(p), 0.0) > 0.0 for p in arena.params]
         tt, ct, nt, nc = arena.tables(opt_flags, dec_flags)
         dev = arena.device

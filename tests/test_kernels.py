@@ -548,7 +548,8 @@ def test_index_gather_and_scatter_rows(dev, dt):
     dsel = torch.randn(B * E, H, generator=g).to(dt)
     add = torch.randn(B * S, H, generator=g).to(dt)
     dx = torch.empty(B * S, H, dtype=dt, device=dev)
-    _lib.check(L.vb_scatter_index_rows(_lib.dtype_code(dt), _lib.ptr(dsel.to(dev)), _lib.ptr(idx_d), _lib.ptr(add.to(dev)),
+    dsel_d, add_d = dsel.to(dev), add.to(dev)               # named: a temporary would be freed before the launch reads it
+    _lib.check(L.vb_scatter_index_rows(_lib.dtype_code(dt), _lib.ptr(dsel_d), _lib.ptr(idx_d), _lib.ptr(add_d),
                                        _lib.ptr(dx), B, S, E, H, _lib.stream_ptr()), "vb_scatter_index_rows")
     refx = add.float().view(B, S, H).clone()
     refx.scatter_add_(1, pos.unsqueeze(2).expand(B, E, H), dsel.float().view(B, E, H))
@@ -574,8 +575,9 @@ def test_flickr_scores_and_gradients(dev, dt):
     scores = torch.empty(B * E, R, dtype=torch.float32, device=dev)
     stats = torch.empty(3, dtype=torch.float32, device=dev)
     q_d, k_d = q.to(dev), k.to(dev)
-    _lib.check(L.vb_flickr_scores_fwd(_lib.dtype_code(dt), _lib.ptr(q_d), d, _lib.ptr(k_d), d, _lib.ptr(im.to(dev)),
-                                      _lib.ptr(lab.to(dev)), _lib.ptr(position.to(dev)), _lib.ptr(scores), _lib.ptr(stats),
+    im_d, lab_d, pos_d = im.to(dev), lab.contiguous().to(dev), position.to(dev)
+    _lib.check(L.vb_flickr_scores_fwd(_lib.dtype_code(dt), _lib.ptr(q_d), d, _lib.ptr(k_d), d, _lib.ptr(im_d),
+                                      _lib.ptr(lab_d), _lib.ptr(pos_d), _lib.ptr(scores), _lib.ptr(stats),
                                       B, E, R, S, T, d, _lib.stream_ptr()), "vb_flickr_scores_fwd")
     qr = q.float().view(B, E, d).requires_grad_(True)
     kr = k.float().view(B, S, d).requires_grad_(True)
@@ -590,7 +592,8 @@ def test_flickr_scores_and_gradients(dev, dt):
     up = torch.tensor([0.5], device=dev)
     dq = torch.empty_like(q_d)
     dk = torch.empty_like(k_d)
-    _lib.check(L.vb_flickr_scores_bwd(_lib.dtype_code(dt), _lib.ptr(ds.to(dev).contiguous()), _lib.ptr(q_d), d,
+    ds_d = ds.to(dev).contiguous()
+    _lib.check(L.vb_flickr_scores_bwd(_lib.dtype_code(dt), _lib.ptr(ds_d), _lib.ptr(q_d), d,
                                       _lib.ptr(k_d), d, _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(up), 3.0,
                                       B, E, R, S, T, d, _lib.stream_ptr()), "vb_flickr_scores_bwd")
     eq = (dq.float().cpu().view(B, E, d) - qr.grad).abs().max().item()

@@ -298,8 +298,12 @@ def prepare_inputs(input_mask, image_dim, image_mask, lm_labels, R):
     am = torch.empty((B, S), dtype=torch.int64, device=dev)
     ma = torch.empty((B, S), dtype=torch.float32, device=dev)
     le = torch.empty((B, S), dtype=torch.int64, device=dev) if lm_labels is not None else None
-    check(_lib.lib().vb_prepare_inputs(ptr(input_mask.contiguous()), ptr(image_dim), ptr(image_mask),
-                                       ptr(lm_labels.contiguous() if lm_labels is not None else None), ptr(am), ptr(ma),
+    # contiguous copies are bound to names: a temporary would be released (and its block possibly reused by the next
+    # allocation) before the launch that reads it is enqueued
+    im_c = input_mask.contiguous()
+    lab_c = lm_labels.contiguous() if lm_labels is not None else None
+    check(_lib.lib().vb_prepare_inputs(ptr(im_c), ptr(image_dim), ptr(image_mask),
+                                       ptr(lab_c), ptr(am), ptr(ma),
                                        ptr(le), B, T, R, stream_ptr()), "vb_prepare_inputs")
     return am, ma, le
 
@@ -994,7 +998,8 @@ class SmallLinearCEFn(torch.autograd.Function):
             if M % choices != 0:
                 raise RuntimeError("visualbert_amd: %d rows do not divide into groups of %d choices" % (M, choices))
             cm, cv = M // choices, N * choices            # the loss sees y as [M / choices, N * choices] (same memory)
-            check(_lib.lib().vb_ce_fwd_bwd(_lib.VB_F32, ptr(y), cv, ptr(labels.reshape(-1).contiguous()), ignore_index,
+            lab_c = labels.reshape(-1).contiguous()
+            check(_lib.lib().vb_ce_fwd_bwd(_lib.VB_F32, ptr(y), cv, ptr(lab_c), ignore_index,
                                            ptr(acc), ptr(l1), ptr(dy), cv, cm, cv, stream_ptr()), "vb_ce_fwd_bwd")
             loss = l1.reshape(())
         ctx.wb = (weight, bias)
@@ -1039,7 +1044,8 @@ class VQAHeadLossFn(torch.autograd.Function):
         T = input_mask.size(1)
         g = torch.empty((B, H), dtype=dt, device=s2.device)
         idx = torch.empty(B, dtype=torch.int64, device=s2.device)
-        check(_lib.lib().vb_gather_rows(_lib.dtype_code(dt), ptr(s2), ptr(input_mask.contiguous()), ptr(g), ptr(idx),
+        im_c = input_mask.contiguous()
+        check(_lib.lib().vb_gather_rows(_lib.dtype_code(dt), ptr(s2), ptr(im_c), ptr(g), ptr(idx),
                                         B, S, T, H, stream_ptr()), "vb_gather_rows")
         seed = next_seed()
         if p_drop > 0.0:
@@ -1087,7 +1093,8 @@ class VQAHeadLossFn(torch.autograd.Function):
         if mask is not None:
             dg = dg * mask
         dseq = torch.zeros((B * S, H), dtype=dt, device=g.device)
-        check(_lib.lib().vb_scatter_rows(_lib.dtype_code(dt), ptr(dg.contiguous()), ptr(idx), ptr(dseq), B, S, H,
+        dg = dg.contiguous()
+        check(_lib.lib().vb_scatter_rows(_lib.dtype_code(dt), ptr(dg), ptr(idx), ptr(dseq), B, S, H,
                                          stream_ptr()), "vb_scatter_rows")
         return dseq.view(B, S, H), None, None, None, None, grad_result(gw, d1), grad_result(gb, d2)
 
@@ -1156,7 +1163,8 @@ class FlickrHeadLossFn(torch.autograd.Function):
         dsel = linear_dgrad(dq, weight_for(wq, dt))
         dseq_k = linear_dgrad(dk, weight_for(wk, dt))
         dseq = torch.empty((B * S, H), dtype=dt, device=s2.device)
-        check(L.vb_scatter_index_rows(_lib.dtype_code(dt), ptr(dsel.contiguous()), ptr(pos), ptr(dseq_k.contiguous()),
+        dsel, dseq_k = dsel.contiguous(), dseq_k.contiguous()
+        check(L.vb_scatter_index_rows(_lib.dtype_code(dt), ptr(dsel), ptr(pos), ptr(dseq_k),
                                       ptr(dseq), B, S, E, H, stream_ptr()), "vb_scatter_index_rows")
         return (dseq.view(B, S, H), None, None, None, None, None, grad_result(gwq, d1), grad_result(gbq, d2),
                 grad_result(gwk, d3), grad_result(gbk, d4))

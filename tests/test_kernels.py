@@ -350,9 +350,12 @@ def decode_keepbits(bits, B, nh, S):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("cfg", [(2, 40, 2, 0.0), (1, 164, 2, 0.0), (2, 23, 3, 0.1), (1, 164, 1, 0.1)])
+@pytest.mark.parametrize("cfg", [(2, 40, 2, 0.0), (1, 164, 2, 0.0), (2, 23, 3, 0.1), (1, 164, 1, 0.1),
+                                 (1, 300, 1, 0.1), (1, 416, 1, 0.1)])    # 416 = NLVR2 as the reference runs it (2x144 + 128)
 def test_attention_fwd_bwd(dev, dt, cfg):
     B, S, nh, p = cfg
+    if S > 256 and dt == torch.float32:
+        pytest.skip("fp32 attention backward keeps the whole sequence in LDS: S <= 192 (DESIGN.md section 7)")
     H = nh * 64
     g = torch.Generator().manual_seed(6)
     qkv = (0.7 * torch.randn(B, S, 3 * H, generator=g)).to(dt).to(dev)

@@ -265,6 +265,34 @@ def test_bert_base_config2_logits_vs_oracle(dev):
     assert err16 < 5e-2 and gap < 0.2
 
 
+def test_nlvr2_reference_shape_long_sequence(dev):
+    """NLVR2 as the reference really feeds it (SURVEY 8d, config 5 note): two images x 144 regions of 1024-d features +
+    128 tokens, S = 416 -- past the S = 164 the kernels are tuned for.  bf16 training step against the bf16-emulating
+    oracle: loss, logits, and the direction of two gradients at opposite ends of the network."""
+    if dev.type != "cuda":
+        pytest.skip("BERT-base at S=416: GPU only")
+    kw = dict(vo.CONFIGS["base"], visual_embedding_dim=1024, num_hidden_layers=4)
+    cfg = vo.OracleConfig(**kw)
+    head = "nlvr"
+    sd = vo.synth_state_dict(cfg, head, 21)
+    batch = vo.synth_batch(cfg, 2, 128, 288, 21, head, ragged=True)
+    model = build_model(cfg, head, sd, dev, dtype=torch.bfloat16, dropout=0.0)
+    model.train()
+    out = model(**to_dev(batch, dev))
+    out["loss"].backward()
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = vo.objective_forward(leaves, cfg, head, mode="bf16", **batch)
+    ref["loss"].backward()
+    assert abs(float(out["loss"].detach()) - float(ref["loss"].detach())) < 2e-2
+    assert maxdiff(out["logits"].detach().float().cpu(), ref["logits"].detach()) < 3e-2
+    named = dict(model.bert.named_parameters())
+    for n in ("classifier.weight", "bert.encoder.layer.0.attention.self.query.weight",
+              "bert.embeddings.projection.weight"):
+        rg, mg = leaves[n].grad, named[n].grad.detach().float().cpu()
+        cos = float((rg * mg).sum() / (rg.norm() * mg.norm() + 1e-30))
+        assert cos > 0.98, (n, cos)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_sparse_mlm_head_matches_dense_head(dev, dtype):
     """the MLM head over the labelled positions only gives the dense head's loss, the dense

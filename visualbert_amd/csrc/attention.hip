@@ -595,6 +595,13 @@ int dispatch_nkf(int which, const AttnArgs& a, hipStream_t s) {
     if (nkf <= 8) return launch_all<T, 8>(which, a, s);
     if (nkf <= 12) return launch_all<T, 12>(which, a, s);
     if (nkf <= 16) return launch_all<T, 16>(which, a, s);
+    if constexpr (sizeof(T) == 2) {
+        // long sequences (NLVR2 as the reference really runs it: 2 x 144 regions + 128 tokens, S = 416).  The dQ pass keeps
+        // K, V and K^T of the whole sequence in LDS: 26 key fragments is what 160 KB holds; beyond that only forward fits.
+        if (nkf <= 20) return launch_all<T, 20>(which, a, s);
+        if (nkf <= 24) return launch_all<T, 24>(which, a, s);
+        if (nkf <= 26) return launch_all<T, 26>(which, a, s);
+    }
     if (nkf <= 32) return launch_all<T, 32>(which, a, s);
     return VB_ERR_UNSUPPORTED;
 }
@@ -611,7 +618,7 @@ int fill_args(AttnArgs& a, int B, int S, int nh, int head_dim, float p, uint64_t
 
 extern "C" int64_t vb_attn_keepbits_words(int S) {
     const int nkf = ((S + 31) / 32) * 2;
-    const int nkft = nkf <= 4 ? 4 : nkf <= 8 ? 8 : nkf <= 12 ? 12 : nkf <= 16 ? 16 : 32;
+    const int nkft = nkf <= 4 ? 4 : nkf <= 8 ? 8 : nkf <= 12 ? 12 : nkf <= 16 ? 16 : 32;   // 17..32 fragments: 2 words either way
     return (int64_t)S * 4 * ((nkft + 15) / 16);               // uint64 words per (batch, head)
 }
 

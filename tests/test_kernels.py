@@ -628,3 +628,41 @@ def test_small_linear_ce_over_choice_groups(dev):
     assert abs(float(loss.detach()) - float(lossr.detach())) < 1e-5
     assert (xd.grad.cpu() - xr.grad).abs().max().item() < 1e-5
     assert (w.grad.cpu() - wr.grad).abs().max().item() < 1e-4
+
+
+def test_rows_past_two_giga_elements(dev):
+    """bench.py's default batch (512 x 164 = 83,968 rows x 30,528 logit columns = 2.56 G elements) indexes past int32:
+    the decoder GEMM's fp32 output and the cross-entropy sweep must use 64-bit offsets.  Rows on both sides of the
+    2^31-element boundary (row 70,344) are checked against torch."""
+    if dev.type != "cuda":
+        pytest.skip("10 GB of logits: GPU only")
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(12)
+    M, V, K = 72000, 30522, 768
+    ld = 30528
+    A = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    W = torch.zeros(ld, K, dtype=torch.bfloat16, device=dev)
+    W[:V] = (torch.randn(V, K, generator=g) * 0.05).to(torch.bfloat16).to(dev)
+    bias = torch.randn(V, generator=g).to(dev)
+    C = torch.empty(M, ld, dtype=torch.float32, device=dev)
+    rc = L.vb_gemm(_lib.VB_BF16, _lib.VB_F32, 0, 0, _lib.ptr(A), K, _lib.ptr(W), K, _lib.ptr(C), ld, M, V, K, 1.0, None,
+                   _lib.ptr(bias), None, 0, 0, None, None, 0, 0, None, _lib.stream_ptr())
+    _lib.check(rc, "vb_gemm")
+    rows = torch.tensor([0, 255, 70343, 70344, 70345, 70400, 71999], device=dev)
+    ref = A[rows].float() @ W[:V].float().t() + bias
+    err = (C[rows, :V] - ref).abs().max().item()
+    assert err <= 2e-3 * max(1.0, ref.abs().max().item()), err
+    lab = torch.full((M,), -1, dtype=torch.int64, device=dev)
+    picks = torch.randint(0, V, (rows.numel(),), generator=g).to(dev)
+    lab[rows] = picks
+    acc = torch.empty(66, device=dev); loss = torch.empty(1, device=dev)
+    n = rows.numel(); n_pad = 64
+    dlc = torch.full((n_pad, ld), 7.0, dtype=torch.bfloat16, device=dev)
+    _lib.check(L.vb_ce_fwd_bwd_rows(_lib.VB_BF16, _lib.ptr(C), ld, _lib.ptr(lab), -1, _lib.ptr(rows), n, n_pad,
+                                    _lib.ptr(acc), _lib.ptr(loss), _lib.ptr(dlc), ld, M, V, _lib.stream_ptr()),
+               "vb_ce_fwd_bwd_rows")
+    ref_in = C[rows, :V].detach().clone().requires_grad_(True)
+    rl = torch.nn.functional.cross_entropy(ref_in, picks)
+    rl.backward()
+    assert abs(loss.item() - rl.item()) <= 2e-5 * max(1.0, abs(rl.item()))
+    assert (dlc[:n, :V].float() - ref_in.grad).abs().max().item() <= 2e-3

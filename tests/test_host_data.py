@@ -40,3 +40,29 @@ def test_mask_tokens_rates():
     assert abs(masked.sum().item() / sel.sum().item() - 0.8) < 0.03
     assert abs(kept.sum().item() / sel.sum().item() - 0.1) < 0.03
     assert torch.equal(labels[sel], ids[sel]) and torch.equal(out[~sel], ids[~sel])
+
+
+def test_collate_pretraining_matches_reference_loops():
+    """caption pairs + ragged region features -> padded batch: the whole-batch collate against the oracle's per-example /
+    per-token restatement of bert_data_utils.py:168-261, bert_field.py:79-100, coco_dataset.py:176-181."""
+    from visualbert_amd.data import collate_pretraining
+    g = torch.Generator().manual_seed(3)
+    V, MASK, CLS, SEP, Dv = 30522, 103, 101, 102, 16
+    la = [5, 1, 9, 3, 7]
+    lb = [4, 0, 2, 6, 0]                               # two single-sentence examples (text_b None)
+    ra = [3, 7, 1, 5, 7]
+    ids_a = [torch.randint(1000, V, (n,), generator=g) for n in la]
+    ids_b = [torch.randint(1000, V, (n,), generator=g) if n else None for n in lb]
+    feats = [torch.rand(r, Dv, generator=g) for r in ra]
+    correct = [True, False, True, True, False]
+    T = max(a + 2 + (b + 1 if b else 0) for a, b in zip(la, lb))
+    u = torch.rand(5, T, generator=g, dtype=torch.float64) * 0.4          # ~37 % selected: every branch is taken
+    r = torch.randint(0, V, (5, T), generator=g)
+    got = collate_pretraining(ids_a, ids_b, correct, feats, V, MASK, CLS, SEP, uniforms=u, random_ids=r, pin=False)
+    ex = [dict(ids_a=a.tolist(), ids_b=(b.tolist() if b is not None else None), is_correct=c, features=f)
+          for a, b, c, f in zip(ids_a, ids_b, correct, feats)]
+    ref = vo.collate_pretraining_loop(ex, u.tolist(), r.tolist(), MASK, CLS, SEP)
+    assert set(got) == set(ref)
+    for k in ref:
+        assert got[k].dtype == ref[k].dtype and torch.equal(got[k], ref[k]), k
+    assert int((got["masked_lm_labels"] != -1).sum()) > 3

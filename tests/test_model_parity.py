@@ -316,3 +316,27 @@ def test_sparse_mlm_head_matches_dense_head(dev, dtype):
     assert lerr <= (1e-4 if dtype == torch.float32 else 5e-2), lerr
     gerr = (gd - gs).abs().max().item()
     assert gerr <= (2e-5 if dtype == torch.float32 else 2e-2) * max(1.0, gd.abs().max().item()), gerr
+
+
+def test_collated_pinned_batch_streams_and_trains(dev):
+    """host data path end to end: collate_pretraining builds the padded batch in pinned memory,
+    FeatureStager streams it to HBM on a side stream, the model takes the kwargs as they are."""
+    if dev.type != "cuda":
+        pytest.skip("pinned memory + async copies: GPU only")
+    from visualbert_amd.data import collate_pretraining, FeatureStager
+    cfg, head, sd, _, _ = load_case("micro_pretraining")
+    g = torch.Generator().manual_seed(2)
+    B = 6
+    ids_a = [torch.randint(5, cfg.vocab_size, (int(n),), generator=g) for n in torch.randint(2, 9, (B,), generator=g)]
+    ids_b = [torch.randint(5, cfg.vocab_size, (int(n),), generator=g) for n in torch.randint(1, 7, (B,), generator=g)]
+    feats = [torch.rand(int(n), cfg.visual_embedding_dim, generator=g) for n in torch.randint(2, 6, (B,), generator=g)]
+    host = collate_pretraining(ids_a, ids_b, [True, False] * 3, feats, cfg.vocab_size, 3, 1, 2, generator=g)
+    assert all(v.is_pinned() for v in host.values())
+    batch, ev = FeatureStager(dev).stage(host)
+    torch.cuda.current_stream().wait_event(ev)
+    model = build_model(cfg, head, sd, dev, dropout=0.0)
+    model.train()
+    out = model(**batch)
+    out["loss"].backward()
+    ref = vo.objective_forward(sd, cfg, head, mode="fp32", **{k: v.clone() for k, v in host.items()})
+    assert abs(float(out["loss"].detach()) - float(ref["loss"])) < 1e-4

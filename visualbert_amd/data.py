@@ -67,6 +67,69 @@ def mask_tokens(input_ids, maskable, vocab_size, mask_id, probability=0.15, gene
     return out, labels
 
 
+def collate_pretraining(ids_a, ids_b, is_correct, features, vocab_size, mask_id, cls_id, sep_id, probability=0.15,
+                        generator=None, uniforms=None, random_ids=None, pin=True):
+    """One pre-training batch from tokenised caption pairs and per-image region features, built with whole-batch tensor
+    operations straight into (pinned) pre-padded buffers (SURVEY 8f / N2 + N3).
+
+    Replaces, for a batch at a time, convert_one_example_to_features_pretraining (dataloaders/bert_data_utils.py:168-247:
+    [CLS] a [SEP] b [SEP], segment ids, lm labels with -1 on the special tokens), the per-field AllenNLP padding
+    (dataloaders/bert_field.py:79-100: ids / mask / type ids with 0, lm labels with -1; coco_dataset.py:176-181: region
+    features zero-padded to the most regions in the batch, image_dim_variable = region count) and the per-token
+    random_word loop (via mask_tokens).  is_random_next = int(is_correct), as the reference's fields carry it
+    (bert_data_utils.py:81, 258-259).
+
+    ids_a / ids_b: lists of 1-D int64 tensors (ids_b entries may be None or empty: single-sentence examples);
+    features: list of float32 [r_i, Dv] tensors.  Returns the kwargs dict of VisualBERTFixedImageEmbedding.forward on
+    the host; with pin=True every tensor sits in pinned memory, ready for FeatureStager's asynchronous copies."""
+    B = len(ids_a)
+    la = torch.tensor([int(x.numel()) for x in ids_a], dtype=torch.int64)
+    lb = torch.tensor([0 if (y is None) else int(y.numel()) for y in ids_b], dtype=torch.int64)
+    has_b = lb > 0
+    lens = la + 2 + torch.where(has_b, lb + 1, torch.zeros_like(lb))
+    T = int(lens.max())
+
+    def new(shape, dtype, fill):
+        t = torch.empty(shape, dtype=dtype, pin_memory=bool(pin))
+        return t.fill_(fill) if fill is not None else t
+
+    ids = new((B, T), torch.int64, 0)
+    ar = torch.arange(T).unsqueeze(0)
+    # token scatter: a at columns 1..la, b at la+2..la+1+lb
+    flat_a = torch.cat([x.reshape(-1) for x in ids_a]) if int(la.sum()) else torch.zeros(0, dtype=torch.int64)
+    rows_a = torch.repeat_interleave(torch.arange(B), la)
+    cols_a = 1 + torch.arange(int(la.sum())) - torch.repeat_interleave(torch.cumsum(la, 0) - la, la)
+    ids[rows_a, cols_a] = flat_a
+    if int(lb.sum()):
+        flat_b = torch.cat([y.reshape(-1) for y in ids_b if y is not None and y.numel()])
+        rows_b = torch.repeat_interleave(torch.arange(B), lb)
+        cols_b = torch.repeat_interleave(la + 2, lb) + torch.arange(int(lb.sum())) - \
+            torch.repeat_interleave(torch.cumsum(lb, 0) - lb, lb)
+        ids[rows_b, cols_b] = flat_b
+    ids[:, 0] = cls_id
+    ids[torch.arange(B), la + 1] = sep_id
+    ids[torch.arange(B)[has_b], (la + lb + 2)[has_b]] = sep_id
+    in_a = (ar >= 1) & (ar <= la.unsqueeze(1))
+    in_b = (ar >= (la + 2).unsqueeze(1)) & (ar <= (la + lb + 1).unsqueeze(1)) & has_b.unsqueeze(1)
+    real = ar < lens.unsqueeze(1)
+    masked, labels = mask_tokens(ids, in_a | in_b, vocab_size, mask_id, probability, generator, uniforms, random_ids)
+    out = {
+        "bert_input_ids": new((B, T), torch.int64, None).copy_(masked),
+        "bert_input_mask": new((B, T), torch.int64, None).copy_(real.to(torch.int64)),
+        "bert_input_type_ids": new((B, T), torch.int64, None).copy_(((ar > (la + 1).unsqueeze(1)) & real).to(torch.int64)),
+        "masked_lm_labels": new((B, T), torch.int64, None).copy_(labels),
+        "is_random_next": new((B,), torch.int64, None).copy_(torch.as_tensor([int(bool(c)) for c in is_correct])),
+    }
+    dims = torch.tensor([int(f.shape[0]) for f in features], dtype=torch.int64)
+    R, Dv = int(dims.max()), int(features[0].shape[1])
+    feats = new((B, R, Dv), torch.float32, 0.0)
+    for b, f in enumerate(features):                       # one contiguous block copy per image into the padded slab
+        feats[b, :f.shape[0]].copy_(f)
+    out["image_dim_variable"] = new((B,), torch.int64, None).copy_(dims)
+    out["image_feat_variable"] = feats
+    return out
+
+
 class FeatureStager(object):
     """Double-buffered pinned-host -> HBM streaming of a batch dict (the features are 295 KB/sample)."""
 

@@ -289,15 +289,27 @@ VB_DEVICE void epi_load8(float (&xa)[8], float (&xd)[8], float (&xc)[8], const G
         if (g.accumulate) load8(xc, (const TO*)g.C + m * g.ldc + ncol);
     }
 }
+// offc / offa: element offsets of (m, e.ncol) in C and in the aux matrix.  The FFN-in (GELU) epilogue of the persistent
+// kernel steps them from row to row with 64-bit adds instead of forming m * ld per row (two matrices written per row:
+// ~100 quarter-rate integer multiplies per lane per tile); measured on one box, A/B/A/B at M = 83,968
+// (profiles/r01_gemm_8phase_notes.txt): FFN-in 623 -> 595 us with it, while the plain epilogues got SLOWER with the same
+// change (QKV 324 -> 334 us, FFN-out 340 -> 364 us) -- so it is compiled in for that activation only.
 template <typename T, typename TO, int ACT, int OPT>
-VB_DEVICE void epi_vec8(float (&v)[8], const GemmArgs& g, EpiLane& e, long m,
+VB_DEVICE void epi_vec8(float (&v)[8], const GemmArgs& g, EpiLane& e, long offc, long offa,
                         const float (&xa)[8], const float (&xd)[8], const float (&xc)[8]) {
     const int act = ACT >= 0 ? ACT : g.act;
-    const int n = e.ncol;
+    if constexpr (ACT == VB_ACT_GELU_SAVE_GRAD) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = v[j] * e.alpha + e.bb[j];
+        for (int j = 0; j < 8; j += 2) {                  // packed fp32 FMA: two columns per issue slot
+            const f32x2 r = vb_fma2(f32x2{v[j], v[j + 1]}, vb_splat2(e.alpha), f32x2{e.bb[j], e.bb[j + 1]});
+            v[j] = r[0]; v[j + 1] = r[1];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = v[j] * e.alpha + e.bb[j];
+    }
     if (act == VB_ACT_GELU) {
-        if (g.aux_out) store8((T*)g.aux_out + m * g.ld_aux + n, v);      // pre-activation, kept for backward
+        if (g.aux_out) store8((T*)g.aux_out + offa, v);                   // pre-activation, kept for backward
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
     } else if (act == VB_ACT_TANH) {
@@ -309,8 +321,12 @@ VB_DEVICE void epi_vec8(float (&v)[8], const GemmArgs& g, EpiLane& e, long m,
     } else if (act == VB_ACT_GELU_SAVE_GRAD) {
         float d[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) gelu_and_grad_f(v[j], v[j], d[j]);
-        store8((T*)g.aux_out + m * g.ld_aux + n, d);                      // gelu'(pre), what backward multiplies by
+        for (int j = 0; j < 8; j += 2) {
+            f32x2 y2, d2;
+            gelu_and_grad2(f32x2{v[j], v[j + 1]}, y2, d2);
+            v[j] = y2[0]; v[j + 1] = y2[1]; d[j] = d2[0]; d[j + 1] = d2[1];
+        }
+        store8((T*)g.aux_out + offa, d);                                  // gelu'(pre), what backward multiplies by
     } else if (act == VB_ACT_MUL_AUX) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] *= xa[j];
@@ -325,7 +341,7 @@ VB_DEVICE void epi_vec8(float (&v)[8], const GemmArgs& g, EpiLane& e, long m,
             for (int j = 0; j < 8; ++j) v[j] += xc[j];
         }
     }
-    TO* cp = (TO*)g.C + m * g.ldc + n;
+    TO* cp = (TO*)g.C + offc;
     if (g.debug & 128) { if (v[0] == 123.456f) store8(cp, v); }           // ablation: no global stores
     else store8(cp, v);
     if constexpr (OPT & EPI_COLSUM) {
@@ -405,7 +421,8 @@ VB_DEVICE void gemm_epilogue(f32x4 (&acc)[4][4], unsigned char* smem, const Gemm
                 f32x4 hi = *(const f32x4*)(src + 16);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { v[j] = lo[j]; v[4 + j] = hi[j]; }
-                epi_vec8<T, TO, ACT, OPT>(v, g, e, m, xa[it], xd[it], xc[it]);
+                epi_vec8<T, TO, ACT, OPT>(v, g, e, (long)m * g.ldc + e.ncol, (long)m * g.ld_aux + e.ncol,
+                                          xa[it], xd[it], xc[it]);
             }
         }
         if constexpr (OPT & EPI_RAGGED) {
@@ -787,9 +804,10 @@ VB_DEVICE void vb_phase_barrier() {
 // receiving the next tile's copies meanwhile.
 constexpr int EPI8_BYTES_PER_WAVE = 16 * 256;
 // one 16-row fragment row (4 fragments = 16 rows x 64 columns) of a wave's block; mrow0 = its first global row
+// offc / offa: element offsets of this lane's FIRST row (mrow0 + lane/8) in C / aux; its second row is 8 rows further
 template <typename T, typename TO, int ACT, int OPT>
 VB_DEVICE void gemm_epilogue_fragrow(f32x4 (&a)[4], unsigned char* slab, const GemmArgs& g, int mrow0, int lane, EpiLane& e,
-                                      const u32x4* pre, int pre_kind) {
+                                      const u32x4* pre, int pre_kind, long offc, long offa) {
     const int li = lane & 15, lg = lane >> 4, cc = lane & 7;
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni)
@@ -822,7 +840,10 @@ VB_DEVICE void gemm_epilogue_fragrow(f32x4 (&a)[4], unsigned char* slab, const G
             f32x4 hi = *(const f32x4*)(src + 16);
 #pragma unroll
             for (int j = 0; j < 4; ++j) { v[j] = lo[j]; v[4 + j] = hi[j]; }
-            epi_vec8<T, TO, ACT, OPT>(v, g, e, m, xa[it], xd[it], xc[it]);
+            if constexpr (ACT == VB_ACT_GELU_SAVE_GRAD)
+                epi_vec8<T, TO, ACT, OPT>(v, g, e, offc + it * 8 * g.ldc, offa + it * 8 * g.ld_aux, xa[it], xd[it], xc[it]);
+            else
+                epi_vec8<T, TO, ACT, OPT>(v, g, e, (long)m * g.ldc + e.ncol, (long)m * g.ld_aux + e.ncol, xa[it], xd[it], xc[it]);
         }
     }
     if constexpr (OPT & EPI_RAGGED) {
@@ -855,6 +876,10 @@ VB_DEVICE void gemm_epilogue_private(f32x4 (&acc)[8][4], unsigned char* slab, co
         if (PRE_AUX) { pbase = (const unsigned char*)g.aux_in; pld = g.ld_aux; pre_kind = 1; }
         else if (g.addend && !g.accumulate) { pbase = (const unsigned char*)g.addend; pld = g.ld_addend; pre_kind = 2; }
     }
+    // row addressing without per-row 64-bit multiplies: one product per matrix here, 64-bit adds from then on
+    const int mlane = mw0 + (lane >> 3);
+    const long stepc = 16 * g.ldc, stepa = 16 * g.ld_aux;
+    long offc = (long)mlane * g.ldc + e.ncol, offa = (long)mlane * g.ld_aux + e.ncol;
     auto preload = [&](int mi0) {
         if constexpr (PRE_AUX || PRE_ADD) {
             if (pre_kind) {
@@ -872,15 +897,16 @@ VB_DEVICE void gemm_epilogue_private(f32x4 (&acc)[8][4], unsigned char* slab, co
     };
     // constant indices spelled out: the accumulators must never be addressed by a loop variable
     preload(0);
-    gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[0], slab, g, mw0 + 0, lane, e, pre[0], pre_kind);
-    gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[1], slab, g, mw0 + 16, lane, e, pre[1], pre_kind);
-    gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[2], slab, g, mw0 + 32, lane, e, pre[2], pre_kind);
-    gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[3], slab, g, mw0 + 48, lane, e, pre[3], pre_kind);
+    gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[0], slab, g, mw0 + 0, lane, e, pre[0], pre_kind, offc, offa);
+    gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[1], slab, g, mw0 + 16, lane, e, pre[1], pre_kind, offc + stepc, offa + stepa);
+    gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[2], slab, g, mw0 + 32, lane, e, pre[2], pre_kind, offc + 2 * stepc, offa + 2 * stepa);
+    gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[3], slab, g, mw0 + 48, lane, e, pre[3], pre_kind, offc + 3 * stepc, offa + 3 * stepa);
     preload(4);
-    gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[4], slab, g, mw0 + 64, lane, e, pre[0], pre_kind);
-    gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[5], slab, g, mw0 + 80, lane, e, pre[1], pre_kind);
-    gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[6], slab, g, mw0 + 96, lane, e, pre[2], pre_kind);
-    gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[7], slab, g, mw0 + 112, lane, e, pre[3], pre_kind);
+    offc += 4 * stepc; offa += 4 * stepa;
+    gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[4], slab, g, mw0 + 64, lane, e, pre[0], pre_kind, offc, offa);
+    gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[5], slab, g, mw0 + 80, lane, e, pre[1], pre_kind, offc + stepc, offa + stepa);
+    gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[6], slab, g, mw0 + 96, lane, e, pre[2], pre_kind, offc + 2 * stepc, offa + 2 * stepa);
+    gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[7], slab, g, mw0 + 112, lane, e, pre[3], pre_kind, offc + 3 * stepc, offa + 3 * stepa);
     if constexpr (OPT & EPI_COLSUM) epi_colsum_flush(e, g, nw0, lane);
 }
 

@@ -287,9 +287,11 @@ VB_DEVICE bool rand8_keep(const Rand8& r, int e, uint32_t thresh16) {
 // ranges used here (softmax arguments <= 0, Gaussian tails)
 #ifdef VB_EMU
 VB_DEVICE float fast_exp(float x) { return expf(x); }
+VB_DEVICE float fast_exp2(float x) { return exp2f(x); }
 VB_DEVICE float fast_rcp(float x) { return 1.0f / x; }
 #else
 VB_DEVICE float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+VB_DEVICE float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 VB_DEVICE float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 #endif
 
@@ -320,6 +322,31 @@ VB_DEVICE void gelu_parts(float x, float& cdf, float& pdf) {
     const float r = 1.0f - p * t * e;                 // erf(|x| / sqrt 2)
     cdf = 0.5f * (1.0f + (x < 0.f ? -r : r));
     pdf = 0.39894228040143267794f * e;
+}
+// Two elements at a time on the packed-fp32 VALU (v_pk_fma_f32 / v_pk_mul_f32: two lanes of work per issue slot):
+// the same A&S 7.1.26 evaluation as gelu_parts written with explicit fused multiply-adds -- 17 packed operations + 2 rcp
+// + 2 exp per PAIR where the scalar form issues ~25 full-rate operations + rcp + exp per ELEMENT (the build uses
+// -ffp-contract=off).  The FFN-in epilogue runs this 128x per lane per tile: it was ~40 % of that GEMM's tile time.
+VB_DEVICE f32x2 vb_fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+VB_DEVICE f32x2 vb_splat2(float c) { return f32x2{c, c}; }
+VB_DEVICE void gelu_and_grad2(f32x2 x, f32x2& y, f32x2& dy) {
+    const f32x2 ax = __builtin_elementwise_abs(x);
+    const f32x2 den = vb_fma2(ax, vb_splat2(0.3275911f * 0.70710678118654752440f), vb_splat2(1.0f));
+    const f32x2 t = f32x2{fast_rcp(den[0]), fast_rcp(den[1])};
+    const f32x2 h = x * vb_splat2(-0.5f * 1.44269504088896340736f);
+    const f32x2 hx = h * x;                                   // -x^2/2 in units of log 2
+    const f32x2 e = f32x2{fast_exp2(hx[0]), fast_exp2(hx[1])};
+    f32x2 p = vb_fma2(t, vb_splat2(1.061405429f), vb_splat2(-1.453152027f));
+    p = vb_fma2(p, t, vb_splat2(1.421413741f));
+    p = vb_fma2(p, t, vb_splat2(-0.284496736f));
+    p = vb_fma2(p, t, vb_splat2(0.254829592f));
+    const f32x2 pt = p * t;
+    const f32x2 r = vb_fma2(-pt, e, vb_splat2(1.0f));         // erf(|x| / sqrt 2)
+    const f32x2 sr = f32x2{__builtin_copysignf(r[0], x[0]), __builtin_copysignf(r[1], x[1])};
+    const f32x2 cdf = vb_fma2(sr, vb_splat2(0.5f), vb_splat2(0.5f));
+    const f32x2 xpdf = x * (e * vb_splat2(0.39894228040143267794f));
+    y = x * cdf;
+    dy = cdf + xpdf;
 }
 VB_DEVICE float gelu_f(float x) { float c, d; gelu_parts(x, c, d); return x * c; }
 // d/dx [x * Phi(x)] = Phi(x) + x * phi(x)

@@ -244,13 +244,15 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) small_linear_fwd_kernel(const T* x, long ldx, con
     if (act && lane == 0) y[(long)m * N + n] = s + (bias ? bias[n] : 0.f);
 }
 
+constexpr int SMALL_LINEAR_ROWS = 32;
 template <typename T>
 VB_KERNEL VB_LAUNCH_BOUNDS(NT) small_linear_bwd_kernel(const float* dy, const T* x, long ldx, const float* W,
                                                       T* dx, long lddx, float* dW, float* db,
                                                       const float* scale_dev, int M, int N, int K) {
+    if (blockIdx.y > 0 && (int)blockIdx.x * NT >= N * K) return;       // row slices > 0 only carry the dW / db sums
     const float sc = scale_dev ? scale_dev[0] : 1.f;
     const int i = blockIdx.x * NT + threadIdx.x;
-    if (i < M * K) {                                     // dx[m,k] = sum_n dy[m,n] W[n,k]
+    if (blockIdx.y == 0 && i < M * K) {                  // dx[m,k] = sum_n dy[m,n] W[n,k]
         if (dx) {
             const int m = i / K, k = i % K;
             float s = 0.f;
@@ -258,18 +260,21 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) small_linear_bwd_kernel(const float* dy, const T*
             dx[(long)m * lddx + k] = from_f32<T>(s * sc);
         }
     }
+    // the reductions over m run in slices of SMALL_LINEAR_ROWS rows (gridDim.y), one fp32 atomic per slice and element:
+    // a single thread walking all M rows was 160 us of pure load latency at M = 512
+    const int m0 = blockIdx.y * SMALL_LINEAR_ROWS, m1 = m0 + SMALL_LINEAR_ROWS < M ? m0 + SMALL_LINEAR_ROWS : M;
     if (i < N * K) {                                     // dW[n,k] += sum_m dy[m,n] x[m,k]
         if (dW) {
             const int n = i / K, k = i % K;
             float s = 0.f;
-            for (int m = 0; m < M; ++m) s += dy[(long)m * N + n] * to_f32(x[(long)m * ldx + k]);
-            dW[i] += s * sc;
+            for (int m = m0; m < m1; ++m) s += dy[(long)m * N + n] * to_f32(x[(long)m * ldx + k]);
+            vb_atomic_add_noret(dW + i, s * sc);
         }
     }
     if (i < N && db) {
         float s = 0.f;
-        for (int m = 0; m < M; ++m) s += dy[(long)m * N + i];
-        db[i] += s * sc;
+        for (int m = m0; m < m1; ++m) s += dy[(long)m * N + i];
+        vb_atomic_add_noret(db + i, s * sc);
     }
 }
 
@@ -343,7 +348,7 @@ extern "C" int vb_small_linear_bwd(int dtype, const float* dy, const void* x, in
     if (!dy || !x || !W || M <= 0 || N <= 0 || K <= 0) return VB_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     const int work = (M > N ? M : N) * K;
-    dim3 grid((unsigned)((work + NT - 1) / NT));
+    dim3 grid((unsigned)((work + NT - 1) / NT), (unsigned)((M + SMALL_LINEAR_ROWS - 1) / SMALL_LINEAR_ROWS));
     if (dtype == VB_BF16) VB_LAUNCH(small_linear_bwd_kernel<bf16>, grid, dim3(NT), 0, s, dy, (const bf16*)x, (long)ldx, W, (bf16*)dx, (long)lddx, dW, db, scale_dev, M, N, K);
     else if (dtype == VB_F32) VB_LAUNCH(small_linear_bwd_kernel<float>, grid, dim3(NT), 0, s, dy, (const float*)x, (long)ldx, W, (float*)dx, (long)lddx, dW, db, scale_dev, M, N, K);
     else return VB_ERR_ARG;

@@ -236,7 +236,12 @@ def main():
             out["samples_per_s_with_pinned_h2d"] = round(h2d, 2)
         if sparse is not None:
             out["samples_per_s_sparse_mlm_head_optin"] = round(sparse, 2)
-        print(json.dumps(out))
+        try:                                    # RCCL's start-up banner sits in a C stdio buffer: push it out first so that
+            import ctypes                       # the JSON line is the LAST line of stdout
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()
 

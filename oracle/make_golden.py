@@ -212,6 +212,30 @@ def make_attention_case(stem="micro_attention_weights", cfg_name="micro", B=2, T
     print("wrote %s (%d KB)" % (path, os.path.getsize(path) // 1024))
 
 
+def make_schedule_fixture():
+    """learning-rate multipliers of EVERY schedule class of the reference (optimization.py:37-173) over a short run,
+    evaluated by the reference's own classes -> tests/golden/schedules.json."""
+    import json
+    _, ref_opt = load_reference()
+    t_total = 40
+    cases = [("ConstantLR", {}), ("WarmupLinearSchedule", dict(warmup=0.1)), ("WarmupConstantSchedule", dict(warmup=0.25)),
+             ("WarmupCosineSchedule", dict(warmup=0.1, cycles=0.5)),
+             ("WarmupCosineWithHardRestartsSchedule", dict(warmup=0.1, cycles=3.0)),
+             ("WarmupCosineWithWarmupRestartsSchedule", dict(warmup=0.05, cycles=4.0))]
+    out = dict(t_total=t_total, cases=[])
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for name, kw in cases:
+            sch = getattr(ref_opt, name)(t_total=t_total, **kw)
+            out["cases"].append(dict(schedule=name, kwargs=kw,
+                                     lr=[float(sch.get_lr(s, nowarn=True)) for s in range(t_total + 4)]))
+    path = os.path.join(GOLDEN_DIR, "schedules.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote %s" % path)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     only = set(sys.argv[1:])                     # optional: the stems to (re)generate
@@ -220,3 +244,5 @@ if __name__ == "__main__":
             make_case(*case)
     if not only or "micro_attention_weights" in only:
         make_attention_case()
+    if not only or "schedules" in only:
+        make_schedule_fixture()

@@ -66,3 +66,19 @@ def test_collate_pretraining_matches_reference_loops():
     for k in ref:
         assert got[k].dtype == ref[k].dtype and torch.equal(got[k], ref[k]), k
     assert int((got["masked_lm_labels"] != -1).sum()) > 3
+
+
+def test_lr_schedules_match_reference_classes():
+    """every _LRSchedule of the reference (optimization.py:37-173), step by step, against values its own classes
+    produced (tests/golden/schedules.json, written by oracle/make_golden.py)."""
+    import json
+    import os
+    from visualbert_amd import optimization as opt
+    here = os.path.dirname(os.path.abspath(__file__))
+    fx = json.load(open(os.path.join(here, "golden", "schedules.json")))
+    assert len(fx["cases"]) == 6
+    for case in fx["cases"]:
+        sch = getattr(opt, case["schedule"])(t_total=fx["t_total"], **case["kwargs"])
+        got = [sch.get_lr(s) for s in range(len(case["lr"]))]
+        assert max(abs(a - b) for a, b in zip(got, case["lr"])) < 1e-12, case["schedule"]
+    assert opt.WarmupLinearSchedule(warmup=0.1, t_total=-1).get_lr(7) == 1.0

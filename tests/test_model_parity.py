@@ -318,6 +318,46 @@ def test_sparse_mlm_head_matches_dense_head(dev, dtype):
     assert gerr <= (2e-5 if dtype == torch.float32 else 2e-2) * max(1.0, gd.abs().max().item()), gerr
 
 
+@pytest.mark.parametrize("name,kw", [("WarmupCosineSchedule", dict(warmup=0.1, cycles=0.5)),
+                                     ("WarmupCosineWithWarmupRestartsSchedule", dict(warmup=0.05, cycles=4.0))])
+def test_bert_adam_host_evaluated_schedules(dev, name, kw):
+    """schedules without a device formula: the fused BertAdam takes the step's multiplier from the host.  Four steps
+    against the oracle's BertAdam restatement driven by the reference's own multipliers (tests/golden/schedules.json)."""
+    import json
+    import os
+    from visualbert_amd import optimization as opt
+    from golden_util import GOLDEN_DIR
+    fx = json.load(open(os.path.join(GOLDEN_DIR, "schedules.json")))
+    ref_lr = [c for c in fx["cases"] if c["schedule"] == name][0]["lr"]
+    cfg, head, sd, batch, g = load_case("micro_nlvr")
+    model = build_model(cfg, head, sd, dev, dropout=0.0)
+    model.train()
+    named = [n for n in model.named_parameters() if "pooler" not in n[0]]
+    no_decay = ["bias", "LayerNorm.bias", "LayerNorm.weight"]
+    groups = [{"params": [p for n, p in named if not any(nd in n for nd in no_decay)], "weight_decay": 0.01},
+              {"params": [p for n, p in named if any(nd in n for nd in no_decay)], "weight_decay": 0.0}]
+    sch = getattr(opt, name)(t_total=fx["t_total"], **kw)
+    optim = opt.BertAdam(groups, lr=1e-3, schedule=sch)
+    ref_sd = copy.deepcopy(sd)
+    state = {}
+    b = to_dev(batch, dev)
+    for step in range(4):
+        optim.zero_grad()
+        out = model(**b)
+        out["loss"].backward()
+        optim.step()
+        leaves = {k: v.detach().clone().requires_grad_(True) for k, v in ref_sd.items()}
+        ro = vo.objective_forward(leaves, cfg, head, mode="fp32", **batch)
+        ro["loss"].backward()
+        grads = {k: v.grad for k, v in leaves.items() if v.grad is not None}
+        with torch.no_grad():
+            vo.bert_adam_step(ref_sd, grads, state, 1e-3, 0.0, -1, schedule=lambda s: ref_lr[s])
+        assert abs(float(out["loss"].detach()) - float(ro["loss"].detach())) < 1e-4, step
+    for n, p in model.bert.named_parameters():
+        assert maxdiff(p.detach().cpu(), ref_sd[n]) < 5e-6, n
+    assert optim.state_dict()["state"][0]["step"] == 4
+
+
 def test_collated_pinned_batch_streams_and_trains(dev):
     """host data path end to end: collate_pretraining builds the padded batch in pinned memory,
     FeatureStager streams it to HBM on a side stream, the model takes the kwargs as they are."""

@@ -4,9 +4,10 @@ HIP kernel sequence over the flat parameter arena (visualbert_amd/csrc/optim.hip
 API mirrors visualbert/pytorch_pretrained_bert/optimization.py:
   _LRSchedule / ConstantLR / WarmupCosineSchedule / WarmupConstantSchedule / WarmupLinearSchedule (:37-173),
   BertAdam(params, lr, warmup, t_total, schedule, b1, b2, e, weight_decay, max_grad_norm) (:185-304).
-The device kernel implements the schedules the reference's training path uses: 'warmup_linear'
-(the default, models/model_wrapper.py:136-139) and 'none'; the others are host-side formulas kept
-for API parity and raise if handed to the fused step.
+The device kernel evaluates the schedules the reference's training path uses -- 'warmup_linear' (the default,
+models/model_wrapper.py:136-139) and 'none' -- from its per-tensor step counters; for every other schedule
+(cosine, constant-after-warmup, the restart variants, any _LRSchedule subclass) the multiplier is evaluated on the host
+from a mirror of the (common) step count and handed to the same kernel as the learning rate of that step.
 """
 import math
 
@@ -53,6 +54,36 @@ class WarmupCosineSchedule(_LRSchedule):
         return 0.5 * (1. + math.cos(math.pi * self.cycles * 2 * progress))
 
 
+class WarmupCosineWithHardRestartsSchedule(WarmupCosineSchedule):
+    """optimization.py:113-129: `cycles` cosine decays with hard restarts after the warm-up."""
+
+    def __init__(self, warmup=0.002, t_total=-1, cycles=1., **kw):
+        super(WarmupCosineWithHardRestartsSchedule, self).__init__(warmup=warmup, t_total=t_total, cycles=cycles, **kw)
+        assert cycles >= 1.
+
+    def get_lr_(self, progress):
+        if progress < self.warmup:
+            return progress / self.warmup
+        progress = (progress - self.warmup) / (1 - self.warmup)
+        return 0.5 * (1. + math.cos(math.pi * ((self.cycles * progress) % 1)))
+
+
+class WarmupCosineWithWarmupRestartsSchedule(WarmupCosineWithHardRestartsSchedule):
+    """optimization.py:132-150: training is cut into `cycles` equal parts, each with its own warm-up and cosine decay."""
+
+    def __init__(self, warmup=0.002, t_total=-1, cycles=1., **kw):
+        assert warmup * cycles < 1.
+        warmup = warmup * cycles if warmup >= 0 else warmup
+        super(WarmupCosineWithWarmupRestartsSchedule, self).__init__(warmup=warmup, t_total=t_total, cycles=cycles, **kw)
+
+    def get_lr_(self, progress):
+        progress = progress * self.cycles % 1.
+        if progress < self.warmup:
+            return progress / self.warmup
+        progress = (progress - self.warmup) / (1 - self.warmup)
+        return 0.5 * (1. + math.cos(math.pi * progress))
+
+
 class WarmupConstantSchedule(_LRSchedule):
     def get_lr_(self, progress):
         if progress < self.warmup:
@@ -70,7 +101,7 @@ class WarmupLinearSchedule(_LRSchedule):
 
 
 SCHEDULES = {None: ConstantLR, "none": ConstantLR, "warmup_cosine": WarmupCosineSchedule,
-             "warmup_constant": WarmupConstantSchedule, "warmup_linear": WarmupLinearSchedule}
+             "warmup_constant": WarmupConstantSchedule, "warmup_linear": WarmupLinearSchedule}      # optimization.py:176-182
 
 
 class BertAdam(Optimizer):
@@ -127,12 +158,12 @@ class BertAdam(Optimizer):
         if len(wds) > 1:
             raise NotImplementedError("fused BertAdam: a single non-zero weight_decay value")
         sch = g0["schedule"]
-        if isinstance(sch, WarmupLinearSchedule):
-            code = 1
-        elif isinstance(sch, ConstantLR) or sch.t_total < 0:
+        if type(sch) is WarmupLinearSchedule:
+            code = 1                                     # evaluated on the device from the per-tensor step counters
+        elif type(sch) is ConstantLR or sch.t_total < 0:
             code = 0
         else:
-            raise NotImplementedError("fused BertAdam: schedule %s has no device kernel" % type(sch).__name__)
+            code = -1                                    # evaluated on the host, see step()
         # parameters the model's loss never reaches keep .grad = None in the reference and BertAdam skips them
         # (optimization.py:254-255): no moments, no weight decay.  The models mark those tensors (_vb_untouched).
         opt_flags = [id(p) in member and not getattr(p, "_vb_untouched", False) for p in arena.params]
@@ -142,7 +173,7 @@ class BertAdam(Optimizer):
         self._fused = dict(arena=arena, tt=tt, ct=ct, nt=nt, nc=nc, code=code, wd=wds[0] if wds else 0.0,
                            m=torch.zeros_like(arena.data), v=torch.zeros_like(arena.data),
                            norm2=torch.zeros(nt, dtype=torch.float32, device=dev),
-                           steps=torch.zeros(nt, dtype=torch.int32, device=dev))
+                           steps=torch.zeros(nt, dtype=torch.int32, device=dev), host_step=0)
         return self._fused
 
     def fused(self):
@@ -174,12 +205,18 @@ class BertAdam(Optimizer):
         g = self.param_groups[0]
         sch = g["schedule"]
         L = _lib.lib()
+        lr, code = float(g["lr"]), f["code"]
+        if code < 0:
+            # every optimised tensor takes every step, so one host counter mirrors the device's per-tensor counters
+            # (optimization.py:283-284 evaluates the schedule at state['step'] BEFORE incrementing it)
+            lr, code = lr * float(sch.get_lr(f["host_step"])), 0
         rc = L.vb_bert_adam_step(_lib.ptr(a.data), _lib.ptr(a.grad), _lib.ptr(f["m"]), _lib.ptr(f["v"]),
                                  _lib.ptr(a.shadow), _lib.ptr(f["ct"]), f["nc"], _lib.ptr(f["tt"]), f["nt"],
-                                 _lib.ptr(f["norm2"]), _lib.ptr(f["steps"]), float(g["lr"]), float(g["b1"]),
+                                 _lib.ptr(f["norm2"]), _lib.ptr(f["steps"]), lr, float(g["b1"]),
                                  float(g["b2"]), float(g["e"]), float(f["wd"]), float(g["max_grad_norm"]),
-                                 float(sch.warmup), float(sch.t_total), f["code"], _lib.stream_ptr())
+                                 float(sch.warmup), float(sch.t_total), code, _lib.stream_ptr())
         _lib.check(rc, "vb_bert_adam_step")
+        f["host_step"] += 1
         # the kernel refreshed the bf16 shadows of every optimised 2-D parameter
         member = set()
         for group in self.param_groups:
@@ -232,3 +269,9 @@ class BertAdam(Optimizer):
                     steps[i] = int(st["step"])
                 k += 1
         f["steps"].copy_(torch.tensor(steps, dtype=torch.int32))
+        flags = f["tt"].view(-1, 4)[:, 3].tolist()
+        taken = sorted(set(st for st, fl in zip(steps, flags) if fl & 1))
+        if f["code"] < 0 and len(taken) > 1:
+            raise NotImplementedError("fused BertAdam: %s is evaluated from ONE step count, the checkpoint holds %s"
+                                      % (type(self.param_groups[0]["schedule"]).__name__, taken))
+        f["host_step"] = taken[-1] if taken else 0

@@ -358,6 +358,34 @@ def test_bert_adam_host_evaluated_schedules(dev, name, kw):
     assert optim.state_dict()["state"][0]["step"] == 4
 
 
+def test_checkpoint_round_trip_resumes_identically(dev, tmp_path):
+    """ModelWrapper.save_checkpoint / restore_checkpoint (models/model_wrapper.py:163-199 file names and keys): a fresh
+    model + optimizer restored from disk continues exactly like the one that kept running (weights, Adam moments,
+    per-tensor step counters, LR schedule position)."""
+    from visualbert_amd.model import ModelWrapper, AttrDict
+    cfg, head, sd, batch, g = load_case("micro_pretraining")
+    args = AttrDict(train_batch_size=1, learning_rate=LR, warmup_proportion=WARMUP, num_train_epochs=1,
+                    gradient_accumulation_steps=1)
+    b = to_dev(batch, dev)
+    mw = ModelWrapper(args, T_TOTAL, model=build_model(cfg, head, sd, dev, dropout=0.0))
+    mw.train()
+    for _ in range(2):
+        mw.step(b)
+    mw.save_checkpoint(str(tmp_path), 3, [0.5, 0.6])
+    mw.save_checkpoint_step(str(tmp_path), 7, 1)
+    mw2 = ModelWrapper(args, T_TOTAL, model=build_model(cfg, head, vo.synth_state_dict(cfg, head, 99), dev, dropout=0.0))
+    mw2.train()
+    epoch, metrics = mw2.restore_checkpoint(str(tmp_path))
+    assert epoch == 4 and metrics == [0.5, 0.6]
+    la, lb = float(mw.step(b)["loss"].detach()), float(mw2.step(b)["loss"].detach())
+    assert abs(la - lb) < 1e-6
+    for (n, p), (_, q) in zip(mw.model.bert.named_parameters(), mw2.model.bert.named_parameters()):
+        assert maxdiff(p.detach().cpu(), q.detach().cpu()) < 1e-7, n
+    assert mw2.optimizer.state_dict()["state"][0]["step"] == 3
+    fresh = ModelWrapper(args, T_TOTAL, model=build_model(cfg, head, sd, dev, dropout=0.0))
+    assert fresh.restore_checkpoint(str(tmp_path / "nothing_here")) == (0, [])
+
+
 def test_collated_pinned_batch_streams_and_trains(dev):
     """host data path end to end: collate_pretraining builds the padded batch in pinned memory,
     FeatureStager streams it to HBM on a side stream, the model takes the kwargs as they are."""

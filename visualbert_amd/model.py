@@ -66,6 +66,25 @@ class VisualBERTFixedImageEmbedding(nn.Module):
         return output_dict
 
 
+def _load_flexible(model, state_dict, strict_first=True):
+    """utils/pytorch_misc.py:246-265: try a full load, then fall back to copying the tensors whose names match."""
+    if strict_first:
+        try:
+            model.load_state_dict(state_dict)
+            return
+        except RuntimeError:
+            pass
+    own_state = model.state_dict()
+    with torch.no_grad():
+        for name, param in state_dict.items():
+            if name not in own_state:
+                continue
+            if isinstance(param, torch.nn.Parameter):
+                param = param.data
+            if own_state[name].shape == param.shape:
+                own_state[name].copy_(param)
+
+
 class AttrDict(dict):
     def __getattr__(self, k):
         try:
@@ -110,6 +129,74 @@ class ModelWrapper(object):
             args.get("num_train_epochs", 1)
         self.num_train_optimization_steps = steps
         self.optimizer = BertAdam(groups, lr=args.learning_rate, warmup=args.warmup_proportion, t_total=steps)
+
+    # -- checkpoints: the reference's file names and dictionary keys (models/model_wrapper.py:150-221,
+    #    utils/pytorch_misc.py:110-330), so that a run can be resumed by either side ------------------------------------
+    def state_dict(self):
+        return {"model": self.model.state_dict(), "optimizer": self.optimizer.state_dict()}
+
+    def load_state_dict(self, state_dict_to_load):
+        _load_flexible(self.model, state_dict_to_load["model"])
+        self.optimizer.load_state_dict(state_dict_to_load["optimizer"])
+        self._after_weights_changed()
+
+    def _after_weights_changed(self):
+        arena = getattr(getattr(self.model, "bert", None), "arena", None)
+        if arena is not None and arena.data.is_cuda:
+            arena.refresh_shadows()                         # bf16 / transposed copies follow the fp32 masters
+
+    def save_checkpoint(self, serialization_dir, epoch, val_metric_per_epoch, is_best=False):
+        import os
+        import shutil
+        assert serialization_dir
+        model_path = os.path.join(serialization_dir, "model_state_epoch_{}.th".format(epoch))
+        torch.save(self.model.state_dict(), model_path)
+        torch.save({"epoch": epoch, "val_metric_per_epoch": val_metric_per_epoch,
+                    "optimizer": self.optimizer.state_dict()},
+                   os.path.join(serialization_dir, "training_state_epoch_{}.th".format(epoch)))
+        if is_best:
+            shutil.copyfile(model_path, os.path.join(serialization_dir, "best.th"))
+
+    def save_checkpoint_step(self, serialization_dir, step, epoch, is_best=False):
+        import os
+        assert serialization_dir
+        torch.save(self.model.state_dict(),
+                   os.path.join(serialization_dir, "model_step_{}_epoch_{}.th".format(step, epoch)))
+        torch.save({"step": step, "epoch": epoch, "val_metric_per_epoch": None, "optimizer": self.optimizer.state_dict()},
+                   os.path.join(serialization_dir, "training_step_{}_epoch_{}.th".format(step, epoch)))
+
+    def restore_checkpoint(self, serialization_dir, epoch_to_load=None):
+        """resume from the newest end-of-epoch checkpoint (or, when there is none, the newest step checkpoint) of a
+        serialization directory; returns (epoch to continue with, val_metric_per_epoch) -- (0, []) if there is none."""
+        import os
+        import re
+        files = os.listdir(serialization_dir) if serialization_dir and os.path.isdir(serialization_dir) else []
+        epochs = sorted(int(m.group(1)) for m in (re.fullmatch(r"model_state_epoch_([0-9]+)\.th", f) for f in files) if m)
+        if epoch_to_load is not None:
+            epochs = [e for e in epochs if e == int(epoch_to_load)]
+        if epochs:
+            e = epochs[-1]
+            pair = ("model_state_epoch_%d.th" % e, "training_state_epoch_%d.th" % e)
+        else:
+            steps = sorted((int(m.group(2)), int(m.group(1)), f) for m, f in
+                           ((re.fullmatch(r"model_step_([0-9]+)_epoch_([0-9]+)\.th", f), f) for f in files) if m)
+            if not steps:
+                return 0, []
+            ep, st, f = steps[-1]
+            pair = (f, "training_step_%d_epoch_%d.th" % (st, ep))
+        model_state = torch.load(os.path.join(serialization_dir, pair[0]), map_location="cpu")
+        training_state = torch.load(os.path.join(serialization_dir, pair[1]), map_location="cpu")
+        self.model.load_state_dict(model_state)
+        self.optimizer.load_state_dict(training_state["optimizer"])
+        self._after_weights_changed()
+        epoch = training_state["epoch"]
+        epoch_to_return = (epoch if isinstance(epoch, int) else int(str(epoch).split(".")[0])) + 1
+        return epoch_to_return, training_state.get("val_metric_per_epoch", [])
+
+    def restore_checkpoint_pretrained(self, restore_bin):
+        """copy every tensor of a saved state dict whose name exists here (models/model_wrapper.py:201-221)."""
+        _load_flexible(self.model, torch.load(restore_bin, map_location="cpu"), strict_first=False)
+        self._after_weights_changed()
 
     def step(self, batch, eval_mode=False):
         if eval_mode:

@@ -6,7 +6,7 @@ import torch
 from visualbert_amd import _lib
 dev = torch.device("cuda", 0)
 L = _lib.lib()
-for blocks in (256, 512):
+for blocks in (64, 128, 256, 512):
     out = torch.empty(blocks * 512, device=dev)
     for kind, name in ((0, "16x16x32"), (1, "32x32x16")):
         iters = 2000

@@ -56,6 +56,27 @@ def pmc_traffic(batch, key):
     return d.get("traffic_bytes_per_launch")
 
 
+def measured_mfma_ceiling(dev):
+    """what this chip's matrix pipes deliver on bf16 operands that change every instruction, with NO memory traffic
+    (vb_mfma_peak kind 2: a register-only v_mfma_f32_16x16x32_bf16 loop on every CU for ~12 ms).  With constant operands the
+    same loop reaches ~2.43 PF/s; with changing ones the chip drops its clock (power) and sustains ~1.75 PF/s -- the
+    ceiling a real GEMM sees (profiles/r01_pmc_clock_under_gemm.txt).  Reported next to the nominal peak, not instead."""
+    import torch
+    from visualbert_amd import _lib
+    L = _lib.lib()
+    blocks, iters = 256, 20000
+    out = torch.empty(blocks * 512, device=dev)
+    L.vb_mfma_peak(2, iters, blocks, _lib.ptr(out), _lib.stream_ptr())
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        L.vb_mfma_peak(2, iters, blocks, _lib.ptr(out), _lib.stream_ptr())
+    e1.record()
+    torch.cuda.synchronize()
+    return blocks * 8 * iters * 524288.0 / (e0.elapsed_time(e1) / 3) / 1e9
+
+
 def cpu_baseline(batch_size, T, R, steps=3):
     """the oracle (a restatement of TrainVisualBERTObjective + ModelWrapper.step + BertAdam) on host cores."""
     from oracle import visualbert_oracle as vo
@@ -213,6 +234,12 @@ def main():
                                                 launches_per_step=v["launches"] / args.steps,
                                                 tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1))
                                            for k, v in summ.items()})
+        if roofline is not None and dtype == torch.bfloat16:
+            ceil_tf = measured_mfma_ceiling(dev)
+            roofline["mfma_ceiling_measured"] = round(ceil_tf, 1)
+            roofline["frac_of_measured_ceiling"] = round(roofline["achieved"] / ceil_tf, 4)
+            roofline["mfma_ceiling_note"] = ("register-only bf16 MFMA loop, operands changing every instruction, all CUs: "
+                                             "what the chip sustains at the clock it holds under real data")
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args.cpu_batch, T, R)

@@ -8,8 +8,8 @@ dev = torch.device("cuda", 0)
 L = _lib.lib()
 for blocks in (64, 128, 256, 512):
     out = torch.empty(blocks * 512, device=dev)
-    for kind, name in ((0, "16x16x32"), (1, "32x32x16")):
-        iters = 2000
+    for kind, name in ((0, "16x16x32"), (1, "32x32x16"), (2, "16x16x32, operands changing every instruction")):
+        iters = 20000
         for _ in range(2):
             L.vb_mfma_peak(kind, iters, blocks, _lib.ptr(out), _lib.stream_ptr())
         torch.cuda.synchronize()

@@ -1636,7 +1636,27 @@ template <int KIND>
 __global__ void __launch_bounds__(512) mfma_peak_kernel(float* out, int iters) {
     bf16x8 a, b;
     for (int j = 0; j < 8; ++j) { a[j] = (bf16)(0.001f * (threadIdx.x + j)); b[j] = (bf16)(0.002f * (threadIdx.x - j)); }
-    if (KIND == 0) {
+    if (KIND == 2) {
+        // like kind 0, but the operands CHANGE from instruction to instruction (8 pseudo-random register pairs per lane):
+        // the switching activity of a real GEMM's operand stream, still without any memory traffic
+        bf16x8 av[8], bv[8];
+        uint32_t h = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
+        for (int q = 0; q < 8; ++q)
+            for (int j = 0; j < 8; ++j) {
+                h = h * 1664525u + 1013904223u; av[q][j] = (bf16)(((int)(h >> 9) & 0xFFFF) * (1.0f / 32768.0f) - 1.0f);
+                h = h * 1664525u + 1013904223u; bv[q][j] = (bf16)(((int)(h >> 9) & 0xFFFF) * (1.0f / 32768.0f) - 1.0f);
+            }
+        f32x4 acc[16];
+        for (int i = 0; i < 16; ++i) acc[i] = f32x4{0, 0, 0, 0};
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[i & 7], bv[(i + 3) & 7], acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[(i + 5) & 7], bv[i & 7], acc[i], 0, 0, 0);
+        }
+        float s = 0; for (int i = 0; i < 16; ++i) s += acc[i][0];
+        out[blockIdx.x * 512 + threadIdx.x] = s;
+    } else if (KIND == 0) {
         f32x4 acc[16];
         for (int i = 0; i < 16; ++i) acc[i] = f32x4{0, 0, 0, 0};
         for (int it = 0; it < iters; ++it) {
@@ -1661,10 +1681,12 @@ __global__ void __launch_bounds__(512) mfma_peak_kernel(float* out, int iters) {
     }
 }
 #endif
-// kind 0: 32 x v_mfma_f32_16x16x32_bf16 per iteration, kind 1: 16 x v_mfma_f32_32x32x16_bf16 (same FLOPs: 524288 per wave-iter)
+// kind 0: 32 x v_mfma_f32_16x16x32_bf16 per iteration, kind 1: 16 x v_mfma_f32_32x32x16_bf16 (same FLOPs: 524288 per wave-iter),
+// kind 2: kind 0 with operands that change every instruction
 extern "C" int vb_mfma_peak(int kind, int iters, int blocks, float* out, void* stream) {
 #ifndef VB_EMU
-    if (kind == 0) hipLaunchKernelGGL(mfma_peak_kernel<0>, dim3(blocks), dim3(512), 0, (hipStream_t)stream, out, iters);
+    if (kind == 2) hipLaunchKernelGGL(mfma_peak_kernel<2>, dim3(blocks), dim3(512), 0, (hipStream_t)stream, out, iters);
+    else if (kind == 0) hipLaunchKernelGGL(mfma_peak_kernel<0>, dim3(blocks), dim3(512), 0, (hipStream_t)stream, out, iters);
     else hipLaunchKernelGGL(mfma_peak_kernel<1>, dim3(blocks), dim3(512), 0, (hipStream_t)stream, out, iters);
     return vb_check_launch();
 #else

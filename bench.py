@@ -179,7 +179,7 @@ def main():
     if use_dist:
         dist.all_reduce(et, op=dist.ReduceOp.MAX)
     elapsed = float(et.item())
-    loss = float(mw.step(batch)["loss"])
+    loss = float(mw.step(batch)["loss"].detach())
 
     h2d = None
     if args.h2d:

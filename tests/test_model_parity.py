@@ -49,7 +49,7 @@ def test_fp32_forward_matches_reference_golden(dev, stem):
     hook.remove()
     assert maxdiff(captured[0][0].float().cpu(), g["sequence_output"]) < 1e-3
     assert maxdiff(captured[0][1].float().cpu(), g["pooled_output"]) < 1e-3
-    assert abs(float(out["loss"]) - float(g["loss"])) < 1e-3
+    assert abs(float(out["loss"].detach()) - float(g["loss"])) < 1e-3
     if head == "vqa_advanced":
         lg = out["logits"].float().cpu()
         assert maxdiff(lg[:, :, ::LOGIT_STRIDE], g["logits_strided"]) < 1e-4
@@ -87,7 +87,7 @@ def test_fp32_train_steps_match_reference_golden(dev, stem):
     mw = ModelWrapper(args, T_TOTAL, model=model)
     b = to_dev(batch, dev)
     out = mw.step(b)
-    assert abs(float(out["loss"]) - float(g["train_loss"])) < 1e-4
+    assert abs(float(out["loss"].detach()) - float(g["train_loss"])) < 1e-4
     named = dict(model.bert.named_parameters())
     gnames = set(str(x) for x in g["grad_names"])
     assert gnames <= set(named.keys())
@@ -101,7 +101,7 @@ def test_fp32_train_steps_match_reference_golden(dev, stem):
         assert maxdiff(gr.reshape(-1)[:16], g["grad_head/" + n]) <= 2e-3 * max(ref_norm, 1e-3), n
     for _ in range(N_STEPS - 1):
         out = mw.step(b)
-    assert abs(float(out["loss"]) - float(g["final_loss"])) < 1e-4
+    assert abs(float(out["loss"].detach()) - float(g["final_loss"])) < 1e-4
     for n, p in named.items():
         assert maxdiff(p.detach().cpu().reshape(-1)[:16], g["post_head/" + n]) < 2e-6, n
         d = float((p.detach().cpu() - sd[n]).double().norm())
@@ -126,7 +126,7 @@ def test_bf16_matches_bf16_oracle(dev, stem):
     gap = maxdiff(lg[:, :, ::LOGIT_STRIDE], g["logits_strided"])
     print("bf16 logits: vs bf16-oracle %.3e, vs fp32 reference %.3e (absmax %.2f)" % (err, gap, float(g["logits_absmax"])))
     assert err < 2e-2, err
-    assert abs(float(out["loss"]) - float(ref["loss"])) < 2e-2
+    assert abs(float(out["loss"].detach()) - float(ref["loss"])) < 2e-2
     assert gap < 0.1
 
 
@@ -141,7 +141,7 @@ def test_dropout_training_step_runs_and_is_seed_deterministic(dev):
         model.train()
         out = model(**to_dev(batch, dev))
         out["loss"].backward()
-        losses.append(float(out["loss"]))
+        losses.append(float(out["loss"].detach()))
         gn = float(model.bert.arena.grad.norm())
         assert np.isfinite(gn) and gn > 0
     assert abs(losses[0] - losses[1]) < 1e-5     # same masks; only atomic summation order may differ
@@ -193,7 +193,7 @@ def test_bf16_small_heads_match_bf16_oracle(dev, stem):
     with torch.no_grad():
         out = model(**to_dev(batch, dev))
         ref = vo.objective_forward(sd, cfg, head, mode="bf16", **batch)
-    assert abs(float(out["loss"]) - float(ref["loss"])) < 2e-2
+    assert abs(float(out["loss"].detach()) - float(ref["loss"])) < 2e-2
     if head == "flickr":
         assert float(out["entity_num"]) == float(ref["entity_num"])
         assert abs(float(out["upperbound_accuracy"]) - float(ref["upperbound_accuracy"])) < 1e-6
@@ -249,9 +249,9 @@ def test_bert_base_config2_logits_vs_oracle(dev):
     lg = out["logits"].float().cpu()
     err = float((lg - ref["logits"]).abs().max())
     print("BERT-base fp32: max|dlogit| %.3e (absmax %.2f), |dloss| %.3e" %
-          (err, float(ref["logits"].abs().max()), abs(float(out["loss"]) - float(ref["loss"]))))
+          (err, float(ref["logits"].abs().max()), abs(float(out["loss"].detach()) - float(ref["loss"]))))
     assert err < 1e-3, err
-    assert abs(float(out["loss"]) - float(ref["loss"])) < 1e-4
+    assert abs(float(out["loss"].detach()) - float(ref["loss"])) < 1e-4
     assert torch.equal(lg.argmax(-1), ref["logits"].argmax(-1))          # token indexing bit-exact
     assert torch.equal(out["seq_relationship_score"].argmax(-1).cpu(), ref["seq_relationship_score"].argmax(-1))
     model.bert.set_compute_dtype(torch.bfloat16)

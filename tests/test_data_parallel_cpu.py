@@ -108,3 +108,78 @@ def test_allreduce_buckets_tile_the_gradient_arena(head, bypass):
     r = sorted((lo, hi) for _, lo, hi in m.bucket_ranges())
     assert r[0][0] == 0 and r[-1][1] == m.arena.grad.numel()
     assert all(r[i][1] == r[i + 1][0] for i in range(len(r) - 1))
+
+
+def _gpu_worker(rank, world, port, q):
+    """two ranks sharing cuda:0 (gloo carries the collectives): the REAL training step -- HIP kernels, autograd hooks
+    firing the per-layer buckets during backward, fused BertAdam on the averaged gradients."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import visualbert_oracle as vo
+        from visualbert_amd.modeling import BertConfig
+        from visualbert_amd.model import VisualBERTFixedImageEmbedding, ModelWrapper, AttrDict
+        from visualbert_amd.parallel import DataParallelGradSync
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(0)
+        cfg = vo.OracleConfig(**vo.CONFIGS["micro"])
+        bc = BertConfig(cfg.vocab_size, hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers,
+                        num_attention_heads=cfg.num_attention_heads, intermediate_size=cfg.intermediate_size,
+                        hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+        model = VisualBERTFixedImageEmbedding(config=bc, training_head_type="pretraining",
+                                              visual_embedding_dim=cfg.visual_embedding_dim).to(dev)
+        sd = vo.synth_state_dict(cfg, "pretraining", 7)
+        if rank == 0:                                      # only rank 0 starts from the test weights: broadcast must spread them
+            own = model.bert.state_dict()
+            with torch.no_grad():
+                for k, v in sd.items():
+                    own[k].copy_(v)
+        sync = DataParallelGradSync(model.bert, overlap=True)
+        sync.broadcast_parameters(0)
+        model.train()
+        mw = ModelWrapper(AttrDict(train_batch_size=4, learning_rate=1e-3, warmup_proportion=0.1, num_train_epochs=1,
+                                   gradient_accumulation_steps=1), 400, model=model, grad_sync=sync)
+        full = vo.synth_batch(cfg, 4, 12, 5, 7, "pretraining")
+        shard = {k: v[rank * 2:(rank + 1) * 2].to(dev) for k, v in full.items()}
+        for _ in range(3):
+            mw.step(shard)
+        # single-process restatement: gradient of the mean over replicas of the per-replica mean losses, BertAdam
+        ref_sd = {k: v.clone() for k, v in sd.items()}
+        state = {}
+        for _ in range(3):
+            leaves = {k: v.detach().clone().requires_grad_(True) for k, v in ref_sd.items()}
+            losses = [vo.objective_forward(leaves, cfg, "pretraining",
+                                           **{k: v[r * 2:(r + 1) * 2] for k, v in full.items()})["loss"] for r in range(world)]
+            torch.stack(losses).mean().backward()
+            grads = {k: v.grad for k, v in leaves.items() if v.grad is not None}
+            with torch.no_grad():
+                vo.bert_adam_step(ref_sd, grads, state, 1e-3, 0.1, 100)
+        worst = 0.0
+        for n, p in model.bert.named_parameters():
+            worst = max(worst, float((p.detach().cpu() - ref_sd[n]).abs().max()))
+        q.put((rank, worst, float(model.bert.arena.data.double().sum())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_train_like_the_reference_data_parallel(dev):
+    if dev.type != "cuda":
+        pytest.skip("two processes driving the HIP kernels: GPU only")
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    res = [q.get(timeout=10) for _ in range(world)]
+    assert sorted(r[0] for r in res) == [0, 1]
+    for r, worst, _ in res:
+        assert worst < 5e-6, (r, worst)                     # three optimizer steps, fp32 kernels vs the oracle
+    assert res[0][2] == res[1][2]                           # replicas bit-identical after the synchronised steps

@@ -408,3 +408,33 @@ def test_collated_pinned_batch_streams_and_trains(dev):
     out["loss"].backward()
     ref = vo.objective_forward(sd, cfg, head, mode="fp32", **{k: v.clone() for k, v in host.items()})
     assert abs(float(out["loss"].detach()) - float(ref["loss"])) < 1e-4
+
+
+def test_degenerate_batches_match_oracle(dev):
+    """edges of the input contract: a sample whose regions are ALL padding (image_dim = 0: its visual slots are masked
+    keys but still produce rows), a sample with a single real token, and a batch without any labelled token -- the
+    reference's CrossEntropyLoss(ignore_index=-1) then averages over nothing and returns NaN (modeling.py:1471-1473)."""
+    cfg, head, sd, batch, g = load_case("micro_pretraining")
+    model = build_model(cfg, head, sd, dev)
+    model.eval()
+    b = {k: v.clone() for k, v in batch.items()}
+    b["image_dim_variable"][0] = 0                                     # no valid region at all
+    b["image_feat_variable"][0] = 0
+    b["bert_input_mask"][1] = 0
+    b["bert_input_mask"][1, 0] = 1                                     # one real token
+    b["bert_input_ids"][1, 1:] = 0
+    b["masked_lm_labels"][1] = -1
+    b["masked_lm_labels"][1, 0] = int(b["bert_input_ids"][1, 0])
+    with torch.no_grad():
+        out = model(**to_dev(b, dev))
+        ref = vo.objective_forward(sd, cfg, head, mode="fp32", **b)
+    assert maxdiff(out["logits"].float().cpu(), ref["logits"]) < 1e-4
+    assert abs(float(out["loss"]) - float(ref["loss"])) < 1e-4
+    assert torch.equal(out["logits"].float().cpu().argmax(-1), ref["logits"].argmax(-1))
+    b2 = {k: v.clone() for k, v in batch.items()}
+    b2["masked_lm_labels"][:] = -1                                     # nothing to predict
+    with torch.no_grad():
+        out2 = model(**to_dev(b2, dev))
+        ref2 = vo.objective_forward(sd, cfg, head, mode="fp32", **b2)
+    assert bool(torch.isnan(ref2["masked_lm_loss"])) and bool(torch.isnan(out2["masked_lm_loss"].cpu()))
+    assert maxdiff(out2["seq_relationship_score"].cpu(), ref2["seq_relationship_score"]) < 1e-4

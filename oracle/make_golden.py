@@ -45,6 +45,7 @@ CASES = [
     ("micro_multichoice", "micro", "multichoice", 2, 10, 6, 6),
     ("micro_vqa_advanced", "micro", "vqa_advanced", 3, 12, 5, 7),
     ("micro_flickr", "micro", "flickr", 3, 12, 6, 8),
+    ("micro_textonly", "micro", "pretraining", 3, 12, 5, 10, dict(text_only=True)),   # image_feat_variable = None
 ]
 
 LR, WARMUP, T_TOTAL = 5e-5, 0.1, 100
@@ -72,10 +73,11 @@ def build_reference_model(cfg_kwargs, head, sd, bypass=False):
 
 def reference_forward(model, batch):
     """Restates models/model.py:262-288 (mask construction + kwargs mapping), then calls the reference."""
-    image_mask = vo.build_image_mask(batch["image_feat_variable"], batch["image_dim_variable"])
+    feats = batch.get("image_feat_variable")
+    image_mask = vo.build_image_mask(feats, batch["image_dim_variable"]) if feats is not None else None   # model.py:269-270
     with cpu_cuda_noop():
         return model(input_ids=batch["bert_input_ids"], token_type_ids=batch["bert_input_type_ids"],
-                     input_mask=batch["bert_input_mask"], visual_embeddings=batch["image_feat_variable"],
+                     input_mask=batch["bert_input_mask"], visual_embeddings=feats,
                      position_embeddings_visual=None, image_mask=image_mask,
                      visual_embeddings_type=batch.get("visual_embeddings_type"),
                      image_text_alignment=batch.get("image_text_alignment"),
@@ -106,6 +108,8 @@ def make_case(stem, cfg_name, head, B, T, R, seed, options=None):
     cfg = vo.OracleConfig(bypass_transformer=bool(options.get("bypass")), **cfg_kwargs)
     sd = vo.synth_state_dict(cfg, head, seed)
     batch = vo.synth_batch(cfg, B, T, R, seed, head, alignment=int(options.get("alignment", 0)))
+    if options.get("text_only"):
+        batch = OrderedDict((k, v) for k, v in batch.items() if not k.startswith("image_"))
     model = build_reference_model(cfg_kwargs, head, sd, bypass=cfg.bypass_transformer)
     rec = OrderedDict()
     rec["meta"] = np.array([B, T, R, seed], dtype=np.int64)

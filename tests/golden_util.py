@@ -18,6 +18,7 @@ CASES = {
     "micro_multichoice": ("micro", "multichoice"),
     "micro_vqa_advanced": ("micro", "vqa_advanced"),
     "micro_flickr": ("micro", "flickr"),
+    "micro_textonly": ("micro", "pretraining", dict(text_only=True)),
 }
 LR, WARMUP, T_TOTAL = 5e-5, 0.1, 100
 LOGIT_STRIDE = 509
@@ -32,6 +33,8 @@ def load_case(stem):
     cfg = vo.OracleConfig(bypass_transformer=bool(options.get("bypass")), **vo.CONFIGS[cfg_name])
     sd = vo.synth_state_dict(cfg, head, seed)
     batch = vo.synth_batch(cfg, B, T, R, seed, head, alignment=int(options.get("alignment", 0)))
+    if options.get("text_only"):
+        batch = type(batch)((k, v) for k, v in batch.items() if not k.startswith("image_"))
     return cfg, head, sd, batch, g
 
 

@@ -438,3 +438,26 @@ def test_degenerate_batches_match_oracle(dev):
         ref2 = vo.objective_forward(sd, cfg, head, mode="fp32", **b2)
     assert bool(torch.isnan(ref2["masked_lm_loss"])) and bool(torch.isnan(out2["masked_lm_loss"].cpu()))
     assert maxdiff(out2["seq_relationship_score"].cpu(), ref2["seq_relationship_score"]) < 1e-4
+
+
+def test_text_only_batch_matches_oracle(dev):
+    """no image features at all (image_feat_variable = None): plain BERT over the text (models/model.py:269-270,
+    modeling.py:1213-1221, 1427-1428) -- forward, loss and gradients against the oracle."""
+    cfg, head, sd, batch, g = load_case("micro_pretraining")
+    b = {k: v for k, v in batch.items() if not k.startswith("image_")}
+    model = build_model(cfg, head, sd, dev, dropout=0.0)
+    model.train()
+    out = model(**to_dev(b, dev))
+    out["loss"].backward()
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = vo.objective_forward(leaves, cfg, head, mode="fp32", **b)
+    ref["loss"].backward()
+    assert out["logits"].shape == ref["logits"].shape
+    assert maxdiff(out["logits"].detach().float().cpu(), ref["logits"].detach()) < 1e-4
+    assert abs(float(out["loss"].detach()) - float(ref["loss"].detach())) < 1e-4
+    named = dict(model.bert.named_parameters())
+    for n in ("bert.embeddings.word_embeddings.weight", "bert.encoder.layer.0.attention.self.query.weight",
+              "cls.predictions.transform.dense.weight"):
+        rg = leaves[n].grad
+        assert maxdiff(named[n].grad.detach().cpu(), rg) <= 2e-3 * max(float(rg.norm()), 1e-3), n
+    assert float(named["bert.embeddings.projection.weight"].grad.abs().max()) == 0.0   # untouched without regions

@@ -123,6 +123,7 @@ class ParameterArena(object):
                 p._vb_shadow_ver = -1
         # buckets for the gradient all-reduce: contiguous [start, end) ranges, in arena order
         self.bucket_of = bucket_of
+        self.touched = set()                    # ids of the parameters a backward pass has written since zero_grad()
         self._tables = None
         self._build_transposed()
 
@@ -186,6 +187,7 @@ class ParameterArena(object):
         return lo, hi
 
     def zero_grad(self):
+        self.touched.clear()
         g = self.grad
         nbytes = g.numel() * 4
         if g.is_cuda and nbytes % 16 == 0 and g.data_ptr() % 16 == 0:
@@ -312,6 +314,8 @@ class BertSelfAttention(nn.Module):
             gw = gq.as_strided((3 * H, q.size(1)), (q.size(1), 1), gq.storage_offset())
             gb0 = self.query.bias._vb_grad
             gb = gb0.as_strided((3 * H,), (1,), gb0.storage_offset())
+            q._vb_arena.touched.update(id(p) for p in (q, self.key.weight, self.value.weight, self.query.bias,
+                                                       self.key.bias, self.value.bias))
             return gw, gb, True
         H = q.size(0)
         return (torch.zeros((3 * H, q.size(1)), dtype=torch.float32, device=q.device),
@@ -874,25 +878,9 @@ class TrainVisualBERTObjective(PreTrainedBertModel):
             raise NotImplementedError("training_head_type %r: the reference has %s"
                                       % (training_head_type, ", ".join(self.SUPPORTED_HEADS)))
         self.apply(self.init_bert_weights)
-        self._mark_untouched_parameters()
         self.arena = None
         self.set_compute_dtype(compute_dtype)
         self.build_arena()
-
-    def _mark_untouched_parameters(self):
-        """parameters this head's loss never reaches.  In the reference their .grad stays None and BertAdam skips
-        them -- no moment update, no weight decay (optimization.py:254-255); here gradients are views into one
-        flat arena (always present, zero), so the fused optimizer is told which tensors to leave alone."""
-        head = self.training_head_type
-        untouched = []
-        if head == "vqa_advanced":                          # seq_relationship_score is returned, not trained on
-            untouched = ["cls.seq_relationship."]
-        elif head == "flickr":                              # cls is constructed but never called; no value projection
-            untouched = ["cls.predictions.bias", "cls.predictions.transform.", "cls.seq_relationship.",
-                         "flickr_attention.value."]
-        for n, p in self.named_parameters():
-            if any(n.startswith(u) for u in untouched):
-                p._vb_untouched = True
 
     # -- storage ---------------------------------------------------------------------------------
     def set_compute_dtype(self, dtype):

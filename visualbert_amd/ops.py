@@ -102,6 +102,7 @@ def grad_target(p):
     """(fp32 tensor to accumulate into, direct?)"""
     g = getattr(p, "_vb_grad", None)
     if g is not None:
+        p._vb_arena.touched.add(id(p))          # "this step wrote a gradient for p" (what `.grad is not None` means upstream)
         return g, True
     return torch.zeros(p.shape, dtype=torch.float32, device=p.device), False
 
@@ -771,8 +772,11 @@ class EmbeddingsFn(torch.autograd.Function):
         g_word, d3 = grad_target(m.word_embeddings.weight)
         g_pos, d4 = grad_target(m.position_embeddings.weight)
         g_type, d5 = grad_target(m.token_type_embeddings.weight)
-        g_posv, d6 = grad_target(m.position_embeddings_visual.weight)
-        g_typev, d7 = grad_target(m.token_type_embeddings_visual.weight)
+        g_posv = g_typev = None
+        d6 = d7 = True
+        if R > 0:                                   # text-only input: the visual tables take no part (their .grad stays None upstream)
+            g_posv, d6 = grad_target(m.position_embeddings_visual.weight)
+            g_typev, d7 = grad_target(m.token_type_embeddings_visual.weight)
         dvp = torch.empty((B * R, H), dtype=dtype, device=dz.device) if R > 0 else None
         W = m.word_embeddings.weight
         check(_lib.lib().vb_embed_bwd(

@@ -164,17 +164,33 @@ class BertAdam(Optimizer):
             code = 0
         else:
             code = -1                                    # evaluated on the host, see step()
-        # parameters the model's loss never reaches keep .grad = None in the reference and BertAdam skips them
-        # (optimization.py:254-255): no moments, no weight decay.  The models mark those tensors (_vb_untouched).
-        opt_flags = [id(p) in member and not getattr(p, "_vb_untouched", False) for p in arena.params]
+        opt_flags = [id(p) in member for p in arena.params]
         dec_flags = [member.get(id(p), 0.0) > 0.0 for p in arena.params]
         tt, ct, nt, nc = arena.tables(opt_flags, dec_flags)
         dev = arena.device
         self._fused = dict(arena=arena, tt=tt, ct=ct, nt=nt, nc=nc, code=code, wd=wds[0] if wds else 0.0,
                            m=torch.zeros_like(arena.data), v=torch.zeros_like(arena.data),
                            norm2=torch.zeros(nt, dtype=torch.float32, device=dev),
-                           steps=torch.zeros(nt, dtype=torch.int32, device=dev), host_step=0)
+                           steps=torch.zeros(nt, dtype=torch.int32, device=dev), host_step=0,
+                           opt_flags=opt_flags, dec_flags=dec_flags, skipped=frozenset(), skip_candidates=frozenset())
         return self._fused
+
+    def _skip_untouched(self, f):
+        """The reference's step() skips a parameter whose .grad is None -- no moment update, no weight decay
+        (optimization.py:254-255): a head's unused tensors (cls.* under `flickr`, seq_relationship under `vqa_advanced`), the
+        visual tables on a text-only batch, ...  Here every gradient is a view into the flat arena and always exists, so
+        the backward pass records which parameters it wrote (ParameterArena.touched) and the optimizer's tensor table
+        drops the others; the table is rebuilt only when that set changes.  A parameter that was not recorded but holds a
+        non-zero gradient is optimised anyway (checked once per change of the set)."""
+        a = f["arena"]
+        cand = frozenset(i for i, p in enumerate(a.params) if f["opt_flags"][i] and id(p) not in a.touched)
+        if cand == f["skip_candidates"]:
+            return
+        confirmed = frozenset(i for i in cand if float(a.params[i]._vb_grad.abs().max()) == 0.0)
+        if confirmed != f["skipped"]:
+            flags = [fl and i not in confirmed for i, fl in enumerate(f["opt_flags"])]
+            f["tt"], f["ct"], f["nt"], f["nc"] = a.tables(flags, f["dec_flags"])
+        f["skip_candidates"], f["skipped"] = cand, confirmed
 
     def fused(self):
         f = self._fused
@@ -205,6 +221,7 @@ class BertAdam(Optimizer):
         g = self.param_groups[0]
         sch = g["schedule"]
         L = _lib.lib()
+        self._skip_untouched(f)
         lr, code = float(g["lr"]), f["code"]
         if code < 0:
             # every optimised tensor takes every step, so one host counter mirrors the device's per-tensor counters

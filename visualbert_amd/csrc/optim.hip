@@ -27,7 +27,10 @@ struct AdamHyper {
 // chunk table entry layout (int64 x 4): tensor id, arena offset of the chunk, length, unused
 // tensor table entry layout (int64 x 4): arena offset, numel, shadow offset (-1: none), flags (bit0: optimise, bit1: decay)
 
-VB_KERNEL VB_LAUNCH_BOUNDS(NT) adam_norm_kernel(const float* grads, const int64_t* chunks, float* norm2) {
+// Squared gradient norms per tensor, DETERMINISTICALLY: a chunk's partial goes to its own slot and one thread per tensor
+// adds its chunks' partials in table order.  (A float atomic per chunk made the clip coefficient differ in the last bit
+// from run to run -- and between data-parallel replicas, whose weights then drift apart ulp by ulp.)
+VB_KERNEL VB_LAUNCH_BOUNDS(NT) adam_norm_kernel(const float* grads, const int64_t* chunks, float* partial) {
     VB_DYN_SMEM(smem);
     float* red = (float*)smem;
     const int64_t* c = chunks + (long)blockIdx.x * 4;
@@ -51,7 +54,16 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) adam_norm_kernel(const float* grads, const int64_
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(&norm2[c[0]], red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+VB_KERNEL VB_LAUNCH_BOUNDS(NT) adam_norm_finish_kernel(const int64_t* chunks, int n_chunks, const float* partial, float* norm2) {
+    const int j = blockIdx.x * NT + threadIdx.x;
+    if (j >= n_chunks) return;
+    const int64_t id = chunks[(long)j * 4];
+    if (j > 0 && chunks[(long)(j - 1) * 4] == id) return;            // not the first chunk of its tensor
+    float s = 0.f;
+    for (int k = j; k < n_chunks && chunks[(long)k * 4] == id; ++k) s += partial[k];
+    norm2[id] = s;
 }
 
 VB_DEVICE float schedule_mult(const AdamHyper& h, int step) {
@@ -169,8 +181,10 @@ extern "C" int vb_bert_adam_step(float* params, const float* grads, float* exp_a
     hipStream_t s = (hipStream_t)stream;
     AdamHyper h{lr, b1, b2, eps, max_grad_norm, warmup, t_total, weight_decay, schedule};
     if (max_grad_norm > 0.f) {
-        if (hipMemsetAsync(norm2_ws, 0, sizeof(float) * (size_t)n_tensors, s) != hipSuccess) return VB_ERR_LAUNCH;
-        VB_LAUNCH(adam_norm_kernel, dim3((unsigned)n_chunks), dim3(NT), 64, s, grads, chunk_table, norm2_ws);
+        float* partial = norm2_ws + n_tensors;              // [n_chunks]
+        VB_LAUNCH(adam_norm_kernel, dim3((unsigned)n_chunks), dim3(NT), 64, s, grads, chunk_table, partial);
+        VB_LAUNCH(adam_norm_finish_kernel, dim3((unsigned)((n_chunks + NT - 1) / NT)), dim3(NT), 0, s, chunk_table, n_chunks,
+                  (const float*)partial, norm2_ws);
     }
     VB_LAUNCH(adam_update_kernel, dim3((unsigned)n_chunks), dim3(NT), 0, s, params, grads, exp_avg, exp_avg_sq,
               (bf16*)bf16_shadow, chunk_table, tensor_table, (const float*)norm2_ws, (const int*)step_counters, h);

@@ -170,7 +170,7 @@ class BertAdam(Optimizer):
         dev = arena.device
         self._fused = dict(arena=arena, tt=tt, ct=ct, nt=nt, nc=nc, code=code, wd=wds[0] if wds else 0.0,
                            m=torch.zeros_like(arena.data), v=torch.zeros_like(arena.data),
-                           norm2=torch.zeros(nt, dtype=torch.float32, device=dev),
+                           norm2=torch.zeros(nt + nc, dtype=torch.float32, device=dev),
                            steps=torch.zeros(nt, dtype=torch.int32, device=dev), host_step=0,
                            opt_flags=opt_flags, dec_flags=dec_flags, skipped=frozenset(), skip_candidates=frozenset())
         return self._fused

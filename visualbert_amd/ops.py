@@ -27,13 +27,21 @@ _ACT = {None: VB_ACT_NONE, "none": VB_ACT_NONE, "gelu": VB_ACT_GELU, "tanh": VB_
 # seeds
 # ------------------------------------------------------------------------------------------------
 _seed_counter = [0]
+_seed_replica = [0]
+
+
+def set_replica(rank):
+    """data-parallel rank of this process: replicas draw DIFFERENT dropout masks from the same torch seed (the
+    reference's DataParallel replicas share one generator and therefore never repeat each other's masks either)."""
+    _seed_replica[0] = int(rank)
 
 
 def next_seed():
-    """64-bit dropout seed: torch's global seed mixed with a call counter (deterministic after
+    """64-bit dropout seed: torch's global seed mixed with a call counter and the replica index (deterministic after
     torch.manual_seed for a fixed call order)."""
     _seed_counter[0] += 1
-    return (torch.initial_seed() * 0x9E3779B97F4A7C15 + _seed_counter[0] * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+    return (torch.initial_seed() * 0x9E3779B97F4A7C15 + _seed_counter[0] * 0xD1B54A32D192ED03 +
+            _seed_replica[0] * 0xA24BAED4963EE407) & 0xFFFFFFFFFFFFFFFF
 
 
 def reset_seed_counter(v=0):

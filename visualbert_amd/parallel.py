@@ -54,6 +54,8 @@ class DataParallelGradSync(object):
         self._works = []
         self._done = set()
         self._reserved = False
+        from . import ops
+        ops.set_replica(dist.get_rank(process_group))       # replicas must not repeat each other's dropout masks
         self._install()
 
     def _install(self):

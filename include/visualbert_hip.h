@@ -166,7 +166,7 @@ int vb_small_linear_bwd(int dtype, const float* dy, const void* x, int64_t ldx, 
  * Fused multi-tensor BertAdam over a flat fp32 arena (params / grads / exp_avg / exp_avg_sq share one
  * layout).  tensor_table: int64[n_tensors][4] = {arena offset, numel, bf16-shadow offset or -1,
  * flags (bit0 optimise, bit1 weight decay)}; chunk_table: int64[n_chunks][4] = {tensor id, arena
- * offset, length, 0}, the chunks of one tensor adjacent.  norm2_ws: fp32[n_tensors + n_chunks] scratch (per-tensor squared
+ * offset, length, number of chunks of this tensor}, the chunks of one tensor adjacent.  norm2_ws: fp32[n_tensors + n_chunks] scratch (per-tensor squared
  * norms, summed in table order -- bit-reproducible, so data-parallel replicas stay identical); step_counters:
  * int32[n_tensors] (state).
  * schedule: 0 none, 1 warmup_linear(warmup, t_total).  bf16_shadow may be NULL.

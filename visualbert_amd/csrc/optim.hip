@@ -24,7 +24,7 @@ struct AdamHyper {
     int schedule;      // 0 = none (multiplier 1), 1 = warmup_linear
 };
 
-// chunk table entry layout (int64 x 4): tensor id, arena offset of the chunk, length, unused
+// chunk table entry layout (int64 x 4): tensor id, arena offset of the chunk, length, number of chunks of this tensor
 // tensor table entry layout (int64 x 4): arena offset, numel, shadow offset (-1: none), flags (bit0: optimise, bit1: decay)
 
 // Squared gradient norms per tensor, DETERMINISTICALLY: a chunk's partial goes to its own slot and one thread per tensor
@@ -56,14 +56,17 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) adam_norm_kernel(const float* grads, const int64_
     __syncthreads();
     if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
-VB_KERNEL VB_LAUNCH_BOUNDS(NT) adam_norm_finish_kernel(const int64_t* chunks, int n_chunks, const float* partial, float* norm2) {
-    const int j = blockIdx.x * NT + threadIdx.x;
-    if (j >= n_chunks) return;
+// one wave per tensor (the workgroup of the tensor's FIRST chunk; the others leave): lane l adds the partials of chunks
+// l, l + 64, ... in that order, then a fixed butterfly -- the same bits every time
+VB_KERNEL VB_LAUNCH_BOUNDS(64) adam_norm_finish_kernel(const int64_t* chunks, int n_chunks, const float* partial, float* norm2) {
+    const int j = blockIdx.x;
     const int64_t id = chunks[(long)j * 4];
-    if (j > 0 && chunks[(long)(j - 1) * 4] == id) return;            // not the first chunk of its tensor
+    if (j > 0 && chunks[(long)(j - 1) * 4] == id) return;
+    const int count = (int)chunks[(long)j * 4 + 3];                  // chunks of this tensor (adjacent in the table)
     float s = 0.f;
-    for (int k = j; k < n_chunks && chunks[(long)k * 4] == id; ++k) s += partial[k];
-    norm2[id] = s;
+    for (int k = threadIdx.x; k < count; k += 64) s += partial[j + k];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) norm2[id] = s;
 }
 
 VB_DEVICE float schedule_mult(const AdamHyper& h, int step) {
@@ -183,7 +186,7 @@ extern "C" int vb_bert_adam_step(float* params, const float* grads, float* exp_a
     if (max_grad_norm > 0.f) {
         float* partial = norm2_ws + n_tensors;              // [n_chunks]
         VB_LAUNCH(adam_norm_kernel, dim3((unsigned)n_chunks), dim3(NT), 64, s, grads, chunk_table, partial);
-        VB_LAUNCH(adam_norm_finish_kernel, dim3((unsigned)((n_chunks + NT - 1) / NT)), dim3(NT), 0, s, chunk_table, n_chunks,
+        VB_LAUNCH(adam_norm_finish_kernel, dim3((unsigned)n_chunks), dim3(64), 0, s, chunk_table, n_chunks,
                   (const float*)partial, norm2_ws);
     }
     VB_LAUNCH(adam_update_kernel, dim3((unsigned)n_chunks), dim3(NT), 0, s, params, grads, exp_avg, exp_avg_sq,

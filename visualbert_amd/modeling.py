@@ -202,8 +202,9 @@ class ParameterArena(object):
             flags = (1 if optimise_flags[i] else 0) | (2 if decay_flags[i] else 0)
             tens += [o, p.numel(), o if p.dim() == 2 else -1, flags]
             n = p.numel()
+            count = (n + self.CHUNK - 1) // self.CHUNK
             for s in range(0, n, self.CHUNK):
-                chunks += [i, o + s, min(self.CHUNK, n - s), 0]
+                chunks += [i, o + s, min(self.CHUNK, n - s), count]
         t = torch.tensor(tens, dtype=torch.int64).to(self.device)
         c = torch.tensor(chunks, dtype=torch.int64).to(self.device)
         return t, c, len(self.params), len(chunks) // 4

@@ -255,6 +255,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(NT, 3) attn_fwd_kernel(AttnArgs a) {
         sum += __shfl_xor(sum, 16);
         sum += __shfl_xor(sum, 32);
         const float inv = 1.0f / sum;
+        const float invk = inv * a.inv_keep;               // normalisation and 1/(1-p) in one factor
         if (a.lse && lg == 0 && qok) a.lse[(long)bh * S + q] = m + logf(sum);
 
         // normalise, dropout (keep-bits recorded), round to T as the MFMA B operand
@@ -271,7 +272,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(NT, 3) attn_fwd_kernel(AttnArgs a) {
                 for (int e = 0; e < 8; ++e) {
                     const int kf = 2 * kp + (e >> 2), r = e & 3;
                     const bool keep = rand8_keep(rnd, e, a.thresh);
-                    st[kf][r] = keep ? st[kf][r] * inv * a.inv_keep : 0.f;
+                    st[kf][r] = keep ? st[kf][r] * invk : 0.f;
                     if (keep) bits[kf >> 4] |= (uint64_t)1 << ((kf & 15) * 4 + r);
                 }
             } else {

@@ -1,4 +1,5 @@
 """Host-side data path: vectorised masking against the oracle's restatement of the reference loop."""
+import pytest
 import torch
 
 from oracle import visualbert_oracle as vo
@@ -82,3 +83,39 @@ def test_lr_schedules_match_reference_classes():
         got = [sch.get_lr(s) for s in range(len(case["lr"]))]
         assert max(abs(a - b) for a, b in zip(got, case["lr"])) < 1e-12, case["schedule"]
     assert opt.WarmupLinearSchedule(warmup=0.1, t_total=-1).get_lr(7) == 1.0
+
+
+def test_from_pretrained_local_archive_and_legacy_names(tmp_path):
+    """PreTrainedBertModel.from_pretrained (modeling.py:486-596) on a local directory: bert_config.json + pytorch_model.bin
+    with the TF-era LayerNorm.gamma / beta names (:556-568); tensors the archive lacks (the visual tables of a plain BERT
+    checkpoint) keep their initialisation; random_initialize=True skips the weights."""
+    import json
+    from visualbert_amd.modeling import BertConfig, TrainVisualBERTObjective
+    cfg = BertConfig(1000, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=512)
+    src = TrainVisualBERTObjective(cfg, "pretraining", visual_embedding_dim=256)
+    sd = {}
+    for k, v in src.state_dict().items():
+        if "_visual" in k or "projection" in k:
+            continue                                          # a text-only BERT archive has none of these
+        sd[k.replace("LayerNorm.weight", "LayerNorm.gamma").replace("LayerNorm.bias", "LayerNorm.beta")] = v.clone()
+    with open(tmp_path / "bert_config.json", "w") as f:
+        f.write(cfg.to_json_string())
+    torch.save(sd, tmp_path / "pytorch_model.bin")
+    assert json.loads(cfg.to_json_string())["hidden_size"] == 128
+    torch.manual_seed(5)
+    got = TrainVisualBERTObjective.from_pretrained(str(tmp_path), training_head_type="pretraining", visual_embedding_dim=256)
+    own, ref = got.state_dict(), src.state_dict()
+    for k in ref:
+        if k.endswith("projection.bias"):
+            continue                                          # zero in both (init_bert_weights)
+        if "_visual" in k or "projection" in k:
+            assert not torch.equal(own[k], ref[k]), k         # not in the archive: fresh initialisation
+        else:
+            assert torch.equal(own[k], ref[k]), k
+    assert got.cls.predictions.decoder.weight is got.bert.embeddings.word_embeddings.weight     # still tied, still in the arena
+    assert got.bert.embeddings.word_embeddings.weight._vb_arena is got.arena
+    rnd = TrainVisualBERTObjective.from_pretrained(str(tmp_path), random_initialize=True, training_head_type="pretraining",
+                                                   visual_embedding_dim=256)
+    assert not torch.equal(rnd.state_dict()["bert.pooler.dense.weight"], ref["bert.pooler.dense.weight"])
+    with pytest.raises(FileNotFoundError):
+        TrainVisualBERTObjective.from_pretrained("bert-base-uncased", training_head_type="pretraining")

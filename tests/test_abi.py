@@ -92,3 +92,16 @@ def test_schedules_match_oracle():
     s = WarmupLinearSchedule(warmup=0.1, t_total=100)
     for step in (0, 1, 5, 10, 11, 50, 99, 100, 150):
         assert abs(s.get_lr(step) - vo.schedule_lr(step, 100, 0.1)) < 1e-12
+
+
+def test_product_package_never_touches_the_oracle():
+    """oracle/ is test infrastructure: nothing under visualbert_amd/ (Python or kernel sources) may import, load or name it."""
+    import glob
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    offenders = []
+    for path in glob.glob(os.path.join(root, "visualbert_amd", "**", "*"), recursive=True):
+        if os.path.isfile(path) and path.endswith((".py", ".hip", ".h", "Makefile")):
+            if "oracle" in open(path, errors="ignore").read():
+                offenders.append(os.path.relpath(path, root))
+    assert not offenders, offenders

@@ -121,15 +121,19 @@ int vb_align_pos_bwd(int dtype, const void* dz, const int64_t* alignment, float*
  * mask_add: fp32 [B,S] additive key mask ((1 - mask) * -10000, modeling.py:1293-1294),
  * ctx: T [B*S, H], lse: fp32 [B,nh,S] row log-sum-exp (saved for backward),
  * keepbits: uint64 [B*nh * vb_attn_keepbits_words(S)] dropout keep-bits (only touched when p_drop > 0).
- * Backward writes dqkv (T [B*S,3H]) completely; dsum_ws is an fp32 [B,nh,S] scratch.
+ * Backward writes dqkv (T [B*S,3H]) completely; dsum_ws is an fp32 [B,nh,S] scratch.  ctx_fwd (optional): the forward
+ * output ctx -- with it, bf16 and S <= 192 the backward runs as ONE kernel (D = rowsum(P o dP) taken as dO . ctx,
+ * scores and probabilities computed once); without it, or for longer sequences / fp32, as two passes (dQ, then dK/dV).
  * Replaces: BertSelfAttention.forward modeling.py:236-256 and its autograd.
  * ---------------------------------------------------------------------------------------------- */
 int64_t vb_attn_keepbits_words(int S);
 int vb_attn_fwd(int dtype, const void* qkv, const float* mask_add, void* ctx, float* lse, uint64_t* keepbits,
                 int B, int S, int nh, int head_dim, float p_drop, uint64_t seed, uint32_t stream_id, void* stream);
 int vb_attn_bwd(int dtype, const void* qkv, const float* mask_add, const void* dctx, const float* lse,
-                const uint64_t* keepbits, float* dsum_ws, void* dqkv, int B, int S, int nh, int head_dim,
-                float p_drop, uint64_t seed, uint32_t stream_id, void* stream);
+                const uint64_t* keepbits, float* dsum_ws, void* dqkv, const void* ctx_fwd,
+                int B, int S, int nh, int head_dim, float p_drop, uint64_t seed, uint32_t stream_id, void* stream);
+/* measurement knob: 1 forces the two-pass backward even when ctx_fwd is given */
+int vb_attn_set_two_pass(int on);
 
 /* ------------------------------------------------------------------------------------------------
  * Losses.  logits are fp32 with leading dimension ld_logits (pad columns are ignored).

@@ -23,4 +23,8 @@ for p in (0.0, 0.1):
     ctx, lse, bits = ops.attn_fwd(qkv, mask, B, S, nh, p, 5, 3)
     tf = bench(lambda: ops.attn_fwd(qkv, mask, B, S, nh, p, 5, 3))
     tb = bench(lambda: ops.attn_bwd(qkv, mask, dctx, lse, bits, B, S, nh, p, 5, 3))
-    print("B=%d p=%.1f: fwd %.1f us (%.0f TF)  bwd %.1f us (%.0f TF)" % (B, p, tf, flops / tf / 1e6, tb, 2.5 * flops / tb / 1e6))
+    t1 = bench(lambda: ops.attn_bwd(qkv, mask, dctx, lse, bits, B, S, nh, p, 5, 3, ctx_fwd=ctx))
+    tb2 = bench(lambda: ops.attn_bwd(qkv, mask, dctx, lse, bits, B, S, nh, p, 5, 3))
+    t12 = bench(lambda: ops.attn_bwd(qkv, mask, dctx, lse, bits, B, S, nh, p, 5, 3, ctx_fwd=ctx))
+    print("B=%d p=%.1f: fwd %.1f us (%.0f TF)  bwd two-pass %.1f / %.1f us (%.0f TF)  bwd one-pass %.1f / %.1f us" % (
+        B, p, tf, flops / tf / 1e6, tb, tb2, 2.5 * flops / tb / 1e6, t1, t12))

@@ -180,7 +180,7 @@ VB_DEVICE void store4(float* p, const f32x4& v) { *(f32x4*)p = v; }
 
 struct AttnArgs {
     const void* qkv; const float* mask_add; void* ctx; float* lse; uint64_t* keepbits;   // forward
-    const void* dctx; void* dqkv; float* dsum;                                            // backward
+    const void* dctx; void* dqkv; float* dsum; const void* ctx_fwd;                       // backward
     int B, S, nh; float scale; float p; float inv_keep; uint32_t thresh; uint32_t stream; uint64_t seed;
 };
 
@@ -564,6 +564,201 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) attn_bwd_dkv_kernel(AttnArgs a) {
     }
 }
 
+
+// =================================================================================================
+// backward in ONE pass (bf16, S <= 192, needs the forward output O = ctx): the two-pass form above computes every
+// score, probability and dP twice (once per pass) and its dQ pass alone is 45 % of the backward time -- per-probability
+// VALU work, not MFMAs, bounds these kernels.  Here one workgroup of 12 waves owns a (batch, head).  Per chunk of 64 queries:
+//   phase A  wave w owns key fragment w exactly like the dK/dV pass (lane <-> key): S, P, dP, dS once; dV^T += dO^T P,
+//            dK^T += Q^T dS; its dS fragment is also written to a [64 queries][192 keys] tile in LDS.
+//            D = rowsum(P o dP) comes from dO . O (same value, dropout included: O = P_drop V), computed while staging.
+//   phase B  the 16 (query fragment, d block) outputs of dQ = dS K for the chunk are split over the waves: full-depth MFMAs
+//            with dS from the tile and K^T from an LDS image built once per (batch, head) -- no atomics, no second exp.
+// (A first version added per-wave dQ partials into an LDS tile with ds_add_f32: 7x slower than two passes.)
+// =================================================================================================
+constexpr int FWPB = 12, FNT = FWPB * 64, FNK = FWPB * 16;  // 192 keys
+constexpr int TSP = FNK * 2 + 8;                           // dS tile pitch in bytes (pad: 16 rows -> distinct banks)
+
+template <int NKF>
+VB_KERNEL VB_LAUNCH_BOUNDS(FNT) attn_bwd_fused_kernel(AttnArgs a) {
+    typedef bf16 T;
+    constexpr int NW = (NKF + 15) / 16;
+    VB_DYN_SMEM(smem);
+    unsigned char* ldsQ = smem;
+    unsigned char* ldsDO = ldsQ + rm_bytes<T>(QC);
+    unsigned char* ldsQT = ldsDO + rm_bytes<T>(QC);
+    unsigned char* ldsDOT = ldsQT + tr_bytes<T>(QC);
+    float* ldsLse = (float*)(ldsDOT + tr_bytes<T>(QC));
+    float* ldsD = ldsLse + QC;
+    uint64_t* ldsBits = (uint64_t*)(ldsD + QC);           // [QC][4][NW]
+    unsigned char* ldsKT = (unsigned char*)(ldsBits + QC * 4 * NW);   // K^T of the whole sequence: [64 d][FNK keys]
+    unsigned char* ldsDS = ldsKT + tr_bytes<T>(FNK);       // dS of the chunk: [QC queries][FNK keys], pitch TSP
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, lg = lane >> 4;
+    const int bh = blockIdx.x, b = bh / a.nh, h = bh % a.nh;
+    const int S = a.S, H = a.nh * D;
+    const long ldx = 3L * H, row0 = (long)b * S;
+    const T* qkv = (const T*)a.qkv;
+    const T* dctx = (const T*)a.dctx;
+    const T* octx = (const T*)a.ctx_fwd;
+
+    {   // K^T image (one row pair x 16-byte chunk per thread: 96 pairs x 8 chunks = 768 items) and a zeroed dS tile
+        PairTile<FNK> tk;
+        pair_load<FNK>(tk, qkv, ldx, row0, H + h * D, S, t);
+        pair_store_tr<FNK>(tk, ldsKT, t);
+        for (int i = t; i < QC * TSP / 8; i += FNT) *(uint64_t*)(ldsDS + i * 8) = 0;
+    }
+    const int kf = wave;
+    const int key = kf * 16 + li;
+    const bool wave_on = kf * 16 < S;                      // wave-uniform
+    const bool kok = key < S;
+    const T* krow = qkv + (row0 + (kok ? key : 0)) * ldx + H + h * D;
+    const T* vrow = qkv + (row0 + (kok ? key : 0)) * ldx + 2 * H + h * D;
+    bf16x8 kb[2], vb[2];
+    kb[0] = frag_g(krow, 0, lg, kok); kb[1] = frag_g(krow, 1, lg, kok);
+    vb[0] = frag_g(vrow, 0, lg, kok); vb[1] = frag_g(vrow, 1, lg, kok);
+    const float mk = kok ? a.mask_add[(long)b * S + key] : -INFINITY;
+    f32x4 dkT[4], dvT[4];
+#pragma unroll
+    for (int df = 0; df < 4; ++df) { dkT[df] = f32x4{0.f, 0.f, 0.f, 0.f}; dvT[df] = dkT[df]; }
+
+    constexpr int BPT = (QC * 4 * NW + FNT - 1) / FNT;
+    const int st = t & 255, role = t >> 8;                 // threads 0..255 stage Q, 256..511 stage dO (and D), 512.. nothing
+    const int sdc = st & 7, sr = (st >> 3) * 2;            // rows q0 + sr, q0 + sr + 1; 16-byte column chunk sdc
+    u32x4 c0 = u32x4{0u, 0u, 0u, 0u}, c1 = c0;
+    float c_lse = INFINITY;
+    uint64_t c_bits[BPT];
+    auto load_chunk = [&](int q0) {
+        const u32x4 z = u32x4{0u, 0u, 0u, 0u};
+        const bool ok0 = q0 + sr < S, ok1 = q0 + sr + 1 < S;
+        if (role == 0) {
+            c0 = ok0 ? *(const u32x4*)(qkv + (row0 + q0 + sr) * ldx + h * D + sdc * 8) : z;
+            c1 = ok1 ? *(const u32x4*)(qkv + (row0 + q0 + sr + 1) * ldx + h * D + sdc * 8) : z;
+        } else if (role == 1) {
+            c0 = ok0 ? *(const u32x4*)(dctx + (row0 + q0 + sr) * (long)H + h * D + sdc * 8) : z;
+            c1 = ok1 ? *(const u32x4*)(dctx + (row0 + q0 + sr + 1) * (long)H + h * D + sdc * 8) : z;
+        }
+        if (t < QC) c_lse = q0 + t < S ? a.lse[(long)bh * S + q0 + t] : INFINITY;      // exp(x - inf) = 0 for padded queries
+#pragma unroll
+        for (int j = 0; j < BPT; ++j) {
+            const int i = t + j * FNT;
+            const int q = q0 + i / (4 * NW);
+            c_bits[j] = (a.p > 0.f && i < QC * 4 * NW && q < S) ? a.keepbits[((long)bh * S + q0) * 4 * NW + i] : ~(uint64_t)0;
+        }
+    };
+    auto store_tr2 = [&](unsigned char* lds, const u32x4& x0, const u32x4& x1) {
+        const int pitch = tr_pitch<bf16>(QC);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const uint32_t a0 = x0[w], b0 = x1[w];
+            *(uint32_t*)(lds + (sdc * 8 + 2 * w) * pitch + sr * 2) = (a0 & 0xFFFFu) | (b0 << 16);
+            *(uint32_t*)(lds + (sdc * 8 + 2 * w + 1) * pitch + sr * 2) = (a0 >> 16) | (b0 & 0xFFFF0000u);
+        }
+    };
+    auto store_chunk = [&](int q0) {
+        if (role < 2) {
+            unsigned char* rm = role == 0 ? ldsQ : ldsDO;
+            *(u32x4*)(rm + rm_off<T>(sr, sdc)) = c0;
+            *(u32x4*)(rm + rm_off<T>(sr + 1, sdc)) = c1;
+            store_tr2(role == 0 ? ldsQT : ldsDOT, c0, c1);
+        }
+        if (role == 1) {                                   // D[q] = dO[q] . O[q]: 8 products per thread, 8 threads per row
+            const u32x4 z = u32x4{0u, 0u, 0u, 0u};          // (O is fetched here, not a chunk ahead: registers)
+            const u32x4 o0 = q0 + sr < S ? *(const u32x4*)(octx + (row0 + q0 + sr) * (long)H + h * D + sdc * 8) : z;
+            const u32x4 o1 = q0 + sr + 1 < S ? *(const u32x4*)(octx + (row0 + q0 + sr + 1) * (long)H + h * D + sdc * 8) : z;
+            const bf16x8 d0 = *(const bf16x8*)&c0, d1 = *(const bf16x8*)&c1, p0 = *(const bf16x8*)&o0, p1 = *(const bf16x8*)&o1;
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s0 += (float)d0[j] * (float)p0[j]; s1 += (float)d1[j] * (float)p1[j]; }
+            s0 += __shfl_xor(s0, 1); s0 += __shfl_xor(s0, 2); s0 += __shfl_xor(s0, 4);
+            s1 += __shfl_xor(s1, 1); s1 += __shfl_xor(s1, 2); s1 += __shfl_xor(s1, 4);
+            if (sdc == 0) { ldsD[sr] = s0; ldsD[sr + 1] = s1; }
+        }
+        if (t < QC) ldsLse[t] = c_lse;
+#pragma unroll
+        for (int j = 0; j < BPT; ++j) if (t + j * FNT < QC * 4 * NW) ldsBits[t + j * FNT] = c_bits[j];
+    };
+    load_chunk(0);
+
+    for (int q0 = 0; q0 < S; q0 += QC) {
+        __syncthreads();                                   // previous chunk fully consumed (phase B done with the dS tile)
+        store_chunk(q0);
+        __syncthreads();
+        if (q0 + QC < S) load_chunk(q0 + QC);
+        // ---- phase A
+        if (wave_on) {
+#pragma unroll
+            for (int qc = 0; qc < QC / 32; ++qc) {
+                if (q0 + qc * 32 >= S) continue;
+                f32x4 pd[2], dsv[2];
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const int qf = 2 * qc + hf;            // fragment index inside the chunk
+                    f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = s;
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        s = vb_mma(frag_rm(ldsQ, qf * 16 + li, ks, lg, T()), kb[ks], s);
+                        dp = vb_mma(frag_rm(ldsDO, qf * 16 + li, ks, lg, T()), vb[ks], dp);
+                    }
+                    // lane: key = kf*16 + li (column), queries q0 + qf*16 + lg*4 + r (rows)
+                    const f32x4 lse4 = *(const f32x4*)(ldsLse + qf * 16 + lg * 4);
+                    const f32x4 d4 = *(const f32x4*)(ldsD + qf * 16 + lg * 4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int ql = qf * 16 + lg * 4 + r;
+                        const float p = fast_exp(s[r] * a.scale + mk - lse4[r]);
+                        const uint64_t w = ldsBits[(ql * 4 + (li >> 2)) * NW + (kf >> 4)];
+                        const bool keep = (w >> ((kf & 15) * 4 + (li & 3))) & 1;
+                        const float pdrop = keep ? p * a.inv_keep : 0.f;
+                        const float dpv = keep ? dp[r] * a.inv_keep : 0.f;
+                        pd[hf][r] = pdrop;
+                        dsv[hf][r] = p * (dpv - d4[r]) * a.scale;
+                        *(bf16*)(ldsDS + ql * TSP + (kf * 16 + li) * 2) = (bf16)dsv[hf][r];      // dS as [query][key]
+                    }
+                }
+                bf16x8 pb, dsb;
+                pack_b(pb, pd[0], pd[1]);
+                pack_b(dsb, dsv[0], dsv[1]);
+#pragma unroll
+                for (int df = 0; df < 4; ++df) {
+                    dvT[df] = vb_mma(frag_tr(ldsDOT, tr_pitch<T>(QC), df * 16 + li, qc, lg, T()), pb, dvT[df]);
+                    dkT[df] = vb_mma(frag_tr(ldsQT, tr_pitch<T>(QC), df * 16 + li, qc, lg, T()), dsb, dkT[df]);
+                }
+            }
+        }
+        __syncthreads();                                   // the chunk's dS tile is complete
+        // ---- phase B: dQ^T block (d rows df*16.., query columns qf*16..) = K^T dS^T over all keys
+        for (int blk = wave; blk < 16; blk += FWPB) {
+            const int qf = blk >> 2, df = blk & 3;
+            const int q = q0 + qf * 16 + li;
+            if (q0 + qf * 16 >= S) continue;
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < FNK / 32; ++ks) {
+                if (ks * 32 >= S) continue;
+                // B operand: lane (n = query li, g = lg) holds dS[q][key(g, j)], key(g, j) = 32 ks + 16 (j >> 2) + 4 g + (j & 3)
+                const unsigned char* src = ldsDS + (qf * 16 + li) * TSP + (32 * ks + 4 * lg) * 2;
+                const bf16x4 lo = *(const bf16x4*)src, hi = *(const bf16x4*)(src + 32);
+                const bf16x8 dsb = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                acc = vb_mma(frag_tr(ldsKT, tr_pitch<T>(FNK), df * 16 + li, ks, lg, T()), dsb, acc);
+            }
+            if (q < S) store4((T*)a.dqkv + (row0 + q) * ldx + h * D + df * 16 + lg * 4, acc);
+        }
+    }
+    if (kok) {
+        T* dkrow = (T*)a.dqkv + (row0 + key) * ldx + H + h * D;
+        T* dvrow = (T*)a.dqkv + (row0 + key) * ldx + 2 * H + h * D;
+#pragma unroll
+        for (int df = 0; df < 4; ++df) {
+            store4(dkrow + df * 16 + lg * 4, dkT[df]);
+            store4(dvrow + df * 16 + lg * 4, dvT[df]);
+        }
+    }
+}
+template <int NKF> size_t fused_smem() {
+    return 2 * rm_bytes<bf16>(QC) + 2 * tr_bytes<bf16>(QC) + 2 * QC * 4 + (size_t)QC * 4 * ((NKF + 15) / 16) * 8 +
+           tr_bytes<bf16>(FNK) + (size_t)QC * TSP;
+}
+
 template <typename T, int NKF> size_t fwd_smem() { return rm_bytes<T>(NKF * 16) + tr_bytes<T>(NKF * 16) + NKF * 16 * 4; }
 template <typename T, int NKF> size_t dq_smem() { return 2 * rm_bytes<T>(NKF * 16) + tr_bytes<T>(NKF * 16) + NKF * 16 * 4; }
 template <typename T, int NKF> size_t dkv_smem() {
@@ -571,6 +766,7 @@ template <typename T, int NKF> size_t dkv_smem() {
 }
 
 constexpr size_t kMaxLds = 160 * 1024;
+static int g_attn_two_pass = 0;                            // measurement knob: force the two-pass backward
 
 template <typename T, int NKF>
 int launch_all(int which, const AttnArgs& a, hipStream_t s) {
@@ -580,6 +776,12 @@ int launch_all(int which, const AttnArgs& a, hipStream_t s) {
         if (sm > kMaxLds) return VB_ERR_UNSUPPORTED;
         VB_LAUNCH((attn_fwd_kernel<T, NKF>), grid, block, sm, s, a);
     } else {
+        if constexpr (sizeof(T) == 2 && NKF <= 12) {
+            if (a.ctx_fwd && a.S <= FWPB * 16 && !g_attn_two_pass) {     // one-pass backward (needs the forward output)
+                VB_LAUNCH((attn_bwd_fused_kernel<NKF>), grid, dim3(FNT), fused_smem<NKF>(), s, a);
+                return vb_check_launch();
+            }
+        }
         const size_t sm1 = dq_smem<T, NKF>(), sm2 = dkv_smem<T, NKF>();
         if (sm1 > kMaxLds || sm2 > kMaxLds) return VB_ERR_UNSUPPORTED;
         VB_LAUNCH((attn_bwd_dq_kernel<T, NKF>), grid, block, sm1, s, a);
@@ -637,15 +839,18 @@ extern "C" int vb_attn_fwd(int dtype, const void* qkv, const float* mask_add, vo
     return VB_ERR_ARG;
 }
 
+extern "C" int vb_attn_set_two_pass(int on) { g_attn_two_pass = on; return VB_OK; }
+
 extern "C" int vb_attn_bwd(int dtype, const void* qkv, const float* mask_add, const void* dctx, const float* lse,
-                           const uint64_t* keepbits, float* dsum_ws, void* dqkv, int B, int S, int nh, int head_dim,
+                           const uint64_t* keepbits, float* dsum_ws, void* dqkv, const void* ctx_fwd,
+                           int B, int S, int nh, int head_dim,
                            float p_drop, uint64_t seed, uint32_t stream_id, void* stream) {
     AttnArgs a{};
     int rc = fill_args(a, B, S, nh, head_dim, p_drop, seed, stream_id);
     if (rc) return rc;
     if (!qkv || !mask_add || !dctx || !lse || !dsum_ws || !dqkv || (p_drop > 0.f && !keepbits)) return VB_ERR_ARG;
     a.qkv = qkv; a.mask_add = mask_add; a.dctx = dctx; a.lse = (float*)lse; a.keepbits = (uint64_t*)keepbits;
-    a.dsum = dsum_ws; a.dqkv = dqkv;
+    a.dsum = dsum_ws; a.dqkv = dqkv; a.ctx_fwd = ctx_fwd;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == VB_BF16) return dispatch_nkf<bf16>(1, a, s);
     if (dtype == VB_F32) return dispatch_nkf<float>(1, a, s);

@@ -185,7 +185,7 @@ extern "C" int vb_bert_layer_bwd(int dtype, const void* h_in, const float* mask_
     // 5. dgrad attention-out: dctx = dao Wo
     VB_TRY(dgrad(dao, H, wo, VB_LWT_AO, H, sc.t_h3, nullptr, VB_ACT_NONE, nullptr));
     // 6-7. attention backward (dQ pass, dK/dV pass)
-    VB_TRY(vb_attn_bwd(dtype, sv.qkv, mask_add, sc.t_h3, sv.lse, sv.keepbits, sc.dsum, sc.t_3h, B, S, nh, 64, p_attn,
+    VB_TRY(vb_attn_bwd(dtype, sv.qkv, mask_add, sc.t_h3, sv.lse, sv.keepbits, sc.dsum, sc.t_3h, sv.ctx, B, S, nh, 64, p_attn,
                        seed, sid, stream));
     // 8. bias gradient QKV
     VB_TRY(vb_colsum(dtype, sc.t_3h, 3 * H, G[VB_LW_QKV_B], nullptr, M, 3 * H, stream));

@@ -125,12 +125,17 @@ VB_DEVICE void vb_glds16(const void* gsrc, unsigned char* lds_wave_base) {
     memcpy(lds_wave_base + ::hipemu::cur()->lane * 16, gsrc, 16);
 }
 VB_DEVICE void vb_atomic_add_noret(float* p, float v) { ::hipemu::atomic_add_f32(p, v); }
+VB_DEVICE void vb_lds_add(float* p, float v) { ::hipemu::atomic_add_f32(p, v); }
 #else
 VB_DEVICE void vb_glds16(const void* gsrc, unsigned char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 VB_DEVICE void vb_atomic_add_noret(float* p, float v) { unsafeAtomicAdd(p, v); }   // global_atomic_add_f32, no return
+// fp32 add into LDS (ds_add_f32): p must point into the workgroup's LDS
+VB_DEVICE void vb_lds_add(float* p, float v) {
+    __builtin_amdgcn_ds_faddf((__attribute__((address_space(3))) float*)p, v, 0, 0, false);
+}
 #endif
 
 // counted wait for outstanding vector-memory operations (LDS-direct copies included) + raw workgroup

@@ -273,13 +273,15 @@ def attn_fwd(qkv, mask_add, B, S, nh, p, seed, sid):
     return ctx, lse, bits
 
 
-def attn_bwd(qkv, mask_add, dctx, lse, bits, B, S, nh, p, seed, sid):
+def attn_bwd(qkv, mask_add, dctx, lse, bits, B, S, nh, p, seed, sid, ctx_fwd=None):
+    """ctx_fwd: the forward output (enables the one-pass bf16 backward, see vb_attn_bwd)."""
     dqkv = torch.empty_like(qkv)
     ws = torch.empty((B, nh, S), dtype=torch.float32, device=qkv.device)
     if not dctx.is_contiguous():
         dctx = dctx.contiguous()
     check(_lib.lib().vb_attn_bwd(_lib.dtype_code(qkv.dtype), ptr(qkv), ptr(mask_add), ptr(dctx), ptr(lse), ptr(bits),
-                                 ptr(ws), ptr(dqkv), B, S, nh, 64, float(p), seed, sid, stream_ptr()), "vb_attn_bwd")
+                                 ptr(ws), ptr(dqkv), ptr(ctx_fwd), B, S, nh, 64, float(p), seed, sid, stream_ptr()),
+          "vb_attn_bwd")
     return dqkv
 
 
@@ -475,17 +477,17 @@ class SelfAttentionCoreFn(torch.autograd.Function):
         c, lse, bits = attn_fwd(q2, mask_add, B, S, nh, p, seed, sid)
         ctx.cfg = (B, S, nh, p, seed, sid)
         ctx.bits = bits
-        ctx.save_for_backward(q2, mask_add, lse)
+        ctx.save_for_backward(q2, mask_add, lse, c)
         return c.view(B, S, H3 // 3)
 
     @staticmethod
     def backward(ctx, dctx):
-        q2, mask_add, lse = ctx.saved_tensors
+        q2, mask_add, lse, c = ctx.saved_tensors
         B, S, nh, p, seed, sid = ctx.cfg
         d2 = dctx.reshape(B * S, -1)
         if d2.dtype != q2.dtype:
             d2 = d2.to(q2.dtype)
-        dqkv = attn_bwd(q2, mask_add, d2, lse, ctx.bits, B, S, nh, p, seed, sid)
+        dqkv = attn_bwd(q2, mask_add, d2, lse, ctx.bits, B, S, nh, p, seed, sid, ctx_fwd=c)
         return dqkv.view(B, S, -1), None, None, None, None
 
 
@@ -538,7 +540,7 @@ class AttentionBlockFn(torch.autograd.Function):
         g_ow, d4 = grad_target(so.dense.weight)
         linear_wgrad(dao, c, g_ow)
         dctx = linear_dgrad(dao, weight_for(so.dense.weight, dt))
-        dqkv = attn_bwd(qkv, mask_add, dctx, lse, ctx.bits, B, S, sa.num_attention_heads, p_attn, seed, sid)
+        dqkv = attn_bwd(qkv, mask_add, dctx, lse, ctx.bits, B, S, sa.num_attention_heads, p_attn, seed, sid, ctx_fwd=c)
         g_qkv_w, g_qkv_b, direct_qkv = sa.qkv_grad_targets()
         colsum(dqkv, g_qkv_b)
         linear_wgrad(dqkv, h2, g_qkv_w)

@@ -579,20 +579,20 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) attn_bwd_dkv_kernel(AttnArgs a) {
 constexpr int FWPB = 12, FNT = FWPB * 64, FNK = FWPB * 16;  // 192 keys
 constexpr int TSP = FNK * 2 + 8;                           // dS tile pitch in bytes (pad: 16 rows -> distinct banks)
 
-template <int NKF>
+template <int NKF, int CQ>
 VB_KERNEL VB_LAUNCH_BOUNDS(FNT) attn_bwd_fused_kernel(AttnArgs a) {
     typedef bf16 T;
     constexpr int NW = (NKF + 15) / 16;
     VB_DYN_SMEM(smem);
     unsigned char* ldsQ = smem;
-    unsigned char* ldsDO = ldsQ + rm_bytes<T>(QC);
-    unsigned char* ldsQT = ldsDO + rm_bytes<T>(QC);
-    unsigned char* ldsDOT = ldsQT + tr_bytes<T>(QC);
-    float* ldsLse = (float*)(ldsDOT + tr_bytes<T>(QC));
-    float* ldsD = ldsLse + QC;
-    uint64_t* ldsBits = (uint64_t*)(ldsD + QC);           // [QC][4][NW]
-    unsigned char* ldsKT = (unsigned char*)(ldsBits + QC * 4 * NW);   // K^T of the whole sequence: [64 d][FNK keys]
-    unsigned char* ldsDS = ldsKT + tr_bytes<T>(FNK);       // dS of the chunk: [QC queries][FNK keys], pitch TSP
+    unsigned char* ldsDO = ldsQ + rm_bytes<T>(CQ);
+    unsigned char* ldsQT = ldsDO + rm_bytes<T>(CQ);
+    unsigned char* ldsDOT = ldsQT + tr_bytes<T>(CQ);
+    float* ldsLse = (float*)(ldsDOT + tr_bytes<T>(CQ));
+    float* ldsD = ldsLse + CQ;
+    uint64_t* ldsBits = (uint64_t*)(ldsD + CQ);           // [CQ][4][NW]
+    unsigned char* ldsKT = (unsigned char*)(ldsBits + CQ * 4 * NW);   // K^T of the whole sequence: [64 d][FNK keys]
+    unsigned char* ldsDS = ldsKT + tr_bytes<T>(FNK);       // dS of the chunk: [CQ queries][FNK keys], pitch TSP
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, lg = lane >> 4;
     const int bh = blockIdx.x, b = bh / a.nh, h = bh % a.nh;
     const int S = a.S, H = a.nh * D;
@@ -605,7 +605,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS(FNT) attn_bwd_fused_kernel(AttnArgs a) {
         PairTile<FNK> tk;
         pair_load<FNK>(tk, qkv, ldx, row0, H + h * D, S, t);
         pair_store_tr<FNK>(tk, ldsKT, t);
-        for (int i = t; i < QC * TSP / 8; i += FNT) *(uint64_t*)(ldsDS + i * 8) = 0;
+        for (int i = t; i < CQ * TSP / 8; i += FNT) *(uint64_t*)(ldsDS + i * 8) = 0;
     }
     const int kf = wave;
     const int key = kf * 16 + li;
@@ -621,8 +621,9 @@ VB_KERNEL VB_LAUNCH_BOUNDS(FNT) attn_bwd_fused_kernel(AttnArgs a) {
 #pragma unroll
     for (int df = 0; df < 4; ++df) { dkT[df] = f32x4{0.f, 0.f, 0.f, 0.f}; dvT[df] = dkT[df]; }
 
-    constexpr int BPT = (QC * 4 * NW + FNT - 1) / FNT;
-    const int st = t & 255, role = t >> 8;                 // threads 0..255 stage Q, 256..511 stage dO (and D), 512.. nothing
+    constexpr int BPT = (CQ * 4 * NW + FNT - 1) / FNT;
+    constexpr int SI = CQ * 4;                             // staging items per tensor (row pair x 16-byte chunk)
+    const int st = t % SI, role = t / SI;                  // role 0 stages Q, role 1 dO (and D), the rest nothing
     const int sdc = st & 7, sr = (st >> 3) * 2;            // rows q0 + sr, q0 + sr + 1; 16-byte column chunk sdc
     u32x4 c0 = u32x4{0u, 0u, 0u, 0u}, c1 = c0;
     float c_lse = INFINITY;
@@ -637,16 +638,16 @@ VB_KERNEL VB_LAUNCH_BOUNDS(FNT) attn_bwd_fused_kernel(AttnArgs a) {
             c0 = ok0 ? *(const u32x4*)(dctx + (row0 + q0 + sr) * (long)H + h * D + sdc * 8) : z;
             c1 = ok1 ? *(const u32x4*)(dctx + (row0 + q0 + sr + 1) * (long)H + h * D + sdc * 8) : z;
         }
-        if (t < QC) c_lse = q0 + t < S ? a.lse[(long)bh * S + q0 + t] : INFINITY;      // exp(x - inf) = 0 for padded queries
+        if (t < CQ) c_lse = q0 + t < S ? a.lse[(long)bh * S + q0 + t] : INFINITY;      // exp(x - inf) = 0 for padded queries
 #pragma unroll
         for (int j = 0; j < BPT; ++j) {
             const int i = t + j * FNT;
             const int q = q0 + i / (4 * NW);
-            c_bits[j] = (a.p > 0.f && i < QC * 4 * NW && q < S) ? a.keepbits[((long)bh * S + q0) * 4 * NW + i] : ~(uint64_t)0;
+            c_bits[j] = (a.p > 0.f && i < CQ * 4 * NW && q < S) ? a.keepbits[((long)bh * S + q0) * 4 * NW + i] : ~(uint64_t)0;
         }
     };
     auto store_tr2 = [&](unsigned char* lds, const u32x4& x0, const u32x4& x1) {
-        const int pitch = tr_pitch<bf16>(QC);
+        const int pitch = tr_pitch<bf16>(CQ);
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
             const uint32_t a0 = x0[w], b0 = x1[w];
@@ -673,21 +674,21 @@ VB_KERNEL VB_LAUNCH_BOUNDS(FNT) attn_bwd_fused_kernel(AttnArgs a) {
             s1 += __shfl_xor(s1, 1); s1 += __shfl_xor(s1, 2); s1 += __shfl_xor(s1, 4);
             if (sdc == 0) { ldsD[sr] = s0; ldsD[sr + 1] = s1; }
         }
-        if (t < QC) ldsLse[t] = c_lse;
+        if (t < CQ) ldsLse[t] = c_lse;
 #pragma unroll
-        for (int j = 0; j < BPT; ++j) if (t + j * FNT < QC * 4 * NW) ldsBits[t + j * FNT] = c_bits[j];
+        for (int j = 0; j < BPT; ++j) if (t + j * FNT < CQ * 4 * NW) ldsBits[t + j * FNT] = c_bits[j];
     };
     load_chunk(0);
 
-    for (int q0 = 0; q0 < S; q0 += QC) {
+    for (int q0 = 0; q0 < S; q0 += CQ) {
         __syncthreads();                                   // previous chunk fully consumed (phase B done with the dS tile)
         store_chunk(q0);
         __syncthreads();
-        if (q0 + QC < S) load_chunk(q0 + QC);
+        if (q0 + CQ < S) load_chunk(q0 + CQ);
         // ---- phase A
         if (wave_on) {
 #pragma unroll
-            for (int qc = 0; qc < QC / 32; ++qc) {
+            for (int qc = 0; qc < CQ / 32; ++qc) {
                 if (q0 + qc * 32 >= S) continue;
                 f32x4 pd[2], dsv[2];
 #pragma unroll
@@ -720,14 +721,14 @@ VB_KERNEL VB_LAUNCH_BOUNDS(FNT) attn_bwd_fused_kernel(AttnArgs a) {
                 pack_b(dsb, dsv[0], dsv[1]);
 #pragma unroll
                 for (int df = 0; df < 4; ++df) {
-                    dvT[df] = vb_mma(frag_tr(ldsDOT, tr_pitch<T>(QC), df * 16 + li, qc, lg, T()), pb, dvT[df]);
-                    dkT[df] = vb_mma(frag_tr(ldsQT, tr_pitch<T>(QC), df * 16 + li, qc, lg, T()), dsb, dkT[df]);
+                    dvT[df] = vb_mma(frag_tr(ldsDOT, tr_pitch<T>(CQ), df * 16 + li, qc, lg, T()), pb, dvT[df]);
+                    dkT[df] = vb_mma(frag_tr(ldsQT, tr_pitch<T>(CQ), df * 16 + li, qc, lg, T()), dsb, dkT[df]);
                 }
             }
         }
         __syncthreads();                                   // the chunk's dS tile is complete
         // ---- phase B: dQ^T block (d rows df*16.., query columns qf*16..) = K^T dS^T over all keys
-        for (int blk = wave; blk < 16; blk += FWPB) {
+        for (int blk = wave; blk < (CQ / 16) * 4; blk += FWPB) {
             const int qf = blk >> 2, df = blk & 3;
             const int q = q0 + qf * 16 + li;
             if (q0 + qf * 16 >= S) continue;
@@ -754,9 +755,9 @@ VB_KERNEL VB_LAUNCH_BOUNDS(FNT) attn_bwd_fused_kernel(AttnArgs a) {
         }
     }
 }
-template <int NKF> size_t fused_smem() {
-    return 2 * rm_bytes<bf16>(QC) + 2 * tr_bytes<bf16>(QC) + 2 * QC * 4 + (size_t)QC * 4 * ((NKF + 15) / 16) * 8 +
-           tr_bytes<bf16>(FNK) + (size_t)QC * TSP;
+template <int NKF, int CQ> size_t fused_smem() {
+    return 2 * rm_bytes<bf16>(CQ) + 2 * tr_bytes<bf16>(CQ) + 2 * CQ * 4 + (size_t)CQ * 4 * ((NKF + 15) / 16) * 8 +
+           tr_bytes<bf16>(FNK) + (size_t)CQ * TSP;
 }
 
 template <typename T, int NKF> size_t fwd_smem() { return rm_bytes<T>(NKF * 16) + tr_bytes<T>(NKF * 16) + NKF * 16 * 4; }
@@ -777,8 +778,10 @@ int launch_all(int which, const AttnArgs& a, hipStream_t s) {
         VB_LAUNCH((attn_fwd_kernel<T, NKF>), grid, block, sm, s, a);
     } else {
         if constexpr (sizeof(T) == 2 && NKF <= 12) {
-            if (a.ctx_fwd && a.S <= FWPB * 16 && !g_attn_two_pass) {     // one-pass backward (needs the forward output)
-                VB_LAUNCH((attn_bwd_fused_kernel<NKF>), grid, dim3(FNT), fused_smem<NKF>(), s, a);
+            if (a.ctx_fwd && a.S <= FWPB * 16 && g_attn_two_pass != 1) {  // one-pass backward (needs the forward output)
+                // 64-query chunks (86 KB of LDS, one workgroup per CU): 528-541 us per layer at B=512; 32-query chunks (two
+                // workgroups per CU, twice the barriers): 575 us
+                VB_LAUNCH((attn_bwd_fused_kernel<NKF, 64>), grid, dim3(FNT), (fused_smem<NKF, 64>()), s, a);
                 return vb_check_launch();
             }
         }

@@ -601,10 +601,18 @@ VB_KERNEL VB_LAUNCH_BOUNDS(FNT) attn_bwd_fused_kernel(AttnArgs a) {
     const T* dctx = (const T*)a.dctx;
     const T* octx = (const T*)a.ctx_fwd;
 
-    {   // K^T image (one row pair x 16-byte chunk per thread: 96 pairs x 8 chunks = 768 items) and a zeroed dS tile
-        PairTile<FNK> tk;
-        pair_load<FNK>(tk, qkv, ldx, row0, H + h * D, S, t);
-        pair_store_tr<FNK>(tk, ldsKT, t);
+    {   // K^T image (one row pair x 16-byte chunk per thread: 96 pairs x 8 chunks = 768 items = FNT) and a zeroed dS tile
+        const int dc = t & 7, r = (t >> 3) * 2;             // exactly one item per thread (PairTile strides by 256)
+        const u32x4 z = u32x4{0u, 0u, 0u, 0u};
+        const u32x4 x0 = r < S ? *(const u32x4*)(qkv + (row0 + r) * ldx + H + h * D + dc * 8) : z;
+        const u32x4 x1 = r + 1 < S ? *(const u32x4*)(qkv + (row0 + r + 1) * ldx + H + h * D + dc * 8) : z;
+        const int pitch = tr_pitch<bf16>(FNK);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const uint32_t lo = x0[w], hi = x1[w];
+            *(uint32_t*)(ldsKT + (dc * 8 + 2 * w) * pitch + r * 2) = (lo & 0xFFFFu) | (hi << 16);
+            *(uint32_t*)(ldsKT + (dc * 8 + 2 * w + 1) * pitch + r * 2) = (lo >> 16) | (hi & 0xFFFF0000u);
+        }
         for (int i = t; i < CQ * TSP / 8; i += FNT) *(uint64_t*)(ldsDS + i * 8) = 0;
     }
     const int kf = wave;

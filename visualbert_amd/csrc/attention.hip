@@ -584,14 +584,21 @@ VB_KERNEL VB_LAUNCH_BOUNDS(FNT) attn_bwd_fused_kernel(AttnArgs a) {
     typedef bf16 T;
     constexpr int NW = (NKF + 15) / 16;
     VB_DYN_SMEM(smem);
-    unsigned char* ldsQ = smem;
-    unsigned char* ldsDO = ldsQ + rm_bytes<T>(CQ);
-    unsigned char* ldsQT = ldsDO + rm_bytes<T>(CQ);
-    unsigned char* ldsDOT = ldsQT + tr_bytes<T>(CQ);
-    float* ldsLse = (float*)(ldsDOT + tr_bytes<T>(CQ));
-    float* ldsD = ldsLse + CQ;
-    uint64_t* ldsBits = (uint64_t*)(ldsD + CQ);           // [CQ][4][NW]
-    unsigned char* ldsKT = (unsigned char*)(ldsBits + CQ * 4 * NW);   // K^T of the whole sequence: [64 d][FNK keys]
+    // two sets of chunk images: chunk c+1 is written to LDS while the slower waves still compute on chunk c
+    constexpr int SETB = 2 * rm_bytes<T>(CQ) + 2 * tr_bytes<T>(CQ) + 2 * CQ * 4 + CQ * 4 * NW * 8;
+    unsigned char *ldsQ, *ldsDO, *ldsQT, *ldsDOT;
+    float *ldsLse, *ldsD;
+    uint64_t* ldsBits;                                     // [CQ][4][NW]
+    auto use_set = [&](int set) {
+        ldsQ = smem + set * SETB;
+        ldsDO = ldsQ + rm_bytes<T>(CQ);
+        ldsQT = ldsDO + rm_bytes<T>(CQ);
+        ldsDOT = ldsQT + tr_bytes<T>(CQ);
+        ldsLse = (float*)(ldsDOT + tr_bytes<T>(CQ));
+        ldsD = ldsLse + CQ;
+        ldsBits = (uint64_t*)(ldsD + CQ);
+    };
+    unsigned char* ldsKT = smem + 2 * SETB;                // K^T of the whole sequence: [64 d][FNK keys]
     unsigned char* ldsDS = ldsKT + tr_bytes<T>(FNK);       // dS of the chunk: [CQ queries][FNK keys], pitch TSP
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, lg = lane >> 4;
     const int bh = blockIdx.x, b = bh / a.nh, h = bh % a.nh;
@@ -687,12 +694,14 @@ VB_KERNEL VB_LAUNCH_BOUNDS(FNT) attn_bwd_fused_kernel(AttnArgs a) {
         for (int j = 0; j < BPT; ++j) if (t + j * FNT < CQ * 4 * NW) ldsBits[t + j * FNT] = c_bits[j];
     };
     load_chunk(0);
+    use_set(0);
+    store_chunk(0);
+    __syncthreads();                                       // chunk 0, the K^T image and the zeroed tile are in LDS
+    if (CQ < S) load_chunk(CQ);
 
-    for (int q0 = 0; q0 < S; q0 += CQ) {
-        __syncthreads();                                   // previous chunk fully consumed (phase B done with the dS tile)
-        store_chunk(q0);
-        __syncthreads();
-        if (q0 + CQ < S) load_chunk(q0 + CQ);
+    int cur = 0;
+    for (int q0 = 0; q0 < S; q0 += CQ, cur ^= 1) {
+        use_set(cur);
         // ---- phase A
         if (wave_on) {
 #pragma unroll
@@ -734,7 +743,12 @@ VB_KERNEL VB_LAUNCH_BOUNDS(FNT) attn_bwd_fused_kernel(AttnArgs a) {
                 }
             }
         }
-        __syncthreads();                                   // the chunk's dS tile is complete
+        if (q0 + CQ < S) {                                 // the next chunk's images go to the other set meanwhile
+            use_set(cur ^ 1);
+            store_chunk(q0 + CQ);
+        }
+        __syncthreads();                                   // the chunk's dS tile is complete, the next chunk is staged
+        if (q0 + 2 * CQ < S) load_chunk(q0 + 2 * CQ);
         // ---- phase B: dQ^T block (d rows df*16.., query columns qf*16..) = K^T dS^T over all keys
         for (int blk = wave; blk < (CQ / 16) * 4; blk += FWPB) {
             const int qf = blk >> 2, df = blk & 3;
@@ -752,6 +766,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS(FNT) attn_bwd_fused_kernel(AttnArgs a) {
             }
             if (q < S) store4((T*)a.dqkv + (row0 + q) * ldx + h * D + df * 16 + lg * 4, acc);
         }
+        __syncthreads();                                   // phase B is done with the tile before the next phase A writes it
     }
     if (kok) {
         T* dkrow = (T*)a.dqkv + (row0 + key) * ldx + H + h * D;
@@ -764,7 +779,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS(FNT) attn_bwd_fused_kernel(AttnArgs a) {
     }
 }
 template <int NKF, int CQ> size_t fused_smem() {
-    return 2 * rm_bytes<bf16>(CQ) + 2 * tr_bytes<bf16>(CQ) + 2 * CQ * 4 + (size_t)CQ * 4 * ((NKF + 15) / 16) * 8 +
+    return 2 * (2 * rm_bytes<bf16>(CQ) + 2 * tr_bytes<bf16>(CQ) + 2 * CQ * 4 + (size_t)CQ * 4 * ((NKF + 15) / 16) * 8) +
            tr_bytes<bf16>(FNK) + (size_t)CQ * TSP;
 }
 

@@ -351,6 +351,7 @@ def decode_keepbits(bits, B, nh, S):
 
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("cfg", [(2, 40, 2, 0.0), (1, 164, 2, 0.0), (2, 23, 3, 0.1), (1, 164, 1, 0.1),
+                                 (1, 192, 1, 0.1), (2, 177, 2, 0.0),     # edges of the one-pass bf16 backward (12 key fragments)
                                  (1, 300, 1, 0.1), (1, 416, 1, 0.1)])    # 416 = NLVR2 as the reference runs it (2x144 + 128)
 def test_attention_fwd_bwd(dev, dt, cfg):
     B, S, nh, p = cfg

@@ -46,11 +46,24 @@ CASES = [
     ("micro_vqa_advanced", "micro", "vqa_advanced", 3, 12, 5, 7),
     ("micro_flickr", "micro", "flickr", 3, 12, 6, 8),
     ("micro_textonly", "micro", "pretraining", 3, 12, 5, 10, dict(text_only=True)),   # image_feat_variable = None
+    # BASELINE.json configs[1], [3], [4] at their REAL size (BERT-base 12L/768), batch large enough that the token-major
+    # GEMMs span several 256-row tiles.  compact=True: large tensors are stored as strided sub-samples (SUB_MAX elements)
+    ("base_pretraining_b16", "base", "pretraining", 16, 128, 36, 31, dict(compact=True)),   # S = 164, M = 2624 tokens
+    ("base_vqa_b16", "base", "vqa", 16, 20, 36, 32, dict(compact=True)),                    # S = 56
+    ("base_nlvr_b8", "base", "nlvr", 8, 40, 72, 33, dict(compact=True)),                    # S = 112 (2 x 36 regions)
 ]
 
 LR, WARMUP, T_TOTAL = 5e-5, 0.1, 100
 LOGIT_STRIDE = 509
 N_STEPS = 3
+SUB_MAX = 1024          # compact cases: at most this many strided elements of a large tensor are stored
+
+
+def sub(t):
+    """strided sub-sample of a tensor (the same rule on both sides of a comparison: tests/golden_util.sub)."""
+    f = t.detach().reshape(-1)
+    step = max(1, f.numel() // SUB_MAX)
+    return f[::step][:SUB_MAX].float().numpy().copy()
 
 
 def build_reference_model(cfg_kwargs, head, sd, bypass=False):
@@ -122,7 +135,11 @@ def make_case(stem, cfg_name, head, B, T, R, seed, options=None):
     with torch.no_grad():
         out = reference_forward(model, batch)
     hook.remove()
-    rec["sequence_output"] = captured[0][0].numpy()
+    compact = bool(options.get("compact"))
+    if compact:
+        rec["sequence_output_sub"] = captured[0][0][:, :, ::13].numpy()
+    else:
+        rec["sequence_output"] = captured[0][0].numpy()
     rec["pooled_output"] = captured[0][1].numpy()
     rec["loss"] = out["loss"].double().numpy()
     if head == "vqa_advanced":
@@ -167,6 +184,8 @@ def make_case(stem, cfg_name, head, B, T, R, seed, options=None):
         gnames.append(n)
         rec["grad_norm/" + n] = p.grad.double().norm().numpy()
         rec["grad_head/" + n] = head16(p.grad)
+        if compact:
+            rec["grad_sub/" + n] = sub(p.grad)
     import warnings
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
@@ -183,6 +202,8 @@ def make_case(stem, cfg_name, head, B, T, R, seed, options=None):
         rec["post_norm/" + n] = p.detach().double().norm().numpy()
         rec["post_head/" + n] = head16(p)
         rec["delta_norm/" + n] = (p.detach() - sd[n]).double().norm().numpy()
+        if compact:
+            rec["delta_sub/" + n] = sub(p.detach() - sd[n])
     rec["grad_names"] = np.array(gnames)
     os.makedirs(GOLDEN_DIR, exist_ok=True)
     path = os.path.join(GOLDEN_DIR, stem + ".npz")

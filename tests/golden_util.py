@@ -20,14 +20,30 @@ CASES = {
     "micro_flickr": ("micro", "flickr"),
     "micro_textonly": ("micro", "pretraining", dict(text_only=True)),
 }
+# BASELINE.json configs[1], [3], [4] at BERT-base size (compact goldens: strided sub-samples of the large tensors);
+# kept out of CASES because the micro-case tests iterate over it and read full tensors
+BASE_CASES = {
+    "base_pretraining_b16": ("base", "pretraining"),
+    "base_vqa_b16": ("base", "vqa"),
+    "base_nlvr_b8": ("base", "nlvr"),
+}
+SUB_MAX = 1024
+
+
+def sub(t):
+    """the strided sub-sample rule of oracle/make_golden.py (compact cases)."""
+    f = t.detach().reshape(-1)
+    step = max(1, f.numel() // SUB_MAX)
+    return f[::step][:SUB_MAX].float()
 LR, WARMUP, T_TOTAL = 5e-5, 0.1, 100
 LOGIT_STRIDE = 509
 N_STEPS = 3
 
 
 def load_case(stem):
-    cfg_name, head = CASES[stem][:2]
-    options = CASES[stem][2] if len(CASES[stem]) > 2 else {}
+    table = CASES if stem in CASES else BASE_CASES
+    cfg_name, head = table[stem][:2]
+    options = table[stem][2] if len(table[stem]) > 2 else {}
     g = np.load(os.path.join(GOLDEN_DIR, stem + ".npz"), allow_pickle=False)
     B, T, R, seed = [int(x) for x in g["meta"]]
     cfg = vo.OracleConfig(bypass_transformer=bool(options.get("bypass")), **vo.CONFIGS[cfg_name])

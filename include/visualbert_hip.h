@@ -17,6 +17,11 @@
  *   - dtype: VB_F32 or VB_BF16 selects the storage type "T" of activations / GEMM operands;
  *     statistics, losses, parameters' master copies and parameter gradients are always fp32.
  *   - row-major everywhere; `ld*` are leading dimensions in ELEMENTS.
+ *   - re-entrant per stream: entry points keep no process-wide tuning state.  Launch options are attached to a STREAM
+ *     (vb_stream_set_opts) and read by the calls enqueued on that stream only; the RCCL communicator is an object the
+ *     caller owns (vb_comm_*).  The one process-wide facility is the opt-in HIP-event recorder vb_gemm_profile (a
+ *     measurement aid).  Knobs that change results or exist only for kernel analysis are NOT in this header: they live
+ *     in visualbert_hip_dev.h and exist only in libvisualbert_hip_dev.so (built with -DVB_DEV_KNOBS).
  */
 #ifndef VISUALBERT_HIP_H
 #define VISUALBERT_HIP_H
@@ -34,6 +39,27 @@ enum { VB_ACT_NONE = 0, VB_ACT_GELU = 1, VB_ACT_TANH = 2, VB_ACT_GELU_GRAD = 3,
 
 /* library / build identification: returns a static string such as "visualbert_hip gfx950 r1" */
 const char* vb_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Per-stream launch options (all zero = defaults).  They select among kernels that compute the SAME result; they
+ * never change numerics beyond summation order.  Calls on other streams are unaffected (tests/test_kernels.py::
+ * test_stream_options_do_not_leak_across_streams).
+ *   persistent_workgroups: workgroups launched by the persistent GEMM kernels; 0 = one per compute unit.  A
+ *                          data-parallel caller lowers it while RCCL kernels are resident (parallel.py).
+ *   nt_kernel: K-contiguous x K-contiguous bf16 GEMM kernel; 0 = chosen from the shape; 22 / 42 = two-barrier 128x128 /
+ *              256x128 tiles; 80 / 81 = persistent 256x256 tile, eight / four slots per K tile; 90 = 256x128 tiles, two
+ *              workgroups per compute unit.
+ *   attn_two_pass: 1 = two-pass attention backward even where the one-pass kernel applies.
+ * vb_stream_set_opts(stream, NULL) forgets the stream's entry (call it before destroying a stream).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct vb_stream_opts {
+    int persistent_workgroups;
+    int nt_kernel;
+    int attn_two_pass;
+    int reserved;
+} vb_stream_opts;
+int vb_stream_set_opts(void* stream, const vb_stream_opts* opts);
+int vb_stream_get_opts(void* stream, vb_stream_opts* out);
 
 /* ------------------------------------------------------------------------------------------------
  * GEMM with fused epilogue.   C[M,N] = epi( alpha * sum_k Aop[m,k] * Bop[n,k] )
@@ -132,8 +158,6 @@ int vb_attn_fwd(int dtype, const void* qkv, const float* mask_add, void* ctx, fl
 int vb_attn_bwd(int dtype, const void* qkv, const float* mask_add, const void* dctx, const float* lse,
                 const uint64_t* keepbits, float* dsum_ws, void* dqkv, const void* ctx_fwd,
                 int B, int S, int nh, int head_dim, float p_drop, uint64_t seed, uint32_t stream_id, void* stream);
-/* measurement knob: 1 forces the two-pass backward even when ctx_fwd is given */
-int vb_attn_set_two_pass(int on);
 
 /* ------------------------------------------------------------------------------------------------
  * Losses.  logits are fp32 with leading dimension ld_logits (pad columns are ignored).
@@ -173,12 +197,16 @@ int vb_small_linear_bwd(int dtype, const float* dy, const void* x, int64_t ldx, 
  * offset, length, number of chunks of this tensor}, the chunks of one tensor adjacent.  norm2_ws: fp32[n_tensors + n_chunks] scratch (per-tensor squared
  * norms, summed in table order -- bit-reproducible, so data-parallel replicas stay identical); step_counters:
  * int32[n_tensors] (state).
+ * touched: optional fp32[n_tensors] on the device; tensor t takes NO step (no moments, no weight decay, no counter
+ * increment) when touched[t] == 0 and its gradient norm is 0 -- what `p.grad is None` means to the reference's loop
+ * (optimization.py:254-255).  The decision is taken on the device, every step, from data that is identical on every
+ * data-parallel rank once the flags have been all-reduced like the gradients (parallel.py).
  * schedule: 0 none, 1 warmup_linear(warmup, t_total).  bf16_shadow may be NULL.
  * Replaces BertAdam.step, optimization.py:239-304 (+ WarmupLinearSchedule :164-173).
  * ---------------------------------------------------------------------------------------------- */
 int vb_bert_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                       void* bf16_shadow, const int64_t* chunk_table, int n_chunks,
-                      const int64_t* tensor_table, int n_tensors, float* norm2_ws, int* step_counters,
+                      const int64_t* tensor_table, int n_tensors, const float* touched, float* norm2_ws, int* step_counters,
                       float lr, float b1, float b2, float eps, float weight_decay,
                       float max_grad_norm, float warmup, float t_total, int schedule, void* stream);
 int vb_refresh_bf16_shadow(const float* params, void* bf16_shadow, const int64_t* chunk_table,
@@ -284,24 +312,26 @@ int vb_wgrad_grouped(int dtype, int n, const void* const* dy, const int64_t* ld_
                      const int64_t* ld_x, void* const* dw, const int64_t* ld_dw, const int* n_out, const int* n_in,
                      int tokens, float alpha, const float* alpha_dev, void* stream);
 
-/* Tuning knob (measurement aid): selects the pipelined K-contiguous x K-contiguous GEMM kernel.
- * variant = 10 * (waves in M: 2 -> 128x128 tile, 4 -> 256x128 tile) + LDS stages (2..4); 0 = generic kernel. */
-int vb_gemm_set_variant(int variant);
-/* ablation switch for kernel analysis (results are WRONG when non-zero): 1 skip tile loads, 2 skip fragment
- * reads, 4 skip MFMAs in the pipelined kernel */
-int vb_gemm_set_debug(int bits);
-/* workgroups launched by the persistent 256x256 eight-phase kernel (variant 80); 0 = one per compute unit.
- * Small values make one workgroup walk several output tiles on small test problems. */
-int vb_gemm_set_persistent_wgs(int n);
-/* debug bit 64 (256x128 pipelined kernel, bf16): waves 0 and 4 of workgroup 0 write per-K-tile shader-clock stamps
- * {landed, barrier, copies issued, frags0, mfma0, frags1, mfma1} to this device buffer (uint64[2][64][8]) */
-int vb_gemm_set_trace(void* device_u64x1024);
-/* MFMA issue-rate ceiling micro-kernel (measurement aid): kind 0 = 16x16x32 bf16, 1 = 32x32x16 bf16; each
- * wave of each 512-thread block issues iters x 524288 FLOP; out: fp32[blocks*512] sink */
-int vb_mfma_peak(int kind, int iters, int blocks, float* out, void* stream);
-/* global -> LDS (LDS-direct) streaming ceiling (measurement aid): each wave of each 512-thread block streams iters
- * 1-KiB pieces from a span-byte window with `depth` (1,2,4,8,16) pieces in flight */
-int vb_glds_stream(int depth, const void* src, int64_t span, int iters, int blocks, float* sink, void* stream);
+/* ------------------------------------------------------------------------------------------------
+ * Gradient all-reduce over RCCL (xGMI), one communicator per process / GPU.
+ * Replaces nn.DataParallel's per-step broadcast + reduce-add (models/model_wrapper.py:75, 146; train.py:146): every rank
+ * owns a replica, and the flat fp32 gradient arena is averaged bucket by bucket while backward is still running.
+ *   vb_comm_unique_id: rank 0 fills VB_COMM_ID_BYTES bytes (ncclGetUniqueId); the caller ships them to the other ranks by
+ *                      any host channel (the Python side uses torch.distributed's store).
+ *   vb_comm_init:      collective over all ranks (ncclCommInitRank on the CURRENT device); *comm receives an opaque handle.
+ *   vb_allreduce_bucket: in-place sum (average != 0: mean over ranks, ncclAvg) of `count` elements of `dtype`
+ *                      (VB_F32 / VB_BF16), enqueued on `stream`; no host synchronisation.
+ *   vb_comm_destroy:   frees the communicator.
+ * librccl is opened at the first vb_comm_* call (the copy already mapped into the process, e.g. PyTorch's, else
+ * librccl.so.1 from the loader path); a single-GPU user never needs it.  Errors: VB_ERR_UNSUPPORTED when RCCL cannot be
+ * loaded, VB_ERR_LAUNCH when an RCCL call fails.
+ * ---------------------------------------------------------------------------------------------- */
+#define VB_COMM_ID_BYTES 128
+int vb_comm_unique_id(void* host_id);
+int vb_comm_init(const void* host_id, int rank, int nranks, void** comm);
+int vb_comm_nranks(void* comm);
+int vb_allreduce_bucket(void* comm, void* buf, int64_t count, int dtype, int average, void* stream);
+int vb_comm_destroy(void* comm);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,31 @@
+/* visualbert_hip_dev.h -- developer-only entry points of libvisualbert_hip_dev.so (built with -DVB_DEV_KNOBS).
+ *
+ * NOT part of the product ABI (include/visualbert_hip.h) and not exported by libvisualbert_hip.so: ablation switches that
+ * make results WRONG, in-kernel timelines and pure measurement kernels.  tools/*.py and bench.py's MFMA-ceiling
+ * measurement bind this library; the visualbert_amd package never needs it.  These knobs are process-wide state. */
+#ifndef VISUALBERT_HIP_DEV_H
+#define VISUALBERT_HIP_DEV_H
+
+#include "visualbert_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ablation switch for kernel analysis (results are WRONG when non-zero): 1 skip tile loads, 2 skip fragment
+ * reads, 4 skip MFMAs in the pipelined kernel, 128 predicate the epilogue's global stores off */
+int vb_gemm_set_debug(int bits);
+/* debug bit 64 (256x128 pipelined kernel, bf16): waves 0 and 4 of workgroup 0 write per-K-tile shader-clock stamps
+ * {landed, barrier, copies issued, frags0, mfma0, frags1, mfma1} to this device buffer (uint64[2][64][8]) */
+int vb_gemm_set_trace(void* device_u64x1024);
+/* MFMA issue-rate ceiling micro-kernel (measurement aid): kind 0 = 16x16x32 bf16, 1 = 32x32x16 bf16, 2 = kind 0 with
+ * operands that change every instruction; each wave of each 512-thread block issues iters x 524288 FLOP; out: fp32[blocks*512] sink */
+int vb_mfma_peak(int kind, int iters, int blocks, float* out, void* stream);
+/* global -> LDS (LDS-direct) streaming ceiling (measurement aid): each wave of each 512-thread block streams iters
+ * 1-KiB pieces from a span-byte window with `depth` (1,2,4,8,16) pieces in flight */
+int vb_glds_stream(int depth, const void* src, int64_t span, int iters, int blocks, float* sink, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

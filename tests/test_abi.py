@@ -11,10 +11,12 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SO = os.path.join(ROOT, "visualbert_amd", "libvisualbert_hip.so")
 HDR = os.path.join(ROOT, "include", "visualbert_hip.h")
+DEV_HDR = os.path.join(ROOT, "include", "visualbert_hip_dev.h")
+DEV_SO = os.path.join(ROOT, "visualbert_amd", "libvisualbert_hip_dev.so")
 
 
-def header_symbols():
-    txt = open(HDR).read()
+def header_symbols(path=HDR):
+    txt = open(path).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(vb_[a-z0-9_]+)\s*\(", txt)))
 
@@ -33,6 +35,22 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     lib.vb_version.restype = ctypes.c_char_p
     assert b"gfx950" in lib.vb_version()
+
+
+def test_developer_knobs_are_not_in_the_product_library():
+    """ablation bits, timelines and measurement kernels (include/visualbert_hip_dev.h) exist only in the developer build."""
+    from visualbert_amd import _lib
+    dev_syms = [s for s in header_symbols(DEV_HDR) if s not in header_symbols()]
+    assert sorted(dev_syms) == sorted(_lib.DEV_SIGNATURES.keys())
+    if not (os.path.isfile(SO) and os.path.isfile(DEV_SO)):
+        import __graft_entry__ as g
+        g.build()
+    lib, dev = ctypes.CDLL(SO), ctypes.CDLL(DEV_SO)
+    for name in dev_syms:
+        assert not hasattr(lib, name), name
+        assert hasattr(dev, name), name
+    for name in header_symbols():
+        assert hasattr(dev, name), name
 
 
 def test_missing_library_fails_loudly(tmp_path):

@@ -118,8 +118,7 @@ def test_wgrad_grouped_transposing_reads(dev, tokens, wgs):
     shapes = [(264, 520), (768, 256), (8, 72), (282, 45)]       # (out, in); the last: neither a multiple of 8
     dys = [padded(tokens, o, dt, dev, g) for o, _ in shapes]
     xs = [padded(tokens, i, dt, dev, g) for _, i in shapes]
-    try:
-        assert L.vb_gemm_set_persistent_wgs(wgs) == 0
+    with _lib.stream_opts(persistent_workgroups=wgs):
         dws = [torch.full((o, i), 1.5, device=dev) for o, i in shapes]
         sc = torch.tensor([0.5], device=dev)
         _wgrad_grouped(dev, dys, xs, dws, tokens, alpha=2.0, alpha_dev=sc)
@@ -131,8 +130,6 @@ def test_wgrad_grouped_transposing_reads(dev, tokens, wgs):
         C = gemm(dev, dt, dys[0], xs[0], shapes[0][0], shapes[0][1], tokens, 1, 1, out_f32=True, acc=acc)
         ref = -1.0 + dys[0].float().t() @ xs[0].float()
         assert (C - ref).abs().max().item() <= 2e-4 * max(1.0, ref.abs().max().item())
-    finally:
-        L.vb_gemm_set_persistent_wgs(0)
 
 
 @pytest.mark.parametrize("dt", DTYPES)
@@ -398,7 +395,7 @@ def test_attention_fwd_bwd(dev, dt, cfg):
         assert err <= tol(dt, 5e-5, 0.04) * max(1.0, gmax), (err, gmax, fwd_out is not None)
 
 
-@pytest.mark.parametrize("variant", [0, 22, 42, 80, 81])
+@pytest.mark.parametrize("variant", [1, 22, 42, 80, 81, 90])
 def test_gemm_pipelined_variants_agree(dev, variant):
     """every pipelined K-contiguous kernel variant (tile shape x LDS stages, counted vmcnt, ping-pong,
     256x256) must give the generic kernel's answer -- on hardware this is what validates the
@@ -411,16 +408,13 @@ def test_gemm_pipelined_variants_agree(dev, variant):
     B = padded(N, K, dt, dev, g)
     bias = torch.randn(N, generator=g).to(dev)
     ref = A.float() @ B.float().t() + bias
-    try:
-        assert L.vb_gemm_set_variant(variant) == 0
+    with _lib.stream_opts(nt_kernel=variant):
         for _ in range(3):
             C = gemm(dev, dt, A, B, M, N, K, 0, 0, out_f32=True, bias=bias)
             assert (C - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
-    finally:
-        L.vb_gemm_set_variant(1)
 
 
-@pytest.mark.parametrize("variant", [22, 42, 80, 81])
+@pytest.mark.parametrize("variant", [22, 42, 80, 81, 90])
 def test_gemm_specialised_epilogues(dev, variant):
     """the K-contiguous fast kernels carry ONE epilogue each (activation and optional operands are template
     parameters, picked by the launcher): bias only, GELU + saved pre-activation, GELU' + fused column sums,
@@ -435,8 +429,7 @@ def test_gemm_specialised_epilogues(dev, variant):
     bias = torch.randn(N, generator=g).to(dev)
     base = A.float() @ B.float().t()
     lim = lambda ref: 1.2e-2 * max(1.0, ref.abs().max().item())
-    try:
-        assert L.vb_gemm_set_variant(variant) == 0
+    with _lib.stream_opts(nt_kernel=variant):
         # bias only
         C = gemm(dev, dt, A, B, M, N, K, 0, 0, bias=bias)
         ref = base + bias
@@ -470,8 +463,6 @@ def test_gemm_specialised_epilogues(dev, variant):
         Cf = torch.full((M, N), 7.0, device=dev)[:, :Nr]
         Cf = gemm(dev, dt, A, B[:Nr], M, Nr, K, 0, 0, out_f32=True, bias=bias[:Nr].contiguous(), acc=None)
         assert (Cf - ref[:, :Nr]).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
-    finally:
-        L.vb_gemm_set_variant(1)
 
 
 @pytest.mark.parametrize("K", [64, 128, 192, 256, 320, 768])
@@ -486,19 +477,57 @@ def test_gemm_eight_phase_k_tails(dev, K):
     B = padded(N, K, dt, dev, g)
     bias = torch.randn(N, generator=g).to(dev)
     ref = A.float() @ B.float().t() + bias
-    try:
-      for variant in (80, 81):              # eight-slot and four-slot schedules of the persistent kernel
-        assert L.vb_gemm_set_variant(variant) == 0
+    for variant in (80, 81, 90):          # eight-slot / four-slot schedules of the persistent kernel; two-workgroup kernel
         for wgs in (0, 1, 2, 4):            # 6 output tiles: one per workgroup, or 6 / 3 / 2 walked by one workgroup
-            assert L.vb_gemm_set_persistent_wgs(wgs) == 0
-            for out_f32 in (True, False):
-                for _ in range(2):
-                    C = gemm(dev, dt, A, B, M, N, K, 0, 0, out_f32=out_f32, bias=bias)
-                    lim = (2e-3 if out_f32 else 1e-2) * ref.abs().max().item()
-                    assert (C.float() - ref).abs().max().item() <= lim
-    finally:
-        L.vb_gemm_set_persistent_wgs(0)
-        L.vb_gemm_set_variant(1)
+            with _lib.stream_opts(nt_kernel=variant, persistent_workgroups=wgs):
+                for out_f32 in (True, False):
+                    for _ in range(2):
+                        C = gemm(dev, dt, A, B, M, N, K, 0, 0, out_f32=out_f32, bias=bias)
+                        lim = (2e-3 if out_f32 else 1e-2) * ref.abs().max().item()
+                        assert (C.float() - ref).abs().max().item() <= lim
+
+
+def test_stream_options_do_not_leak_across_streams(dev):
+    """launch options belong to a stream (vb_stream_set_opts): a GEMM on stream A keeps A's kernel choice and workgroup
+    count while stream B runs with the defaults, both concurrently, and removing A's entry restores the defaults."""
+    import ctypes
+    L = _lib.lib()
+    M, N, K = 530, 270, 192
+    g = torch.Generator().manual_seed(3)
+    dt = torch.bfloat16
+    A = padded(M, K, dt, dev, g)
+    B = padded(N, K, dt, dev, g)
+    ref = A.float() @ B.float().t()
+    if dev.type != "cuda":
+        sa = sb = None
+    else:
+        sa, sb = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        sa.wait_stream(torch.cuda.current_stream())
+        sb.wait_stream(torch.cuda.current_stream())
+
+    def on(stream):
+        import contextlib
+        return torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
+
+    got = _lib.StreamOpts()
+    with on(sa):
+        with _lib.stream_opts(nt_kernel=80, persistent_workgroups=2):
+            _lib.check(L.vb_stream_get_opts(_lib.stream_ptr(), ctypes.byref(got)), "get")
+            assert (got.nt_kernel, got.persistent_workgroups) == (80, 2)
+            if sb is not None:
+                with on(sb):                                    # the other stream sees the defaults, not A's options
+                    _lib.check(L.vb_stream_get_opts(_lib.stream_ptr(), ctypes.byref(got)), "get")
+                    assert (got.nt_kernel, got.persistent_workgroups, got.attn_two_pass) == (0, 0, 0)
+                    Cb = gemm(dev, dt, A, B, M, N, K, 0, 0, out_f32=True)
+            Ca = gemm(dev, dt, A, B, M, N, K, 0, 0, out_f32=True)
+        _lib.check(L.vb_stream_get_opts(_lib.stream_ptr(), ctypes.byref(got)), "get")
+        assert (got.nt_kernel, got.persistent_workgroups) == (0, 0)         # entry removed on exit
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+        assert (Cb - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+    assert (Ca - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+    bad = _lib.StreamOpts(0, 7, 0, 0)
+    assert L.vb_stream_set_opts(_lib.stream_ptr(), ctypes.byref(bad)) != 0        # unknown kernel id is refused
 
 
 # ---- SURVEY 8f / N4 kernels ------------------------------------------------------------------------------------------

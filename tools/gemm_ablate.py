@@ -7,7 +7,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from visualbert_amd import _lib, ops
 dev = torch.device("cuda", 0)
-L = _lib.lib()
+import _knobs
+L = _knobs.L
 M = 64 * 164
 g = torch.Generator().manual_seed(0)
 def bench(fn, iters=20):
@@ -23,7 +24,7 @@ for name, n, k in [("ffn-out", 768, 3072), ("qkv", 2304, 768)]:
     w = (torch.randn(n, k, generator=g) * 0.05).to(torch.bfloat16).to(dev)
     out = torch.empty(M, n, dtype=torch.bfloat16, device=dev)
     for v in (42,):
-        L.vb_gemm_set_variant(v)
+        _knobs.variant(v)
         row = []
         for dbg, label in [(0, "full"), (1, "no tile loads"), (2, "no fragment reads"), (4, "no MFMAs")]:
             L.vb_gemm_set_debug(dbg)

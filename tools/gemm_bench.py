@@ -9,7 +9,8 @@ from visualbert_amd import _lib, ops
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 M = B * 164
 dev = torch.device("cuda", 0)
-L = _lib.lib()
+import _knobs
+L = _knobs.L
 shapes = [("qkv fwd", M, 2304, 768), ("attn-out fwd", M, 768, 768), ("ffn-in fwd(gelu)", M, 3072, 768), ("ffn-in fwd(savegrad)", M, 3072, 768),
           ("ffn-out fwd", M, 768, 3072), ("qkv dgrad", M, 768, 2304), ("decoder fwd f32", M, 30522, 768)]
 
@@ -40,7 +41,7 @@ for name, m, n, k in shapes:
     row = []
     outs = {}
     for v in (42, 80, 81):
-        assert L.vb_gemm_set_variant(v) == 0
+        assert _knobs.variant(v) == 0
         def fn():
             ops.gemm(a, w, m, n, k, out=out, bias=bias, act=actc, aux_out=pre)
         ms = bench(fn)
@@ -48,7 +49,7 @@ for name, m, n, k in shapes:
         outs[v] = out[:, :n].float().clone() if n < 8192 else out[::7, :n:5].float().clone()
     dif = max((outs[v] - outs[42]).abs().max().item() for v in outs)     # all kernels must agree (async-copy race screen)
     print("%-18s N=%5d K=%5d | %s | maxdiff %.2e" % (name, n, k, " | ".join(row), dif))
-L.vb_gemm_set_variant(1); L.vb_gemm_set_debug(0)
+_knobs.variant(1); L.vb_gemm_set_debug(0)
 # wgrad (both K-strided, split-K)
 for name, n_out, k_in in [("wgrad qkv", 2304, 768), ("wgrad attn-out", 768, 768), ("wgrad ffn-in", 3072, 768), ("wgrad ffn-out", 768, 3072)]:
     dy = (torch.randn(M, n_out, generator=g) * 0.1).to(torch.bfloat16).to(dev)

@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from visualbert_amd import _lib, ops
 dev = torch.device("cuda", 0)
-L = _lib.lib()
+import _knobs
+L = _knobs.L
 M = int(sys.argv[1]) * 164 if len(sys.argv) > 1 else 64 * 164
 g = torch.Generator().manual_seed(0)
 def bench(fn, iters=30):
@@ -19,7 +20,7 @@ def bench(fn, iters=30):
     d = list(summ.values())[0]
     return d["ms"] / d["launches"] * 1e3
 for v, dbg in ((80, 0), (81, 0)):
-    L.vb_gemm_set_variant(v); L.vb_gemm_set_debug(dbg)
+    _knobs.variant(v); L.vb_gemm_set_debug(dbg)
     for n in (768, 2304, 3072):
         row = ["dbg=%d" % dbg]
         for k in (64, 128, 256, 768, 1536, 3072):

@@ -7,13 +7,14 @@ from visualbert_amd import _lib, ops
 n, k, v = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 dbg = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 dev = torch.device("cuda", 0)
-L = _lib.lib()
+import _knobs
+L = _knobs.L
 M = int(os.environ.get("M_ROWS", 128 * 164))
 g = torch.Generator().manual_seed(0)
 a = (torch.randn(M, k, generator=g) * 0.5).to(torch.bfloat16).to(dev)
 w = (torch.randn(n, k, generator=g) * 0.05).to(torch.bfloat16).to(dev)
 out = torch.empty(M, n, dtype=torch.bfloat16, device=dev)
-L.vb_gemm_set_variant(v); L.vb_gemm_set_debug(dbg); L.vb_gemm_set_persistent_wgs(int(os.environ.get("WGS", 0)))
+_knobs.variant(v); L.vb_gemm_set_debug(dbg); _knobs.wgs(int(os.environ.get("WGS", 0)))
 for _ in range(5):
     ops.gemm(a, w, M, n, k, out=out)
 torch.cuda.synchronize()

@@ -7,7 +7,8 @@ import torch
 from visualbert_amd import _lib, ops
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 dev = torch.device("cuda", 0)
-L = _lib.lib()
+import _knobs
+L = _knobs.L
 M = B * 164
 g = torch.Generator().manual_seed(0)
 shapes = [("decoder fwd f32", 30522, 768, True, 0), ("ffn-in fwd gelu", 3072, 768, False, _lib.VB_ACT_GELU_SAVE_GRAD),

@@ -6,7 +6,8 @@ import torch
 from visualbert_amd import _lib, ops
 n, k = int(sys.argv[1]), int(sys.argv[2])
 dev = torch.device("cuda", 0)
-L = _lib.lib()
+import _knobs
+L = _knobs.L
 M = 64 * 164
 g = torch.Generator().manual_seed(0)
 a = (torch.randn(M, k, generator=g) * 0.5).to(torch.bfloat16).to(dev)
@@ -14,7 +15,7 @@ w = (torch.randn(n, k, generator=g) * 0.05).to(torch.bfloat16).to(dev)
 out = torch.empty(M, n, dtype=torch.bfloat16, device=dev)
 tr = torch.zeros(2 * 64 * 8, dtype=torch.int64, device=dev)
 dbg = int(sys.argv[3]) if len(sys.argv) > 3 else 64
-L.vb_gemm_set_variant(42); L.vb_gemm_set_trace(_lib.ptr(tr)); L.vb_gemm_set_debug(dbg)
+_knobs.variant(42); L.vb_gemm_set_trace(_lib.ptr(tr)); L.vb_gemm_set_debug(dbg)
 for _ in range(3):
     ops.gemm(a, w, M, n, k, out=out)
 torch.cuda.synchronize()

@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from visualbert_amd import _lib
 dev = torch.device("cuda", 0)
-L = _lib.lib()
+import _knobs
+L = _knobs.L
 buf = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
 sink = torch.empty(4096, device=dev)
 iters = 4000

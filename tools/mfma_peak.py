@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from visualbert_amd import _lib
 dev = torch.device("cuda", 0)
-L = _lib.lib()
+import _knobs
+L = _knobs.L
 for blocks in (64, 128, 256, 512):
     out = torch.empty(blocks * 512, device=dev)
     for kind, name in ((0, "16x16x32"), (1, "32x32x16"), (2, "16x16x32, operands changing every instruction")):

@@ -6,7 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from visualbert_amd import _lib, ops
 dev = torch.device("cuda", 0)
-L = _lib.lib()
+import _knobs
+L = _knobs.L
 g = torch.Generator().manual_seed(123)
 bad = 0
 n_checks = 0
@@ -15,22 +16,22 @@ for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 6):
         a = (torch.randn(m, k, generator=g) * 0.5).to(torch.bfloat16).to(dev)
         w = (torch.randn(n, k, generator=g) * 0.1).to(torch.bfloat16).to(dev)
         ref = a.float() @ w.float().t()
-        for variant, wgs in ((81, 0), (81, 64), (80, 0), (81, 24)):
-            L.vb_gemm_set_variant(variant); L.vb_gemm_set_persistent_wgs(wgs)
+        for variant, wgs in ((81, 0), (81, 64), (80, 0), (81, 24), (90, 0), (90, 0)):
+            _knobs.variant(variant); _knobs.wgs(wgs)
             out = torch.empty(m, n, dtype=torch.float32, device=dev)
             ops.gemm(a, w, m, n, k, out=out)
             err = (out - ref).abs().max().item() / max(1.0, ref.abs().max().item())
             n_checks += 1
             if not err < 2e-3:
                 bad += 1; print("NT MISMATCH", it, (m, n, k), variant, wgs, err)
-    L.vb_gemm_set_variant(1); L.vb_gemm_set_persistent_wgs(0)
+    _knobs.variant(1); _knobs.wgs(0)
     for tokens, shapes in [(20992, [(768, 3072), (3072, 768), (768, 768), (2304, 768)]), (2496, [(30522, 768)]), (4608, [(768, 2048), (264, 520)])]:
         dys = [ops.alloc2d(tokens, o, torch.bfloat16, dev) for o, _ in shapes]
         xs = [ops.alloc2d(tokens, i, torch.bfloat16, dev) for _, i in shapes]
         for t in dys + xs:
             t.copy_((torch.randn(t.shape, generator=g) * 0.3).to(torch.bfloat16))
         for wgs in (0, 40):
-            L.vb_gemm_set_persistent_wgs(wgs)
+            _knobs.wgs(wgs)
             dws = [torch.zeros(o, i, device=dev) for o, i in shapes]
             n_ = len(shapes)
             PA, I64, I32 = ctypes.c_void_p * n_, ctypes.c_int64 * n_, ctypes.c_int * n_
@@ -45,6 +46,6 @@ for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 6):
                 n_checks += 1
                 if not err < 2e-3:
                     bad += 1; print("TN MISMATCH", it, tokens, tuple(dw.shape), wgs, err)
-    L.vb_gemm_set_persistent_wgs(0)
+    _knobs.wgs(0)
 print("race screen: %d checks, %d mismatches" % (n_checks, bad))
 sys.exit(1 if bad else 0)

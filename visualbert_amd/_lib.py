@@ -22,6 +22,8 @@ _u32, _u64 = ctypes.c_uint32, ctypes.c_uint64
 # name -> (restype, argtypes); kept in the order of include/visualbert_hip.h
 SIGNATURES = {
     "vb_version": (ctypes.c_char_p, []),
+    "vb_stream_set_opts": (_i, [_p, _p]),
+    "vb_stream_get_opts": (_i, [_p, _p]),
     "vb_gemm": (_i, [_i, _i, _i, _i, _p, _i64, _p, _i64, _p, _i64, _i, _i, _i, _f, _p, _p, _p, _i64, _i,
                      _p, _p, _i64, _i, _p, _p]),
     "vb_ln_fwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _f, _u32, _f, _u32, _u64, _p]),
@@ -35,13 +37,12 @@ SIGNATURES = {
     "vb_attn_keepbits_words": (_i64, [_i]),
     "vb_attn_fwd": (_i, [_i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _u64, _u32, _p]),
     "vb_attn_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _u64, _u32, _p]),
-    "vb_attn_set_two_pass": (_i, [_i]),
     "vb_ce_fwd_bwd": (_i, [_i, _p, _i64, _p, _i, _p, _p, _p, _i64, _i, _i, _p]),
     "vb_ce_fwd_bwd_rows": (_i, [_i, _p, _i64, _p, _i, _p, _i, _i, _p, _p, _p, _i64, _i, _i, _p]),
     "vb_kldiv_fwd_bwd": (_i, [_p, _i64, _p, _i64, _p, _p, _p, _i64, _i, _i, _p]),
     "vb_small_linear_fwd": (_i, [_i, _p, _i64, _p, _p, _p, _i, _i, _i, _p]),
     "vb_small_linear_bwd": (_i, [_i, _p, _p, _i64, _p, _p, _i64, _p, _p, _p, _i, _i, _i, _p]),
-    "vb_bert_adam_step": (_i, [_p, _p, _p, _p, _p, _p, _i, _p, _i, _p, _p, _f, _f, _f, _f, _f, _f, _f, _f, _i, _p]),
+    "vb_bert_adam_step": (_i, [_p, _p, _p, _p, _p, _p, _i, _p, _i, _p, _p, _p, _f, _f, _f, _f, _f, _f, _f, _f, _i, _p]),
     "vb_refresh_bf16_shadow": (_i, [_p, _p, _p, _i, _p, _p]),
     "vb_refresh_transposed_shadow": (_i, [_p, _p, _p, _p, _i, _p]),
     "vb_prepare_inputs": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
@@ -56,19 +57,31 @@ SIGNATURES = {
     "vb_colsum": (_i, [_i, _p, _i64, _p, _p, _i, _i, _p]),
     "vb_act_bwd": (_i, [_i, _p, _p, _p, _i64, _i, _p]),
     "vb_wgrad_grouped": (_i, [_i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _f, _p, _p]),
-    "vb_gemm_set_variant": (_i, [_i]),
-    "vb_gemm_set_debug": (_i, [_i]),
-    "vb_gemm_set_persistent_wgs": (_i, [_i]),
-    "vb_gemm_set_trace": (_i, [_p]),
-    "vb_mfma_peak": (_i, [_i, _i, _i, _p, _p]),
-    "vb_glds_stream": (_i, [_i, _p, _i64, _i, _i, _p, _p]),
     "vb_gemm_profile": (_i, [_i]),
     "vb_gemm_profile_read": (_i64, [_p, _p, _p, _i64]),
     "vb_bert_layer_saved_bytes": (_i64, [_i, _i, _i, _i, _i, _i, _f]),
     "vb_bert_layer_scratch_bytes": (_i64, [_i, _i, _i, _i, _i, _i]),
     "vb_bert_layer_fwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _f, _u64, _u32, _p]),
     "vb_bert_layer_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _u64, _u32, _p]),
+    "vb_comm_unique_id": (_i, [_p]),
+    "vb_comm_init": (_i, [_p, _i, _i, _p]),
+    "vb_comm_nranks": (_i, [_p]),
+    "vb_allreduce_bucket": (_i, [_p, _p, _i64, _i, _i, _p]),
+    "vb_comm_destroy": (_i, [_p]),
 }
+# developer build only (include/visualbert_hip_dev.h, libvisualbert_hip_dev.so): never needed by the package
+DEV_SIGNATURES = {
+    "vb_gemm_set_debug": (_i, [_i]),
+    "vb_gemm_set_trace": (_i, [_p]),
+    "vb_mfma_peak": (_i, [_i, _i, _i, _p, _p]),
+    "vb_glds_stream": (_i, [_i, _p, _i64, _i, _i, _p, _p]),
+}
+VB_COMM_ID_BYTES = 128
+
+
+class StreamOpts(ctypes.Structure):
+    """include/visualbert_hip.h: vb_stream_opts"""
+    _fields_ = [("persistent_workgroups", _i), ("nt_kernel", _i), ("attn_two_pass", _i), ("reserved", _i)]
 
 _ERRORS = {-1: "VB_ERR_ARG (bad argument)", -2: "VB_ERR_LAUNCH (hip launch failed)",
            -3: "VB_ERR_UNSUPPORTED (shape/dtype not supported by this kernel)"}
@@ -100,15 +113,86 @@ def lib():
             "visualbert_amd: %s not found -- the HIP extension is required (no CPU fallback exists). "
             "Build it: python -c 'import __graft_entry__ as g; g.build()'" % path)
     L = ctypes.CDLL(path)
-    for name, (res, args) in SIGNATURES.items():
+    _bind(L, SIGNATURES, path)
+    _lib, _lib_path = L, path
+    return L
+
+
+def _bind(L, table, path):
+    for name, (res, args) in table.items():
         try:
             fn = getattr(L, name)
         except AttributeError:
             raise RuntimeError("visualbert_amd: %s does not export %s (stale build?)" % (path, name))
         fn.restype = res
         fn.argtypes = args
-    _lib, _lib_path = L, path
+
+
+_dev = None
+
+
+def dev_lib(required=False):
+    """libvisualbert_hip_dev.so (the product's objects + the developer knobs of include/visualbert_hip_dev.h) or None.
+    Tools that use it bind it INSTEAD of the product library: call `use_dev_library()` before anything else."""
+    global _dev
+    if _dev is not None:
+        return _dev
+    path = os.path.join(_HERE, "libvisualbert_hip_dev.so")
+    if not os.path.isfile(path):
+        if required:
+            raise RuntimeError("visualbert_amd: %s not found (make -C visualbert_amd/csrc)" % path)
+        return None
+    L = ctypes.CDLL(path)
+    _bind(L, SIGNATURES, path)
+    _bind(L, DEV_SIGNATURES, path)
+    _dev = L
     return L
+
+
+def use_dev_library():
+    """route the whole package through the developer build (tools/ only): same kernels plus the dev knobs."""
+    global _lib, _lib_path
+    L = dev_lib(required=True)
+    _lib, _lib_path = L, os.path.join(_HERE, "libvisualbert_hip_dev.so")
+    return L
+
+
+class stream_opts(object):
+    """with stream_opts(nt_kernel=42, persistent_workgroups=8): ...   -- launch options of the CURRENT stream
+    (vb_stream_set_opts); restored on exit.  They never change results beyond summation order."""
+
+    def __init__(self, persistent_workgroups=None, nt_kernel=None, attn_two_pass=None, stream=None):
+        self.kw = dict(persistent_workgroups=persistent_workgroups, nt_kernel=nt_kernel, attn_two_pass=attn_two_pass)
+        self.stream = stream
+
+    def _sp(self):
+        if self.stream is not None:
+            return ctypes.c_void_p(self.stream.cuda_stream)
+        return stream_ptr()
+
+    def __enter__(self):
+        L = lib()
+        self.old = StreamOpts()
+        check(L.vb_stream_get_opts(self._sp(), ctypes.byref(self.old)), "vb_stream_get_opts")
+        new = StreamOpts(self.old.persistent_workgroups, self.old.nt_kernel, self.old.attn_two_pass, 0)
+        for k, v in self.kw.items():
+            if v is not None:
+                setattr(new, k, int(v))
+        check(L.vb_stream_set_opts(self._sp(), ctypes.byref(new)), "vb_stream_set_opts")
+        return self
+
+    def __exit__(self, *exc):
+        L = lib()
+        zero = not (self.old.persistent_workgroups or self.old.nt_kernel or self.old.attn_two_pass)
+        check(L.vb_stream_set_opts(self._sp(), None if zero else ctypes.byref(self.old)), "vb_stream_set_opts")
+        return False
+
+
+def set_opts(persistent_workgroups=0, nt_kernel=0, attn_two_pass=0):
+    """attach launch options to the CURRENT stream until changed again (tools; library code uses `stream_opts`)."""
+    o = StreamOpts(int(persistent_workgroups), int(nt_kernel), int(attn_two_pass), 0)
+    zero = not (o.persistent_workgroups or o.nt_kernel or o.attn_two_pass)
+    check(lib().vb_stream_set_opts(stream_ptr(), None if zero else ctypes.byref(o)), "vb_stream_set_opts")
 
 
 def check(rc, what):

@@ -21,6 +21,7 @@
 // Transposed operands (V^T, K^T, Q^T, dO^T) are built while staging into LDS.
 #include "vb_rt.h"
 #include "../../include/visualbert_hip.h"
+#include "vb_opts.h"
 
 namespace {
 
@@ -790,7 +791,7 @@ template <typename T, int NKF> size_t dkv_smem() {
 }
 
 constexpr size_t kMaxLds = 160 * 1024;
-static int g_attn_two_pass = 0;                            // measurement knob: force the two-pass backward
+
 
 template <typename T, int NKF>
 int launch_all(int which, const AttnArgs& a, hipStream_t s) {
@@ -801,7 +802,7 @@ int launch_all(int which, const AttnArgs& a, hipStream_t s) {
         VB_LAUNCH((attn_fwd_kernel<T, NKF>), grid, block, sm, s, a);
     } else {
         if constexpr (sizeof(T) == 2 && NKF <= 12) {
-            if (a.ctx_fwd && a.S <= FWPB * 16 && g_attn_two_pass != 1) {  // one-pass backward (needs the forward output)
+            if (a.ctx_fwd && a.S <= FWPB * 16 && vb_opts_for((void*)s).attn_two_pass != 1) {  // one-pass backward (needs the forward output)
                 // 64-query chunks (86 KB of LDS, one workgroup per CU): 528-541 us per layer at B=512; 32-query chunks (two
                 // workgroups per CU, twice the barriers): 575 us
                 VB_LAUNCH((attn_bwd_fused_kernel<NKF, 64>), grid, dim3(FNT), (fused_smem<NKF, 64>()), s, a);
@@ -865,7 +866,6 @@ extern "C" int vb_attn_fwd(int dtype, const void* qkv, const float* mask_add, vo
     return VB_ERR_ARG;
 }
 
-extern "C" int vb_attn_set_two_pass(int on) { g_attn_two_pass = on; return VB_OK; }
 
 extern "C" int vb_attn_bwd(int dtype, const void* qkv, const float* mask_add, const void* dctx, const float* lse,
                            const uint64_t* keepbits, float* dsum_ws, void* dqkv, const void* ctx_fwd,

@@ -29,8 +29,13 @@
 // so every global access of the epilogue is a full 128-byte row segment.
 #include "vb_rt.h"
 #include "../../include/visualbert_hip.h"
+#include "vb_opts.h"
+#ifdef VB_DEV_KNOBS
+#include "../../include/visualbert_hip_dev.h"
+#endif
 #include <vector>
 #include <type_traits>
+#include <utility>
 
 namespace {
 
@@ -183,7 +188,18 @@ VB_DEVICE f32x8 load_frag(const unsigned char* lds, int row, int ks, int g, floa
 
 #ifndef VB_EMU
 struct ProfRec { hipEvent_t e0, e1; double flops; int key; };
-static std::vector<ProfRec>* g_prof = nullptr;
+static std::vector<ProfRec>* g_prof = nullptr;      // opt-in measurement recorder (vb_gemm_profile): the one process-wide facility
+#endif
+// launch options of the call being served: copied from the stream's entry (vb_stream_set_opts) at every extern "C" entry of
+// this file; thread-local, so concurrent callers on different streams never see each other's settings
+static thread_local vb_stream_opts t_opts = {0, 0, 0, 0};
+// developer builds only (include/visualbert_hip_dev.h): ablation bits and the timeline buffer; constants in the product
+#ifdef VB_DEV_KNOBS
+static int g_debug = 0;
+static unsigned long long* g_trace = nullptr;
+#else
+static constexpr int g_debug = 0;
+static constexpr unsigned long long* g_trace = nullptr;
 #endif
 
 // XCD-aware, bijective remap of the linear workgroup id: hardware places workgroup b on XCD b % 8
@@ -1118,8 +1134,6 @@ VB_KERNEL VB_LAUNCH_BOUNDS(512) gemm_nt_8ph_kernel(GemmArgs g) {
     if (wr == 0) vb_phase_barrier();               // balance the stagger barrier
 }
 
-static int g_persistent_wgs = 0;       // 0 = one workgroup per CU
-static int g_8ph_sched = 0;             // 0 = eight slots per K tile, 1 = four (measurement knob: variant 81)
 template <typename T, typename TO, int ACT, int OPT, int SCHED>
 int launch_8ph_sched(const GemmArgs& g, dim3 grid, dim3 block, int smem_bytes, hipStream_t stream) {
 #ifndef VB_EMU
@@ -1140,8 +1154,8 @@ int launch_8ph_sched(const GemmArgs& g, dim3 grid, dim3 block, int smem_bytes, h
 }
 template <typename T, typename TO, int ACT, int OPT>
 int launch_8ph_act(const GemmArgs& g, dim3 grid, dim3 block, int smem_bytes, hipStream_t stream) {
-    if (g_8ph_sched == 1) return launch_8ph_sched<T, TO, ACT, OPT, 1>(g, grid, block, smem_bytes, stream);
-    return launch_8ph_sched<T, TO, ACT, OPT, 0>(g, grid, block, smem_bytes, stream);
+    if (t_opts.nt_kernel != 80) return launch_8ph_sched<T, TO, ACT, OPT, 1>(g, grid, block, smem_bytes, stream);   // four slots
+    return launch_8ph_sched<T, TO, ACT, OPT, 0>(g, grid, block, smem_bytes, stream);                                // eight slots
 }
 template <typename T, typename TO>
 int launch_8ph(GemmArgs g, hipStream_t stream) {
@@ -1155,7 +1169,7 @@ int launch_8ph(GemmArgs g, hipStream_t stream) {
         const int ntiles = g.tiles_m * g.tiles_n;
         // persistent: one workgroup per CU walks tiles b, b + wgs, ...; the XCD-aware tile remap assumes workgroups b and
         // b + wgs share an XCD (wgs % 8 == 0), which only matters when a workgroup has more than one tile
-        int wgs = g_persistent_wgs > 0 ? g_persistent_wgs : vb_num_cus();
+        int wgs = t_opts.persistent_workgroups > 0 ? t_opts.persistent_workgroups : vb_num_cus();
         if (wgs >= ntiles) wgs = ntiles;
         else if (wgs >= 8) wgs &= ~7;
         dim3 grid((unsigned)wgs), block(512);
@@ -1171,6 +1185,183 @@ int launch_8ph(GemmArgs g, hipStream_t stream) {
         }
 #undef VB_TRY_EPI
         return launch_8ph_act<T, TO, -1, EPI_ALL>(g, grid, block, SM, stream);
+    }
+    return VB_ERR_UNSUPPORTED;
+}
+
+// =================================================================================================
+// 256x128 tile, 4 waves as 2 (M) x 2 (N), TWO WORKGROUPS PER COMPUTE UNIT (nt_kernel 90).
+//
+// Why: the persistent 256x256 kernel above holds a CU alone (136 KB of LDS), so nothing overlaps its per-tile epilogue
+// -- LDS transpose, bias / GELU arithmetic, a 128 KB store burst: ~9 us of a ~26 us tile at K = 768, ~20 us with the GELU
+// + GELU' epilogue of the FFN-in GEMM (more than the tile's 17 us of MFMA work).  The matrix pipe and the VALU / store
+// path are different resources: here every SIMD hosts one wave of EACH of two independent workgroups, so one workgroup's
+// epilogue (VALU, LDS, stores) and its prologue's HBM latency run under the other workgroup's MFMA phases, and the two
+// drift apart by themselves because nothing synchronises them.  Per wave the work is unchanged: a 128x64 output block,
+// 128 accumulator registers, the same fragment reads per MFMA as the 256x256 kernel.
+//
+// LDS: exactly half a CU, 80 KB = a ring of FIVE 16-KB half-tiles; a K tile is three of them (A0, B, A1; A_mh holds tile
+// rows (r>>6)*128 + mh*64 + (r&63) like the kernel above, B holds the tile's 128 rows of W).  Half-tile index
+// h = 3k + {0: A0, 1: B, 2: A1} lives in slot h % 5, so the K loop is unrolled five times and every LDS address is a
+// constant.  Per K tile k, two phases, one barrier each:
+//   E(k): wait until only the newest 2 half-tiles are in flight | barrier | issue B(k+1) | read A0 B | 32 MFMAs (0,0) (0,1)
+//   O(k): wait (same count)                                      | barrier | issue A1(k+1) A0(k+2) | read A1 | 32 MFMAs (1,1) (1,0)
+// A half-tile is needed >= one K tile after it was issued (A0(k): O(k-2), B(k): E(k-1), A1(k): O(k-1)); the barrier
+// that opens a phase publishes everyone's landed copies AND proves every wave has finished the previous phase's reads,
+// whose slots the phase then refills (E(k): slot of A1(k-1); O(k): slots of A0(k) and B(k)).  No wave-group stagger: the
+// co-resident workgroup is the other half of the pipeline.  The epilogue is the wave-private one of the kernel above; its
+// slabs alias the (by then idle) ring.
+// =================================================================================================
+template <typename TO, int ACT, int OPT>
+VB_KERNEL VB_LAUNCH_BOUNDS2(256, 2) gemm_nt_dual_kernel(GemmArgs g) {
+    typedef bf16 T;
+    constexpr int BK = 64, KSTEPS = 2, HALF = 128 * 128;
+    VB_DYN_SMEM(smem);
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = vb_uniform(t >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int li = lane & 15, lg = lane >> 4;
+    const int ntiles = g.tiles_m * g.tiles_n;
+    const int tile = xcd_remap((int)blockIdx.x, ntiles);
+    const int m0 = (tile / g.tiles_n) * 256, n0 = (tile % g.tiles_n) * 128;
+    const vb_buf A = vb_make_buf(g.A);
+    const vb_buf B = vb_make_buf(g.B);
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // LDS-direct copies: a half-tile is 16 one-KiB instructions, 4 per wave; instruction i of wave w fills half-tile rows
+    // (4 w + i) 8 + lane/8, chunk slot lane % 8 <- global chunk (lane % 8) ^ swz(row).  Per-lane BYTE offsets from the
+    // operand bases (32 bits, checked by the launcher) go in a VGPR, the K tile's offset in an SGPR, the base in a buffer
+    // descriptor: issuing a copy is one s_mov m0 + one buffer_load ... lds, no vector arithmetic.
+    unsigned offA[2][4], offB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wave * 4 + i) * 8 + (lane >> 3);
+        const unsigned csrc = (unsigned)(((lane & 7) ^ swz(r)) * 16);
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh) {
+            int a = m0 + (r >> 6) * 128 + mh * 64 + (r & 63);
+            a = a < g.M ? a : g.M - 1;                          // clamped rows are computed but never stored
+            offA[mh][i] = (unsigned)(a * (int)g.lda) * 2u + csrc;
+        }
+        int b = n0 + r;
+        b = b < g.N ? b : g.N - 1;
+        offB[i] = (unsigned)(b * (int)g.ldb) * 2u + csrc;
+    }
+    auto issue = [&](const vb_buf& buf, const unsigned (&off)[4], int kt, int slot) {
+        unsigned char* dst = smem + slot * HALF + wave * 4096;
+        const unsigned koff = (unsigned)kt * (BK * 2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) vb_glds16_buf(buf, off[i], koff, dst + i * 1024);
+    };
+
+    bf16x8 fa[4][KSTEPS], fb0[2][KSTEPS], fb1[2][KSTEPS];
+    auto readA = [&](const unsigned char* half) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) fa[f][ks] = load_frag(half, wr * 64 + f * 16 + li, ks, lg, T());
+    };
+    auto readB = [&](bf16x8 (&fb)[2][KSTEPS], const unsigned char* half, int nh) {
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) fb[f][ks] = load_frag(half, wc * 64 + nh * 32 + f * 16 + li, ks, lg, T());
+    };
+    auto quad = [&](int mh, int nh, bf16x8 (&fb)[2][KSTEPS]) {
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                    acc[mh * 4 + f][nh * 2 + q] = vb_mma(fa[f][ks], fb[q][ks], acc[mh * 4 + f][nh * 2 + q]);
+    };
+
+    const int nk = g.K / BK;
+    // prologue: h = 0 .. 3 (A0(0) B(0) A1(0) A0(1)); E(0) adds h = 4
+    issue(A, offA[0], 0, 0); issue(B, offB, 0, 1); issue(A, offA[1], 0, 2);
+    if (nk > 1) issue(A, offA[0], 1, 3);
+
+    // one K tile; J = k % 5 fixes the ring slots: A0 -> (3J) % 5, B -> (3J+1) % 5, A1 -> (3J+2) % 5
+    auto step = [&](auto jtag, int k) {
+        constexpr int J = decltype(jtag)::value;
+        constexpr int SA0 = (3 * J) % 5, SB = (3 * J + 1) % 5, SA1 = (3 * J + 2) % 5;
+        constexpr int SE = (3 * J + 4) % 5;                    // E refills the slot of A1(k-1)
+        const bool last = (k + 1 == nk);
+        // ---- E(k): A0(k), B(k) must have landed; A1(k) and A0(k+1) may still be in flight
+        if (last) vb_wait_vmcnt<4>(); else vb_wait_vmcnt<8>();
+        vb_phase_barrier();
+        if (!last) issue(B, offB, k + 1, SE);
+        readB(fb0, smem + SB * HALF, 0);
+        readA(smem + SA0 * HALF);
+        readB(fb1, smem + SB * HALF, 1);
+        quad(0, 0, fb0);
+        quad(0, 1, fb1);
+        // ---- O(k): A1(k) must have landed; A0(k+1) and B(k+1) may still be in flight
+        if (last) vb_wait_vmcnt<0>(); else vb_wait_vmcnt<8>();
+        vb_phase_barrier();
+        if (!last) issue(A, offA[1], k + 1, SA0);              // A1(k+1) into the slot A0(k) just left
+        if (k + 2 < nk) issue(A, offA[0], k + 2, SB);          // A0(k+2) into the slot B(k) just left
+        readA(smem + SA1 * HALF);
+        quad(1, 1, fb1);
+        quad(1, 0, fb0);
+    };
+    for (int k = 0;;) {
+        step(std::integral_constant<int, 0>(), k); if (++k == nk) break;
+        step(std::integral_constant<int, 1>(), k); if (++k == nk) break;
+        step(std::integral_constant<int, 2>(), k); if (++k == nk) break;
+        step(std::integral_constant<int, 3>(), k); if (++k == nk) break;
+        step(std::integral_constant<int, 4>(), k); if (++k == nk) break;
+    }
+    vb_phase_barrier();                                        // every wave is done with the ring: the slabs may alias it
+    gemm_epilogue_private<T, TO, ACT, OPT>(acc, smem + wave * EPI8_BYTES_PER_WAVE, g, m0 + wr * 128, n0 + wc * 64, lane);
+}
+
+template <typename TO, int ACT, int OPT>
+int launch_dual_act(const GemmArgs& g, dim3 grid, hipStream_t stream) {
+    constexpr int SM = 5 * 128 * 128;                           // 80 KB: two workgroups per compute unit
+#ifndef VB_EMU
+    if (g_prof) {
+        ProfRec r;
+        if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return VB_ERR_LAUNCH;
+        r.flops = 2.0 * g.M * g.N * g.K;
+        r.key = (sizeof(TO) == 4 ? 4 : 0) | 64;
+        (void)hipEventRecord(r.e0, stream);
+        VB_LAUNCH((gemm_nt_dual_kernel<TO, ACT, OPT>), grid, dim3(256), SM, stream, g);
+        (void)hipEventRecord(r.e1, stream);
+        g_prof->push_back(r);
+        return vb_check_launch();
+    }
+#endif
+    VB_LAUNCH((gemm_nt_dual_kernel<TO, ACT, OPT>), grid, dim3(256), SM, stream, g);
+    return vb_check_launch();
+}
+template <typename T, typename TO>
+int launch_dual(GemmArgs g, hipStream_t stream) {
+    // bf16 operands, 32-bit byte offsets inside the kernel (rows x pitch + K below 2^31 elements = 2^32 bytes)
+    if (sizeof(T) != 2 || (long)g.M * g.lda >= (1L << 30) || (long)g.N * g.ldb >= (1L << 30))
+        return launch_pipe<T, TO, 4, 2>(g, stream);
+    if constexpr (sizeof(T) == 2) {
+        g.tiles_m = (g.M + 255) / 256;
+        g.tiles_n = (g.N + 127) / 128;
+        dim3 grid((unsigned)(g.tiles_m * g.tiles_n));
+        const int needs = epi_needs(g, sizeof(T), sizeof(TO));
+#define VB_TRY_EPI(A, O) if (g.act == (A) && (needs & ~(O)) == 0) return launch_dual_act<TO, A, O>(g, grid, stream)
+        if constexpr (kActSpecialised<T, TO>) {
+            VB_TRY_EPI(VB_ACT_NONE, 0);
+            VB_TRY_EPI(VB_ACT_GELU_SAVE_GRAD, 0);
+            VB_TRY_EPI(VB_ACT_MUL_AUX, EPI_COLSUM);
+            VB_TRY_EPI(VB_ACT_NONE, EPI_ADD);
+        } else {
+            VB_TRY_EPI(VB_ACT_NONE, EPI_RAGGED);
+        }
+#undef VB_TRY_EPI
+        return launch_dual_act<TO, -1, EPI_ALL>(g, grid, stream);
     }
     return VB_ERR_UNSUPPORTED;
 }
@@ -1428,7 +1619,7 @@ static int launch_tn_group(TnArgs& g, int K, hipStream_t stream) {
         P.tiles = P.tiles_m * P.tiles_n;
         tiles += P.tiles;
     }
-    int wgs = g_persistent_wgs > 0 ? g_persistent_wgs : vb_num_cus();
+    int wgs = t_opts.persistent_workgroups > 0 ? t_opts.persistent_workgroups : vb_num_cus();
     g.splits = tn_pick_splits(tiles, g.KT, wgs);
     g.kps = (g.KT + g.splits - 1) / g.splits;
     int item0 = 0;
@@ -1460,16 +1651,12 @@ static bool tn_eligible(const void* A, long lda, const void* B, long ldb, const 
            64L * lda * 2 + 2L * Mo < (1L << 31) && 64L * ldb * 2 + 2L * Ni < (1L << 31);
 }
 
-// variant of the pipelined kernel: tens = waves in M (2 -> 128-row tile, 4 -> 256-row tile), units = stages.
-// 0 = use the generic kernel.
-static int g_nt_variant = 1;     // 1 = auto: 256x256 tile where the grid still fills the chip and K or N is large, else 256x128
-static int g_debug = 0;
-static unsigned long long* g_trace = nullptr;
-
+// kernel for a K-contiguous x K-contiguous problem (vb_stream_opts.nt_kernel): 0 = chosen from the shape; 1 = the generic
+// register-staged kernel; tens = waves in M (2 -> 128-row tile, 4 -> 256-row tile), units = LDS stages; 80 / 81 persistent
 template <typename T, typename TO>
 int dispatch_pipe(const GemmArgs& g, hipStream_t s) {
-    int variant = g_nt_variant;
-    if (variant == 1) {
+    int variant = t_opts.nt_kernel;
+    if (variant == 0) {
         // measured on MI355X (profiles/r01_gemm_variant_sweep_b128.txt)
         const long t256 = (long)((g.M + 255) / 256) * ((g.N + 255) / 256);
         const long t128 = (long)((g.M + 255) / 256) * ((g.N + 127) / 128);
@@ -1480,8 +1667,9 @@ int dispatch_pipe(const GemmArgs& g, hipStream_t s) {
     switch (variant) {
         case 22: return launch_pipe<T, TO, 2, 2>(g, s);
         case 42: return launch_pipe<T, TO, 4, 2>(g, s);
-        case 80: g_8ph_sched = 0; return launch_8ph<T, TO>(g, s);
-        case 81: g_8ph_sched = 1; return launch_8ph<T, TO>(g, s);
+        case 80: return launch_8ph<T, TO>(g, s);
+        case 81: return launch_8ph<T, TO>(g, s);
+        case 90: return launch_dual<T, TO>(g, s);
         default: return VB_ERR_UNSUPPORTED;
     }
 }
@@ -1489,7 +1677,7 @@ int dispatch_pipe(const GemmArgs& g, hipStream_t s) {
 template <typename T>
 int dispatch(int out_dtype_is_f32, int al, int bl, const GemmArgs& g, hipStream_t s) {
     if (al == VB_KCONTIG && bl == VB_KCONTIG) {
-        if (g.fast_a && g.fast_b && g.splits == 1 && g_nt_variant != 0)
+        if (g.fast_a && g.fast_b && g.splits == 1 && t_opts.nt_kernel != 1)
             return out_dtype_is_f32 ? dispatch_pipe<T, float>(g, s) : dispatch_pipe<T, T>(g, s);
         return out_dtype_is_f32 ? launch_gemm<T, float, VB_KCONTIG, VB_KCONTIG>(g, s)
                                 : launch_gemm<T, T, VB_KCONTIG, VB_KCONTIG>(g, s);
@@ -1514,6 +1702,7 @@ extern "C" int vb_gemm(int dtype, int out_dtype, int a_layout, int b_layout,
     if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C) return VB_ERR_ARG;
     if (dtype != VB_F32 && dtype != VB_BF16) return VB_ERR_ARG;
     if (out_dtype != VB_F32 && out_dtype != dtype) return VB_ERR_ARG;
+    t_opts = vb_opts_for(stream);
     const int epc = dtype == VB_BF16 ? 8 : 4;
     // vector loads are 16 bytes: leading dimensions and base pointers must keep them aligned
     if ((lda % 8) || (ldb % 8) || (((uintptr_t)A | (uintptr_t)B) & 15)) return VB_ERR_ARG;
@@ -1547,7 +1736,7 @@ extern "C" int vb_gemm(int dtype, int out_dtype, int a_layout, int b_layout,
     hipStream_t s = (hipStream_t)stream;
     const int of32 = (out_dtype == VB_F32) ? 1 : 0;
     if (dtype == VB_BF16 && of32 && a_layout == VB_KSTRIDED && b_layout == VB_KSTRIDED && accumulate && !bias && !addend &&
-        !colsum_out && act == VB_ACT_NONE && g_nt_variant != 0 && tn_eligible(A, lda, B, ldb, (const float*)C, ldc, M, N, K)) {
+        !colsum_out && act == VB_ACT_NONE && t_opts.nt_kernel != 1 && tn_eligible(A, lda, B, ldb, (const float*)C, ldc, M, N, K)) {
         TnArgs tg;
         tg.nprob = 1; tg.alpha = alpha; tg.alpha_dev = alpha_dev;
         tg.p[0].A = A; tg.p[0].B = B; tg.p[0].C = (float*)C; tg.p[0].lda = lda; tg.p[0].ldb = ldb; tg.p[0].ldc = ldc;
@@ -1564,7 +1753,8 @@ extern "C" int vb_wgrad_grouped(int dtype, int n, const void* const* dy, const i
     if (n <= 0 || n > VB_TN_MAX || !dy || !ld_dy || !x || !ld_x || !dw || !ld_dw || !n_out || !n_in || tokens <= 0)
         return VB_ERR_ARG;
     if (dtype != VB_F32 && dtype != VB_BF16) return VB_ERR_ARG;
-    bool fast = dtype == VB_BF16 && g_nt_variant != 0;
+    t_opts = vb_opts_for(stream);
+    bool fast = dtype == VB_BF16 && t_opts.nt_kernel != 1;
     for (int i = 0; i < n && fast; ++i)
         fast = tn_eligible(dy[i], ld_dy[i], x[i], ld_x[i], (const float*)dw[i], ld_dw[i], n_out[i], n_in[i], tokens);
     if (fast) {
@@ -1620,14 +1810,8 @@ extern "C" int64_t vb_gemm_profile_read(double* ms, double* flops, int* key, int
 #endif
 }
 
-extern "C" int vb_gemm_set_variant(int variant) {
-    if (variant != 0 && variant != 1 && variant != 22 && variant != 42 && variant != 80 && variant != 81) return VB_ERR_ARG;
-    g_nt_variant = variant;
-    return VB_OK;
-}
-
+#ifdef VB_DEV_KNOBS
 extern "C" int vb_gemm_set_debug(int bits) { g_debug = bits; return VB_OK; }
-extern "C" int vb_gemm_set_persistent_wgs(int n) { if (n < 0) return VB_ERR_ARG; g_persistent_wgs = n; return VB_OK; }
 
 // ---- measurement aid: issue-rate ceiling of the two bf16 MFMA shapes at the clocks this chip really holds ---
 #ifndef VB_EMU
@@ -1737,3 +1921,4 @@ extern "C" int vb_glds_stream(int depth, const void* src, int64_t span, int iter
 }
 
 extern "C" int vb_gemm_set_trace(void* device_u64x1024) { g_trace = (unsigned long long*)device_u64x1024; return VB_OK; }
+#endif  // VB_DEV_KNOBS

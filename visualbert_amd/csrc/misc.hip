@@ -230,3 +230,48 @@ extern "C" int vb_act_bwd(int dtype, const void* dy, const void* aux, void* dx, 
     else return VB_ERR_ARG;
     return vb_check_launch();
 }
+
+
+// ---- per-stream launch options (include/visualbert_hip.h) ---------------------------------------------------------------
+// A handful of entries at most (one per stream that ever set options): a vector under a mutex; a lookup is a few
+// nanoseconds next to a kernel launch.
+#include "vb_opts.h"
+#include <mutex>
+#include <vector>
+#include <utility>
+namespace {
+std::mutex g_opts_mutex;
+std::vector<std::pair<void*, vb_stream_opts>>& opts_table() {
+    static std::vector<std::pair<void*, vb_stream_opts>> t;
+    return t;
+}
+}  // namespace
+
+vb_stream_opts vb_opts_for(void* stream) {
+    std::lock_guard<std::mutex> lock(g_opts_mutex);
+    for (auto& e : opts_table()) if (e.first == stream) return e.second;
+    return vb_stream_opts{0, 0, 0, 0};
+}
+
+extern "C" int vb_stream_set_opts(void* stream, const vb_stream_opts* opts) {
+    if (opts) {
+        const int k = opts->nt_kernel;
+        if (opts->persistent_workgroups < 0 || (k != 0 && k != 1 && k != 22 && k != 42 && k != 80 && k != 81 && k != 90))
+            return VB_ERR_ARG;
+    }
+    std::lock_guard<std::mutex> lock(g_opts_mutex);
+    auto& t = opts_table();
+    for (size_t i = 0; i < t.size(); ++i)
+        if (t[i].first == stream) {
+            if (opts) t[i].second = *opts; else t.erase(t.begin() + i);
+            return VB_OK;
+        }
+    if (opts) t.emplace_back(stream, *opts);
+    return VB_OK;
+}
+
+extern "C" int vb_stream_get_opts(void* stream, vb_stream_opts* out) {
+    if (!out) return VB_ERR_ARG;
+    *out = vb_opts_for(stream);
+    return VB_OK;
+}

@@ -80,14 +80,22 @@ VB_DEVICE float schedule_mult(const AdamHyper& h, int step) {
     return (float)r;
 }
 
+// a tensor no backward pass wrote to this step (and whose gradient is zero): the reference's `if p.grad is None: continue`
+// (optimization.py:254-255).  Device-side, per step: no host-cached decision can go stale between data-parallel ranks.
+VB_DEVICE bool adam_skips(const float* touched, const float* norm2, const AdamHyper& h, long tid) {
+    if (!touched || touched[tid] != 0.f) return false;
+    return !(h.max_grad_norm > 0.f && norm2[tid] > 0.f);
+}
+
 VB_KERNEL VB_LAUNCH_BOUNDS(NT) adam_update_kernel(float* params, const float* grads, float* m, float* v, bf16* shadow,
                                                  const int64_t* chunks, const int64_t* tensors, const float* norm2,
-                                                 const int* steps, AdamHyper h) {
+                                                 const int* steps, const float* touched, AdamHyper h) {
     const int64_t* c = chunks + (long)blockIdx.x * 4;
     const long tid = c[0], off = c[1], len = c[2];
     const int64_t* te = tensors + tid * 4;
     const long t_off = te[0], sh_off = te[2], flags = te[3];
     if (!(flags & 1)) return;
+    if (adam_skips(touched, norm2, h, tid)) return;
     const float wd = (flags & 2) ? h.weight_decay : 0.0f;
     float clip = 1.0f;
     if (h.max_grad_norm > 0.f) {
@@ -109,9 +117,9 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) adam_update_kernel(float* params, const float* gr
     }
 }
 
-VB_KERNEL adam_step_inc_kernel(int* steps, const int64_t* tensors, int n) {
+VB_KERNEL adam_step_inc_kernel(int* steps, const int64_t* tensors, int n, const float* touched, const float* norm2, AdamHyper h) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && (tensors[(long)i * 4 + 3] & 1)) steps[i] += 1;
+    if (i < n && (tensors[(long)i * 4 + 3] & 1) && !adam_skips(touched, norm2, h, i)) steps[i] += 1;
 }
 
 VB_KERNEL VB_LAUNCH_BOUNDS(NT) shadow_refresh_kernel(const float* params, bf16* shadow, const int64_t* chunks,
@@ -175,7 +183,8 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) shadow_transpose_kernel(const bf16* src, bf16* ds
 
 extern "C" int vb_bert_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                                  void* bf16_shadow, const int64_t* chunk_table, int n_chunks,
-                                 const int64_t* tensor_table, int n_tensors, float* norm2_ws, int* step_counters,
+                                 const int64_t* tensor_table, int n_tensors, const float* touched, float* norm2_ws,
+                                 int* step_counters,
                                  float lr, float b1, float b2, float eps, float weight_decay,
                                  float max_grad_norm, float warmup, float t_total, int schedule, void* stream) {
     if (!params || !grads || !exp_avg || !exp_avg_sq || !chunk_table || !tensor_table || !norm2_ws || !step_counters)
@@ -190,9 +199,9 @@ extern "C" int vb_bert_adam_step(float* params, const float* grads, float* exp_a
                   (const float*)partial, norm2_ws);
     }
     VB_LAUNCH(adam_update_kernel, dim3((unsigned)n_chunks), dim3(NT), 0, s, params, grads, exp_avg, exp_avg_sq,
-              (bf16*)bf16_shadow, chunk_table, tensor_table, (const float*)norm2_ws, (const int*)step_counters, h);
+              (bf16*)bf16_shadow, chunk_table, tensor_table, (const float*)norm2_ws, (const int*)step_counters, touched, h);
     VB_LAUNCH(adam_step_inc_kernel, dim3((unsigned)((n_tensors + 63) / 64)), dim3(64), 0, s, step_counters,
-              tensor_table, n_tensors);
+              tensor_table, n_tensors, touched, (const float*)norm2_ws, h);
     return vb_check_launch();
 }
 

@@ -138,6 +138,26 @@ VB_DEVICE void vb_lds_add(float* p, float v) {
 }
 #endif
 
+// The same copy through a BUFFER descriptor (buffer_load_dwordx4 ... offen lds): address = descriptor base (4 SGPRs) + per-lane
+// 32-bit byte offset (VGPR) + wave-uniform 32-bit byte offset (SGPR).  A K tile advances the SGPR offset, so issuing a copy
+// costs no vector arithmetic at all -- the flat form above needs a 64-bit per-lane add unless the compiler happens to match
+// its scalar-base addressing mode.  Raw buffer (stride 0) over the whole 32-bit range: callers keep offsets below 2^32.
+#ifdef VB_EMU
+struct vb_buf { const unsigned char* base; };
+VB_DEVICE vb_buf vb_make_buf(const void* p) { return vb_buf{(const unsigned char*)p}; }
+VB_DEVICE void vb_glds16_buf(vb_buf b, unsigned voff, unsigned soff, unsigned char* lds_wave_base) {
+    memcpy(lds_wave_base + ::hipemu::cur()->lane * 16, b.base + voff + soff, 16);
+}
+#else
+typedef __amdgpu_buffer_rsrc_t vb_buf;
+VB_DEVICE vb_buf vb_make_buf(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, -1, 0x00020000);      // gfx9-family raw buffer, 2^32 - 1 records
+}
+VB_DEVICE void vb_glds16_buf(vb_buf b, unsigned voff, unsigned soff, unsigned char* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(b, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, (int)soff, 0, 0);
+}
+#endif
+
 // counted wait for outstanding vector-memory operations (LDS-direct copies included) + raw workgroup
 // barrier: lets the newest K tile(s) stay in flight across the barrier (guide: "Pipelining across
 // barriers").  N must be an immediate.
@@ -196,6 +216,20 @@ VB_DEVICE float vb_pair_sum32(float x) {
 VB_DEVICE int vb_uniform(int v) { return v; }
 #else
 VB_DEVICE int vb_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+#endif
+
+// a pointer known to be wave-uniform, made OPAQUE to the optimiser as a scalar-register pair: `p + zext(per-lane 32-bit
+// offset)` then selects the scalar-base + vector-offset form of global_load / global_load_lds instead of 64-bit per-lane
+// address arithmetic (LLVM otherwise re-associates base + k * stride + lane_offset into per-lane 64-bit induction variables)
+#ifdef VB_EMU
+VB_DEVICE const unsigned char* vb_uniform_ptr(const unsigned char* p) { return p; }
+#else
+VB_DEVICE const unsigned char* vb_uniform_ptr(const unsigned char* p) {
+    const uint64_t v = (uint64_t)p;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return (const unsigned char*)(((uint64_t)hi << 32) | lo);
+}
 #endif
 
 // wave-level ordering point for data exchanged through LDS by the lanes of ONE wave (no workgroup barrier):

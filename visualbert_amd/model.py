@@ -186,7 +186,11 @@ class ModelWrapper(object):
             pair = (f, "training_step_%d_epoch_%d.th" % (st, ep))
         model_state = torch.load(os.path.join(serialization_dir, pair[0]), map_location="cpu")
         training_state = torch.load(os.path.join(serialization_dir, pair[1]), map_location="cpu")
-        self.model.load_state_dict(model_state)
+        # a checkpoint saved from the reference's nn.DataParallel wrapper carries a "module." prefix on every key
+        # (models/model_wrapper.py:146, 163-169); _load_flexible tolerates missing / extra keys like the reference's
+        # restore (utils/pytorch_misc.py:246-265)
+        model_state = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in model_state.items()}
+        _load_flexible(self.model, model_state)
         self.optimizer.load_state_dict(training_state["optimizer"])
         self._after_weights_changed()
         epoch = training_state["epoch"]

@@ -124,6 +124,9 @@ class ParameterArena(object):
         # buckets for the gradient all-reduce: contiguous [start, end) ranges, in arena order
         self.bucket_of = bucket_of
         self.touched = set()                    # ids of the parameters a backward pass has written since zero_grad()
+        self._touched_dev = None                # device fp32 [n_params] image of `touched` (rewritten when the set changes)
+        self._touched_key = None
+        self.touched_synced = None              # set by DataParallelGradSync: this step's flags combined over the ranks
         self._tables = None
         self._build_transposed()
 
@@ -186,6 +189,18 @@ class ParameterArena(object):
                 hi = e if hi is None else max(hi, e)
         return lo, hi
 
+    def touched_flags(self):
+        """fp32 [n_params] on the arena's device: 1 where a backward pass wrote the parameter's gradient since zero_grad().
+        Uploaded only when the set differs from the previous step's (it is the same set step after step)."""
+        key = frozenset(self.touched)
+        if self._touched_dev is None or key != self._touched_key:
+            host = torch.tensor([1.0 if id(p) in key else 0.0 for p in self.params], dtype=torch.float32)
+            if self._touched_dev is None:
+                self._touched_dev = torch.empty(len(self.params), dtype=torch.float32, device=self.device)
+            self._touched_dev.copy_(host, non_blocking=False)
+            self._touched_key = key
+        return self._touched_dev
+
     def zero_grad(self):
         self.touched.clear()
         g = self.grad
@@ -216,6 +231,9 @@ class ParameterArena(object):
         for p in self.params:
             if p.dim() == 2:
                 p._vb_shadow_ver = p._version
+        # a raw write into `data` (broadcast, checkpoint restore) does not move p._version, so the W^T shadows cannot rely
+        # on version counters either: re-transpose now (one launch)
+        self.refresh_transposed()
 
 
 # ------------------------------------------------------------------------------------------------
@@ -947,6 +965,39 @@ class TrainVisualBERTObjective(PreTrainedBertModel):
             self.build_arena()
         return out
 
+    def zero_grad(self, set_to_none=False):
+        """nn.Module.zero_grad() would set every p.grad to None and leave the flat gradient arena -- which the kernels
+        accumulate into -- untouched, so a loop calling model.zero_grad() instead of optimizer.zero_grad() would sum
+        gradients across steps.  One memset of the arena; p.grad stays bound to its arena view."""
+        if self.arena is not None:
+            self.arena.zero_grad()
+            for p in self.arena.params:
+                p.grad = p._vb_grad
+
+    def _check_inputs(self, input_ids, token_type_ids, masked_lm_labels):
+        """the reference fails loudly on corrupt inputs (nn.Embedding raises on an out-of-range index, CrossEntropyLoss on
+        a label >= V); the gather kernels clamp instead of faulting, so the range checks live here.  The sequence-length
+        check is free and always on; the value-range checks read the tensors back (a device synchronisation per
+        forward), so they are the debug mode VB_CHECK_INPUTS=1."""
+        cfg = self.config
+        T = input_ids.size(-1)
+        if T > cfg.max_position_embeddings:
+            raise IndexError("sequence length %d exceeds max_position_embeddings %d" % (T, cfg.max_position_embeddings))
+        import os
+        if os.environ.get("VB_CHECK_INPUTS", "0") != "1":
+            return
+        lo, hi = int(input_ids.min()), int(input_ids.max())
+        if lo < 0 or hi >= cfg.vocab_size:
+            raise IndexError("input_ids out of range [0, %d): min %d max %d" % (cfg.vocab_size, lo, hi))
+        if token_type_ids is not None and token_type_ids.numel():
+            lo, hi = int(token_type_ids.min()), int(token_type_ids.max())
+            if lo < 0 or hi >= cfg.type_vocab_size:
+                raise IndexError("token_type_ids out of range [0, %d): min %d max %d" % (cfg.type_vocab_size, lo, hi))
+        if masked_lm_labels is not None and masked_lm_labels.numel():
+            lo, hi = int(masked_lm_labels.min()), int(masked_lm_labels.max())
+            if lo < -1 or hi >= cfg.vocab_size:
+                raise IndexError("masked_lm_labels out of range [-1, %d): min %d max %d" % (cfg.vocab_size, lo, hi))
+
     def bucket_ranges(self):
         """[(start, end)] element ranges of the gradient arena, one per all-reduce bucket, listed in the
         order backward completes them: heads+pooler, layer L-1 ... layer 0, embeddings."""
@@ -973,6 +1024,7 @@ class TrainVisualBERTObjective(PreTrainedBertModel):
                                       "both (modeling.py:1198-1257); refusing rather than dropping them silently")
         flat_input_ids = transform_to_batch_sequence(input_ids)
         flat_token_type_ids = transform_to_batch_sequence(token_type_ids)
+        self._check_inputs(flat_input_ids, flat_token_type_ids, masked_lm_labels)
         flat_input_mask = transform_to_batch_sequence(input_mask)
         flat_image_mask = transform_to_batch_sequence(image_mask)
         flat_masked_lm_labels = transform_to_batch_sequence(masked_lm_labels)

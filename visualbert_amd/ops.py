@@ -158,7 +158,8 @@ def gemm_key_name(key):
     if (key & 19) == 19:
         return "gemm_tn_8ph_kernel<bf16->fp32, grouped persistent 256x256 wgrad, ds_read_b64_tr_b16 gathers, fp32 atomics>"
     if not (key & 3):
-        kind = ("gemm_nt_8ph_kernel<%s->%s, persistent 256x256 tile, four-slot LDS-direct schedule>" if key & 16 else
+        kind = ("gemm_nt_dual_kernel<%s->%s, 256x128 tile, two workgroups per CU, five-slot LDS-direct ring>" if key & 64 else
+                "gemm_nt_8ph_kernel<%s->%s, persistent 256x256 tile, four-slot LDS-direct schedule>" if key & 16 else
                 "gemm_nt_experimental<%s->%s>" if key & 32 else
                 "gemm_nt_pipe_kernel<%s->%s, 256x128 tile, 2-stage LDS-direct>")
         return kind % ("fp32" if key & 8 else "bf16", "fp32" if (key & 4 or key & 8) else "bf16")

@@ -102,6 +102,9 @@ class WarmupLinearSchedule(_LRSchedule):
 
 SCHEDULES = {None: ConstantLR, "none": ConstantLR, "warmup_cosine": WarmupCosineSchedule,
              "warmup_constant": WarmupConstantSchedule, "warmup_linear": WarmupLinearSchedule}      # optimization.py:176-182
+_SCHEDULE_CLASSES = {c.__name__: c for c in (ConstantLR, WarmupCosineSchedule, WarmupCosineWithHardRestartsSchedule,
+                                             WarmupCosineWithWarmupRestartsSchedule, WarmupConstantSchedule,
+                                             WarmupLinearSchedule)}
 
 
 class BertAdam(Optimizer):
@@ -172,30 +175,44 @@ class BertAdam(Optimizer):
                            m=torch.zeros_like(arena.data), v=torch.zeros_like(arena.data),
                            norm2=torch.zeros(nt + nc, dtype=torch.float32, device=dev),
                            steps=torch.zeros(nt, dtype=torch.int32, device=dev), host_step=0,
-                           opt_flags=opt_flags, dec_flags=dec_flags, skipped=frozenset(), skip_candidates=frozenset())
+                           opt_flags=opt_flags, dec_flags=dec_flags)
         return self._fused
 
-    def _skip_untouched(self, f):
+    def _touched_flags(self, f):
         """The reference's step() skips a parameter whose .grad is None -- no moment update, no weight decay
         (optimization.py:254-255): a head's unused tensors (cls.* under `flickr`, seq_relationship under `vqa_advanced`), the
         visual tables on a text-only batch, ...  Here every gradient is a view into the flat arena and always exists, so
-        the backward pass records which parameters it wrote (ParameterArena.touched) and the optimizer's tensor table
-        drops the others; the table is rebuilt only when that set changes.  A parameter that was not recorded but holds a
-        non-zero gradient is optimised anyway (checked once per change of the set)."""
+        the backward pass records which parameters it wrote (ParameterArena.touched) and hands the optimizer KERNEL one
+        flag per tensor; the kernel skips a tensor iff its flag is 0 and its gradient norm is 0.  Nothing is cached on the
+        host between steps: under data parallelism the flags are all-reduced with the gradients
+        (DataParallelGradSync.finish_step -> arena.touched_synced), so every rank takes the same decision every step."""
         a = f["arena"]
-        cand = frozenset(i for i, p in enumerate(a.params) if f["opt_flags"][i] and id(p) not in a.touched)
-        if cand == f["skip_candidates"]:
-            return
-        confirmed = frozenset(i for i in cand if float(a.params[i]._vb_grad.abs().max()) == 0.0)
-        if confirmed != f["skipped"]:
-            flags = [fl and i not in confirmed for i, fl in enumerate(f["opt_flags"])]
-            f["tt"], f["ct"], f["nt"], f["nc"] = a.tables(flags, f["dec_flags"])
-        f["skip_candidates"], f["skipped"] = cand, confirmed
+        synced = getattr(a, "touched_synced", None)
+        if synced is not None:                                  # this step's flags, already combined over the ranks
+            a.touched_synced = None
+            return synced
+        return a.touched_flags()
 
     def fused(self):
         f = self._fused
         if f is None or f["arena"] is not getattr(self.param_groups[0]["params"][0], "_vb_arena", None):
+            old = f
             f = self._build()
+            if old is not None and int(old["steps"].max()) > 0:
+                # the model was moved / re-laid-out after training had started (TrainVisualBERTObjective._apply rebuilds the
+                # arena): the moments and step counters follow their parameters by NAME instead of silently restarting
+                a0, a1 = old["arena"], f["arena"]
+                where = {n: (o, p.numel(), i) for i, (n, p, o) in enumerate(zip(a0.names, a0.params, a0.offsets))}
+                steps0, steps1 = old["steps"].tolist(), f["steps"].tolist()
+                for i, (n, p, o) in enumerate(zip(a1.names, a1.params, a1.offsets)):
+                    if n not in where or where[n][1] != p.numel():
+                        raise RuntimeError("visualbert_amd.BertAdam: parameter %r changed under a running optimizer" % n)
+                    o0, cnt, i0 = where[n]
+                    f["m"][o:o + cnt].copy_(old["m"][o0:o0 + cnt])
+                    f["v"][o:o + cnt].copy_(old["v"][o0:o0 + cnt])
+                    steps1[i] = steps0[i0]
+                f["steps"].copy_(torch.tensor(steps1, dtype=torch.int32))
+                f["host_step"] = old["host_step"]
         return f
 
     def zero_grad(self, set_to_none=False):
@@ -221,7 +238,7 @@ class BertAdam(Optimizer):
         g = self.param_groups[0]
         sch = g["schedule"]
         L = _lib.lib()
-        self._skip_untouched(f)
+        touched = self._touched_flags(f)
         lr, code = float(g["lr"]), f["code"]
         if code < 0:
             # every optimised tensor takes every step, so one host counter mirrors the device's per-tensor counters
@@ -229,7 +246,7 @@ class BertAdam(Optimizer):
             lr, code = lr * float(sch.get_lr(f["host_step"])), 0
         rc = L.vb_bert_adam_step(_lib.ptr(a.data), _lib.ptr(a.grad), _lib.ptr(f["m"]), _lib.ptr(f["v"]),
                                  _lib.ptr(a.shadow), _lib.ptr(f["ct"]), f["nc"], _lib.ptr(f["tt"]), f["nt"],
-                                 _lib.ptr(f["norm2"]), _lib.ptr(f["steps"]), lr, float(g["b1"]),
+                                 _lib.ptr(touched), _lib.ptr(f["norm2"]), _lib.ptr(f["steps"]), lr, float(g["b1"]),
                                  float(g["b2"]), float(g["e"]), float(f["wd"]), float(g["max_grad_norm"]),
                                  float(sch.warmup), float(sch.t_total), code, _lib.stream_ptr())
         _lib.check(rc, "vb_bert_adam_step")
@@ -265,12 +282,34 @@ class BertAdam(Optimizer):
                 k += 1
             gd = {kk: vv for kk, vv in group.items() if kk not in ("params", "schedule")}
             gd["params"] = ids
-            gd["schedule"] = type(group["schedule"]).__name__
+            sch = group["schedule"]
+            # a plain dict, not the object and not a bare class name: torch.save-able by either side and enough to
+            # rebuild the schedule on load
+            gd["schedule"] = {"class": type(sch).__name__, "warmup": float(getattr(sch, "warmup", -1)),
+                              "t_total": float(getattr(sch, "t_total", -1)), "cycles": getattr(sch, "cycles", None)}
             groups.append(gd)
         return dict(state=state, param_groups=groups)
 
     def load_state_dict(self, sd):
+        # hyper-parameters and the schedule travel with the checkpoint (saved as {"class", "warmup", "t_total", "cycles"});
+        # a checkpoint written by the reference carries the schedule OBJECT of its own module -- rebuilt here by class name
+        for group, saved in zip(self.param_groups, sd.get("param_groups", [])):
+            for k, v in saved.items():
+                if k in ("params", "schedule"):
+                    continue
+                group[k] = v
+            sch = saved.get("schedule")
+            if sch is not None and not isinstance(sch, dict):
+                sch = {"class": type(sch).__name__, "warmup": float(getattr(sch, "warmup", -1)),
+                       "t_total": float(getattr(sch, "t_total", -1)), "cycles": getattr(sch, "cycles", None)}
+            if isinstance(sch, dict) and sch.get("class") in _SCHEDULE_CLASSES:
+                kw = dict(warmup=sch["warmup"], t_total=sch["t_total"])
+                if sch.get("cycles") is not None:
+                    kw["cycles"] = sch["cycles"]
+                group["schedule"] = _SCHEDULE_CLASSES[sch["class"]](**kw)
         f = self.fused()
+        sch0 = self.param_groups[0]["schedule"]
+        f["code"] = 1 if type(sch0) is WarmupLinearSchedule else (0 if (type(sch0) is ConstantLR or sch0.t_total < 0) else -1)
         a = f["arena"]
         idx = {id(p): i for i, p in enumerate(a.params)}
         steps = f["steps"].tolist()

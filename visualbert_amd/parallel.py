@@ -9,9 +9,12 @@ means exactly -- in L+2 contiguous buckets launched while backward is still runn
 
     heads+pooler | layer L-1 | ... | layer 0 | embeddings (incl. the tied decoder weight, last)
 
-Each bucket is handed to RCCL (torch.distributed backend "nccl" == RCCL on ROCm) from an autograd
-hook the moment its layer's wgrad kernels have been enqueued; the collective runs on RCCL's own
-stream behind an event, so it overlaps the remaining backward compute.  xGMI is point-to-point
+Each bucket is handed to RCCL from an autograd hook the moment its layer's wgrad kernels have been
+enqueued.  Default path: the C ABI's communicator (include/visualbert_hip.h: vb_comm_init from an RCCL
+unique id shipped through torch.distributed's store, vb_allreduce_bucket on a side HIP stream behind an
+event recorded on the compute stream) -- launch, stream ordering and the compute-unit reservation below
+are then one mechanism owned by this class.  `use_abi_comm=False` (and every non-RCCL backend, e.g. the
+gloo CPU tests) goes through torch.distributed's all_reduce instead.  xGMI is point-to-point
 (7 links x ~153 GB/s per GPU): a ring all-reduce moves 2(N-1)/N x payload per GPU and is per-link
 bound, so buckets are whole layers (28 MB fp32 at BERT-base) -- large enough to run at link speed,
 small enough that the last one (embeddings, 94 MB + heads) is the only exposed tail.
@@ -41,8 +44,40 @@ def configure_rccl_env():
         os.environ.setdefault("NCCL_MAX_NCHANNELS", str(comm_cus()))
 
 
+class RcclCommunicator(object):
+    """the C ABI's communicator (vb_comm_*): rank 0 draws the RCCL unique id, torch.distributed's process group carries
+    its 128 bytes to the other ranks (a host-side object broadcast), every rank joins on its CURRENT device."""
+
+    def __init__(self, process_group=None):
+        import ctypes
+        L = _lib.lib()
+        rank, world = dist.get_rank(process_group), dist.get_world_size(process_group)
+        idbuf = (ctypes.c_char * _lib.VB_COMM_ID_BYTES)()
+        payload = [None]
+        if rank == 0:
+            _lib.check(L.vb_comm_unique_id(idbuf), "vb_comm_unique_id")
+            payload = [bytes(idbuf.raw)]
+        dist.broadcast_object_list(payload, src=0, group=process_group)
+        idbuf.raw = payload[0]
+        handle = ctypes.c_void_p()
+        _lib.check(L.vb_comm_init(idbuf, rank, world, ctypes.byref(handle)), "vb_comm_init")
+        self.handle, self.rank, self.world = handle, rank, world
+
+    def allreduce(self, t, average, stream):
+        """in place on `t` (contiguous fp32 / bf16), enqueued on `stream` (a torch.cuda.Stream)."""
+        import ctypes
+        _lib.check(_lib.lib().vb_allreduce_bucket(self.handle, _lib.ptr(t), t.numel(), _lib.dtype_code(t.dtype),
+                                                  1 if average else 0, ctypes.c_void_p(stream.cuda_stream)),
+                   "vb_allreduce_bucket")
+
+    def close(self):
+        if self.handle is not None:
+            _lib.lib().vb_comm_destroy(self.handle)
+            self.handle = None
+
+
 class DataParallelGradSync(object):
-    def __init__(self, objective, process_group=None, overlap=True):
+    def __init__(self, objective, process_group=None, overlap=True, use_abi_comm=True):
         """objective: visualbert_amd.modeling.TrainVisualBERTObjective (owns the ParameterArena)."""
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
@@ -54,9 +89,21 @@ class DataParallelGradSync(object):
         self._works = []
         self._done = set()
         self._reserved = False
+        self.comm = None
+        self.comm_stream = None
+        if use_abi_comm and self.backend == "nccl":
+            self.comm = RcclCommunicator(process_group)
+            self.comm_stream = torch.cuda.Stream(device=objective.arena.grad.device)
+        self.comm_kind = "C-ABI vb_allreduce_bucket" if self.comm is not None else "torch.distributed %s" % self.backend
         from . import ops
         ops.set_replica(dist.get_rank(process_group))       # replicas must not repeat each other's dropout masks
         self._install()
+
+    def close(self):
+        if self.comm is not None:
+            torch.cuda.synchronize()
+            self.comm.close()
+            self.comm = None
 
     def _install(self):
         self.buckets = self.obj.bucket_ranges()              # [(name, lo, hi)] in completion order
@@ -86,6 +133,14 @@ class DataParallelGradSync(object):
             return
         view = self.obj.arena.grad[lo:hi]
         self._reserve_cus(True)
+        if self.comm is not None:
+            # the bucket's producers are enqueued on the compute stream: the side stream waits for an event recorded there
+            # now, then RCCL averages the bucket in place while the compute stream goes on with the next layer's backward
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(view.device))
+            self.comm_stream.wait_event(ready)
+            self.comm.allreduce(view, True, self.comm_stream)
+            return
         if self.backend == "nccl":
             w = dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.pg, async_op=True)
         else:                                                 # gloo (CPU tests): SUM then scale
@@ -93,27 +148,80 @@ class DataParallelGradSync(object):
         self._works.append((w, view))
 
     def _reserve_cus(self, on):
-        """leave comm_cus() CUs to RCCL while buckets are in flight (see the module docstring)."""
+        """leave comm_cus() CUs to RCCL while buckets are in flight (see the module docstring): a launch option of the
+        COMPUTE stream (vb_stream_set_opts), not a process-wide switch."""
         if self.backend != "nccl" or self.world == 1 or comm_cus() <= 0 or on == self._reserved:
             return
         self._reserved = on
-        wgs = 0
+        import ctypes
+        sp = _lib.stream_ptr()
         if on:
             cus = torch.cuda.get_device_properties(self.obj.arena.grad.device).multi_processor_count
-            wgs = max(8, (cus - comm_cus()) // 8 * 8)
-        _lib.check(_lib.lib().vb_gemm_set_persistent_wgs(wgs), "vb_gemm_set_persistent_wgs")
+            o = _lib.StreamOpts(max(8, (cus - comm_cus()) // 8 * 8), 0, 0, 0)
+            _lib.check(_lib.lib().vb_stream_set_opts(sp, ctypes.byref(o)), "vb_stream_set_opts")
+        else:
+            _lib.check(_lib.lib().vb_stream_set_opts(sp, None), "vb_stream_set_opts")
 
     def _layer_ready(self, layer_index):
         # everything above this layer in the graph has finished enqueuing its backward
         self._reduce("heads")
         self._reduce("layer%d" % layer_index)
 
+    def _reduce_touched(self):
+        """which parameters received a gradient on ANY rank this step: the per-tensor flags the fused optimizer skips on
+        (optimization.BertAdam._touched_flags) ride one more tiny all-reduce, so that every rank takes the same decision --
+        a rank-local flag would let replicas diverge silently (weight decay applied on one rank only)."""
+        a = self.obj.arena
+        flags = a.touched_flags().clone()
+        if self.comm is not None:
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(flags.device))
+            self.comm_stream.wait_event(ready)
+            self.comm.allreduce(flags, True, self.comm_stream)      # mean > 0  <=>  touched somewhere
+            flags.record_stream(self.comm_stream)
+        elif self.backend == "nccl":
+            self._works.append((dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.pg, async_op=True), None))
+        else:
+            self._works.append((dist.all_reduce(flags, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), None))
+        a.touched_synced = flags
+
     def finish_step(self):
         for name, _, _ in self.buckets:                       # whatever the hooks did not cover
             self._reduce(name)
+        self._reduce_touched()
         for w, view in self._works:
             w.wait()
-            if self.backend != "nccl":
+            if self.backend != "nccl" and view is not None:
                 view.div_(self.world)
         self._works = []
+        if self.comm is not None:                             # the optimizer (compute stream) waits for the last bucket
+            done = torch.cuda.Event()
+            done.record(self.comm_stream)
+            torch.cuda.current_stream(self.obj.arena.grad.device).wait_event(done)
         self._reserve_cus(False)
+
+    def measure_allreduce(self, barrier, reps=5):
+        """stand-alone all-reduce of the whole gradient arena in the step's buckets (nothing to overlap with): payload,
+        milliseconds and bus bandwidth 2(N-1)/N x bytes / time -- to be read against xGMI's ~153 GB/s per link."""
+        import time
+        g = self.obj.arena.grad
+        nbytes = g.numel() * g.element_size()
+        saved = g.clone()
+
+        def once():
+            self.begin_step()
+            self.finish_step()
+
+        once()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            once()
+        barrier()
+        dt = (time.perf_counter() - t0) / reps
+        g.copy_(saved)
+        self.obj.arena.touched_synced = None
+        n = self.world
+        return dict(payload_bytes=nbytes, buckets=len(self.buckets), ms=round(dt * 1e3, 3),
+                    bus_GBps=round(2.0 * (n - 1) / n * nbytes / dt / 1e9, 2) if n > 1 else 0.0,
+                    algo_GBps=round(nbytes / dt / 1e9, 2), ranks=n, path=self.comm_kind)

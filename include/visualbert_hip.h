@@ -48,7 +48,8 @@ const char* vb_version(void);
  *                          data-parallel caller lowers it while RCCL kernels are resident (parallel.py).
  *   nt_kernel: K-contiguous x K-contiguous bf16 GEMM kernel; 0 = chosen from the shape; 22 / 42 = two-barrier 128x128 /
  *              256x128 tiles; 80 / 81 = persistent 256x256 tile, eight / four slots per K tile; 90 = 256x128 tiles, two
- *              workgroups per compute unit.
+ *              workgroups per compute unit (91: the same with the copies issued ahead of the fragment reads); 1 = the
+ *              generic register-staged kernel.
  *   attn_two_pass: 1 = two-pass attention backward even where the one-pass kernel applies.
  * vb_stream_set_opts(stream, NULL) forgets the stream's entry (call it before destroying a stream).
  * ---------------------------------------------------------------------------------------------- */

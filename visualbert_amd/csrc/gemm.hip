@@ -1212,7 +1212,11 @@ int launch_8ph(GemmArgs g, hipStream_t stream) {
 // co-resident workgroup is the other half of the pipeline.  The epilogue is the wave-private one of the kernel above; its
 // slabs alias the (by then idle) ring.
 // =================================================================================================
-template <typename TO, int ACT, int OPT>
+// VAR: bit 0 = fragment reads before the phase's copies are issued, bit 1 = s_setprio 1 around the MFMA block.  Both on
+// (VAR 3, nt_kernel 90) is what ships; VAR 0 (nt_kernel 91) is kept for A/B.  Measured and dropped
+// (profiles/r02_gemm_dual_notes.txt): copies issued one by one between the MFMAs; a half-tile start offset for one of
+// the two workgroups that open a CU.
+template <typename TO, int ACT, int OPT, int VAR>
 VB_KERNEL VB_LAUNCH_BOUNDS2(256, 2) gemm_nt_dual_kernel(GemmArgs g) {
     typedef bf16 T;
     constexpr int BK = 64, KSTEPS = 2, HALF = 128 * 128;
@@ -1281,6 +1285,12 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(256, 2) gemm_nt_dual_kernel(GemmArgs g) {
                 for (int q = 0; q < 2; ++q)
                     acc[mh * 4 + f][nh * 2 + q] = vb_mma(fa[f][ks], fb[q][ks], acc[mh * 4 + f][nh * 2 + q]);
     };
+    auto prio = [&](int p) {
+#ifndef VB_EMU
+        if constexpr ((VAR & 2) != 0) { if (p) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+#endif
+        (void)p;
+    };
 
     const int nk = g.K / BK;
     // prologue: h = 0 .. 3 (A0(0) B(0) A1(0) A0(1)); E(0) adds h = 4
@@ -1296,20 +1306,27 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(256, 2) gemm_nt_dual_kernel(GemmArgs g) {
         // ---- E(k): A0(k), B(k) must have landed; A1(k) and A0(k+1) may still be in flight
         if (last) vb_wait_vmcnt<4>(); else vb_wait_vmcnt<8>();
         vb_phase_barrier();
-        if (!last) issue(B, offB, k + 1, SE);
+        if constexpr ((VAR & 1) == 0) { if (!last) issue(B, offB, k + 1, SE); }
         readB(fb0, smem + SB * HALF, 0);
         readA(smem + SA0 * HALF);
         readB(fb1, smem + SB * HALF, 1);
+        if constexpr ((VAR & 1) != 0) { vb_sched_fence(); if (!last) issue(B, offB, k + 1, SE); vb_sched_fence(); }
+        prio(1);
         quad(0, 0, fb0);
         quad(0, 1, fb1);
+        prio(0);
         // ---- O(k): A1(k) must have landed; A0(k+1) and B(k+1) may still be in flight
         if (last) vb_wait_vmcnt<0>(); else vb_wait_vmcnt<8>();
         vb_phase_barrier();
+        if constexpr ((VAR & 1) != 0) { readA(smem + SA1 * HALF); vb_sched_fence(); }
         if (!last) issue(A, offA[1], k + 1, SA0);              // A1(k+1) into the slot A0(k) just left
         if (k + 2 < nk) issue(A, offA[0], k + 2, SB);          // A0(k+2) into the slot B(k) just left
-        readA(smem + SA1 * HALF);
+        if constexpr ((VAR & 1) == 0) readA(smem + SA1 * HALF);
+        else vb_sched_fence();
+        prio(1);
         quad(1, 1, fb1);
         quad(1, 0, fb0);
+        prio(0);
     };
     for (int k = 0;;) {
         step(std::integral_constant<int, 0>(), k); if (++k == nk) break;
@@ -1322,8 +1339,8 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(256, 2) gemm_nt_dual_kernel(GemmArgs g) {
     gemm_epilogue_private<T, TO, ACT, OPT>(acc, smem + wave * EPI8_BYTES_PER_WAVE, g, m0 + wr * 128, n0 + wc * 64, lane);
 }
 
-template <typename TO, int ACT, int OPT>
-int launch_dual_act(const GemmArgs& g, dim3 grid, hipStream_t stream) {
+template <typename TO, int ACT, int OPT, int VAR>
+int launch_dual_var(const GemmArgs& g, dim3 grid, hipStream_t stream) {
     constexpr int SM = 5 * 128 * 128;                           // 80 KB: two workgroups per compute unit
 #ifndef VB_EMU
     if (g_prof) {
@@ -1332,14 +1349,19 @@ int launch_dual_act(const GemmArgs& g, dim3 grid, hipStream_t stream) {
         r.flops = 2.0 * g.M * g.N * g.K;
         r.key = (sizeof(TO) == 4 ? 4 : 0) | 64;
         (void)hipEventRecord(r.e0, stream);
-        VB_LAUNCH((gemm_nt_dual_kernel<TO, ACT, OPT>), grid, dim3(256), SM, stream, g);
+        VB_LAUNCH((gemm_nt_dual_kernel<TO, ACT, OPT, VAR>), grid, dim3(256), SM, stream, g);
         (void)hipEventRecord(r.e1, stream);
         g_prof->push_back(r);
         return vb_check_launch();
     }
 #endif
-    VB_LAUNCH((gemm_nt_dual_kernel<TO, ACT, OPT>), grid, dim3(256), SM, stream, g);
+    VB_LAUNCH((gemm_nt_dual_kernel<TO, ACT, OPT, VAR>), grid, dim3(256), SM, stream, g);
     return vb_check_launch();
+}
+template <typename TO, int ACT, int OPT>
+int launch_dual_act(const GemmArgs& g, dim3 grid, hipStream_t stream) {
+    if (t_opts.nt_kernel == 91) return launch_dual_var<TO, ACT, OPT, 0>(g, grid, stream);
+    return launch_dual_var<TO, ACT, OPT, 3>(g, grid, stream);
 }
 template <typename T, typename TO>
 int launch_dual(GemmArgs g, hipStream_t stream) {
@@ -1662,14 +1684,19 @@ int dispatch_pipe(const GemmArgs& g, hipStream_t s) {
         const long t128 = (long)((g.M + 255) / 256) * ((g.N + 127) / 128);
         // big persistent tiles when they fill most of the chip; otherwise the two-barrier kernels, with the 128x128 tile
         // when even 256x128 tiles would leave CUs idle (small batches)
-        variant = (sizeof(T) == 2 && t256 >= 160) ? 81 : (t128 >= 256 ? 42 : 22);
+        // Problems that fill the chip (B >= ~128 at S = 164): the two-workgroups-per-CU kernel, whose epilogues run under the
+        // partner workgroup's MFMAs -- except long-K GEMMs with a plain epilogue (FFN-out forward: K = 3072), where the
+        // persistent 256x256 kernel's K loop is ~10 % faster and the epilogue is 1/48 of the tile
+        // (profiles/r02_gemm_ab_*.txt: per step 36.6 -> 34.6 ms of NT GEMMs at B = 512).
+        const bool plain = !g.addend && !g.aux_in && !g.aux_out && !g.colsum && g.act == VB_ACT_NONE && sizeof(TO) == 2;
+        variant = (sizeof(T) == 2 && t256 >= 160) ? ((g.K >= 2048 && plain) ? 81 : 90) : (t128 >= 256 ? 42 : 22);
     }
     switch (variant) {
         case 22: return launch_pipe<T, TO, 2, 2>(g, s);
         case 42: return launch_pipe<T, TO, 4, 2>(g, s);
         case 80: return launch_8ph<T, TO>(g, s);
         case 81: return launch_8ph<T, TO>(g, s);
-        case 90: return launch_dual<T, TO>(g, s);
+        case 90: case 91: return launch_dual<T, TO>(g, s);
         default: return VB_ERR_UNSUPPORTED;
     }
 }

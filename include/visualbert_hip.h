@@ -148,16 +148,20 @@ int vb_align_pos_bwd(int dtype, const void* dz, const int64_t* alignment, float*
  * mask_add: fp32 [B,S] additive key mask ((1 - mask) * -10000, modeling.py:1293-1294),
  * ctx: T [B*S, H], lse: fp32 [B,nh,S] row log-sum-exp (saved for backward),
  * keepbits: uint64 [B*nh * vb_attn_keepbits_words(S)] dropout keep-bits (only touched when p_drop > 0).
- * Backward writes dqkv (T [B*S,3H]) completely; dsum_ws is an fp32 [B,nh,S] scratch.  ctx_fwd (optional): the forward
- * output ctx -- with it, bf16 and S <= 192 the backward runs as ONE kernel (D = rowsum(P o dP) taken as dO . ctx,
- * scores and probabilities computed once); without it, or for longer sequences / fp32, as two passes (dQ, then dK/dV).
+ * Backward writes dqkv (T [B*S,3H]) completely; dsum_ws is an fp32 scratch of vb_attn_bwd_ws_floats(B, S, nh) elements.
+ * ctx_fwd (optional): the forward output ctx -- with it, bf16 and S <= 192 the backward runs as ONE kernel (D = rowsum(P o dP)
+ * taken as dO . ctx, scores and probabilities computed once); without it, or for longer sequences / fp32, as two passes
+ * (dQ, then dK/dV).  dqkv_bias (optional, fp32 [3H]): += column sums of dqkv over the B*S tokens, i.e. the gradient of
+ * the packed q | k | v bias (modeling.py:232-234) -- from the one-pass kernel's fp32 accumulators through per-sample
+ * partial sums (no pass over dqkv), else by one column-sum pass.
  * Replaces: BertSelfAttention.forward modeling.py:236-256 and its autograd.
  * ---------------------------------------------------------------------------------------------- */
 int64_t vb_attn_keepbits_words(int S);
 int vb_attn_fwd(int dtype, const void* qkv, const float* mask_add, void* ctx, float* lse, uint64_t* keepbits,
                 int B, int S, int nh, int head_dim, float p_drop, uint64_t seed, uint32_t stream_id, void* stream);
+int64_t vb_attn_bwd_ws_floats(int B, int S, int nh);
 int vb_attn_bwd(int dtype, const void* qkv, const float* mask_add, const void* dctx, const float* lse,
-                const uint64_t* keepbits, float* dsum_ws, void* dqkv, const void* ctx_fwd,
+                const uint64_t* keepbits, float* dsum_ws, void* dqkv, const void* ctx_fwd, float* dqkv_bias,
                 int B, int S, int nh, int head_dim, float p_drop, uint64_t seed, uint32_t stream_id, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

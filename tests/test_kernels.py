@@ -383,16 +383,22 @@ def test_attention_fwd_bwd(dev, dt, cfg):
     dctx = torch.randn(B, S, H, generator=g).to(dt).to(dev)
     ctx_r.backward(dctx.float())
     dqkv = torch.full((B, S, 3 * H), float("nan"), dtype=dt, device=dev)
-    ws = torch.empty(B, nh, S, device=dev)
+    ws = torch.empty(L.vb_attn_bwd_ws_floats(B, S, nh), device=dev)
     gmax = qr.grad.abs().max().item()
+    bias_ref = qr.grad.sum(dim=(0, 1))                             # gradient of the packed q | k | v bias: column sums over tokens
     for fwd_out in (None, ctx):          # two passes (dQ, dK/dV) and -- bf16, S <= 192 -- the one-pass kernel that takes D from dO . ctx
-        dqkv.fill_(float("nan"))
-        rc = L.vb_attn_bwd(_lib.dtype_code(dt), _lib.ptr(qkv), _lib.ptr(mask_add), _lib.ptr(dctx), _lib.ptr(lse),
-                           _lib.ptr(bits), _lib.ptr(ws), _lib.ptr(dqkv), _lib.ptr(fwd_out), B, S, nh, 64, p, 77, 3,
-                           _lib.stream_ptr())
-        _lib.check(rc, "vb_attn_bwd")
-        err = (dqkv.float() - qr.grad).abs().max().item()
-        assert err <= tol(dt, 5e-5, 0.04) * max(1.0, gmax), (err, gmax, fwd_out is not None)
+        for with_bias in (False, True):
+            dqkv.fill_(float("nan"))
+            dbias = torch.full((3 * H,), 2.0, device=dev)           # an accumulation target: must come back as 2 + sums
+            rc = L.vb_attn_bwd(_lib.dtype_code(dt), _lib.ptr(qkv), _lib.ptr(mask_add), _lib.ptr(dctx), _lib.ptr(lse),
+                               _lib.ptr(bits), _lib.ptr(ws), _lib.ptr(dqkv), _lib.ptr(fwd_out),
+                               _lib.ptr(dbias) if with_bias else None, B, S, nh, 64, p, 77, 3, _lib.stream_ptr())
+            _lib.check(rc, "vb_attn_bwd")
+            err = (dqkv.float() - qr.grad).abs().max().item()
+            assert err <= tol(dt, 5e-5, 0.04) * max(1.0, gmax), (err, gmax, fwd_out is not None)
+            if with_bias:
+                berr = (dbias - 2.0 - bias_ref).abs().max().item()
+                assert berr <= tol(dt, 2e-4, 0.04) * max(1.0, bias_ref.abs().max().item()), (berr, fwd_out is not None)
 
 
 @pytest.mark.parametrize("variant", [1, 22, 42, 80, 81, 90])

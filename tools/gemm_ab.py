@@ -6,6 +6,9 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from visualbert_amd import _lib, ops
+if os.environ.get("VB_DEV") == "1":
+    _lib.use_dev_library()
+NOCHECK = os.environ.get("VB_NOCHECK") == "1"
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 arms = [int(x) for x in sys.argv[2:]] or [81, 90]
 dev = torch.device("cuda", 0)
@@ -51,7 +54,7 @@ for name, n, k, f32, epi in shapes:
                     ref = cur
                 else:
                     d = (cur - ref).abs().max().item()
-                    assert d <= 2e-2 * max(1.0, ref.abs().max().item()), (name, arm, d)
+                    assert NOCHECK or d <= 2e-2 * max(1.0, ref.abs().max().item()), (name, arm, d)
     _lib.set_opts()
     fl = 2.0 * M * n * k
     print("%-34s" % name + "   ".join("k%d %7.1f us (%6.1f TF)" % (arm, min(res[arm]), fl / min(res[arm]) / 1e6) for arm in arms), flush=True)

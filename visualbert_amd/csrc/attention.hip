@@ -182,6 +182,7 @@ VB_DEVICE void store4(float* p, const f32x4& v) { *(f32x4*)p = v; }
 struct AttnArgs {
     const void* qkv; const float* mask_add; void* ctx; float* lse; uint64_t* keepbits;   // forward
     const void* dctx; void* dqkv; float* dsum; const void* ctx_fwd;                       // backward
+    float* bias_ws;                  // one-pass backward: per-sample column sums of dQ | dK | dV, fp32 [B][3H] (or NULL)
     int B, S, nh; float scale; float p; float inv_keep; uint32_t thresh; uint32_t stream; uint64_t seed;
 };
 
@@ -194,13 +195,18 @@ VB_DEVICE long keep_index(const AttnArgs& a, int bh, int q, int g, int w, int nw
 // =================================================================================================
 // forward
 // =================================================================================================
+// NKF = key fragments of 16 that hold real keys (scores, softmax and dropout run over exactly these: S = 164 -> 11, where
+// rounding up to an even 12 spent 1/12 of the per-probability VALU work -- the bound of this kernel -- on padding);
+// the P.V MFMAs consume keys 32 at a time, so V^T (and the packed probabilities) are padded to NKV = even(NKF) fragments
+// with an all-zero upper half.
 template <typename T, int NKF>
 VB_KERNEL VB_LAUNCH_BOUNDS2(NT, 3) attn_fwd_kernel(AttnArgs a) {
-    constexpr int NK = NKF * 16, NKS = NKF / 2, NW = (NKF + 15) / 16;
+    constexpr int NKV = (NKF + 1) / 2 * 2;
+    constexpr int NK = NKF * 16, NKVK = NKV * 16, NKS = NKV / 2, NW = (NKF + 15) / 16;
     VB_DYN_SMEM(smem);
     unsigned char* ldsK = smem;
     unsigned char* ldsVT = ldsK + rm_bytes<T>(NK);
-    float* ldsMask = (float*)(ldsVT + tr_bytes<T>(NK));
+    float* ldsMask = (float*)(ldsVT + tr_bytes<T>(NKVK));
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, lg = lane >> 4;
     const int bh = blockIdx.x, b = bh / a.nh, h = bh % a.nh;
     const int S = a.S, H = a.nh * D;
@@ -208,14 +214,15 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(NT, 3) attn_fwd_kernel(AttnArgs a) {
     const T* qkv = (const T*)a.qkv;
 
     if constexpr (sizeof(T) == 2) {
-        PairTile<NK> tk, tv;
+        PairTile<NK> tk;
+        PairTile<NKVK> tv;
         pair_load<NK>(tk, qkv, ldx, row0, H + h * D, S, t);
-        pair_load<NK>(tv, qkv, ldx, row0, 2 * H + h * D, S, t);
+        pair_load<NKVK>(tv, qkv, ldx, row0, 2 * H + h * D, S, t);
         pair_store_rm<NK>(tk, ldsK, t);
-        pair_store_tr<NK>(tv, ldsVT, t);
+        pair_store_tr<NKVK>(tv, ldsVT, t);                  // rows >= S arrive as zeros: the padded key columns are 0
     } else {
         stage_rm<T>(ldsK, qkv, ldx, row0, H + h * D, S, NK, t);
-        stage_tr(ldsVT, qkv, ldx, row0, 2 * H + h * D, S, NK, t);
+        stage_tr(ldsVT, qkv, ldx, row0, 2 * H + h * D, S, NKVK, t);
     }
     for (int k = t; k < NK; k += NT) ldsMask[k] = k < S ? a.mask_add[(long)b * S + k] : -INFINITY;
     __syncthreads();
@@ -272,13 +279,14 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(NT, 3) attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int kf = 2 * kp + (e >> 2), r = e & 3;
+                    if (kf >= NKF) continue;                // the padding half of an odd fragment count
                     const bool keep = rand8_keep(rnd, e, a.thresh);
                     st[kf][r] = keep ? st[kf][r] * invk : 0.f;
                     if (keep) bits[kf >> 4] |= (uint64_t)1 << ((kf & 15) * 4 + r);
                 }
             } else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) st[2 * kp + (e >> 2)][e & 3] *= inv;
+                for (int e = 0; e < 8; ++e) if (2 * kp + (e >> 2) < NKF) st[2 * kp + (e >> 2)][e & 3] *= inv;
             }
         }
         if (a.p > 0.f && a.keepbits && qok) {
@@ -287,7 +295,10 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(NT, 3) attn_fwd_kernel(AttnArgs a) {
         }
         typename VecOf<T>::v8 pb[NKS];
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) pack_b(pb[ks], st[2 * ks], st[2 * ks + 1]);
+        for (int ks = 0; ks < NKS; ++ks) {
+            if (2 * ks + 1 < NKF) pack_b(pb[ks], st[2 * ks], st[2 * ks + 1]);
+            else pack_b(pb[ks], st[2 * ks], f32x4{0.f, 0.f, 0.f, 0.f});
+        }
 
         T* crow = (T*)a.ctx + (row0 + (qok ? q : 0)) * H + h * D;
 #pragma unroll
@@ -296,7 +307,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(NT, 3) attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
                 if (ks * 32 < S)
-                    acc = vb_mma(frag_tr(ldsVT, tr_pitch<T>(NK), df * 16 + li, ks, lg, T()), pb[ks], acc);
+                    acc = vb_mma(frag_tr(ldsVT, tr_pitch<T>(NKVK), df * 16 + li, ks, lg, T()), pb[ks], acc);
             }
             if (qok) store4(crow + df * 16 + lg * 4, acc);     // lane: query q, d = df*16 + lg*4 + 0..3
         }
@@ -601,6 +612,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS(FNT) attn_bwd_fused_kernel(AttnArgs a) {
     };
     unsigned char* ldsKT = smem + 2 * SETB;                // K^T of the whole sequence: [64 d][FNK keys]
     unsigned char* ldsDS = ldsKT + tr_bytes<T>(FNK);       // dS of the chunk: [CQ queries][FNK keys], pitch TSP
+    float* ldsBias = (float*)(ldsDS + CQ * TSP);           // [3][64]: column sums of dQ | dK | dV over this sample's tokens
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, lg = lane >> 4;
     const int bh = blockIdx.x, b = bh / a.nh, h = bh % a.nh;
     const int S = a.S, H = a.nh * D;
@@ -622,6 +634,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS(FNT) attn_bwd_fused_kernel(AttnArgs a) {
             *(uint32_t*)(ldsKT + (dc * 8 + 2 * w + 1) * pitch + r * 2) = (lo >> 16) | (hi & 0xFFFF0000u);
         }
         for (int i = t; i < CQ * TSP / 8; i += FNT) *(uint64_t*)(ldsDS + i * 8) = 0;
+        if (t < 3 * D) ldsBias[t] = 0.f;
     }
     const int kf = wave;
     const int key = kf * 16 + li;
@@ -700,6 +713,11 @@ VB_KERNEL VB_LAUNCH_BOUNDS(FNT) attn_bwd_fused_kernel(AttnArgs a) {
     __syncthreads();                                       // chunk 0, the K^T image and the zeroed tile are in LDS
     if (CQ < S) load_chunk(CQ);
 
+    // q/k/v bias gradients = column sums of dqkv over tokens.  This kernel holds dK^T, dV^T (and, block by block, dQ^T) in
+    // fp32 registers with the token index along the LANES (li): a 16-lane butterfly per value, once per workgroup, gives the
+    // per-sample sums, which leave through a [B][3H] workspace (one slot per workgroup: no same-address global atomics --
+    // those cost +140 us per layer in round 1) and a tiny reduction kernel.  Replaces an 85 us pass over dqkv per layer.
+    f32x4 dqsum = f32x4{0.f, 0.f, 0.f, 0.f};               // this wave's phase-B blocks all have df = wave & 3 (12 % 4 == 0)
     int cur = 0;
     for (int q0 = 0; q0 < S; q0 += CQ, cur ^= 1) {
         use_set(cur);
@@ -766,6 +784,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS(FNT) attn_bwd_fused_kernel(AttnArgs a) {
                 acc = vb_mma(frag_tr(ldsKT, tr_pitch<T>(FNK), df * 16 + li, ks, lg, T()), dsb, acc);
             }
             if (q < S) store4((T*)a.dqkv + (row0 + q) * ldx + h * D + df * 16 + lg * 4, acc);
+            dqsum += acc;                                   // columns of padded queries are exactly 0 (their dS rows are)
         }
         __syncthreads();                                   // phase B is done with the tile before the next phase A writes it
     }
@@ -778,13 +797,52 @@ VB_KERNEL VB_LAUNCH_BOUNDS(FNT) attn_bwd_fused_kernel(AttnArgs a) {
             store4(dvrow + df * 16 + lg * 4, dvT[df]);
         }
     }
+    if (a.bias_ws) {
+        auto sum16 = [&](float v) {                         // over the 16 lanes that share lg (tokens of the fragment)
+            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+            return v;
+        };
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float sq = sum16(dqsum[r]);
+            if (li == 0 && wave < (CQ / 16) * 4) vb_lds_add(ldsBias + (wave & 3) * 16 + lg * 4 + r, sq);
+        }
+#pragma unroll
+        for (int df = 0; df < 4; ++df)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float sk = sum16(dkT[df][r]), sv = sum16(dvT[df][r]);     // padded keys contribute exact zeros
+                if (li == 0 && wave_on) {
+                    vb_lds_add(ldsBias + D + df * 16 + lg * 4 + r, sk);
+                    vb_lds_add(ldsBias + 2 * D + df * 16 + lg * 4 + r, sv);
+                }
+            }
+        __syncthreads();
+        if (t < 3 * D) a.bias_ws[((long)b * 3 + t / D) * H + h * D + (t % D)] = ldsBias[t];
+    }
+}
+
+// out[c] += sum over samples of ws[b][c]  (c < 3H): 256 columns x a slice of the batch per workgroup
+VB_KERNEL VB_LAUNCH_BOUNDS(256) attn_bias_reduce_kernel(const float* ws, float* out, int B, int C, int rows_per_block) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int b0 = blockIdx.y * rows_per_block;
+    const int b1 = b0 + rows_per_block < B ? b0 + rows_per_block : B;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int bi = b0;
+    for (; bi + 3 < b1; bi += 4) {
+        s0 += ws[(long)bi * C + c]; s1 += ws[(long)(bi + 1) * C + c];
+        s2 += ws[(long)(bi + 2) * C + c]; s3 += ws[(long)(bi + 3) * C + c];
+    }
+    for (; bi < b1; ++bi) s0 += ws[(long)bi * C + c];
+    vb_atomic_add_noret(out + c, (s0 + s1) + (s2 + s3));
 }
 template <int NKF, int CQ> size_t fused_smem() {
     return 2 * (2 * rm_bytes<bf16>(CQ) + 2 * tr_bytes<bf16>(CQ) + 2 * CQ * 4 + (size_t)CQ * 4 * ((NKF + 15) / 16) * 8) +
-           tr_bytes<bf16>(FNK) + (size_t)CQ * TSP;
+           tr_bytes<bf16>(FNK) + (size_t)CQ * TSP + 3 * D * 4;
 }
 
-template <typename T, int NKF> size_t fwd_smem() { return rm_bytes<T>(NKF * 16) + tr_bytes<T>(NKF * 16) + NKF * 16 * 4; }
+template <typename T, int NKF> size_t fwd_smem() { return rm_bytes<T>(NKF * 16) + tr_bytes<T>((NKF + 1) / 2 * 32) + NKF * 16 * 4; }
 template <typename T, int NKF> size_t dq_smem() { return 2 * rm_bytes<T>(NKF * 16) + tr_bytes<T>(NKF * 16) + NKF * 16 * 4; }
 template <typename T, int NKF> size_t dkv_smem() {
     return 2 * rm_bytes<T>(QC) + 2 * tr_bytes<T>(QC) + 2 * QC * 4 + (size_t)QC * 4 * ((NKF + 15) / 16) * 8;
@@ -806,7 +864,7 @@ int launch_all(int which, const AttnArgs& a, hipStream_t s) {
                 // 64-query chunks (86 KB of LDS, one workgroup per CU): 528-541 us per layer at B=512; 32-query chunks (two
                 // workgroups per CU, twice the barriers): 575 us
                 VB_LAUNCH((attn_bwd_fused_kernel<NKF, 64>), grid, dim3(FNT), (fused_smem<NKF, 64>()), s, a);
-                return vb_check_launch();
+                return vb_check_launch() == VB_OK ? 1 : VB_ERR_LAUNCH;      // 1: the bias workspace (if any) was filled
             }
         }
         const size_t sm1 = dq_smem<T, NKF>(), sm2 = dkv_smem<T, NKF>();
@@ -821,6 +879,11 @@ int launch_all(int which, const AttnArgs& a, hipStream_t s) {
 template <typename T>
 int dispatch_nkf(int which, const AttnArgs& a, hipStream_t s) {
     const int nkf = ((a.S + 31) / 32) * 2;          // key fragments, padded to an even count
+    if (which == 0 && (a.S + 15) / 16 == 11) {      // forward at S = 161..176 (BASELINE: 164): exactly 11 fragments of work
+        const size_t sm = fwd_smem<T, 11>();
+        VB_LAUNCH((attn_fwd_kernel<T, 11>), dim3((unsigned)(a.B * a.nh)), dim3(NT), sm, s, a);
+        return vb_check_launch();
+    }
     if (nkf <= 4) return launch_all<T, 4>(which, a, s);
     if (nkf <= 8) return launch_all<T, 8>(which, a, s);
     if (nkf <= 12) return launch_all<T, 12>(which, a, s);
@@ -867,8 +930,13 @@ extern "C" int vb_attn_fwd(int dtype, const void* qkv, const float* mask_add, vo
 }
 
 
+extern "C" int64_t vb_attn_bwd_ws_floats(int B, int S, int nh) {
+    const int64_t d = (int64_t)B * nh * S, bias = (int64_t)B * 3 * nh * D;
+    return d > bias ? d : bias;
+}
+
 extern "C" int vb_attn_bwd(int dtype, const void* qkv, const float* mask_add, const void* dctx, const float* lse,
-                           const uint64_t* keepbits, float* dsum_ws, void* dqkv, const void* ctx_fwd,
+                           const uint64_t* keepbits, float* dsum_ws, void* dqkv, const void* ctx_fwd, float* dqkv_bias,
                            int B, int S, int nh, int head_dim,
                            float p_drop, uint64_t seed, uint32_t stream_id, void* stream) {
     AttnArgs a{};
@@ -877,8 +945,20 @@ extern "C" int vb_attn_bwd(int dtype, const void* qkv, const float* mask_add, co
     if (!qkv || !mask_add || !dctx || !lse || !dsum_ws || !dqkv || (p_drop > 0.f && !keepbits)) return VB_ERR_ARG;
     a.qkv = qkv; a.mask_add = mask_add; a.dctx = dctx; a.lse = (float*)lse; a.keepbits = (uint64_t*)keepbits;
     a.dsum = dsum_ws; a.dqkv = dqkv; a.ctx_fwd = ctx_fwd;
+    a.bias_ws = dqkv_bias ? dsum_ws : nullptr;              // the one-pass kernel does not need D in memory: same scratch
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == VB_BF16) return dispatch_nkf<bf16>(1, a, s);
-    if (dtype == VB_F32) return dispatch_nkf<float>(1, a, s);
-    return VB_ERR_ARG;
+    if (dtype == VB_BF16) rc = dispatch_nkf<bf16>(1, a, s);
+    else if (dtype == VB_F32) rc = dispatch_nkf<float>(1, a, s);
+    else return VB_ERR_ARG;
+    if (rc < 0 || !dqkv_bias) return rc < 0 ? rc : VB_OK;
+    const int C = 3 * nh * D;
+    if (rc == 1) {                                          // per-sample partial sums are in the workspace
+        const int slices = B >= 64 ? 16 : (B >= 8 ? 4 : 1);
+        const int rows = (B + slices - 1) / slices;
+        VB_LAUNCH(attn_bias_reduce_kernel, dim3((unsigned)((C + 255) / 256), (unsigned)((B + rows - 1) / rows)), dim3(256), 0, s,
+                  (const float*)dsum_ws, dqkv_bias, B, C, rows);
+        return vb_check_launch();
+    }
+    // two-pass kernels (fp32 parity mode, long sequences): one column-sum pass over dqkv
+    return vb_colsum(dtype, dqkv, C, dqkv_bias, nullptr, B * S, C, stream);
 }

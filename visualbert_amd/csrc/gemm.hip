@@ -1215,7 +1215,7 @@ int launch_8ph(GemmArgs g, hipStream_t stream) {
 // VAR: bit 0 = fragment reads before the phase's copies are issued, bit 1 = s_setprio 1 around the MFMA block.  Both on
 // (VAR 3, nt_kernel 90) is what ships; VAR 0 (nt_kernel 91) is kept for A/B.  Measured and dropped
 // (profiles/r02_gemm_dual_notes.txt): copies issued one by one between the MFMAs; a half-tile start offset for one of
-// the two workgroups that open a CU.
+// the two workgroups that open a CU; v_mfma_f32_32x32x16_bf16 instead of 16x16x32 (same fragment reads, 7 % slower).
 template <typename TO, int ACT, int OPT, int VAR>
 VB_KERNEL VB_LAUNCH_BOUNDS2(256, 2) gemm_nt_dual_kernel(GemmArgs g) {
     typedef bf16 T;

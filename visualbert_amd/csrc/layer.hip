@@ -62,7 +62,7 @@ Scratch carve_scratch(unsigned char* base, const Dims& d) {
     s.t_h5 = take((size_t)d.M * d.H * d.es);
     s.t_i = take((size_t)d.M * d.I * d.es);
     s.t_3h = take((size_t)d.M * 3 * d.H * d.es);
-    s.dsum = (float*)take((size_t)d.B * d.nh * d.S * 4);
+    s.dsum = (float*)take((size_t)vb_attn_bwd_ws_floats((int)d.B, (int)d.S, (int)d.nh) * 4);
     s.ln_ws = (float*)take((size_t)vb_ln_bwd_ws_bytes((int)d.M, d.H));
     s.total = o;
     return s;
@@ -184,11 +184,10 @@ extern "C" int vb_bert_layer_bwd(int dtype, const void* h_in, const float* mask_
                      G[VB_LW_AO_B], M, H, p_hidden, sid + 1, 0.f, 0, seed, sc.ln_ws, stream));
     // 5. dgrad attention-out: dctx = dao Wo
     VB_TRY(dgrad(dao, H, wo, VB_LWT_AO, H, sc.t_h3, nullptr, VB_ACT_NONE, nullptr));
-    // 6-7. attention backward (dQ pass, dK/dV pass)
-    VB_TRY(vb_attn_bwd(dtype, sv.qkv, mask_add, sc.t_h3, sv.lse, sv.keepbits, sc.dsum, sc.t_3h, sv.ctx, B, S, nh, 64, p_attn,
-                       seed, sid, stream));
-    // 8. bias gradient QKV
-    VB_TRY(vb_colsum(dtype, sc.t_3h, 3 * H, G[VB_LW_QKV_B], nullptr, M, 3 * H, stream));
+    // 6-8. attention backward (one pass for bf16 and S <= 192, else dQ pass + dK/dV pass) + the q | k | v bias gradient
+    //      (per-sample sums out of the one-pass kernel's accumulators; a column-sum pass over dqkv otherwise)
+    VB_TRY(vb_attn_bwd(dtype, sv.qkv, mask_add, sc.t_h3, sv.lse, sv.keepbits, sc.dsum, sc.t_3h, sv.ctx, G[VB_LW_QKV_B], B, S, nh,
+                       64, p_attn, seed, sid, stream));
     // 9. dgrad QKV + residual gradient: dh = dqkv Wqkv + dz1
     VB_TRY(dgrad(sc.t_3h, 3 * H, wqkv, VB_LWT_QKV, H, d_in, dz1, VB_ACT_NONE, nullptr));
     // 10. the four weight gradients: dW_fo[H,I] += dfo^T inter, dW_fi[I,H] += dpre^T a_out, dW_ao[H,H] += dao^T ctx,

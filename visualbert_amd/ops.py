@@ -274,14 +274,16 @@ def attn_fwd(qkv, mask_add, B, S, nh, p, seed, sid):
     return ctx, lse, bits
 
 
-def attn_bwd(qkv, mask_add, dctx, lse, bits, B, S, nh, p, seed, sid, ctx_fwd=None):
-    """ctx_fwd: the forward output (enables the one-pass bf16 backward, see vb_attn_bwd)."""
+def attn_bwd(qkv, mask_add, dctx, lse, bits, B, S, nh, p, seed, sid, ctx_fwd=None, dqkv_bias=None):
+    """ctx_fwd: the forward output (enables the one-pass bf16 backward, see vb_attn_bwd); dqkv_bias: fp32 [3H] that
+    receives += the column sums of dqkv (the packed q | k | v bias gradient)."""
     dqkv = torch.empty_like(qkv)
-    ws = torch.empty((B, nh, S), dtype=torch.float32, device=qkv.device)
+    ws = torch.empty(_lib.lib().vb_attn_bwd_ws_floats(B, S, nh), dtype=torch.float32, device=qkv.device)
     if not dctx.is_contiguous():
         dctx = dctx.contiguous()
     check(_lib.lib().vb_attn_bwd(_lib.dtype_code(qkv.dtype), ptr(qkv), ptr(mask_add), ptr(dctx), ptr(lse), ptr(bits),
-                                 ptr(ws), ptr(dqkv), ptr(ctx_fwd), B, S, nh, 64, float(p), seed, sid, stream_ptr()),
+                                 ptr(ws), ptr(dqkv), ptr(ctx_fwd), ptr(dqkv_bias), B, S, nh, 64, float(p), seed, sid,
+                                 stream_ptr()),
           "vb_attn_bwd")
     return dqkv
 
@@ -541,9 +543,9 @@ class AttentionBlockFn(torch.autograd.Function):
         g_ow, d4 = grad_target(so.dense.weight)
         linear_wgrad(dao, c, g_ow)
         dctx = linear_dgrad(dao, weight_for(so.dense.weight, dt))
-        dqkv = attn_bwd(qkv, mask_add, dctx, lse, ctx.bits, B, S, sa.num_attention_heads, p_attn, seed, sid, ctx_fwd=c)
         g_qkv_w, g_qkv_b, direct_qkv = sa.qkv_grad_targets()
-        colsum(dqkv, g_qkv_b)
+        dqkv = attn_bwd(qkv, mask_add, dctx, lse, ctx.bits, B, S, sa.num_attention_heads, p_attn, seed, sid, ctx_fwd=c,
+                        dqkv_bias=g_qkv_b)
         linear_wgrad(dqkv, h2, g_qkv_w)
         wqkv, _ = _packed_qkv(sa, dt)
         dh = linear_dgrad(dqkv, wqkv, addend=dz)          # + gradient of the residual connection

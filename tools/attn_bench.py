@@ -26,5 +26,8 @@ for p in (0.0, 0.1):
     t1 = bench(lambda: ops.attn_bwd(qkv, mask, dctx, lse, bits, B, S, nh, p, 5, 3, ctx_fwd=ctx))
     tb2 = bench(lambda: ops.attn_bwd(qkv, mask, dctx, lse, bits, B, S, nh, p, 5, 3))
     t12 = bench(lambda: ops.attn_bwd(qkv, mask, dctx, lse, bits, B, S, nh, p, 5, 3, ctx_fwd=ctx))
+    db = torch.zeros(3 * H, device=dev)
+    t1b = bench(lambda: ops.attn_bwd(qkv, mask, dctx, lse, bits, B, S, nh, p, 5, 3, ctx_fwd=ctx, dqkv_bias=db))
+    print("B=%d p=%.1f: one-pass backward + q|k|v bias gradient %.1f us" % (B, p, t1b))
     print("B=%d p=%.1f: fwd %.1f us (%.0f TF)  bwd two-pass %.1f / %.1f us (%.0f TF)  bwd one-pass %.1f / %.1f us" % (
         B, p, tf, flops / tf / 1e6, tb, tb2, 2.5 * flops / tb / 1e6, t1, t12))

@@ -612,7 +612,6 @@ VB_KERNEL VB_LAUNCH_BOUNDS(FNT) attn_bwd_fused_kernel(AttnArgs a) {
     };
     unsigned char* ldsKT = smem + 2 * SETB;                // K^T of the whole sequence: [64 d][FNK keys]
     unsigned char* ldsDS = ldsKT + tr_bytes<T>(FNK);       // dS of the chunk: [CQ queries][FNK keys], pitch TSP
-    float* ldsBias = (float*)(ldsDS + CQ * TSP);           // [3][64]: column sums of dQ | dK | dV over this sample's tokens
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, lg = lane >> 4;
     const int bh = blockIdx.x, b = bh / a.nh, h = bh % a.nh;
     const int S = a.S, H = a.nh * D;
@@ -634,7 +633,6 @@ VB_KERNEL VB_LAUNCH_BOUNDS(FNT) attn_bwd_fused_kernel(AttnArgs a) {
             *(uint32_t*)(ldsKT + (dc * 8 + 2 * w + 1) * pitch + r * 2) = (lo >> 16) | (hi & 0xFFFF0000u);
         }
         for (int i = t; i < CQ * TSP / 8; i += FNT) *(uint64_t*)(ldsDS + i * 8) = 0;
-        if (t < 3 * D) ldsBias[t] = 0.f;
     }
     const int kf = wave;
     const int key = kf * 16 + li;
@@ -798,27 +796,35 @@ VB_KERNEL VB_LAUNCH_BOUNDS(FNT) attn_bwd_fused_kernel(AttnArgs a) {
         }
     }
     if (a.bias_ws) {
-        auto sum16 = [&](float v) {                         // over the 16 lanes that share lg (tokens of the fragment)
-            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
-            return v;
-        };
+        // the dS tile is idle now (the loop ended on a barrier): per-wave partial sums [wave][16 dQ | 64 dK | 64 dV]
+        float* part = (float*)ldsDS;
+        constexpr int PW = 16 + 2 * D;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float sq = sum16(dqsum[r]);
-            if (li == 0 && wave < (CQ / 16) * 4) vb_lds_add(ldsBias + (wave & 3) * 16 + lg * 4 + r, sq);
+            const float sq = row16_sum(dqsum[r]);
+            if (li == 0) part[wave * PW + lg * 4 + r] = sq;
         }
 #pragma unroll
         for (int df = 0; df < 4; ++df)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float sk = sum16(dkT[df][r]), sv = sum16(dvT[df][r]);     // padded keys contribute exact zeros
-                if (li == 0 && wave_on) {
-                    vb_lds_add(ldsBias + D + df * 16 + lg * 4 + r, sk);
-                    vb_lds_add(ldsBias + 2 * D + df * 16 + lg * 4 + r, sv);
+                const float sk = row16_sum(dkT[df][r]), sv = row16_sum(dvT[df][r]);     // padded keys contribute exact zeros
+                if (li == 0) {
+                    part[wave * PW + 16 + df * 16 + lg * 4 + r] = sk;
+                    part[wave * PW + 16 + D + df * 16 + lg * 4 + r] = sv;
                 }
             }
         __syncthreads();
-        if (t < 3 * D) a.bias_ws[((long)b * 3 + t / D) * H + h * D + (t % D)] = ldsBias[t];
+        if (t < 3 * D) {
+            const int which = t / D, dd = t % D;
+            float sum = 0.f;
+            if (which == 0) {                               // dQ^T block df lives in the waves with (wave & 3) == df
+                for (int w = dd >> 4; w < FWPB; w += 4) sum += part[w * PW + (dd & 15)];
+            } else {
+                for (int w = 0; w < FWPB; ++w) sum += part[w * PW + 16 + (which - 1) * D + dd];
+            }
+            a.bias_ws[((long)b * 3 + which) * H + h * D + dd] = sum;
+        }
     }
 }
 
@@ -839,7 +845,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS(256) attn_bias_reduce_kernel(const float* ws, float* 
 }
 template <int NKF, int CQ> size_t fused_smem() {
     return 2 * (2 * rm_bytes<bf16>(CQ) + 2 * tr_bytes<bf16>(CQ) + 2 * CQ * 4 + (size_t)CQ * 4 * ((NKF + 15) / 16) * 8) +
-           tr_bytes<bf16>(FNK) + (size_t)CQ * TSP + 3 * D * 4;
+           tr_bytes<bf16>(FNK) + (size_t)CQ * TSP;
 }
 
 template <typename T, int NKF> size_t fwd_smem() { return rm_bytes<T>(NKF * 16) + tr_bytes<T>((NKF + 1) / 2 * 32) + NKF * 16 * 4; }

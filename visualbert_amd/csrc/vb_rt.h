@@ -280,6 +280,23 @@ VB_DEVICE float wave_max(float v) {
     for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
     return v;
 }
+// sum over the 16 lanes of a DPP row (lanes 16 i .. 16 i + 15), result in every lane of the row: four row-rotate adds on
+// the VALU (v_add_f32 ... row_ror) instead of four LDS-crossbar shuffles (ds_bpermute + lgkmcnt wait each)
+#ifdef VB_EMU
+VB_DEVICE float row16_sum(float v) {
+    v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+    return v;
+}
+#else
+template <int N> VB_DEVICE float vb_row_ror(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xF, 0xF, false));
+}
+VB_DEVICE float row16_sum(float v) {
+    v += vb_row_ror<8>(v); v += vb_row_ror<4>(v); v += vb_row_ror<2>(v); v += vb_row_ror<1>(v);
+    return v;
+}
+#endif
+
 // reduction across the 32 lanes of a half-wave (lanes [0,32) and [32,64) independently)
 VB_DEVICE float half_sum(float v) {
 #pragma unroll

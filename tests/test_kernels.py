@@ -132,6 +132,26 @@ def test_wgrad_grouped_transposing_reads(dev, tokens, wgs):
         assert (C - ref).abs().max().item() <= 2e-4 * max(1.0, ref.abs().max().item())
 
 
+def test_wgrad_grouped_helper_layout_on_the_full_chip(dev):
+    """An encoder layer's four weight gradients are 108 tiles: two token slices each leave 40 of 256 compute units idle, so
+    the launch switches to the helper layout (slices over the first KT - rem K tiles, the idle CUs take the last `rem` of
+    tiles h, h + 40, ...).  BERT-base shapes at 20,992 tokens against fp32 matmuls, twice (atomics: no stale state)."""
+    if dev.type != "cuda":
+        pytest.skip("needs the real chip's workgroup count (the simulator runs 4)")
+    tokens = 20992
+    g = torch.Generator().manual_seed(5)
+    dt = torch.bfloat16
+    shapes = [(768, 3072), (3072, 768), (768, 768), (2304, 768)]
+    dys = [(0.3 * torch.randn(tokens, o, generator=g)).to(dt).to(dev) for o, _ in shapes]
+    xs = [(0.3 * torch.randn(tokens, i, generator=g)).to(dt).to(dev) for _, i in shapes]
+    for rep in range(2):
+        dws = [torch.full((o, i), 0.25, device=dev) for o, i in shapes]
+        _wgrad_grouped(dev, dys, xs, dws, tokens)
+        for dy, x, dw in zip(dys, xs, dws):
+            ref = 0.25 + dy.float().t() @ x.float()
+            assert (dw - ref).abs().max().item() <= 2e-4 * max(1.0, ref.abs().max().item())
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("V", [1000, 33000])        # register-cached single pass (V <= 32768) / rolled two-pass rows
 def test_cross_entropy_dense_and_compact_rows(dev, dt, V):

@@ -5,8 +5,11 @@ import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from visualbert_amd import _lib, ops
+if os.environ.get("VB_DEV") == "1":
+    _lib.use_dev_library()
 dev = torch.device("cuda", 0)
 L = _lib.lib()
+TOK = [int(x) for x in os.environ.get('VB_TOKENS', '20992,41984,83968').split(',')]
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 H, I = 768, 3072
 shapes = [(H, I), (I, H), (H, H), (3 * H, H)]            # (out, in): FFN-out, FFN-in, attention-out, QKV
@@ -39,6 +42,14 @@ def run(tokens, group):
     ref = (dys[3].float().t() @ xs[3].float()) * (iters + 2)
     err = (dws[3] - ref).abs().max().item() / ref.abs().max().item()
     return ms * 1e3, fl / ms / 1e9, err
-for tokens in (2624, 5248, 10496, 20992):
-    a = run(tokens, True); b = run(tokens, False)
-    print("tokens %6d | grouped %7.1f us %5.0f TF (relerr %.1e) | four launches %7.1f us %5.0f TF" % (tokens, a[0], a[1], a[2], b[0], b[1]))
+for tokens in TOK:
+    # helper layout (default at 256 workgroups) against the classic two-slice layout (216 workgroups = 216 items), A/B/A/B
+    res = {"helper": [], "classic": []}
+    for rep in range(2):
+        for name, wgs in (("helper", 0), ("classic", 216)):
+            _lib.set_opts(persistent_workgroups=wgs)
+            res[name].append(run(tokens, True))
+    _lib.set_opts()
+    h = min(res["helper"]); c = min(res["classic"])
+    print("tokens %6d | helper layout %7.1f us %5.0f TF (relerr %.1e) | classic 216 items %7.1f us %5.0f TF (relerr %.1e)" % (
+        tokens, h[0], h[1], h[2], c[0], c[1], c[2]))

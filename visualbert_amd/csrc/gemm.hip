@@ -1413,10 +1413,16 @@ struct TnProblem {
     int tiles_n, tiles;                           // 256x256 tiles: columns, total
     int tiles_m;                                  // rows; tiles are walked along the SHORTER dimension first (see decode)
     int item0;                                    // first item of this problem
+    int tile0;                                    // first tile of this problem in the group-wide tile numbering
 };
 struct TnArgs {
     TnProblem p[VB_TN_MAX];
     int nprob, KT, splits, kps, nitems;           // K tiles of 64 tokens; token slices; K tiles per slice; items
+    // "helper" layout (rem > 0), for item counts that do not fill the chip -- an encoder layer has 108 tiles, i.e. 216
+    // two-slice items for 256 CUs: the slices cover only the first KT - rem K tiles of every tile, and the compute units the
+    // items leave idle (nhelp_x per XCD next to nmain_x item-owning workgroups) take the last `rem` K tiles of the tiles
+    // h, h + nhelp, ... (all of them in the same token range: shared panels in the XCD's L2).
+    int rem, nmain_x, nhelp_x, ntiles;
     float alpha;
     const float* alpha_dev;
 };
@@ -1430,7 +1436,14 @@ VB_KERNEL VB_LAUNCH_BOUNDS(512) gemm_tn_8ph_kernel(TnArgs g) {
     const int lane = t & 63, wave = vb_uniform(t >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int G = (int)gridDim.x;
-    const int my_items = (g.nitems - (int)blockIdx.x + G - 1) / G;
+    // helper layout: workgroup b sits on XCD b % 8 (observed placement: speed only); slots 0 .. nmain_x - 1 of an XCD own one
+    // (tile, slice) item each, the remaining nhelp_x slots are helpers
+    const int xslot = (int)blockIdx.x >> 3;
+    const bool helper = g.rem > 0 && xslot >= g.nmain_x;
+    const int nhelp = 8 * g.nhelp_x;
+    const int hidx = ((int)blockIdx.x & 7) * g.nhelp_x + (xslot - g.nmain_x);
+    const int my_items = g.rem == 0 ? (g.nitems - (int)blockIdx.x + G - 1) / G
+                                    : (helper ? (g.ntiles - hidx + nhelp - 1) / nhelp : 1);
     unsigned char* slab = smem + 2 * BUF + wave * EPI8_BYTES_PER_WAVE;
 
     f32x4 acc[8][4];
@@ -1442,19 +1455,30 @@ VB_KERNEL VB_LAUNCH_BOUNDS(512) gemm_tn_8ph_kernel(TnArgs g) {
     struct Item { int p, m0, n0, kt0, nk; };
     auto decode = [&](int j) {
         Item it;
-        const int v = xcd_remap((int)blockIdx.x + G * j, g.nitems);
-        int p = 0;
-        for (int q = 1; q < g.nprob; ++q) if (v >= g.p[q].item0) p = q;
-        const int local = v - g.p[p].item0;
-        const int s = local / g.p[p].tiles, tl = local - s * g.p[p].tiles;
+        int p = 0, tl, s = 0;
+        if (helper) {
+            const int gt = hidx + nhelp * j;                // group-wide tile number
+            for (int q = 1; q < g.nprob; ++q) if (gt >= g.p[q].tile0) p = q;
+            tl = gt - g.p[p].tile0;
+        } else {
+            const int v = g.rem == 0 ? xcd_remap((int)blockIdx.x + G * j, g.nitems) : ((int)blockIdx.x & 7) * g.nmain_x + xslot;
+            for (int q = 1; q < g.nprob; ++q) if (v >= g.p[q].item0) p = q;
+            const int local = v - g.p[p].item0;
+            s = local / g.p[p].tiles;
+            tl = local - s * g.p[p].tiles;
+        }
         it.p = p;
         // consecutive items (= one XCD's concurrent workgroups) cover whole rows / columns of the shorter tile
         // dimension: the fewest distinct operand panels per XCD L2
         const int tm = g.p[p].tiles_m, tn = g.p[p].tiles_n;
         if (tm < tn) { it.m0 = (tl % tm) * 256; it.n0 = (tl / tm) * 256; }
         else { it.m0 = (tl / tn) * 256; it.n0 = (tl % tn) * 256; }
-        it.kt0 = s * g.kps;
-        it.nk = g.KT - it.kt0 < g.kps ? g.KT - it.kt0 : g.kps;
+        const int kend = g.KT - g.rem;                      // the slices end here; the helpers take the rest
+        if (helper) { it.kt0 = kend; it.nk = g.rem; }
+        else {
+            it.kt0 = s * g.kps;
+            it.nk = kend - it.kt0 < g.kps ? kend - it.kt0 : g.kps;
+        }
         return it;
     };
 
@@ -1644,11 +1668,35 @@ static int launch_tn_group(TnArgs& g, int K, hipStream_t stream) {
     int wgs = t_opts.persistent_workgroups > 0 ? t_opts.persistent_workgroups : vb_num_cus();
     g.splits = tn_pick_splits(tiles, g.KT, wgs);
     g.kps = (g.KT + g.splits - 1) / g.splits;
-    int item0 = 0;
-    for (int i = 0; i < g.nprob; ++i) { g.p[i].item0 = item0; item0 += g.p[i].tiles * g.splits; }
+    g.rem = 0; g.nmain_x = g.nhelp_x = 0; g.ntiles = tiles;
+    {
+        // helper layout (see TnArgs): s slices per tile leave wgs - tiles * s compute units idle for the whole launch (an
+        // encoder layer: 108 tiles x 2 = 216 items on 256 CUs).  Give those CUs the tail `rem` of every tile's token range,
+        // u tiles each, sized so that a slice + its drain takes as long as a helper's u pieces + u drains.
+        const double drain = 24.0;                         // K tiles' worth of time to add a 256x256 tile with atomics (measured)
+        const int s = tiles > 0 ? wgs / tiles : 0;
+        const int nmain = tiles * s, nhelp = wgs - nmain;
+        if (s >= 1 && (wgs % 8) == 0 && (nmain % 8) == 0 && nhelp >= 8) {
+            const int u = (tiles + nhelp - 1) / nhelp;
+            int rem = (int)(((double)g.KT / s - (u - 1) * drain) / (u + 1.0 / s));
+            const int lmain = rem > 0 ? (g.KT - rem + s - 1) / s : 0;
+            const double classic = ((tiles * g.splits + wgs - 1) / wgs) * (g.kps + drain);     // rounds x (slice + drain)
+            if (rem >= 16 && lmain >= 16 && lmain + drain < 0.97 * classic) {
+                g.rem = rem; g.splits = s; g.kps = lmain;
+                g.nmain_x = nmain / 8; g.nhelp_x = nhelp / 8;
+            }
+        }
+    }
+    int item0 = 0, tile0 = 0;
+    for (int i = 0; i < g.nprob; ++i) {
+        g.p[i].item0 = item0; item0 += g.p[i].tiles * g.splits;
+        g.p[i].tile0 = tile0; tile0 += g.p[i].tiles;
+    }
     g.nitems = item0;
-    if (wgs >= g.nitems) wgs = g.nitems;
-    else if (wgs >= 8) wgs &= ~7;
+    if (g.rem == 0) {
+        if (wgs >= g.nitems) wgs = g.nitems;
+        else if (wgs >= 8) wgs &= ~7;
+    }
     dim3 grid((unsigned)wgs), block(512);
 #ifndef VB_EMU
     if (g_prof) {

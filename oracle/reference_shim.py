@@ -73,3 +73,71 @@ def cpu_cuda_noop():
         yield
     finally:
         torch.Tensor.cuda = orig
+
+
+# ---- the reference's host-side data functions ---------------------------------------------------------------
+class _Anything(type):
+    """metaclass of the universal placeholder: attribute access, calls, subscripts and subclassing all yield placeholders, so
+    `from allennlp.x import Y`, `class Z(Y[K, V])` and `@overrides` at import time of the reference's modules succeed."""
+
+    def __getattr__(cls, name):
+        if name.startswith("__") and name.endswith("__"):
+            raise AttributeError(name)
+        return _Stub
+
+    def __getitem__(cls, item):
+        return _Stub
+
+
+class _Stub(metaclass=_Anything):
+    def __init__(self, *a, **k):
+        pass
+
+    def __new__(cls, *a, **k):
+        if len(a) == 1 and callable(a[0]) and not k and cls is _Stub:
+            return a[0]                       # used as a decorator (@overrides): hand the function back
+        return super().__new__(cls)
+
+    def __call__(self, *a, **k):
+        return _Stub()
+
+    def __getattr__(self, name):
+        return _Stub()
+
+
+class _StubModule(types.ModuleType):
+    __path__ = []                             # a package: `import a.b.c` resolves through sys.modules entries below
+
+    def __getattr__(self, name):
+        if name.startswith("__") and name.endswith("__"):
+            raise AttributeError(name)
+        return _Stub
+
+
+_ABSENT = ["allennlp", "allennlp.data", "allennlp.data.dataset", "allennlp.data.fields", "allennlp.data.instance",
+           "allennlp.data.token_indexers", "allennlp.data.tokenizers", "allennlp.data.vocabulary", "allennlp.nn",
+           "allennlp.nn.util", "allennlp.common", "allennlp.common.checks", "allennlp.data.fields.sequence_field",
+           "allennlp.data.fields.field", "allennlp.data.tokenizers.token", "allennlp.data.token_indexers.token_indexer",
+           "h5py", "overrides", "spacy", "spacy.tokens", "torchvision", "torchvision.datasets", "torchvision.datasets.folder",
+           "torchvision.transforms", "matplotlib", "scipy.misc"]
+
+
+def load_reference_data_utils():
+    """-> (fine_tuning module, bert_data_utils module) of the reference, imported in place.  Their import-time dependencies
+    that are absent here (allennlp 0.8, h5py, spacy, overrides, torchvision, matplotlib) are replaced by inert placeholder
+    modules: the two functions this repo pins -- fine_tuning.random_word (:272-308) and
+    InputFeatures.convert_one_example_to_features_pretraining (dataloaders/bert_data_utils.py:168-247) -- are plain Python
+    over lists and a tokenizer's vocab dict and touch none of them."""
+    load_reference()
+    import importlib
+    for name in _ABSENT:
+        if name not in sys.modules:
+            try:
+                importlib.import_module(name)
+            except Exception:
+                sys.modules[name] = _StubModule(name)
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        from pytorch_pretrained_bert import fine_tuning as ref_ft
+        from dataloaders import bert_data_utils as ref_bdu
+    return ref_ft, ref_bdu

@@ -113,8 +113,10 @@ def test_fp32_train_steps_match_reference_golden(dev, stem):
 
 # (max|dlogit| vs the bf16-emulating oracle, vs the fp32 REFERENCE golden, |dloss|): 1.5 x the values measured on MI355X
 # (profiles/r02_parity_small.json)
-BF16_FWD_BOUNDS = {"micro_pretraining": (2e-2, 0.1, 2e-2), "tiny_pretraining": (2e-2, 0.1, 2e-2),
-                   "micro_bypass": (2e-2, 0.1, 2e-2), "micro_align": (2e-2, 0.1, 2e-2)}
+#   measured: micro_pretraining 5.6e-3 / 3.2e-3 / 5.5e-4   tiny_pretraining 7.2e-3 / 6.4e-3 / 5.6e-4
+#             micro_bypass      5.2e-3 / 3.8e-3 / 1.2e-3   micro_align      5.8e-3 / 5.5e-3 / 6e-5   (|dloss|: 3 x, few samples)
+BF16_FWD_BOUNDS = {"micro_pretraining": (8.5e-3, 4.8e-3, 1.7e-3), "tiny_pretraining": (1.1e-2, 9.7e-3, 1.7e-3),
+                   "micro_bypass": (7.9e-3, 5.7e-3, 3.6e-3), "micro_align": (8.8e-3, 8.2e-3, 1.0e-3)}
 
 
 @pytest.mark.parametrize("stem", ["micro_pretraining", "tiny_pretraining", "micro_bypass", "micro_align"])
@@ -211,8 +213,10 @@ def test_bf16_small_heads_match_bf16_oracle(dev, stem):
 
 
 # per-tensor relative L2 (median, worst) of the bf16 gradients against the bf16-emulating oracle: 1.5 x measured
-BF16_GRAD_BOUNDS = {"micro_pretraining": (0.05, 0.15), "tiny_pretraining": (0.05, 0.15), "micro_bypass": (0.05, 0.15),
-                    "micro_align": (0.05, 0.15), "micro_flickr": (0.05, 0.15)}
+#   measured (median / worst): micro_pretraining 7.8e-3 / 1.06e-2, tiny_pretraining 7.2e-3 / 7.5e-2 (pooler bias), micro_bypass
+#   6.9e-3 / 1.38e-2, micro_align 6.6e-3 / 8.2e-3, micro_flickr 1.66e-2 / 7.3e-2 (projection bias)
+BF16_GRAD_BOUNDS = {"micro_pretraining": (0.0117, 0.0159), "tiny_pretraining": (0.0109, 0.113), "micro_bypass": (0.0103, 0.0208),
+                    "micro_align": (0.0099, 0.0123), "micro_flickr": (0.0249, 0.109)}
 
 
 @pytest.mark.parametrize("stem", ["micro_pretraining", "tiny_pretraining", "micro_bypass", "micro_align", "micro_flickr"])
@@ -281,8 +285,9 @@ def test_bert_base_config2_logits_vs_oracle(dev):
     err16 = float((lg16 - ref16["logits"]).abs().max())
     print("BERT-base bf16: max|dlogit| vs fp32 reference %.3e, vs bf16-emulating oracle %.3e" % (gap, err16))
     record("bf16_base_b2", "logits", dict(vs_fp32_reference=gap, vs_bf16_oracle=err16))
-    # measured on MI355X (round 1): 3.2e-2 / 3.9e-2; the B = 16 case with statistics is tests/test_parity_at_scale.py
-    assert gap < 4.8e-2 and err16 < 5.9e-2
+    # measured on MI355X: 3.7e-2 vs the fp32 reference, 3.3e-2 vs the bf16-emulating oracle (1.5 x asserted); the B = 16
+    # case with mean / p99.9 / top-1 statistics is tests/test_parity_at_scale.py
+    assert gap < 5.5e-2 and err16 < 4.9e-2
 
 
 def test_nlvr2_reference_shape_long_sequence(dev):

@@ -236,6 +236,10 @@ int vb_prepare_inputs(const int64_t* input_mask, const int64_t* image_dim, const
 int vb_zero(void* dst, int64_t bytes, void* stream);
 /* elementwise dtype conversion (VB_F32 / VB_BF16 in any combination) */
 int vb_cast(int src_dtype, const void* src, int dst_dtype, void* dst, int64_t n, void* stream);
+/* nn.Dropout on a contiguous T[n] (modeling.py:1495, 1509, 1557: the [B, H] state in front of the multichoice / VQA / NLVR2
+ * heads): y = keep ? x / (1 - p) : 0, keep-bits from (seed, stream_id, element index).  Its own backward: call it on dy with
+ * the same seed and stream_id.  x == y (in place) is allowed. */
+int vb_dropout(int dtype, const void* x, void* y, int64_t n, float p, uint64_t seed, uint32_t stream_id, void* stream);
 /* VQA head gather (modeling.py:1503-1505): out[b] = x[b, input_mask[b].sum() - 2]; index_out int64[B] */
 int vb_gather_rows(int dtype, const void* x, const int64_t* input_mask, void* out, int64_t* index_out,
                    int B, int S, int T, int H, void* stream);

@@ -61,10 +61,23 @@ def _worker(rank, world, port, q):
         named = dict(m.named_parameters())
         for k, v in leaves.items():
             named[k]._vb_grad.copy_(v.grad)
+        # which parameters "a backward pass wrote": rank 1 pretends its shard never reached the visual tables (a text-only
+        # shard) -- the flags the optimizer kernel skips on must still come out as the UNION over the ranks on both of them
+        m.arena.touched.clear()
+        for k in leaves:
+            if not (rank == 1 and k.endswith("_visual.weight")):
+                m.arena.touched.add(id(named[k]))
         # fire the hooks in backward order, then finish
         for i in reversed(range(cfg.num_hidden_layers)):
             m.bert.encoder.layer[i].grad_ready_hook(i)
         sync.finish_step()
+        flags = m.arena.touched_synced
+        assert flags is not None and flags.numel() == len(m.arena.params)
+        for i, p in enumerate(m.arena.params):
+            want = id(p) in {id(named[k]) for k in leaves}
+            assert bool(flags[i] > 0) == want, (rank, m.arena.names[i])
+        assert float(m.arena.touched_flags()[m.arena.names.index("bert.embeddings.position_embeddings_visual.weight")]) == (
+            0.0 if rank == 1 else 1.0)                      # the rank-local view differs; the synced one does not
         # single-process reference: mean over replicas of per-replica mean losses
         leaves2 = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
         losses = []
@@ -183,3 +196,76 @@ def test_two_ranks_on_one_gpu_train_like_the_reference_data_parallel(dev):
     for r, worst, _ in res:
         assert worst < 5e-6, (r, worst)                     # three optimizer steps, fp32 kernels vs the oracle
     assert res[0][2] == res[1][2]                           # replicas bit-identical after the synchronised steps
+
+
+def _abi_comm_worker(port, q):
+    """one rank, RCCL through the C ABI (vb_comm_init from a unique id, vb_allreduce_bucket on the side stream): with a single
+    rank the averaged gradient is the gradient, so two synchronised steps must land exactly where two plain steps do."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        from oracle import visualbert_oracle as vo
+        from visualbert_amd import _lib
+        from visualbert_amd.modeling import BertConfig
+        from visualbert_amd.model import VisualBERTFixedImageEmbedding, ModelWrapper, AttrDict
+        from visualbert_amd.parallel import DataParallelGradSync, RcclCommunicator
+        comm = RcclCommunicator()
+        assert _lib.lib().vb_comm_nranks(comm.handle) == 1
+        x = torch.arange(1000, dtype=torch.float32, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        comm.allreduce(x, True, side)
+        xb = torch.ones(64, dtype=torch.bfloat16, device=dev)
+        comm.allreduce(xb, False, side)
+        side.synchronize()
+        assert torch.equal(x.cpu(), torch.arange(1000, dtype=torch.float32)) and bool((xb == 1).all())
+        comm.close()
+        cfg = vo.OracleConfig(**vo.CONFIGS["micro"])
+        sd = vo.synth_state_dict(cfg, "pretraining", 7)
+        batch = {k: v.to(dev) for k, v in vo.synth_batch(cfg, 4, 12, 5, 7, "pretraining").items()}
+        finals = []
+        for use_sync in (False, True):
+            bc = BertConfig(cfg.vocab_size, hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers,
+                            num_attention_heads=cfg.num_attention_heads, intermediate_size=cfg.intermediate_size,
+                            hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+            model = VisualBERTFixedImageEmbedding(config=bc, training_head_type="pretraining",
+                                                  visual_embedding_dim=cfg.visual_embedding_dim).to(dev)
+            own = model.bert.state_dict()
+            with torch.no_grad():
+                for k, v in sd.items():
+                    own[k].copy_(v)
+            sync = DataParallelGradSync(model.bert, overlap=True, use_abi_comm=True) if use_sync else None
+            if sync is not None:
+                assert sync.comm is not None and sync.comm_kind.startswith("C-ABI")
+                sync.broadcast_parameters(0)
+            model.train()
+            mw = ModelWrapper(AttrDict(train_batch_size=4, learning_rate=1e-3, warmup_proportion=0.1, num_train_epochs=1,
+                                       gradient_accumulation_steps=1), 400, model=model, grad_sync=sync)
+            for _ in range(3):
+                mw.step(batch)
+            torch.cuda.synchronize()
+            finals.append(model.bert.arena.data.detach().cpu().clone())
+            if sync is not None:
+                m = sync.measure_allreduce(torch.cuda.synchronize, reps=2)
+                assert m["ranks"] == 1 and m["payload_bytes"] == model.bert.arena.grad.numel() * 4
+                sync.close()
+        q.put(float((finals[0] - finals[1]).abs().max()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_abi_communicator_single_rank_is_transparent(dev):
+    if dev.type != "cuda":
+        pytest.skip("RCCL: GPU only")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_abi_comm_worker, args=(_free_port(), q))
+    p.start()
+    p.join(600)
+    assert p.exitcode == 0
+    assert q.get(timeout=10) <= 1e-6        # weight-gradient atomics order differs run to run; everything else is identical

@@ -725,3 +725,25 @@ def test_rows_past_two_giga_elements(dev):
     rl.backward()
     assert abs(loss.item() - rl.item()) <= 2e-5 * max(1.0, abs(rl.item()))
     assert (dlc[:n, :V].float() - ref_in.grad).abs().max().item() <= 2e-3
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_head_dropout_kernel(dev, dt):
+    """vb_dropout (nn.Dropout in front of the fine-tuning heads): keep rate, 1/(1-p) scaling, the same mask again for the
+    same (seed, stream id) -- which is what makes it its own backward -- and a different one for another seed."""
+    from visualbert_amd import ops
+    n = 4099                                    # not a multiple of the 8-element generator group
+    x = torch.linspace(1.0, 2.0, n).to(dt).to(dev)
+    p = 0.1
+    y1 = ops.dropout_apply(x, p, 1234, 10)
+    y2 = ops.dropout_apply(x, p, 1234, 10)
+    y3 = ops.dropout_apply(x, p, 1235, 10)
+    assert torch.equal(y1, y2) and not torch.equal(y1, y3)
+    keep = y1 != 0
+    assert abs(keep.float().mean().item() - (1 - p)) < 0.02
+    ref = (x.float() / (1 - p)).to(dt)
+    assert (y1[keep].float() - ref[keep].float()).abs().max().item() <= (1e-6 if dt == torch.float32 else 0.016)
+    xr = x.clone().requires_grad_(True)
+    out = ops.DropoutFn.apply(xr, p, 10)
+    out.float().sum().backward()
+    assert torch.equal(xr.grad != 0, out != 0)                   # gradient flows exactly where the forward kept

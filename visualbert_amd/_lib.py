@@ -49,6 +49,7 @@ SIGNATURES = {
     "vb_prepare_inputs": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "vb_zero": (_i, [_p, _i64, _p]),
     "vb_cast": (_i, [_i, _p, _i, _p, _i64, _p]),
+    "vb_dropout": (_i, [_i, _p, _p, _i64, _f, _u64, _u32, _p]),
     "vb_gather_rows": (_i, [_i, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "vb_scatter_rows": (_i, [_i, _p, _p, _p, _i, _i, _i, _p]),
     "vb_gather_index_rows": (_i, [_i, _p, _p, _p, _i, _i, _i, _i, _p]),

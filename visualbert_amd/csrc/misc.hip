@@ -185,6 +185,35 @@ extern "C" int vb_cast(int src_dtype, const void* src, int dst_dtype, void* dst,
     return vb_check_launch();
 }
 
+// nn.Dropout on a small tensor (the pooled / gathered [B, H] state in front of the fine-tuning heads, modeling.py:1495, 1509,
+// 1557): y = keep ? x / (1 - p) : 0 with the counter-based bits every other dropout site uses (vb_dropout_bits8: keyed by
+// seed, stream id and the 8-element group index) -- the backward pass calls it again on dy with the same key and gets the
+// same mask, so no mask tensor exists.
+template <typename T>
+VB_KERNEL VB_LAUNCH_BOUNDS(NT) dropout_kernel(const T* x, T* y, long n, float inv_keep, uint32_t thresh, uint64_t seed, uint32_t sid) {
+    for (long grp = (long)blockIdx.x * NT + threadIdx.x; grp * 8 < n; grp += (long)gridDim.x * NT) {
+        const Rand8 rnd = vb_dropout_bits8(seed, (uint64_t)grp, sid);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const long i = grp * 8 + e;
+            if (i < n) y[i] = rand8_keep(rnd, e, thresh) ? from_f32<T>(to_f32(x[i]) * inv_keep) : from_f32<T>(0.0f);
+        }
+    }
+}
+
+extern "C" int vb_dropout(int dtype, const void* x, void* y, int64_t n, float p, uint64_t seed, uint32_t stream_id, void* stream) {
+    if (!x || !y || n <= 0 || p < 0.f || p >= 1.f) return VB_ERR_ARG;
+    long blocks = ((n + 7) / 8 + NT - 1) / NT;
+    if (blocks > 2048) blocks = 2048;
+    const float inv_keep = 1.0f / (1.0f - p);
+    const uint32_t thresh = (uint32_t)(p * 65536.0f + 0.5f);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == VB_BF16) VB_LAUNCH(dropout_kernel<bf16>, dim3((unsigned)blocks), dim3(NT), 0, s, (const bf16*)x, (bf16*)y, (long)n, inv_keep, thresh, seed, stream_id);
+    else if (dtype == VB_F32) VB_LAUNCH(dropout_kernel<float>, dim3((unsigned)blocks), dim3(NT), 0, s, (const float*)x, (float*)y, (long)n, inv_keep, thresh, seed, stream_id);
+    else return VB_ERR_ARG;
+    return vb_check_launch();
+}
+
 extern "C" int vb_gather_rows(int dtype, const void* x, const int64_t* input_mask, void* out, int64_t* index_out,
                               int B, int S, int T, int H, void* stream) {
     if (!x || !input_mask || !out || B <= 0 || S <= 0 || T <= 0 || H <= 0) return VB_ERR_ARG;

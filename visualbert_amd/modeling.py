@@ -1184,7 +1184,6 @@ class FlickrAttention(nn.Module):
 
 
 def _small_dropout(x, p):
-    """nn.Dropout on the [B,H] pooled vector of the NLVR2 / VQA fine-tune heads (modeling.py:1557): B x H
-    elements, outside the pre-training hot path -- one elementwise multiply on the device."""
-    keep = (torch.rand_like(x, dtype=torch.float32) >= p).to(x.dtype) / (1.0 - p)
-    return x * keep
+    """nn.Dropout on the [B, H] pooled vector of the multichoice / NLVR2 fine-tune heads (modeling.py:1495, 1557): the
+    counter-based HIP dropout of every other site (vb_dropout; mask regenerated in backward, stream id 10)."""
+    return ops.DropoutFn.apply(x, float(p), 10)

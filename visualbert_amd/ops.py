@@ -437,6 +437,30 @@ class LinearFn(torch.autograd.Function):
         return dx, grad_result(gw, direct_w), gb_out, None, None
 
 
+def dropout_apply(x, p, seed, sid):
+    """y = dropout(x) with the counter-based mask of (seed, sid); the same call on a gradient is the backward."""
+    xc = x.contiguous()
+    y = torch.empty_like(xc)
+    check(_lib.lib().vb_dropout(_lib.dtype_code(xc.dtype), ptr(xc), ptr(y), xc.numel(), float(p), seed, sid, stream_ptr()),
+          "vb_dropout")
+    return y
+
+
+class DropoutFn(torch.autograd.Function):
+    """nn.Dropout in front of the fine-tuning heads (modeling.py:1495, 1557) without a mask tensor."""
+
+    @staticmethod
+    def forward(ctx, x, p, sid):
+        seed = next_seed()
+        ctx.cfg = (p, seed, sid)
+        return dropout_apply(x, p, seed, sid).view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, seed, sid = ctx.cfg
+        return dropout_apply(dy, p, seed, sid).view(dy.shape), None, None
+
+
 class LayerNormFn(torch.autograd.Function):
     """y = dropout_out(LN(dropout_in(x) + resid)) -- modeling.py:171-175 with :272-273 / :317-318 / :1255-1256."""
 
@@ -1066,13 +1090,7 @@ class VQAHeadLossFn(torch.autograd.Function):
                                         B, S, T, H, stream_ptr()), "vb_gather_rows")
         seed = next_seed()
         if p_drop > 0.0:
-            # nn.Dropout on the gathered state (modeling.py:1509): identity LayerNorm-free path is not
-            # available, so it is applied through the LN kernel's input-dropout with gamma=1/beta=0 skipped;
-            # the VQA fine-tune configs are out of the pre-training hot path -> plain torch for this B x H op.
-            mask = (torch.rand((B, H), device=s2.device, generator=None) >= p_drop).to(dt) / (1.0 - p_drop)
-            g = g * mask
-        else:
-            mask = None
+            g = dropout_apply(g, p_drop, seed, sid)         # nn.Dropout on the gathered state (modeling.py:1509); regenerated in backward
         N = weight.size(0)
         logits = linear_fwd(g, weight_for(weight, dt), bias.detach(), out_dtype=torch.float32)
         loss = torch.zeros(1, dtype=torch.float32, device=s2.device)
@@ -1084,8 +1102,8 @@ class VQAHeadLossFn(torch.autograd.Function):
             check(_lib.lib().vb_kldiv_fwd_bwd(ptr(logits), _ld(logits), ptr(tg), tg.stride(0), ptr(loss), ptr(score),
                                               ptr(dlogits), _ld(dlogits), B, N, stream_ptr()), "vb_kldiv_fwd_bwd")
         ctx.wb = (weight, bias)
-        ctx.cfg = (B, S, H, N)
-        ctx.save_for_backward(g, idx, dlogits, mask)
+        ctx.cfg = (B, S, H, N, p_drop, seed, sid)
+        ctx.save_for_backward(g, idx, dlogits)
         out = logits.contiguous().view(B, 1, N)
         ctx.mark_non_differentiable(out, idx)
         ctx.set_materialize_grads(False)
@@ -1093,11 +1111,11 @@ class VQAHeadLossFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, _dl, dloss, _ds, _di):
-        g, idx, dlogits, mask = ctx.saved_tensors
+        g, idx, dlogits = ctx.saved_tensors
         if dlogits is None:
             raise RuntimeError("visualbert_amd: backward through the VQA head needs labels")
         weight, bias = ctx.wb
-        B, S, H, N = ctx.cfg
+        B, S, H, N, p_drop, seed, sid = ctx.cfg
         dt = g.dtype
         up = _upstream_scalar(dloss)
         dl = alloc2d(B, N, dt, g.device, zero=True)
@@ -1107,8 +1125,8 @@ class VQAHeadLossFn(torch.autograd.Function):
         linear_wgrad(dl, g, gw)
         colsum(dl, gb)
         dg = linear_dgrad(dl, weight_for(weight, dt))
-        if mask is not None:
-            dg = dg * mask
+        if p_drop > 0.0:
+            dg = dropout_apply(dg, p_drop, seed, sid)       # the forward's mask, regenerated from (seed, sid)
         dseq = torch.zeros((B * S, H), dtype=dt, device=g.device)
         dg = dg.contiguous()
         check(_lib.lib().vb_scatter_rows(_lib.dtype_code(dt), ptr(dg), ptr(idx), ptr(dseq), B, S, H,

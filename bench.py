@@ -90,11 +90,15 @@ def pmc_traffic(batch, key, workload):
             d = json.load(f)
     except (OSError, ValueError):
         return None, "no profiles/pmc_traffic.json"
-    if workload != "pretrain" or d.get("per_gpu_batch") != batch or not (key & 16) or (key & 15):
+    if workload != "pretrain" or d.get("per_gpu_batch") != batch or (key & 15):
         return None, "committed PMC pass is for another configuration"
-    return d.get("traffic_bytes_per_launch"), ("committed PMC pass profiles/pmc_traffic.json (tools/gpu_pmc_traffic.sh: separate "
-                                               "FETCH_SIZE / WRITE_SIZE runs of this command, 2 x FETCH_SIZE + WRITE_SIZE); "
-                                               "not measured inside this run")
+    fam = "gemm_nt_dual_kernel<bf16->bf16>" if key & 64 else ("gemm_nt_8ph_kernel<bf16->bf16>" if key & 16 else None)
+    ent = d.get("kernels", {}).get(fam)
+    if ent is None:
+        return None, "committed PMC pass has no entry for this kernel"
+    return ent["traffic_bytes_per_launch"], ("committed PMC pass profiles/pmc_traffic.json (tools/gpu_pmc_traffic.sh: separate "
+                                             "FETCH_SIZE / WRITE_SIZE runs of this command, 2 x FETCH_SIZE + WRITE_SIZE); "
+                                             "not measured inside this run")
 
 
 def measured_mfma_ceiling(dev):

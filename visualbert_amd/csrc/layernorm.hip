@@ -365,11 +365,15 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) embed_bwd_kernel(EmbBwdArgs a) {
     const bool text = s < a.T;
     for (int i = threadIdx.x; i < H * (1 + a.TV); i += NT) lds_pos[i] = 0.f;
     __syncthreads();
-    float acc[NC][8];
+    // two token types (every BERT configuration of the reference): the type-1 rows are summed in registers next to the
+    // all-rows sum and type 0 is the difference -- the general path below pays one LDS float atomic per ELEMENT (64 M of
+    // them per step at B = 512: most of this kernel's 435 us)
+    const bool two_types = a.TV == 2;
+    float acc[NC][8], acc1[NC][8];
 #pragma unroll
     for (int ci = 0; ci < NC; ++ci)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[ci][j] = 0.f;
+        for (int j = 0; j < 8; ++j) { acc[ci][j] = 0.f; acc1[ci][j] = 0.f; }
     const int bper = (a.B + (int)gridDim.y - 1) / (int)gridDim.y;
     const int b_lo = (int)blockIdx.y * bper, b_hi = b_lo + bper < a.B ? b_lo + bper : a.B;
     for (int b = b_lo + hw; b < b_hi; b += HW_PER_BLOCK) {
@@ -391,7 +395,8 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) embed_bwd_kernel(EmbBwdArgs a) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     acc[ci][j] += v[j];
-                    atomicAdd(&lds_type[tt * H + col + j], v[j]);
+                    if (two_types) acc1[ci][j] += tt ? v[j] : 0.f;
+                    else atomicAdd(&lds_type[tt * H + col + j], v[j]);
                 }
                 if (text) {
                     if (a.d_word) {
@@ -409,7 +414,13 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) embed_bwd_kernel(EmbBwdArgs a) {
         const int col = (l32 + 32 * ci) * 8;
         if (col < H) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) atomicAdd(&lds_pos[col + j], acc[ci][j]);
+            for (int j = 0; j < 8; ++j) {
+                atomicAdd(&lds_pos[col + j], acc[ci][j]);
+                if (two_types) {                            // 8 half-waves per workgroup: a handful of LDS adds per column
+                    atomicAdd(&lds_type[H + col + j], acc1[ci][j]);
+                    atomicAdd(&lds_type[col + j], acc[ci][j] - acc1[ci][j]);
+                }
+            }
         }
     }
     __syncthreads();

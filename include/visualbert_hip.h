@@ -164,6 +164,21 @@ int vb_attn_bwd(int dtype, const void* qkv, const float* mask_add, const void* d
                 const uint64_t* keepbits, float* dsum_ws, void* dqkv, const void* ctx_fwd, float* dqkv_bias,
                 int B, int S, int nh, int head_dim, float p_drop, uint64_t seed, uint32_t stream_id, void* stream);
 
+/* Cross-attention with the same kernels (forward; two-pass backward): queries from one tensor, keys / values from another,
+ * with their own sequence lengths and row pitches (elements; multiples of 8).  q: T [B*Sq, >= nh*64 columns from the pointer],
+ * k, v: T [B*Sk, ...]; mask_add: fp32 [B, Sk] over the KEYS; ctx: T [B*Sq, ldctx]; lse / dsum_ws: fp32 [B, nh, Sq];
+ * keepbits: uint64 [B*nh * vb_attn_cross_keepbits_words(Sq, Sk)].  Backward writes dq [B*Sq], dk, dv [B*Sk] completely.
+ * Replaces: BertAttention.forward with context != hidden_states in the sibling LXRT model
+ * (unsupervised_visualbert/src/lxrt/modeling.py:347-411, used by BertCrossattLayer :427-436 / LXRTXLayer :660-712). */
+int64_t vb_attn_cross_keepbits_words(int Sq, int Sk);
+int vb_attn_cross_fwd(int dtype, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                      const float* mask_add, void* ctx, int64_t ldctx, float* lse, uint64_t* keepbits,
+                      int B, int Sq, int Sk, int nh, int head_dim, float p_drop, uint64_t seed, uint32_t stream_id, void* stream);
+int vb_attn_cross_bwd(int dtype, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                      const float* mask_add, const void* dctx, int64_t lddctx, const float* lse, const uint64_t* keepbits,
+                      float* dsum_ws, void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv,
+                      int B, int Sq, int Sk, int nh, int head_dim, float p_drop, uint64_t seed, uint32_t stream_id, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Losses.  logits are fp32 with leading dimension ld_logits (pad columns are ignored).
  * vb_ce_fwd_bwd: CrossEntropyLoss(ignore_index) mean over counted rows -> loss[0]; acc2 is an fp32[66]

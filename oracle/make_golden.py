@@ -237,6 +237,49 @@ def make_attention_case(stem="micro_attention_weights", cfg_name="micro", B=2, T
     print("wrote %s (%d KB)" % (path, os.path.getsize(path) // 1024))
 
 
+def make_lxrt_case(stem="micro_lxrt", B=3, Tl=12, Rv=7, seed=12, feat_dim=256):
+    """the sibling model's cross-modality blocks (unsupervised_visualbert/src/lxrt/modeling.py): one LXRTXLayer (:660-712)
+    and a VisualFeatEncoder (:715-747) of the REAL reference on the oracle's synthetic weights / inputs -- outputs, and
+    the gradients of every parameter and both inputs for the loss sum(lang_out * Wl) + sum(visn_out * Wv) (eval mode)."""
+    from oracle.reference_shim import load_reference_lxrt
+    lx = load_reference_lxrt()
+    cfg_kwargs = dict(vo.CONFIGS["micro"])
+    cfg = vo.OracleConfig(**cfg_kwargs)
+    kw = dict(cfg_kwargs)
+    kw.pop("visual_embedding_dim")
+    V = kw.pop("vocab_size")
+    rc = lx.BertConfig(V, **kw)
+    lx.VISUAL_CONFIG.set_visual_dims(feat_dim, 4)
+    layer = lx.LXRTXLayer(rc)
+    enc = lx.VisualFeatEncoder(rc)
+    sd = vo.lxrt_synth_state_dict(cfg, seed, feat_dim)
+    missing = layer.load_state_dict({k: v for k, v in sd.items() if not k.startswith("enc.")}, strict=True)
+    enc.load_state_dict({k[4:]: v for k, v in sd.items() if k.startswith("enc.")}, strict=True)
+    layer.eval()
+    enc.eval()
+    x = vo.lxrt_synth_inputs(cfg, B, Tl, Rv, seed, feat_dim)
+    lang = x["lang"].clone().requires_grad_(True)
+    feats = x["feats"].clone().requires_grad_(True)
+    visn_in = enc((feats, x["boxes"]))                   # the visual stream enters through the feature encoder
+    lo, vo_ = layer(lang, x["lang_ext_mask"], visn_in, x["visn_ext_mask"])
+    g = torch.Generator().manual_seed(9000 + seed)
+    wl, wv = torch.randn(lo.shape, generator=g), torch.randn(vo_.shape, generator=g)
+    loss = (lo * wl).sum() + (vo_ * wv).sum()
+    loss.backward()
+    rec = OrderedDict(meta=np.array([B, Tl, Rv, seed, feat_dim], dtype=np.int64))
+    rec["visn_encoded"] = visn_in.detach().numpy()
+    rec["lang_out"] = lo.detach().numpy()
+    rec["visn_out"] = vo_.detach().numpy()
+    rec["loss"] = loss.detach().double().numpy()
+    rec["grad_in/lang"] = lang.grad.numpy()
+    rec["grad_in/feats"] = feats.grad.numpy()
+    for n, p_ in list(layer.named_parameters()) + [("enc." + n, p_) for n, p_ in enc.named_parameters()]:
+        rec["grad/" + n] = p_.grad.numpy()
+    path = os.path.join(GOLDEN_DIR, stem + ".npz")
+    np.savez_compressed(path, **rec)
+    print("wrote %s (%d KB)" % (path, os.path.getsize(path) // 1024))
+
+
 def make_schedule_fixture():
     """learning-rate multipliers of EVERY schedule class of the reference (optimization.py:37-173) over a short run,
     evaluated by the reference's own classes -> tests/golden/schedules.json."""
@@ -271,3 +314,5 @@ if __name__ == "__main__":
         make_attention_case()
     if not only or "schedules" in only:
         make_schedule_fixture()
+    if not only or "micro_lxrt" in only:
+        make_lxrt_case()

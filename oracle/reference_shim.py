@@ -141,3 +141,32 @@ def load_reference_data_utils():
         from pytorch_pretrained_bert import fine_tuning as ref_ft
         from dataloaders import bert_data_utils as ref_bdu
     return ref_ft, ref_bdu
+
+
+def load_reference_lxrt(l_layers=2, x_layers=1, r_layers=0, **arg_overrides):
+    """-> the sibling model's module unsupervised_visualbert/src/lxrt/modeling.py, imported in place.  It reads a global
+    `args` (src/param.py runs argparse at import time): a stand-in `param` module supplies an args object with the three
+    layer counts VisualConfig wants and .get(name, default) for every optional switch (all off unless overridden)."""
+    _install_stubs()
+    src = os.path.join(REFERENCE_ROOT, "unsupervised_visualbert", "src")
+    if not os.path.isfile(os.path.join(src, "lxrt", "modeling.py")):
+        raise RuntimeError("reference tree not present at %s" % src)
+
+    class _Args(dict):
+        def __getattr__(self, k):
+            try:
+                return self[k]
+            except KeyError:
+                raise AttributeError(k)
+
+    a = _Args(llayers=l_layers, xlayers=x_layers, rlayers=r_layers)
+    a.update(arg_overrides)
+    mod = types.ModuleType("param")
+    mod.args = a
+    sys.modules["param"] = mod
+    if src not in sys.path:
+        sys.path.insert(0, src)
+    import io
+    import importlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        return importlib.import_module("lxrt.modeling")

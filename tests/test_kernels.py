@@ -421,6 +421,76 @@ def test_attention_fwd_bwd(dev, dt, cfg):
                 assert berr <= tol(dt, 2e-4, 0.04) * max(1.0, bias_ref.abs().max().item()), (berr, fwd_out is not None)
 
 
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("cfg", [(2, 20, 36, 2, 0.0), (2, 36, 20, 2, 0.0), (1, 40, 164, 1, 0.1), (3, 7, 5, 1, 0.0)])
+def test_cross_attention_fwd_bwd(dev, dt, cfg):
+    """queries and keys / values from different sequences of different lengths (LXRT: language <-> vision): forward and the
+    two-pass backward against a torch fp32 reference; keys masked per sample; dropout keep-bits decoded and replayed."""
+    from visualbert_amd import ops
+    B, Sq, Sk, nh, p = cfg
+    H = nh * 64
+    g = torch.Generator().manual_seed(Sq * 100 + Sk)
+    q = (0.7 * torch.randn(B, Sq, H, generator=g)).to(dt).to(dev)
+    kv = (0.7 * torch.randn(B, Sk, 2 * H + 8, generator=g)).to(dt).to(dev)          # k | v | pad: pitches differ from H
+    k, v = kv[:, :, :H], kv[:, :, H:2 * H]
+    lens = torch.randint(max(Sk // 2, 1), Sk + 1, (B,), generator=g)
+    mask = (torch.arange(Sk).unsqueeze(0) < lens.unsqueeze(1)).float()
+    mask_add = ((1 - mask) * -10000.0).to(dev)
+    L = _lib.lib()
+    k2, v2, q2 = k.reshape(B * Sk, H), v.reshape(B * Sk, H), q.reshape(B * Sq, H)
+    assert k2.stride(0) == 2 * H + 8
+    ctx = torch.empty(B * Sq, H, dtype=dt, device=dev)
+    lse = torch.empty(B, nh, Sq, device=dev)
+    bits = torch.zeros(B * nh * L.vb_attn_cross_keepbits_words(Sq, Sk), dtype=torch.int64, device=dev)
+    code = _lib.dtype_code(dt)
+    _lib.check(L.vb_attn_cross_fwd(code, _lib.ptr(q2), H, _lib.ptr(k2), k2.stride(0), _lib.ptr(v2), v2.stride(0),
+                                   _lib.ptr(mask_add), _lib.ptr(ctx), H, _lib.ptr(lse), _lib.ptr(bits), B, Sq, Sk, nh, 64, p, 99, 4,
+                                   _lib.stream_ptr()), "vb_attn_cross_fwd")
+    keep = None
+    if p > 0:
+        nw = L.vb_attn_cross_keepbits_words(Sq, Sk) // (Sq * 4)
+        words = bits.view(B, nh, Sq, 4, nw).cpu()
+        keep = torch.zeros(B, nh, Sq, Sk)
+        for key in range(Sk):
+            kf, gg, r = key // 16, (key % 16) // 4, key % 4
+            keep[:, :, :, key] = ((words[:, :, :, gg, kf // 16] >> ((kf % 16) * 4 + r)) & 1).float()
+        keep = keep.to(dev)
+        assert abs(keep.mean().item() - (1 - p)) < 0.03
+    qr = q.float().detach().requires_grad_(True)
+    kr = k.float().detach().clone().requires_grad_(True)
+    vr = v.float().detach().clone().requires_grad_(True)
+
+    def heads(t, S):
+        return t.view(B, S, nh, 64).permute(0, 2, 1, 3)
+    sc = heads(qr, Sq) @ heads(kr, Sk).transpose(-1, -2) / 8.0 + mask_add.view(B, 1, 1, Sk)
+    pr = torch.softmax(sc, -1)
+    if keep is not None:
+        pr = pr * keep / (1 - p)
+    ref = (pr @ heads(vr, Sk)).permute(0, 2, 1, 3).reshape(B, Sq, H)
+    t = tol(dt, 2e-5, 0.03)
+    assert (ctx.float().view(B, Sq, H) - ref).abs().max().item() <= t
+    dctx = torch.randn(B, Sq, H, generator=g).to(dt).to(dev)
+    ref.backward(dctx.float())
+    dq = torch.full_like(q2, float("nan"))
+    dkv = torch.full((B * Sk, 2 * H + 8), float("nan"), dtype=dt, device=dev)
+    dk, dv = dkv[:, :H], dkv[:, H:2 * H]
+    ws = torch.empty(B, nh, Sq, device=dev)
+    d2 = dctx.reshape(B * Sq, H)
+    _lib.check(L.vb_attn_cross_bwd(code, _lib.ptr(q2), H, _lib.ptr(k2), k2.stride(0), _lib.ptr(v2), v2.stride(0),
+                                   _lib.ptr(mask_add), _lib.ptr(d2), H, _lib.ptr(lse), _lib.ptr(bits), _lib.ptr(ws), _lib.ptr(dq), H,
+                                   _lib.ptr(dk), dk.stride(0), _lib.ptr(dv), dv.stride(0), B, Sq, Sk, nh, 64, p, 99, 4,
+                                   _lib.stream_ptr()), "vb_attn_cross_bwd")
+    gm = max(qr.grad.abs().max().item(), kr.grad.abs().max().item(), vr.grad.abs().max().item(), 1.0)
+    lim = tol(dt, 5e-5, 0.04) * gm
+    assert (dq.float().view(B, Sq, H) - qr.grad).abs().max().item() <= lim
+    assert (dk.float().reshape(B, Sk, H) - kr.grad).abs().max().item() <= lim
+    assert (dv.float().reshape(B, Sk, H) - vr.grad).abs().max().item() <= lim
+    # the autograd wrapper (contiguous copies of the strided views) gives the same context
+    out = ops.CrossAttentionCoreFn.apply(q, k, v, mask_add, nh, 0.0, 4)
+    if p == 0:
+        assert (out.float() - ref).abs().max().item() <= t
+
+
 @pytest.mark.parametrize("variant", [1, 22, 42, 80, 81, 90])
 def test_gemm_pipelined_variants_agree(dev, variant):
     """every pipelined K-contiguous kernel variant (tile shape x LDS stages, counted vmcnt, ping-pong,

@@ -37,6 +37,10 @@ SIGNATURES = {
     "vb_attn_keepbits_words": (_i64, [_i]),
     "vb_attn_fwd": (_i, [_i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _u64, _u32, _p]),
     "vb_attn_bwd_ws_floats": (_i64, [_i, _i, _i]),
+    "vb_attn_cross_keepbits_words": (_i64, [_i, _i]),
+    "vb_attn_cross_fwd": (_i, [_i, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _p, _i, _i, _i, _i, _i, _f, _u64, _u32, _p]),
+    "vb_attn_cross_bwd": (_i, [_i, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _p, _p, _p, _i64, _p, _i64, _p, _i64,
+                               _i, _i, _i, _i, _i, _f, _u64, _u32, _p]),
     "vb_attn_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _u64, _u32, _p]),
     "vb_ce_fwd_bwd": (_i, [_i, _p, _i64, _p, _i, _p, _p, _p, _i64, _i, _i, _p]),
     "vb_ce_fwd_bwd_rows": (_i, [_i, _p, _i64, _p, _i, _p, _i, _i, _p, _p, _p, _i64, _i, _i, _p]),

@@ -183,13 +183,20 @@ struct AttnArgs {
     const void* qkv; const float* mask_add; void* ctx; float* lse; uint64_t* keepbits;   // forward
     const void* dctx; void* dqkv; float* dsum; const void* ctx_fwd;                       // backward
     float* bias_ws;                  // one-pass backward: per-sample column sums of dQ | dK | dV, fp32 [B][3H] (or NULL)
+    // General form (self- AND cross-attention; the forward and the two-pass backward kernels read only these): queries come
+    // from q [B*Sq rows, pitch ldq], keys / values from k, v [B*S rows, pitch ldk / ldv] -- for self-attention three column
+    // blocks of the packed qkv matrix, for cross-attention (LXRT: language attends to vision and back) different tensors
+    // with different sequence lengths.  Pointers are to column 0 of head 0; pitches in elements.
+    const void *q, *k, *v; void *dq, *dk, *dv;
+    long ldq, ldk, ldv, ldc, lddo, lddq, lddk, lddv;
+    int Sq;                          // queries per sample (S = keys per sample)
     int B, S, nh; float scale; float p; float inv_keep; uint32_t thresh; uint32_t stream; uint64_t seed;
 };
 
 // keep-bits: one uint64 per (b, h, q, g = key&15>>2, word w): nibble (kf & 15) of word (kf >> 4)
 // holds keys kf*16 + g*4 + {0..3}.  Written by forward, read by both backward passes.
 VB_DEVICE long keep_index(const AttnArgs& a, int bh, int q, int g, int w, int nw) {
-    return (((long)bh * a.S + q) * 4 + g) * nw + w;
+    return (((long)bh * a.Sq + q) * 4 + g) * nw + w;
 }
 
 // =================================================================================================
@@ -209,39 +216,41 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(NT, 3) attn_fwd_kernel(AttnArgs a) {
     float* ldsMask = (float*)(ldsVT + tr_bytes<T>(NKVK));
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, lg = lane >> 4;
     const int bh = blockIdx.x, b = bh / a.nh, h = bh % a.nh;
-    const int S = a.S, H = a.nh * D;
-    const long ldx = 3L * H, row0 = (long)b * S;
-    const T* qkv = (const T*)a.qkv;
+    const int S = a.S, Sq = a.Sq;                          // keys / queries per sample
+    const long rowk = (long)b * S, rowq = (long)b * Sq;
+    const T* Qp = (const T*)a.q;
+    const T* Kp = (const T*)a.k;
+    const T* Vp = (const T*)a.v;
 
     if constexpr (sizeof(T) == 2) {
         PairTile<NK> tk;
         PairTile<NKVK> tv;
-        pair_load<NK>(tk, qkv, ldx, row0, H + h * D, S, t);
-        pair_load<NKVK>(tv, qkv, ldx, row0, 2 * H + h * D, S, t);
+        pair_load<NK>(tk, Kp, a.ldk, rowk, h * D, S, t);
+        pair_load<NKVK>(tv, Vp, a.ldv, rowk, h * D, S, t);
         pair_store_rm<NK>(tk, ldsK, t);
         pair_store_tr<NKVK>(tv, ldsVT, t);                  // rows >= S arrive as zeros: the padded key columns are 0
     } else {
-        stage_rm<T>(ldsK, qkv, ldx, row0, H + h * D, S, NK, t);
-        stage_tr(ldsVT, qkv, ldx, row0, 2 * H + h * D, S, NKVK, t);
+        stage_rm<T>(ldsK, Kp, a.ldk, rowk, h * D, S, NK, t);
+        stage_tr(ldsVT, Vp, a.ldv, rowk, h * D, S, NKVK, t);
     }
     for (int k = t; k < NK; k += NT) ldsMask[k] = k < S ? a.mask_add[(long)b * S + k] : -INFINITY;
     __syncthreads();
 
-    const int nqf = (S + 15) / 16;
+    const int nqf = (Sq + 15) / 16;
     // the Q fragment of a wave's NEXT query block is fetched while the current one computes: a rolled loop whose first
     // instruction consumes a fresh global load pays one HBM round trip per trip (3 per wave here)
     typename VecOf<T>::v8 qn[2];
     auto fetch_q = [&](int qf) {
         const int q = qf * 16 + li;
-        const bool ok = qf < nqf && q < S;
-        const T* qrow = qkv + (row0 + (ok ? q : 0)) * ldx + h * D;
+        const bool ok = qf < nqf && q < Sq;
+        const T* qrow = Qp + (rowq + (ok ? q : 0)) * a.ldq + h * D;
         qn[0] = frag_g(qrow, 0, lg, ok);
         qn[1] = frag_g(qrow, 1, lg, ok);
     };
     fetch_q(wave);
     for (int qf = wave; qf < nqf; qf += 4) {
         const int q = qf * 16 + li;
-        const bool qok = q < S;
+        const bool qok = q < Sq;
         typename VecOf<T>::v8 qb[2];
         qb[0] = qn[0];
         qb[1] = qn[1];
@@ -275,7 +284,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(NT, 3) attn_fwd_kernel(AttnArgs a) {
         sum += __shfl_xor(sum, 32);
         const float inv = 1.0f / sum;
         const float invk = inv * a.inv_keep;               // normalisation and 1/(1-p) in one factor
-        if (a.lse && lg == 0 && qok) a.lse[(long)bh * S + q] = m + logf(sum);
+        if (a.lse && lg == 0 && qok) a.lse[(long)bh * Sq + q] = m + logf(sum);
 
         // normalise, dropout (keep-bits recorded), round to T as the MFMA B operand
         uint64_t bits[NW];
@@ -285,7 +294,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(NT, 3) attn_fwd_kernel(AttnArgs a) {
         for (int kp = 0; kp < NKS; ++kp) {
             if (a.p > 0.f) {
                 // one generator call covers this lane's 8 probabilities of fragments 2kp, 2kp+1
-                const uint64_t grp = ((((uint64_t)bh * S + q) * 4 + lg) << 5) + kp;
+                const uint64_t grp = ((((uint64_t)bh * Sq + q) * 4 + lg) << 5) + kp;
                 Rand8 rnd = vb_dropout_bits8(a.seed, grp, a.stream);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -311,7 +320,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(NT, 3) attn_fwd_kernel(AttnArgs a) {
             else pack_b(pb[ks], st[2 * ks], f32x4{0.f, 0.f, 0.f, 0.f});
         }
 
-        T* crow = (T*)a.ctx + (row0 + (qok ? q : 0)) * H + h * D;
+        T* crow = (T*)a.ctx + (rowq + (qok ? q : 0)) * a.ldc + h * D;
 #pragma unroll
         for (int df = 0; df < 4; ++df) {
             f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -338,35 +347,37 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) attn_bwd_dq_kernel(AttnArgs a) {
     float* ldsMask = (float*)(ldsKT + tr_bytes<T>(NK));
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, lg = lane >> 4;
     const int bh = blockIdx.x, b = bh / a.nh, h = bh % a.nh;
-    const int S = a.S, H = a.nh * D;
-    const long ldx = 3L * H, row0 = (long)b * S;
-    const T* qkv = (const T*)a.qkv;
+    const int S = a.S, Sq = a.Sq;                          // keys / queries per sample
+    const long rowk = (long)b * S, rowq = (long)b * Sq;
+    const T* Qp = (const T*)a.q;
+    const T* Kp = (const T*)a.k;
+    const T* Vp = (const T*)a.v;
 
     if constexpr (sizeof(T) == 2) {
         PairTile<NK> tk, tv;                               // K is fetched once for both of its LDS images
-        pair_load<NK>(tk, qkv, ldx, row0, H + h * D, S, t);
-        pair_load<NK>(tv, qkv, ldx, row0, 2 * H + h * D, S, t);
+        pair_load<NK>(tk, Kp, a.ldk, rowk, h * D, S, t);
+        pair_load<NK>(tv, Vp, a.ldv, rowk, h * D, S, t);
         pair_store_rm<NK>(tk, ldsK, t);
         pair_store_tr<NK>(tk, ldsKT, t);
         pair_store_rm<NK>(tv, ldsV, t);
     } else {
-        stage_rm<T>(ldsK, qkv, ldx, row0, H + h * D, S, NK, t);
-        stage_rm<T>(ldsV, qkv, ldx, row0, 2 * H + h * D, S, NK, t);
-        stage_tr(ldsKT, qkv, ldx, row0, H + h * D, S, NK, t);
+        stage_rm<T>(ldsK, Kp, a.ldk, rowk, h * D, S, NK, t);
+        stage_rm<T>(ldsV, Vp, a.ldv, rowk, h * D, S, NK, t);
+        stage_tr(ldsKT, Kp, a.ldk, rowk, h * D, S, NK, t);
     }
     for (int k = t; k < NK; k += NT) ldsMask[k] = k < S ? a.mask_add[(long)b * S + k] : -INFINITY;
     __syncthreads();
 
-    const int nqf = (S + 15) / 16;
+    const int nqf = (Sq + 15) / 16;
     for (int qf = wave; qf < nqf; qf += 4) {
         const int q = qf * 16 + li;
-        const bool qok = q < S;
-        const T* qrow = qkv + (row0 + (qok ? q : 0)) * ldx + h * D;
-        const T* dorow = (const T*)a.dctx + (row0 + (qok ? q : 0)) * H + h * D;
+        const bool qok = q < Sq;
+        const T* qrow = Qp + (rowq + (qok ? q : 0)) * a.ldq + h * D;
+        const T* dorow = (const T*)a.dctx + (rowq + (qok ? q : 0)) * a.lddo + h * D;
         typename VecOf<T>::v8 qb[2], dob[2];
         qb[0] = frag_g(qrow, 0, lg, qok); qb[1] = frag_g(qrow, 1, lg, qok);
         dob[0] = frag_g(dorow, 0, lg, qok); dob[1] = frag_g(dorow, 1, lg, qok);
-        const float lse = qok ? a.lse[(long)bh * S + q] : 0.f;
+        const float lse = qok ? a.lse[(long)bh * Sq + q] : 0.f;
         uint64_t bits[NW];
 #pragma unroll
         for (int w = 0; w < NW; ++w)
@@ -397,7 +408,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) attn_bwd_dq_kernel(AttnArgs a) {
         }
         dsum += __shfl_xor(dsum, 16);
         dsum += __shfl_xor(dsum, 32);
-        if (a.dsum && lg == 0 && qok) a.dsum[(long)bh * S + q] = dsum;
+        if (a.dsum && lg == 0 && qok) a.dsum[(long)bh * Sq + q] = dsum;
         // dS^T = P o (dP - D) * scale, rounded to T as the MFMA B operand
         typename VecOf<T>::v8 dsb[NKS];
 #pragma unroll
@@ -410,7 +421,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) attn_bwd_dq_kernel(AttnArgs a) {
             }
             pack_b(dsb[ks], x0, x1);
         }
-        T* dqrow = (T*)a.dqkv + (row0 + (qok ? q : 0)) * ldx + h * D;
+        T* dqrow = (T*)a.dq + (rowq + (qok ? q : 0)) * a.lddq + h * D;
 #pragma unroll
         for (int df = 0; df < 4; ++df) {
             f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -444,17 +455,19 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) attn_bwd_dkv_kernel(AttnArgs a) {
     uint64_t* ldsBits = (uint64_t*)(ldsD + QC);           // [QC][4][NW]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, lg = lane >> 4;
     const int bh = blockIdx.x, b = bh / a.nh, h = bh % a.nh;
-    const int S = a.S, H = a.nh * D;
-    const long ldx = 3L * H, row0 = (long)b * S;
-    const T* qkv = (const T*)a.qkv;
+    const int S = a.S, Sq = a.Sq;                          // keys / queries per sample
+    const long rowk = (long)b * S, rowq = (long)b * Sq;
+    const T* Qp = (const T*)a.q;
+    const T* Kp = (const T*)a.k;
+    const T* Vp = (const T*)a.v;
     const T* dctx = (const T*)a.dctx;
 
     const int kf = blockIdx.y * 4 + wave;
     const int key = kf * 16 + li;
     const bool wave_on = kf * 16 < S;                      // wave-uniform
     const bool kok = key < S;
-    const T* krow = qkv + (row0 + (kok ? key : 0)) * ldx + H + h * D;
-    const T* vrow = qkv + (row0 + (kok ? key : 0)) * ldx + 2 * H + h * D;
+    const T* krow = Kp + (rowk + (kok ? key : 0)) * a.ldk + h * D;
+    const T* vrow = Vp + (rowk + (kok ? key : 0)) * a.ldv + h * D;
     typename VecOf<T>::v8 kb[2], vb[2];
     kb[0] = frag_g(krow, 0, lg, kok); kb[1] = frag_g(krow, 1, lg, kok);
     vb[0] = frag_g(vrow, 0, lg, kok); vb[1] = frag_g(vrow, 1, lg, kok);
@@ -474,21 +487,21 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) attn_bwd_dkv_kernel(AttnArgs a) {
     auto load_chunk = [&](int q0) {
         const int dc = t & 7, r = (t >> 3) * 2;             // rows q0 + r, q0 + r + 1; 16-byte column chunk dc
         const u32x4 z = u32x4{0u, 0u, 0u, 0u};
-        const bool ok0 = q0 + r < S, ok1 = q0 + r + 1 < S;
-        cq0 = ok0 ? *(const u32x4*)(qkv + (row0 + q0 + r) * ldx + h * D + dc * 8) : z;
-        cq1 = ok1 ? *(const u32x4*)(qkv + (row0 + q0 + r + 1) * ldx + h * D + dc * 8) : z;
-        cd0 = ok0 ? *(const u32x4*)(dctx + (row0 + q0 + r) * (long)H + h * D + dc * 8) : z;
-        cd1 = ok1 ? *(const u32x4*)(dctx + (row0 + q0 + r + 1) * (long)H + h * D + dc * 8) : z;
+        const bool ok0 = q0 + r < Sq, ok1 = q0 + r + 1 < Sq;
+        cq0 = ok0 ? *(const u32x4*)(Qp + (rowq + q0 + r) * a.ldq + h * D + dc * 8) : z;
+        cq1 = ok1 ? *(const u32x4*)(Qp + (rowq + q0 + r + 1) * a.ldq + h * D + dc * 8) : z;
+        cd0 = ok0 ? *(const u32x4*)(dctx + (rowq + q0 + r) * a.lddo + h * D + dc * 8) : z;
+        cd1 = ok1 ? *(const u32x4*)(dctx + (rowq + q0 + r + 1) * a.lddo + h * D + dc * 8) : z;
         if (t < QC) {
             const int q = q0 + t;
-            c_lse = q < S ? a.lse[(long)bh * S + q] : INFINITY;     // exp(x - inf) = 0 for padded queries
-            c_d = q < S ? a.dsum[(long)bh * S + q] : 0.f;
+            c_lse = q < Sq ? a.lse[(long)bh * Sq + q] : INFINITY;   // exp(x - inf) = 0 for padded queries
+            c_d = q < Sq ? a.dsum[(long)bh * Sq + q] : 0.f;
         }
 #pragma unroll
         for (int j = 0; j < BPT; ++j) {
             const int i = t + j * NT;
             const int q = q0 + i / (4 * NW);
-            c_bits[j] = (a.p > 0.f && i < QC * 4 * NW && q < S) ? a.keepbits[((long)bh * S + q0) * 4 * NW + i] : ~(uint64_t)0;
+            c_bits[j] = (a.p > 0.f && i < QC * 4 * NW && q < Sq) ? a.keepbits[((long)bh * Sq + q0) * 4 * NW + i] : ~(uint64_t)0;
         }
     };
     auto store_tr2 = [&](unsigned char* lds, const u32x4& x0, const u32x4& x1) {
@@ -515,32 +528,32 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) attn_bwd_dkv_kernel(AttnArgs a) {
     };
     if constexpr (PIPE) load_chunk(0);
 
-    for (int q0 = 0; q0 < S; q0 += QC) {
+    for (int q0 = 0; q0 < Sq; q0 += QC) {
         __syncthreads();                                   // previous chunk fully consumed
         if constexpr (PIPE) {
             store_chunk();
             __syncthreads();
-            if (q0 + QC < S) load_chunk(q0 + QC);
+            if (q0 + QC < Sq) load_chunk(q0 + QC);
         } else {
-            stage_rm<T>(ldsQ, qkv, ldx, row0 + q0, h * D, S - q0, QC, t);
-            stage_rm<T>(ldsDO, dctx, (long)H, row0 + q0, h * D, S - q0, QC, t);
-            stage_tr(ldsQT, qkv, ldx, row0 + q0, h * D, S - q0, QC, t);
-            stage_tr(ldsDOT, dctx, (long)H, row0 + q0, h * D, S - q0, QC, t);
+            stage_rm<T>(ldsQ, Qp, a.ldq, rowq + q0, h * D, Sq - q0, QC, t);
+            stage_rm<T>(ldsDO, dctx, a.lddo, rowq + q0, h * D, Sq - q0, QC, t);
+            stage_tr(ldsQT, Qp, a.ldq, rowq + q0, h * D, Sq - q0, QC, t);
+            stage_tr(ldsDOT, dctx, a.lddo, rowq + q0, h * D, Sq - q0, QC, t);
             for (int k = t; k < QC; k += NT) {
                 const int q = q0 + k;
-                ldsLse[k] = q < S ? a.lse[(long)bh * S + q] : INFINITY;   // exp(x - inf) = 0 for padded queries
-                ldsD[k] = q < S ? a.dsum[(long)bh * S + q] : 0.f;
+                ldsLse[k] = q < Sq ? a.lse[(long)bh * Sq + q] : INFINITY;   // exp(x - inf) = 0 for padded queries
+                ldsD[k] = q < Sq ? a.dsum[(long)bh * Sq + q] : 0.f;
             }
             for (int i = t; i < QC * 4 * NW; i += NT) {
                 const int q = q0 + i / (4 * NW);
-                ldsBits[i] = (a.p > 0.f && q < S) ? a.keepbits[((long)bh * S + q0) * 4 * NW + i] : ~(uint64_t)0;
+                ldsBits[i] = (a.p > 0.f && q < Sq) ? a.keepbits[((long)bh * Sq + q0) * 4 * NW + i] : ~(uint64_t)0;
             }
             __syncthreads();
         }
         if (!wave_on) continue;
 #pragma unroll
         for (int qc = 0; qc < QC / 32; ++qc) {
-            if (q0 + qc * 32 >= S) continue;
+            if (q0 + qc * 32 >= Sq) continue;
             f32x4 pd[2], dsv[2];
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
@@ -577,8 +590,8 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) attn_bwd_dkv_kernel(AttnArgs a) {
         }
     }
     if (kok) {
-        T* dkrow = (T*)a.dqkv + (row0 + key) * ldx + H + h * D;
-        T* dvrow = (T*)a.dqkv + (row0 + key) * ldx + 2 * H + h * D;
+        T* dkrow = (T*)a.dk + (rowk + key) * a.lddk + h * D;
+        T* dvrow = (T*)a.dv + (rowk + key) * a.lddv + h * D;
 #pragma unroll
         for (int df = 0; df < 4; ++df) {
             store4(dkrow + df * 16 + lg * 4, dkT[df]);
@@ -877,7 +890,7 @@ int launch_all(int which, const AttnArgs& a, hipStream_t s) {
         VB_LAUNCH((attn_fwd_kernel<T, NKF>), grid, block, sm, s, a);
     } else {
         if constexpr (sizeof(T) == 2 && NKF <= 12) {
-            if (a.ctx_fwd && a.S <= FWPB * 16 && vb_opts_for((void*)s).attn_two_pass != 1) {  // one-pass backward (needs the forward output)
+            if (a.ctx_fwd && a.qkv && a.Sq == a.S && a.S <= FWPB * 16 && vb_opts_for((void*)s).attn_two_pass != 1) {  // one-pass backward (needs the forward output)
                 // 64-query chunks (86 KB of LDS, one workgroup per CU): 528-541 us per layer at B=512; 32-query chunks (two
                 // workgroups per CU, twice the barriers): 575 us
                 VB_LAUNCH((attn_bwd_fused_kernel<NKF, 64>), grid, dim3(FNT), (fused_smem<NKF, 64>()), s, a);
@@ -918,18 +931,76 @@ int dispatch_nkf(int which, const AttnArgs& a, hipStream_t s) {
 
 int fill_args(AttnArgs& a, int B, int S, int nh, int head_dim, float p, uint64_t seed, uint32_t stream_id) {
     if (B <= 0 || S <= 0 || nh <= 0 || head_dim != D || p < 0.f || p >= 1.f) return VB_ERR_ARG;
-    a.B = B; a.S = S; a.nh = nh; a.scale = 0.125f;           // 1/sqrt(64), modeling.py:242
+    a.B = B; a.S = S; a.Sq = S; a.nh = nh; a.scale = 0.125f; // 1/sqrt(64), modeling.py:242
     a.p = p; a.inv_keep = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
     a.thresh = (uint32_t)(p * 65536.0f + 0.5f); a.stream = stream_id; a.seed = seed;
     return VB_OK;
 }
 
+// self-attention over the packed qkv matrix expressed in the general form: three column blocks, one pitch
+void set_self(AttnArgs& a, int dtype, const void* qkv, void* dqkv) {
+    const long H = (long)a.nh * D, es = dtype == VB_BF16 ? 2 : 4;
+    a.Sq = a.S;
+    a.q = qkv; a.k = (const char*)qkv + H * es; a.v = (const char*)qkv + 2 * H * es;
+    a.ldq = a.ldk = a.ldv = 3 * H;
+    a.ldc = a.lddo = H;
+    a.dq = dqkv;
+    a.dk = dqkv ? (char*)dqkv + H * es : nullptr;
+    a.dv = dqkv ? (char*)dqkv + 2 * H * es : nullptr;
+    a.lddq = a.lddk = a.lddv = 3 * H;
+}
+
+int keepbits_nw(int Sk) {
+    const int nkf = ((Sk + 31) / 32) * 2;
+    const int nkft = nkf <= 4 ? 4 : nkf <= 8 ? 8 : nkf <= 12 ? 12 : nkf <= 16 ? 16 : 32;   // 17..32 fragments: 2 words either way
+    return (nkft + 15) / 16;
+}
+
 }  // namespace
 
+// ---- cross-attention (LXRT: unsupervised_visualbert/src/lxrt/modeling.py:347-411 BertAttention with context != hidden_states) -----
+extern "C" int64_t vb_attn_cross_keepbits_words(int Sq, int Sk) { return (int64_t)Sq * 4 * keepbits_nw(Sk); }
+
+extern "C" int vb_attn_cross_fwd(int dtype, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                                 const float* mask_add, void* ctx, int64_t ldctx, float* lse, uint64_t* keepbits,
+                                 int B, int Sq, int Sk, int nh, int head_dim, float p_drop, uint64_t seed, uint32_t stream_id,
+                                 void* stream) {
+    AttnArgs a{};
+    int rc = fill_args(a, B, Sk, nh, head_dim, p_drop, seed, stream_id);
+    if (rc) return rc;
+    if (Sq <= 0 || !q || !k || !v || !mask_add || !ctx || (p_drop > 0.f && !keepbits)) return VB_ERR_ARG;
+    if ((ldq % 8) || (ldk % 8) || (ldv % 8) || (ldctx % 4)) return VB_ERR_ARG;          // 16-byte vector loads per (row, head)
+    a.Sq = Sq; a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldc = ldctx;
+    a.mask_add = mask_add; a.ctx = ctx; a.lse = lse; a.keepbits = keepbits;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == VB_BF16) return dispatch_nkf<bf16>(0, a, s);
+    if (dtype == VB_F32) return dispatch_nkf<float>(0, a, s);
+    return VB_ERR_ARG;
+}
+
+extern "C" int vb_attn_cross_bwd(int dtype, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                                 const float* mask_add, const void* dctx, int64_t lddctx, const float* lse,
+                                 const uint64_t* keepbits, float* dsum_ws, void* dq, int64_t lddq, void* dk, int64_t lddk,
+                                 void* dv, int64_t lddv, int B, int Sq, int Sk, int nh, int head_dim, float p_drop,
+                                 uint64_t seed, uint32_t stream_id, void* stream) {
+    AttnArgs a{};
+    int rc = fill_args(a, B, Sk, nh, head_dim, p_drop, seed, stream_id);
+    if (rc) return rc;
+    if (Sq <= 0 || !q || !k || !v || !mask_add || !dctx || !lse || !dsum_ws || !dq || !dk || !dv || (p_drop > 0.f && !keepbits))
+        return VB_ERR_ARG;
+    if ((ldq % 8) || (ldk % 8) || (ldv % 8) || (lddctx % 8) || (lddq % 4) || (lddk % 4) || (lddv % 4)) return VB_ERR_ARG;
+    a.Sq = Sq; a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.lddo = lddctx;
+    a.dq = dq; a.dk = dk; a.dv = dv; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
+    a.mask_add = mask_add; a.dctx = dctx; a.lse = (float*)lse; a.keepbits = (uint64_t*)keepbits; a.dsum = dsum_ws;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == VB_BF16) rc = dispatch_nkf<bf16>(1, a, s);
+    else if (dtype == VB_F32) rc = dispatch_nkf<float>(1, a, s);
+    else return VB_ERR_ARG;
+    return rc < 0 ? rc : VB_OK;
+}
+
 extern "C" int64_t vb_attn_keepbits_words(int S) {
-    const int nkf = ((S + 31) / 32) * 2;
-    const int nkft = nkf <= 4 ? 4 : nkf <= 8 ? 8 : nkf <= 12 ? 12 : nkf <= 16 ? 16 : 32;   // 17..32 fragments: 2 words either way
-    return (int64_t)S * 4 * ((nkft + 15) / 16);               // uint64 words per (batch, head)
+    return (int64_t)S * 4 * keepbits_nw(S);                   // uint64 words per (batch, head)
 }
 
 extern "C" int vb_attn_fwd(int dtype, const void* qkv, const float* mask_add, void* ctx, float* lse,
@@ -940,6 +1011,7 @@ extern "C" int vb_attn_fwd(int dtype, const void* qkv, const float* mask_add, vo
     if (rc) return rc;
     if (!qkv || !mask_add || !ctx || (p_drop > 0.f && !keepbits)) return VB_ERR_ARG;
     a.qkv = qkv; a.mask_add = mask_add; a.ctx = ctx; a.lse = lse; a.keepbits = keepbits;
+    set_self(a, dtype, qkv, nullptr);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == VB_BF16) return dispatch_nkf<bf16>(0, a, s);
     if (dtype == VB_F32) return dispatch_nkf<float>(0, a, s);
@@ -962,6 +1034,7 @@ extern "C" int vb_attn_bwd(int dtype, const void* qkv, const float* mask_add, co
     if (!qkv || !mask_add || !dctx || !lse || !dsum_ws || !dqkv || (p_drop > 0.f && !keepbits)) return VB_ERR_ARG;
     a.qkv = qkv; a.mask_add = mask_add; a.dctx = dctx; a.lse = (float*)lse; a.keepbits = (uint64_t*)keepbits;
     a.dsum = dsum_ws; a.dqkv = dqkv; a.ctx_fwd = ctx_fwd;
+    set_self(a, dtype, qkv, dqkv);
     a.bias_ws = dqkv_bias ? dsum_ws : nullptr;              // the one-pass kernel does not need D in memory: same scratch
     hipStream_t s = (hipStream_t)stream;
     if (dtype == VB_BF16) rc = dispatch_nkf<bf16>(1, a, s);

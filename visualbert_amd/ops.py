@@ -518,6 +518,50 @@ class SelfAttentionCoreFn(torch.autograd.Function):
         return dqkv.view(B, S, -1), None, None, None, None
 
 
+class CrossAttentionCoreFn(torch.autograd.Function):
+    """softmax(Q K^T / 8 + mask) V with queries and keys / values from DIFFERENT sequences: q [B, Sq, H], k, v [B, Sk, H]
+    (any row pitch), mask_add fp32 [B, Sk] over the keys -> context [B, Sq, H].  The core of the LXRT sibling's
+    BertAttention(hidden_states, context) (unsupervised_visualbert/src/lxrt/modeling.py:377-411)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, mask_add, nh, p, sid):
+        B, Sq, H = q.shape
+        Sk = k.size(1)
+        q2, k2, v2 = (t.reshape(-1, H) if t.is_contiguous() else t.contiguous().reshape(-1, H) for t in (q, k, v))
+        dt = q2.dtype
+        out = torch.empty((B * Sq, H), dtype=dt, device=q2.device)
+        lse = torch.empty((B, nh, Sq), dtype=torch.float32, device=q2.device)
+        L = _lib.lib()
+        bits = None
+        if p > 0.0:
+            bits = torch.empty(B * nh * L.vb_attn_cross_keepbits_words(Sq, Sk), dtype=torch.int64, device=q2.device)
+        seed = next_seed()
+        check(L.vb_attn_cross_fwd(_lib.dtype_code(dt), ptr(q2), _ld(q2), ptr(k2), _ld(k2), ptr(v2), _ld(v2), ptr(mask_add),
+                                  ptr(out), _ld(out), ptr(lse), ptr(bits), B, Sq, Sk, nh, 64, float(p), seed, sid,
+                                  stream_ptr()), "vb_attn_cross_fwd")
+        ctx.cfg = (B, Sq, Sk, H, nh, p, seed, sid)
+        ctx.bits = bits
+        ctx.save_for_backward(q2, k2, v2, mask_add, lse)
+        return out.view(B, Sq, H)
+
+    @staticmethod
+    def backward(ctx, dctx):
+        q2, k2, v2, mask_add, lse = ctx.saved_tensors
+        B, Sq, Sk, H, nh, p, seed, sid = ctx.cfg
+        d2 = dctx.reshape(B * Sq, H)
+        if d2.dtype != q2.dtype:
+            d2 = d2.to(q2.dtype)
+        if not d2.is_contiguous():
+            d2 = d2.contiguous()
+        dq, dk, dv = torch.empty_like(q2), torch.empty_like(k2), torch.empty_like(v2)
+        ws = torch.empty((B, nh, Sq), dtype=torch.float32, device=q2.device)
+        check(_lib.lib().vb_attn_cross_bwd(_lib.dtype_code(q2.dtype), ptr(q2), _ld(q2), ptr(k2), _ld(k2), ptr(v2), _ld(v2),
+                                           ptr(mask_add), ptr(d2), _ld(d2), ptr(lse), ptr(ctx.bits), ptr(ws), ptr(dq), _ld(dq),
+                                           ptr(dk), _ld(dk), ptr(dv), _ld(dv), B, Sq, Sk, nh, 64, float(p), seed, sid,
+                                           stream_ptr()), "vb_attn_cross_bwd")
+        return dq.view(B, Sq, H), dk.view(B, Sk, H), dv.view(B, Sk, H), None, None, None, None
+
+
 def _packed_qkv(attn_self, dtype):
     """(weight [3H,H] in `dtype`, bias [3H] fp32) of a BertSelfAttention with packed storage."""
     w = weight_for(attn_self.qkv_weight, dtype)

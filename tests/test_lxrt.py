@@ -11,8 +11,8 @@ from test_oracle_golden import lxrt_case
 pytestmark = pytest.mark.gpu
 
 # bf16: max |d(out)|, worst / median per-tensor gradient relative L2 -- 1.5 x the values measured on MI355X
-# (profiles/r02_parity_small.json: out 3.3e-2 on outputs of magnitude ~3.5 after two LayerNorms, grads median 9.6e-3, worst 2.4e-2)
-BF16_BOUNDS = dict(out=5e-2, grad_median=1.5e-2, grad_worst=3.6e-2)
+# (profiles/r02_parity_small.json: outputs 2.9e-2 at |out| <= 3.9, i.e. after three LayerNorms; gradients median 5.3e-3, worst 1.39e-2)
+BF16_BOUNDS = dict(out=4.4e-2, grad_median=8e-3, grad_worst=2.1e-2)
 
 
 def build(dev, dtype):

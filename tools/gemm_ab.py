@@ -10,7 +10,15 @@ if os.environ.get("VB_DEV") == "1":
     _lib.use_dev_library()
 NOCHECK = os.environ.get("VB_NOCHECK") == "1"
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
-arms = [int(x) for x in sys.argv[2:]] or [81, 90]
+arms = sys.argv[2:] or ["81", "90"]            # "90:8" = kernel 90 with the tile walk in stripes of 8 column tiles (VB_DEV=1)
+
+
+def select(arm):
+    k, _, stripe = arm.partition(":")
+    _lib.set_opts(nt_kernel=int(k))
+    if os.environ.get("VB_DEV") == "1":
+        _lib.dev_lib().vb_gemm_set_debug((int(stripe) << 8) if stripe else 0)
+
 dev = torch.device("cuda", 0)
 M = B * 164
 g = torch.Generator().manual_seed(0)
@@ -39,7 +47,7 @@ for name, n, k, f32, epi in shapes:
     ref = None
     for rep in range(3):
         for arm in arms:
-            _lib.set_opts(nt_kernel=arm)
+            select(arm)
             for _ in range(2):
                 ops.gemm(a, w[:n], M, n, k, **kw)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -55,10 +63,10 @@ for name, n, k, f32, epi in shapes:
                 else:
                     d = (cur - ref).abs().max().item()
                     assert NOCHECK or d <= 2e-2 * max(1.0, ref.abs().max().item()), (name, arm, d)
-    _lib.set_opts()
+    select("0")
     fl = 2.0 * M * n * k
-    print("%-34s" % name + "   ".join("k%d %7.1f us (%6.1f TF)" % (arm, min(res[arm]), fl / min(res[arm]) / 1e6) for arm in arms), flush=True)
+    print("%-34s" % name + "   ".join("k%s %7.1f us (%6.1f TF)" % (arm, min(res[arm]), fl / min(res[arm]) / 1e6) for arm in arms), flush=True)
     for arm in arms:
         tot[arm] += min(res[arm]) * (1 if "decoder" in name else 12)
     del a, w, out, kw
-print("per step (12 layers + decoder): " + "   ".join("k%d %.2f ms" % (arm, tot[arm] / 1e3) for arm in arms))
+print("per step (12 layers + decoder): " + "   ".join("k%s %.2f ms" % (arm, tot[arm] / 1e3) for arm in arms))

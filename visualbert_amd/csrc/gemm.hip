@@ -76,6 +76,7 @@ struct GemmArgs {
     unsigned long long* trace;    // measurement builds: per-iteration timestamps of waves 0 and 4 of workgroup 0
     float* colsum;                // optional fp32 [N]: += column sums of the stored values (bias gradient)
     int debug;                    // ablation bits (measurement only): 1 skip tile loads, 2 skip fragment reads, 4 skip MFMAs
+    int stripe;                   // dual kernel: column tiles per stripe of the tile walk (tiles_n = one stripe = row-major)
 };
 
 // ---- global -> register staging -------------------------------------------------------------
@@ -1226,8 +1227,14 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(256, 2) gemm_nt_dual_kernel(GemmArgs g) {
     const int wr = wave >> 1, wc = wave & 1;
     const int li = lane & 15, lg = lane >> 4;
     const int ntiles = g.tiles_m * g.tiles_n;
+    // tile walk: column stripes of g.stripe tiles, row panels inside a stripe, columns inside a row panel.  An XCD (a
+    // contiguous run of the walk) keeps one stripe of B in its L2 while it streams row panels of A past it.
     const int tile = xcd_remap((int)blockIdx.x, ntiles);
-    const int m0 = (tile / g.tiles_n) * 256, n0 = (tile % g.tiles_n) * 128;
+    const int per = g.tiles_m * g.stripe;
+    const int sidx = tile / per, srem = tile - sidx * per;
+    const int sleft = g.tiles_n - sidx * g.stripe;
+    const int swid = g.stripe < sleft ? g.stripe : sleft;
+    const int m0 = (srem / swid) * 256, n0 = (sidx * g.stripe + srem % swid) * 128;
     const vb_buf A = vb_make_buf(g.A);
     const vb_buf B = vb_make_buf(g.B);
 
@@ -1371,6 +1378,12 @@ int launch_dual(GemmArgs g, hipStream_t stream) {
     if constexpr (sizeof(T) == 2) {
         g.tiles_m = (g.M + 255) / 256;
         g.tiles_n = (g.N + 127) / 128;
+        // tile walk (see the kernel): one stripe = row-major.  Measured at M = 83,968 (profiles/r02_gemm_raster.txt): thirds of
+        // the columns help the 18-column QKV projection (312 -> 299 us: a 1.2 MB stripe of B stays in the XCD's L2); every
+        // other shape of the step is within noise or slower with stripes (the decoder +5 %: A re-read per stripe costs more
+        // than B re-read per row panel, which the memory-side cache serves)
+        g.stripe = (g.tiles_n > 12 && g.tiles_n <= 20) ? (g.tiles_n + 2) / 3 : g.tiles_n;
+        if ((g.debug >> 8) > 0) g.stripe = (g.debug >> 8) < g.tiles_n ? (g.debug >> 8) : g.tiles_n;      // developer library only: walk override
         dim3 grid((unsigned)(g.tiles_m * g.tiles_n));
         const int needs = epi_needs(g, sizeof(T), sizeof(TO));
 #define VB_TRY_EPI(A, O) if (g.act == (A) && (needs & ~(O)) == 0) return launch_dual_act<TO, A, O>(g, grid, stream)
@@ -1530,24 +1543,27 @@ VB_KERNEL VB_LAUNCH_BOUNDS(512) gemm_tn_8ph_kernel(TnArgs g) {
     const int lane_off = (kg >> 1) * 1024 + ((kg & 1) * 4 + (s16 >> 2)) * 32 + ((s16 >> 1) & 1) * 16 + (s16 & 1) * 8;
     const int offa_w = wr * 8192 + lane_off;                                   // F = wr
     const int offb_w = (wc >> 1) * 8192 + (wc & 1) * 512 + lane_off;           // F = wc >> 1, f16l = (wc & 1) 2 + g
-    bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
-    auto gather = [&](const unsigned char* p) {
-        const bf16x4 lo = vb_lds_read_tr(p), hi = vb_lds_read_tr(p + 2048);     // k + 0..3, k + 4..7  (h = 0, 1)
-        return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    // fragments stay in their two transposed halves (k + 0..3 | k + 4..7) until the MFMA that consumes them: the reads are
+    // inline asm (vb_lds_read_tr_pair: no compiler-inserted vmcnt(0) in front of them), so nothing may touch their
+    // results before the phase's lgkmcnt(0) (vb_raw_barrier)
+    bf16x4 fal[4][2], fah[4][2], fb0l[2][2], fb0h[2][2], fb1l[2][2], fb1h[2][2];
+    auto readA = [&](auto slot, const unsigned char* buf) {
+        constexpr int BASE = decltype(slot)::value * HALF;
+        const unsigned char* p = buf + offa_w;
+        vb_static_for<0, 8>([&](auto i) {
+            constexpr int f = decltype(i)::value >> 1, ks = decltype(i)::value & 1;
+            vb_lds_read_tr_pair<BASE + ks * 4096 + f * 256>(fal[f][ks], fah[f][ks], p);
+        });
     };
-    auto readA = [&](const unsigned char* half) {
-#pragma unroll
-        for (int f = 0; f < 4; ++f)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) fa[f][ks] = gather(half + offa_w + ks * 4096 + f * 256);
+    auto readB = [&](bf16x4 (&lo)[2][2], bf16x4 (&hi)[2][2], auto slot, const unsigned char* buf) {
+        constexpr int BASE = decltype(slot)::value * HALF;
+        const unsigned char* p = buf + offb_w;
+        vb_static_for<0, 4>([&](auto i) {
+            constexpr int f = decltype(i)::value >> 1, ks = decltype(i)::value & 1;
+            vb_lds_read_tr_pair<BASE + ks * 4096 + f * 256>(lo[f][ks], hi[f][ks], p);
+        });
     };
-    auto readB = [&](bf16x8 (&fb)[2][2], const unsigned char* half) {
-#pragma unroll
-        for (int f = 0; f < 2; ++f)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) fb[f][ks] = gather(half + offb_w + ks * 4096 + f * 256);
-    };
-    auto quad = [&](int mh, int nh, bf16x8 (&fb)[2][2]) {
+    auto quad = [&](int mh, int nh, bf16x4 (&bl)[2][2], bf16x4 (&bh)[2][2]) {
 #ifndef VB_EMU
         __builtin_amdgcn_s_setprio(1);
 #endif
@@ -1557,7 +1573,8 @@ VB_KERNEL VB_LAUNCH_BOUNDS(512) gemm_tn_8ph_kernel(TnArgs g) {
             for (int f = 0; f < 4; ++f)
 #pragma unroll
                 for (int q = 0; q < 2; ++q)
-                    acc[mh * 4 + f][nh * 2 + q] = vb_mma(fa[f][ks], fb[q][ks], acc[mh * 4 + f][nh * 2 + q]);
+                    acc[mh * 4 + f][nh * 2 + q] = vb_mma(vb_join(fal[f][ks], fah[f][ks]), vb_join(bl[q][ks], bh[q][ks]),
+                                                         acc[mh * 4 + f][nh * 2 + q]);
 #ifndef VB_EMU
         __builtin_amdgcn_s_setprio(0);
 #endif
@@ -1605,24 +1622,24 @@ VB_KERNEL VB_LAUNCH_BOUNDS(512) gemm_tn_8ph_kernel(TnArgs g) {
         const unsigned char* buf = smem + par * BUF;
         const bool n1 = gk + 1 < GK, n2 = gk + 2 < GK;
         // ---- E
-        readB(fb0, buf + SLOT_B0 * HALF);
-        readA(buf + SLOT_A0 * HALF);
-        readB(fb1, buf + SLOT_B1 * HALF);
+        readB(fb0l, fb0h, std::integral_constant<int, SLOT_B0>(), buf);
+        readA(std::integral_constant<int, SLOT_A0>(), buf);
+        readB(fb1l, fb1h, std::integral_constant<int, SLOT_B1>(), buf);
         if (n1) { issueA(1, par ^ 1); vb_wait_vmcnt<8>(); } else vb_wait_vmcnt<0>();
         vb_raw_barrier();                          // lgkmcnt(0) first: my gathers of A0 B0 B1 are done
         vb_sched_fence();
-        quad(0, 0, fb0);
-        quad(0, 1, fb1);
+        quad(0, 0, fb0l, fb0h);
+        quad(0, 1, fb1l, fb1h);
         vb_phase_barrier();
         // ---- O
-        readA(buf + SLOT_A1 * HALF);
+        readA(std::integral_constant<int, SLOT_A1>(), buf);
         if (n2) { ld_advance(); issueA(0, par); issueB(0, par); issueB(1, par); vb_wait_vmcnt<8>(); }
         else if (n1) vb_wait_vmcnt<2>();
         else vb_wait_vmcnt<0>();
         vb_raw_barrier();
         vb_sched_fence();
-        quad(1, 1, fb1);
-        quad(1, 0, fb0);
+        quad(1, 1, fb1l, fb1h);
+        quad(1, 0, fb0l, fb0h);
         vb_phase_barrier();
         if (++ct == cur.nk) {
             drain(cur);

@@ -6,6 +6,7 @@
 #pragma once
 #include <stdint.h>
 #include <stddef.h>
+#include <type_traits>
 
 #ifdef VB_EMU
 #include "hipemu.h"
@@ -193,6 +194,32 @@ VB_DEVICE bf16x4 vb_lds_read_tr(const unsigned char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p);
 }
 #endif
+
+// The two transposing reads of one operand fragment (k + 0..3 -> lo, k + 4..7 -> hi, 2 KB apart) at p + OFF, as INLINE ASM.
+// Why not the builtin above: hipcc 7.2 puts `s_waitcnt vmcnt(0)` in front of every builtin transposing read that follows an
+// LDS-direct copy (it cannot tell the copy's destination from the read's source; plain ds_read_b128 loads do not get that
+// wait) -- in a pipelined K loop that drains the whole copy stream twice per K tile.  The asm form is invisible to that
+// pass AND to its lgkmcnt bookkeeping: the caller must execute `s_waitcnt lgkmcnt(0)` (vb_raw_barrier does) before the
+// first use of lo / hi, and must not combine or move them before that point.
+#ifdef VB_EMU
+template <int OFF> VB_DEVICE void vb_lds_read_tr_pair(bf16x4& lo, bf16x4& hi, const unsigned char* p) {
+    lo = vb_lds_read_tr(p + OFF);
+    hi = vb_lds_read_tr(p + OFF + 2048);
+}
+#else
+template <int OFF> VB_DEVICE void vb_lds_read_tr_pair(bf16x4& lo, bf16x4& hi, const unsigned char* p) {
+    static_assert(OFF >= 0 && OFF + 2048 < 65536, "DS instruction offsets are 16 bits");
+    const unsigned a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)p;
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
+                 : "=&v"(lo), "=&v"(hi) : "v"(a), "n"(OFF), "n"(OFF + 2048));
+}
+#endif
+VB_DEVICE bf16x8 vb_join(bf16x4 lo, bf16x4 hi) { return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}; }
+
+// compile-time loop: f(std::integral_constant<int, I>()) for I = 0 .. N - 1 (indices usable as template arguments / asm immediates)
+template <int I, int N, typename F> VB_DEVICE void vb_static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>()); vb_static_for<I + 1, N>(f); }
+}
 
 // x(lane) + x(lane ^ 32): the two 32-lane halves of a wave exchanged with ONE VALU instruction (v_permlane32_swap,
 // gfx950) instead of an LDS-crossbar shuffle

@@ -194,10 +194,10 @@ class stream_opts(object):
         return False
 
 
-def set_opts(persistent_workgroups=0, nt_kernel=0, attn_two_pass=0):
+def set_opts(persistent_workgroups=0, nt_kernel=0, attn_two_pass=0, reserved=0):
     """attach launch options to the CURRENT stream until changed again (tools; library code uses `stream_opts`)."""
-    o = StreamOpts(int(persistent_workgroups), int(nt_kernel), int(attn_two_pass), 0)
-    zero = not (o.persistent_workgroups or o.nt_kernel or o.attn_two_pass)
+    o = StreamOpts(int(persistent_workgroups), int(nt_kernel), int(attn_two_pass), int(reserved))
+    zero = not (o.persistent_workgroups or o.nt_kernel or o.attn_two_pass or o.reserved)
     check(lib().vb_stream_set_opts(stream_ptr(), None if zero else ctypes.byref(o)), "vb_stream_set_opts")
 
 

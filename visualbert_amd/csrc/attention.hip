@@ -92,6 +92,8 @@ VB_DEVICE void stage_tr(unsigned char* lds, const float* X, long ldx, long row0,
 // per trip, 9 serial round trips per workgroup in the forward kernel).  Here a thread first issues ALL its loads of a
 // [NROWS][64] tile -- pair-item i = rows (2j, 2j+1) x 16-byte chunk dc -- and only then stores, row-major and / or
 // transposed, from the same registers.
+// zero fill as a select on a value that was loaded UNCONDITIONALLY (see frag_g)
+VB_DEVICE u32x4 zsel(bool ok, const u32x4& x) { return u32x4{ok ? x[0] : 0u, ok ? x[1] : 0u, ok ? x[2] : 0u, ok ? x[3] : 0u}; }
 template <int NROWS>
 struct PairTile {
     static constexpr int ITEMS = (NROWS / 2) * 8, PER = (ITEMS + NT - 1) / NT;
@@ -99,14 +101,21 @@ struct PairTile {
 };
 template <int NROWS>
 VB_DEVICE void pair_load(PairTile<NROWS>& p, const bf16* X, long ldx, long row0, int c0, int S, int t) {
+    // unconditional loads from clamped rows first, the zero fill of rows >= S as selects afterwards (see frag_g)
 #pragma unroll
     for (int k = 0; k < PairTile<NROWS>::PER; ++k) {
         const int idx = t + k * NT;
         const int dc = idx & 7, r = (idx >> 3) * 2;
-        const u32x4 z = u32x4{0u, 0u, 0u, 0u};
+        p.x0[k] = *(const u32x4*)(X + (row0 + (r < S ? r : S - 1)) * ldx + c0 + dc * 8);
+        p.x1[k] = *(const u32x4*)(X + (row0 + (r + 1 < S ? r + 1 : S - 1)) * ldx + c0 + dc * 8);
+    }
+#pragma unroll
+    for (int k = 0; k < PairTile<NROWS>::PER; ++k) {
+        const int idx = t + k * NT;
+        const int r = (idx >> 3) * 2;
         const bool in = idx < PairTile<NROWS>::ITEMS;
-        p.x0[k] = (in && r < S) ? *(const u32x4*)(X + (row0 + r) * ldx + c0 + dc * 8) : z;
-        p.x1[k] = (in && r + 1 < S) ? *(const u32x4*)(X + (row0 + r + 1) * ldx + c0 + dc * 8) : z;
+        p.x0[k] = zsel(in && r < S, p.x0[k]);
+        p.x1[k] = zsel(in && r + 1 < S, p.x1[k]);
     }
 }
 template <int NROWS>
@@ -149,14 +158,17 @@ VB_DEVICE f32x8 frag_rm(const unsigned char* lds, int row, int ks, int g, float)
     return f32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 // same 8 elements straight from global memory (row pointer already offset to the head's column 0)
+// rowp must be readable even when !ok (callers clamp the row): the load is UNCONDITIONAL and the zeroing a select on its
+// result.  A load under `if (ok)` compiles to an exec-masked branch with a zero-fill of the destination registers, and the
+// compiler then serialises neighbouring loads with s_waitcnt vmcnt(0) (write-after-write on those registers).
 VB_DEVICE bf16x8 frag_g(const bf16* rowp, int ks, int g, bool ok) {
-    if (!ok) { bf16x8 z; for (int j = 0; j < 8; ++j) z[j] = (bf16)0.0f; return z; }
-    return *(const bf16x8*)(rowp + ks * 32 + g * 8);
+    const u32x4 x = zsel(ok, *(const u32x4*)(rowp + ks * 32 + g * 8));
+    return *(const bf16x8*)&x;
 }
 VB_DEVICE f32x8 frag_g(const float* rowp, int ks, int g, bool ok) {
-    if (!ok) return f32x8{0, 0, 0, 0, 0, 0, 0, 0};
     f32x4 lo = *(const f32x4*)(rowp + ks * 32 + g * 8), hi = *(const f32x4*)(rowp + ks * 32 + g * 8 + 4);
-    return f32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return f32x8{ok ? lo[0] : 0.f, ok ? lo[1] : 0.f, ok ? lo[2] : 0.f, ok ? lo[3] : 0.f,
+                 ok ? hi[0] : 0.f, ok ? hi[1] : 0.f, ok ? hi[2] : 0.f, ok ? hi[3] : 0.f};
 }
 // A fragment from a transposed tile: row d, MFMA k index (g, j) <-> r = 32*ks + 16*(j>>2) + 4*g + (j&3)
 VB_DEVICE bf16x8 frag_tr(const unsigned char* lds, int pitch, int d, int ks, int g, bf16) {
@@ -206,7 +218,9 @@ VB_DEVICE long keep_index(const AttnArgs& a, int bh, int q, int g, int w, int nw
 // rounding up to an even 12 spent 1/12 of the per-probability VALU work -- the bound of this kernel -- on padding);
 // the P.V MFMAs consume keys 32 at a time, so V^T (and the packed probabilities) are padded to NKV = even(NKF) fragments
 // with an all-zero upper half.
-template <typename T, int NKF>
+// PF (bf16): the Q fragment of a wave's next query block is fetched while the current block computes and pinned until the
+// top of the next iteration (vb_pin) -- one HBM round trip per block leaves the wave's critical path.
+template <typename T, int NKF, bool PF = false>
 VB_KERNEL VB_LAUNCH_BOUNDS2(NT, 3) attn_fwd_kernel(AttnArgs a) {
     constexpr int NKV = (NKF + 1) / 2 * 2;
     constexpr int NK = NKF * 16, NKVK = NKV * 16, NKS = NKV / 2, NW = (NKF + 15) / 16;
@@ -237,15 +251,29 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(NT, 3) attn_fwd_kernel(AttnArgs a) {
     __syncthreads();
 
     const int nqf = (Sq + 15) / 16;
+    u32x4 qn[2] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
+    auto fetch_q = [&](int qf) {                           // unconditional, from a clamped row
+        const int q = qf * 16 + li;
+        const T* qrow = Qp + (rowq + (q < Sq ? q : Sq - 1)) * a.ldq + h * D;
+        qn[0] = *(const u32x4*)(qrow + lg * 8);
+        qn[1] = *(const u32x4*)(qrow + 32 + lg * 8);
+    };
+    if constexpr (PF) fetch_q(wave);
     for (int qf = wave; qf < nqf; qf += 4) {
         const int q = qf * 16 + li;
         const bool qok = q < Sq;
-        const T* qrow = Qp + (rowq + (qok ? q : 0)) * a.ldq + h * D;
         typename VecOf<T>::v8 qb[2];
-        qb[0] = frag_g(qrow, 0, lg, qok);
-        qb[1] = frag_g(qrow, 1, lg, qok);
-        // (fetching the NEXT block's Q fragment here, a block ahead, measured 5 % slower -- 180 -> 190 us per layer at
-        //  B = 512 on three boxes: the loads' registers cost more than the round trip they hide at 3 workgroups per CU)
+        if constexpr (PF) {
+            vb_pin(qn[0]); vb_pin(qn[1]);
+            const u32x4 z0 = zsel(qok, qn[0]), z1 = zsel(qok, qn[1]);
+            qb[0] = *(const typename VecOf<T>::v8*)&z0;
+            qb[1] = *(const typename VecOf<T>::v8*)&z1;
+            fetch_q(qf + 4);                               // past the last block: a clamped (valid, unused) row
+        } else {
+            const T* qrow = Qp + (rowq + (qok ? q : 0)) * a.ldq + h * D;
+            qb[0] = frag_g(qrow, 0, lg, qok);
+            qb[1] = frag_g(qrow, 1, lg, qok);
+        }
 
         f32x4 st[NKF];
         float m = -INFINITY;
@@ -635,57 +663,60 @@ VB_KERNEL VB_LAUNCH_BOUNDS(FNT) attn_bwd_fused_kernel(AttnArgs a) {
     const T* dctx = (const T*)a.dctx;
     const T* octx = (const T*)a.ctx_fwd;
 
-    {   // K^T image (one row pair x 16-byte chunk per thread: 96 pairs x 8 chunks = 768 items = FNT) and a zeroed dS tile
-        const int dc = t & 7, r = (t >> 3) * 2;             // exactly one item per thread (PairTile strides by 256)
-        const u32x4 z = u32x4{0u, 0u, 0u, 0u};
-        const u32x4 x0 = r < S ? *(const u32x4*)(qkv + (row0 + r) * ldx + H + h * D + dc * 8) : z;
-        const u32x4 x1 = r + 1 < S ? *(const u32x4*)(qkv + (row0 + r + 1) * ldx + H + h * D + dc * 8) : z;
-        const int pitch = tr_pitch<bf16>(FNK);
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const uint32_t lo = x0[w], hi = x1[w];
-            *(uint32_t*)(ldsKT + (dc * 8 + 2 * w) * pitch + r * 2) = (lo & 0xFFFFu) | (hi << 16);
-            *(uint32_t*)(ldsKT + (dc * 8 + 2 * w + 1) * pitch + r * 2) = (lo >> 16) | (hi & 0xFFFF0000u);
-        }
-        for (int i = t; i < CQ * TSP / 8; i += FNT) *(uint64_t*)(ldsDS + i * 8) = 0;
-    }
+    // Every global load below is UNCONDITIONAL from a clamped (always readable) row, and the zero / -inf / all-ones fill of the
+    // rows past S is a select at the point of use: the loads carry no branches, nothing waits between them, and a chunk's
+    // fetch really runs a chunk ahead (with `ok ? load : fill` the compiler put s_waitcnt vmcnt(0) between the loads of the
+    // "prefetch" -- the registers' fill is a write-after-write on a pending load -- and the workgroup, alone on its compute
+    // unit, sat through four HBM round trips before its first MFMA and one more per chunk).
     const int kf = wave;
     const int key = kf * 16 + li;
     const bool wave_on = kf * 16 < S;                      // wave-uniform
     const bool kok = key < S;
-    const T* krow = qkv + (row0 + (kok ? key : 0)) * ldx + H + h * D;
-    const T* vrow = qkv + (row0 + (kok ? key : 0)) * ldx + 2 * H + h * D;
+    const int keyc = kok ? key : S - 1;
+    // K^T image source: one row pair x 16-byte chunk per thread (96 pairs x 8 chunks = 768 items = FNT)
+    const int kdc = t & 7, kr = (t >> 3) * 2;
+    const u32x4 kx0 = *(const u32x4*)(qkv + (row0 + (kr < S ? kr : S - 1)) * ldx + H + h * D + kdc * 8);
+    const u32x4 kx1 = *(const u32x4*)(qkv + (row0 + (kr + 1 < S ? kr + 1 : S - 1)) * ldx + H + h * D + kdc * 8);
+    const T* krow = qkv + (row0 + keyc) * ldx + H + h * D;
+    const T* vrow = qkv + (row0 + keyc) * ldx + 2 * H + h * D;
     bf16x8 kb[2], vb[2];
     kb[0] = frag_g(krow, 0, lg, kok); kb[1] = frag_g(krow, 1, lg, kok);
     vb[0] = frag_g(vrow, 0, lg, kok); vb[1] = frag_g(vrow, 1, lg, kok);
-    const float mk = kok ? a.mask_add[(long)b * S + key] : -INFINITY;
+    const float mk_raw = a.mask_add[(long)b * S + keyc];
     f32x4 dkT[4], dvT[4];
 #pragma unroll
     for (int df = 0; df < 4; ++df) { dkT[df] = f32x4{0.f, 0.f, 0.f, 0.f}; dvT[df] = dkT[df]; }
 
     constexpr int BPT = (CQ * 4 * NW + FNT - 1) / FNT;
     constexpr int SI = CQ * 4;                             // staging items per tensor (row pair x 16-byte chunk)
-    const int st = t % SI, role = t / SI;                  // role 0 stages Q, role 1 dO (and D), the rest nothing
+    static_assert(SI % 64 == 0 && CQ == 64, "the staging role must be wave-uniform; wave 0 carries the chunk's lse values");
+    const int st = t % SI, role = vb_uniform(t / SI);      // role 0 stages Q, role 1 dO (and D from dO . O), the rest nothing
     const int sdc = st & 7, sr = (st >> 3) * 2;            // rows q0 + sr, q0 + sr + 1; 16-byte column chunk sdc
-    u32x4 c0 = u32x4{0u, 0u, 0u, 0u}, c1 = c0;
-    float c_lse = INFINITY;
+    const T* ssrc = (role == 0 ? qkv : dctx) + h * D + sdc * 8;
+    const long sld = role == 0 ? ldx : (long)H;
+    u32x4 c0 = u32x4{0u, 0u, 0u, 0u}, c1 = c0, o0 = c0, o1 = c0;
+    float c_lse = 0.f;
     uint64_t c_bits[BPT];
-    auto load_chunk = [&](int q0) {
-        const u32x4 z = u32x4{0u, 0u, 0u, 0u};
-        const bool ok0 = q0 + sr < S, ok1 = q0 + sr + 1 < S;
-        if (role == 0) {
-            c0 = ok0 ? *(const u32x4*)(qkv + (row0 + q0 + sr) * ldx + h * D + sdc * 8) : z;
-            c1 = ok1 ? *(const u32x4*)(qkv + (row0 + q0 + sr + 1) * ldx + h * D + sdc * 8) : z;
-        } else if (role == 1) {
-            c0 = ok0 ? *(const u32x4*)(dctx + (row0 + q0 + sr) * (long)H + h * D + sdc * 8) : z;
-            c1 = ok1 ? *(const u32x4*)(dctx + (row0 + q0 + sr + 1) * (long)H + h * D + sdc * 8) : z;
-        }
-        if (t < CQ) c_lse = q0 + t < S ? a.lse[(long)bh * S + q0 + t] : INFINITY;      // exp(x - inf) = 0 for padded queries
 #pragma unroll
-        for (int j = 0; j < BPT; ++j) {
-            const int i = t + j * FNT;
-            const int q = q0 + i / (4 * NW);
-            c_bits[j] = (a.p > 0.f && i < CQ * 4 * NW && q < S) ? a.keepbits[((long)bh * S + q0) * 4 * NW + i] : ~(uint64_t)0;
+    for (int j = 0; j < BPT; ++j) c_bits[j] = 0;
+    auto load_chunk = [&](int q0) {
+        const long r0 = row0 + (q0 + sr < S ? q0 + sr : S - 1), r1 = row0 + (q0 + sr + 1 < S ? q0 + sr + 1 : S - 1);
+        if (role < 2) {                                    // wave-uniform: a scalar branch
+            c0 = *(const u32x4*)(ssrc + r0 * sld);
+            c1 = *(const u32x4*)(ssrc + r1 * sld);
+        }
+        if (role == 1) {                                   // O rows for D = dO . O, fetched with the chunk
+            o0 = *(const u32x4*)(octx + r0 * (long)H + h * D + sdc * 8);
+            o1 = *(const u32x4*)(octx + r1 * (long)H + h * D + sdc * 8);
+        }
+        if (wave == 0) c_lse = a.lse[(long)bh * S + (q0 + t < S ? q0 + t : S - 1)];      // CQ = 64 queries = wave 0
+        if (a.p > 0.f) {
+#pragma unroll
+            for (int j = 0; j < BPT; ++j) {
+                if (vb_uniform((t & ~63) + j * FNT) >= CQ * 4 * NW) continue;          // whole waves: a scalar branch
+                const long i = ((long)bh * S + q0) * 4 * NW + t + j * FNT, last = ((long)bh * S + S) * 4 * NW - 1;
+                c_bits[j] = a.keepbits[i < last ? i : last];
+            }
         }
     };
     auto store_tr2 = [&](unsigned char* lds, const u32x4& x0, const u32x4& x1) {
@@ -698,29 +729,46 @@ VB_KERNEL VB_LAUNCH_BOUNDS(FNT) attn_bwd_fused_kernel(AttnArgs a) {
         }
     };
     auto store_chunk = [&](int q0) {
+        // the fetched registers are consumed from here on, not earlier (the compiler would hoist the selects and the
+        // D products -- and with them the wait for the fetch -- above the phase the fetch is supposed to run under)
+        vb_pin(c0); vb_pin(c1); vb_pin(o0); vb_pin(o1); vb_pin(c_lse);
+#pragma unroll
+        for (int j = 0; j < BPT; ++j) vb_pin(c_bits[j]);
+        const u32x4 z0 = zsel(q0 + sr < S, c0), z1 = zsel(q0 + sr + 1 < S, c1);        // rows past S are zeros
         if (role < 2) {
             unsigned char* rm = role == 0 ? ldsQ : ldsDO;
-            *(u32x4*)(rm + rm_off<T>(sr, sdc)) = c0;
-            *(u32x4*)(rm + rm_off<T>(sr + 1, sdc)) = c1;
-            store_tr2(role == 0 ? ldsQT : ldsDOT, c0, c1);
+            *(u32x4*)(rm + rm_off<T>(sr, sdc)) = z0;
+            *(u32x4*)(rm + rm_off<T>(sr + 1, sdc)) = z1;
+            store_tr2(role == 0 ? ldsQT : ldsDOT, z0, z1);
         }
         if (role == 1) {                                   // D[q] = dO[q] . O[q]: 8 products per thread, 8 threads per row
-            const u32x4 z = u32x4{0u, 0u, 0u, 0u};          // (O is fetched here, not a chunk ahead: registers)
-            const u32x4 o0 = q0 + sr < S ? *(const u32x4*)(octx + (row0 + q0 + sr) * (long)H + h * D + sdc * 8) : z;
-            const u32x4 o1 = q0 + sr + 1 < S ? *(const u32x4*)(octx + (row0 + q0 + sr + 1) * (long)H + h * D + sdc * 8) : z;
-            const bf16x8 d0 = *(const bf16x8*)&c0, d1 = *(const bf16x8*)&c1, p0 = *(const bf16x8*)&o0, p1 = *(const bf16x8*)&o1;
+            const bf16x8 d0 = *(const bf16x8*)&z0, d1 = *(const bf16x8*)&z1, p0 = *(const bf16x8*)&o0, p1 = *(const bf16x8*)&o1;
             float s0 = 0.f, s1 = 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) { s0 += (float)d0[j] * (float)p0[j]; s1 += (float)d1[j] * (float)p1[j]; }
-            s0 += __shfl_xor(s0, 1); s0 += __shfl_xor(s0, 2); s0 += __shfl_xor(s0, 4);
-            s1 += __shfl_xor(s1, 1); s1 += __shfl_xor(s1, 2); s1 += __shfl_xor(s1, 4);
+            s0 = oct_sum(s0); s1 = oct_sum(s1);
             if (sdc == 0) { ldsD[sr] = s0; ldsD[sr + 1] = s1; }
         }
-        if (t < CQ) ldsLse[t] = c_lse;
+        if (wave == 0) ldsLse[t] = q0 + t < S ? c_lse : INFINITY;                     // exp(x - inf) = 0 for padded queries
 #pragma unroll
-        for (int j = 0; j < BPT; ++j) if (t + j * FNT < CQ * 4 * NW) ldsBits[t + j * FNT] = c_bits[j];
+        for (int j = 0; j < BPT; ++j) {
+            const int i = t + j * FNT;
+            if (i < CQ * 4 * NW) ldsBits[i] = (a.p > 0.f && q0 + i / (4 * NW) < S) ? c_bits[j] : ~(uint64_t)0;
+        }
     };
     load_chunk(0);
+    const float mk = kok ? mk_raw : -INFINITY;
+    {   // K^T image and a zeroed dS tile
+        const u32x4 x0 = zsel(kr < S, kx0), x1 = zsel(kr + 1 < S, kx1);
+        const int pitch = tr_pitch<bf16>(FNK);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const uint32_t lo = x0[w], hi = x1[w];
+            *(uint32_t*)(ldsKT + (kdc * 8 + 2 * w) * pitch + kr * 2) = (lo & 0xFFFFu) | (hi << 16);
+            *(uint32_t*)(ldsKT + (kdc * 8 + 2 * w + 1) * pitch + kr * 2) = (lo >> 16) | (hi & 0xFFFF0000u);
+        }
+        for (int i = t; i < CQ * TSP / 8; i += FNT) *(uint64_t*)(ldsDS + i * 8) = 0;
+    }
     use_set(0);
     store_chunk(0);
     __syncthreads();                                       // chunk 0, the K^T image and the zeroed tile are in LDS
@@ -902,6 +950,12 @@ int dispatch_nkf(int which, const AttnArgs& a, hipStream_t s) {
     const int nkf = ((a.S + 31) / 32) * 2;          // key fragments, padded to an even count
     if (which == 0 && (a.S + 15) / 16 == 11) {      // forward at S = 161..176 (BASELINE: 164): exactly 11 fragments of work
         const size_t sm = fwd_smem<T, 11>();
+        if constexpr (sizeof(T) == 2) {
+            if ((vb_opts_for((void*)s).reserved & 1) == 0) {   // reserved bit 0: A/B switch of the Q prefetch (measurement only)
+                VB_LAUNCH((attn_fwd_kernel<T, 11, true>), dim3((unsigned)(a.B * a.nh)), dim3(NT), sm, s, a);
+                return vb_check_launch();
+            }
+        }
         VB_LAUNCH((attn_fwd_kernel<T, 11>), dim3((unsigned)(a.B * a.nh)), dim3(NT), sm, s, a);
         return vb_check_launch();
     }

@@ -324,6 +324,30 @@ VB_DEVICE float row16_sum(float v) {
 }
 #endif
 
+// "the value becomes available HERE": an empty volatile asm that redefines its operand.  Consumers of a register that a
+// prefetch load fills cannot be scheduled above it, so the load's s_waitcnt lands at the pin (after the work the load was
+// meant to run under) instead of right behind the load.
+#ifdef VB_EMU
+template <typename V> VB_DEVICE void vb_pin(V&) {}
+#else
+template <typename V> VB_DEVICE void vb_pin(V& v) { asm volatile("" : "+v"(v)); }
+#endif
+
+// sum over aligned groups of 8 lanes (quad swaps + half-row mirror on the VALU, no LDS-crossbar shuffles)
+#ifdef VB_EMU
+VB_DEVICE float oct_sum(float v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); return v; }
+#else
+template <int CTRL> VB_DEVICE float vb_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+VB_DEVICE float oct_sum(float v) {
+    v += vb_dpp<0xB1>(v);                                  // quad_perm [1 0 3 2]
+    v += vb_dpp<0x4E>(v);                                  // quad_perm [2 3 0 1]
+    v += vb_dpp<0x141>(v);                                 // row_half_mirror: lane i <-> 7 - i of its group of 8
+    return v;
+}
+#endif
+
 // reduction across the 32 lanes of a half-wave (lanes [0,32) and [32,64) independently)
 VB_DEVICE float half_sum(float v) {
 #pragma unroll

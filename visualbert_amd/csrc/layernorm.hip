@@ -52,52 +52,65 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) ln_fwd_kernel(LnFwdArgs a) {
     for (int base = blockIdx.x * HW_PER_BLOCK; base < a.M; base += gridDim.x * HW_PER_BLOCK) {
         const int row = base + hw;
         const bool act = row < a.M;
+        const long rowc = act ? row : a.M - 1;
+        // loads are UNCONDITIONAL from a clamped (row, column) and everything that must not happen for a lane outside the
+        // matrix is a select or a predicated store: `if (ok) load` compiled to one exec-masked branch per load with
+        // s_waitcnt vmcnt(0) between them -- six serialized HBM round trips per row
         float v[NC][8];
         float s = 0.f;
 #pragma unroll
         for (int ci = 0; ci < NC; ++ci) {
             const int col = (l32 + 32 * ci) * 8;
-            if (act && col < H) {
-                const long e = (long)row * H + col;
-                load8(v[ci], (const T*)a.x + e);
+            const long e = rowc * H + (col < H ? col : 0);
+            load8(v[ci], (const T*)a.x + e);
+        }
+        if (a.resid) {
+#pragma unroll
+            for (int ci = 0; ci < NC; ++ci) {
+                const int col = (l32 + 32 * ci) * 8;
+                const long e = rowc * H + (col < H ? col : 0);
+                float r[8]; load8(r, (const T*)a.resid + e);
                 if (a.din.p > 0.f) apply_dropout8(v[ci], a.din, (uint64_t)e >> 3);
-                if (a.resid) {
-                    float r[8]; load8(r, (const T*)a.resid + e);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[ci][j] += r[j];
-                }
-                if (a.z_out) store8((T*)a.z_out + e, v[ci]);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) s += v[ci][j];
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[ci][j] = 0.f;
+                for (int j = 0; j < 8; ++j) v[ci][j] += r[j];
             }
+        } else if (a.din.p > 0.f) {
+#pragma unroll
+            for (int ci = 0; ci < NC; ++ci) {
+                const int col = (l32 + 32 * ci) * 8;
+                apply_dropout8(v[ci], a.din, (uint64_t)(rowc * H + (col < H ? col : 0)) >> 3);
+            }
+        }
+#pragma unroll
+        for (int ci = 0; ci < NC; ++ci) {
+            const int col = (l32 + 32 * ci) * 8;
+            const bool ok = act && col < H;
+            if (a.z_out && ok) store8((T*)a.z_out + (long)row * H + col, v[ci]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { v[ci][j] = ok ? v[ci][j] : 0.f; s += v[ci][j]; }
         }
         const float mean = half_sum(s) * invH;
         float q = 0.f;
 #pragma unroll
         for (int ci = 0; ci < NC; ++ci) {
             const int col = (l32 + 32 * ci) * 8;
-            if (act && col < H) {
+            const bool ok = act && col < H;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { const float d = v[ci][j] - mean; q += d * d; }
-            }
+            for (int j = 0; j < 8; ++j) { const float d = ok ? v[ci][j] - mean : 0.f; q += d * d; }
         }
         const float var = half_sum(q) * invH;
         const float rstd = 1.0f / sqrtf(var + a.eps);
 #pragma unroll
         for (int ci = 0; ci < NC; ++ci) {
             const int col = (l32 + 32 * ci) * 8;
-            if (act && col < H) {
-                float gm[8], bt[8], o[8];
-                load8(gm, a.gamma + col); load8(bt, a.beta + col);
+            const int colc = col < H ? col : 0;
+            float gm[8], bt[8], o[8];
+            load8(gm, a.gamma + colc); load8(bt, a.beta + colc);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = gm[j] * ((v[ci][j] - mean) * rstd) + bt[j];
-                const long e = (long)row * H + col;
-                if (a.dout.p > 0.f) apply_dropout8(o, a.dout, (uint64_t)e >> 3);
-                store8((T*)a.y + e, o);
-            }
+            for (int j = 0; j < 8; ++j) o[j] = gm[j] * ((v[ci][j] - mean) * rstd) + bt[j];
+            const long e = (long)row * H + col;
+            if (a.dout.p > 0.f) apply_dropout8(o, a.dout, (uint64_t)(rowc * H + colc) >> 3);
+            if (act && col < H) store8((T*)a.y + e, o);
         }
         if (act && l32 == 0) {
             if (a.mean) a.mean[row] = mean;
@@ -172,93 +185,94 @@ VB_DEVICE void lds_acc8(float* p, const float (&v)[8]) {
     *(f32x4*)p = lo; *(f32x4*)(p + 4) = hi;
 }
 
-// The column accumulators (dgamma, dbeta, bias gradient) live in LDS as [wave][3][H] fp32 -- in registers they cost 72
-// VGPRs and halved the occupancy of this latency-bound streaming kernel.  A wave works on two rows (one per 32-lane
-// half); the halves' contributions are added with v_permlane32_swap and the lower half alone updates LDS, so a
-// workgroup needs 36 KB (4 workgroups = 16 waves per CU; the [half-wave] form needed 74 KB = 8 waves per CU).
+// One WAVE per row: lane l owns the 8-column chunks l and l + 64 (H = 768: the second chunk on lanes 0..31 only).  The
+// column accumulators (dgamma, dbeta, bias gradient) are REGISTERS of the lane that owns the columns -- 48 for H <= 1024 --
+// and reach LDS once, at the end.  (The previous form gave a row to each 32-lane half: three chunks per lane, accumulators
+// in LDS updated by read-modify-write every row, the halves' contributions combined with 72 v_permlane32_swap per pair of
+// rows -- ~500 instructions per row, which is what bounded the kernel at 3.9 TB/s, not HBM.)  All loads of a row are
+// unconditional from clamped columns and issued together.
 constexpr int WAVES_PER_BLOCK = NT / 64;
-template <typename T, int NC>
-VB_KERNEL VB_LAUNCH_BOUNDS(NT) ln_bwd_kernel(LnBwdArgs a) {
+VB_DEVICE float wave_sum64(float v) {
+    v = row16_sum(v);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+template <typename T, int NC2, int MINW>
+VB_KERNEL VB_LAUNCH_BOUNDS2(NT, MINW) ln_bwd_kernel(LnBwdArgs a) {
     VB_DYN_SMEM(smem);
     float* lds = (float*)smem;
-    const int l32 = threadIdx.x & 31, hw = threadIdx.x >> 5, wave = threadIdx.x >> 6;
-    const bool lower = (threadIdx.x & 32) == 0;
+    const int lane = threadIdx.x & 63, wave = vb_uniform((int)threadIdx.x >> 6);
     const int H = a.H;
     const float invH = 1.0f / (float)H;
-    float* my = lds + (long)wave * 3 * H;               // this wave's [3][H] accumulators
-    if (lower) {
+    float accg[NC2][8], accb[NC2][8], accx[NC2][8];
 #pragma unroll
-        for (int ci = 0; ci < NC; ++ci) {               // every lane zeroes exactly the columns it owns
-            const int col = (l32 + 32 * ci) * 8;
-            if (col < H) {
+    for (int ci = 0; ci < NC2; ++ci)
 #pragma unroll
-                for (int w = 0; w < 3; ++w) {
-                    *(f32x4*)(my + w * H + col) = f32x4{0.f, 0.f, 0.f, 0.f};
-                    *(f32x4*)(my + w * H + col + 4) = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
+        for (int j = 0; j < 8; ++j) { accg[ci][j] = 0.f; accb[ci][j] = 0.f; accx[ci][j] = 0.f; }
+
+    for (int row = blockIdx.x * WAVES_PER_BLOCK + wave; row < a.M; row += gridDim.x * WAVES_PER_BLOCK) {
+        const float mean = a.mean[row], rstd = a.rstd[row];
+        float dy[NC2][8], xh[NC2][8];
+#pragma unroll
+        for (int ci = 0; ci < NC2; ++ci) {
+            const int col = (lane + 64 * ci) * 8;
+            load8(dy[ci], (const T*)a.dy + (long)row * H + (col < H ? col : 0));
+        }
+#pragma unroll
+        for (int ci = 0; ci < NC2; ++ci) {
+            const int col = (lane + 64 * ci) * 8;
+            load8(xh[ci], (const T*)a.z + (long)row * H + (col < H ? col : 0));
+        }
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int ci = 0; ci < NC2; ++ci) {
+            const int col = (lane + 64 * ci) * 8;
+            const int colc = col < H ? col : 0;
+            const bool ok = col < H;
+            float gm[8];
+            load8(gm, a.gamma + colc);
+            if (a.dout.p > 0.f) apply_dropout8(dy[ci], a.dout, (uint64_t)((long)row * H + colc) >> 3);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float d = ok ? dy[ci][j] : 0.f;         // columns past H contribute exact zeros
+                xh[ci][j] = (xh[ci][j] - mean) * rstd;
+                accg[ci][j] += d * xh[ci][j];                 // dgamma
+                accb[ci][j] += d;                             // dbeta
+                dy[ci][j] = d * gm[j];                        // g = dy * gamma
+                s1 += dy[ci][j];
+                s2 += dy[ci][j] * xh[ci][j];
+            }
+        }
+        s1 = wave_sum64(s1) * invH;
+        s2 = wave_sum64(s2) * invH;
+#pragma unroll
+        for (int ci = 0; ci < NC2; ++ci) {
+            const int col = (lane + 64 * ci) * 8;
+            const bool ok = col < H;
+            const long e = (long)row * H + col;
+            float dz[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dz[j] = rstd * (dy[ci][j] - s1 - xh[ci][j] * s2);
+            if (ok) store8((T*)a.dz + e, dz);
+            if (a.dx) {
+                if (a.din.p > 0.f) apply_dropout8(dz, a.din, (uint64_t)((long)row * H + (ok ? col : 0)) >> 3);
+                if (a.dx != a.dz && ok) store8((T*)a.dx + e, dz);
+            }
+            if (a.dbias) {                                   // bias gradient of the Linear in front: column sums of dx
+#pragma unroll
+                for (int j = 0; j < 8; ++j) accx[ci][j] += ok ? dz[j] : 0.f;
             }
         }
     }
-
-    for (int base = blockIdx.x * HW_PER_BLOCK; base < a.M; base += gridDim.x * HW_PER_BLOCK) {
-        const int row = base + hw;
-        const bool act = row < a.M;
-        const float mean = act ? a.mean[row] : 0.f, rstd = act ? a.rstd[row] : 0.f;
-        float dy[NC][8], xh[NC][8];
-        float s1 = 0.f, s2 = 0.f;
+    // the waves' accumulators -> LDS [wave][3][H]
+    float* my = lds + (long)wave * 3 * H;
 #pragma unroll
-        for (int ci = 0; ci < NC; ++ci) {
-            const int col = (l32 + 32 * ci) * 8;
-            float pg[8], pb[8];
+    for (int ci = 0; ci < NC2; ++ci) {
+        const int col = (lane + 64 * ci) * 8;
+        if (col < H) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { pg[j] = 0.f; pb[j] = 0.f; dy[ci][j] = 0.f; xh[ci][j] = 0.f; }
-            if (act && col < H) {
-                const long e = (long)row * H + col;
-                load8(dy[ci], (const T*)a.dy + e);
-                if (a.dout.p > 0.f) apply_dropout8(dy[ci], a.dout, (uint64_t)e >> 3);
-                float zz[8], gm[8];
-                load8(zz, (const T*)a.z + e);
-                load8(gm, a.gamma + col);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    xh[ci][j] = (zz[j] - mean) * rstd;
-                    pg[j] = dy[ci][j] * xh[ci][j];            // dgamma contribution
-                    pb[j] = dy[ci][j];                        // dbeta contribution
-                    dy[ci][j] *= gm[j];                       // g = dy * gamma
-                    s1 += dy[ci][j];
-                    s2 += dy[ci][j] * xh[ci][j];
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { pg[j] = vb_pair_sum32(pg[j]); pb[j] = vb_pair_sum32(pb[j]); }
-            if (lower && col < H) {
-                lds_acc8(my + col, pg);
-                lds_acc8(my + H + col, pb);
-            }
-        }
-        s1 = half_sum(s1) * invH;
-        s2 = half_sum(s2) * invH;
-#pragma unroll
-        for (int ci = 0; ci < NC; ++ci) {
-            const int col = (l32 + 32 * ci) * 8;
-            float dz[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) dz[j] = 0.f;
-            if (act && col < H) {
-                const long e = (long)row * H + col;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) dz[j] = rstd * (dy[ci][j] - s1 - xh[ci][j] * s2);
-                store8((T*)a.dz + e, dz);
-                if (a.dx) {
-                    if (a.din.p > 0.f) apply_dropout8(dz, a.din, (uint64_t)e >> 3);
-                    if (a.dx != a.dz) store8((T*)a.dx + e, dz);
-                }
-            }
-            if (a.dbias) {                                   // bias-gradient partials (of dx); wave-uniform branch
-#pragma unroll
-                for (int j = 0; j < 8; ++j) dz[j] = vb_pair_sum32(dz[j]);
-                if (lower && col < H) lds_acc8(my + 2 * H + col, dz);
-            }
+            for (int j = 0; j < 8; ++j) { my[col + j] = accg[ci][j]; my[H + col + j] = accb[ci][j]; my[2 * H + col + j] = accx[ci][j]; }
         }
     }
     __syncthreads();
@@ -386,18 +400,25 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) embed_bwd_kernel(EmbBwdArgs a) {
             tt = a.vis_type ? a.vis_type[(long)b * a.R + (s - a.T)] : 0;
         }
         tt = tt < 0 ? 0 : (tt >= a.TV ? a.TV - 1 : tt);
+        float vv[NC][8];                                   // the row's chunks are fetched together, unconditionally (clamped column)
 #pragma unroll
         for (int ci = 0; ci < NC; ++ci) {
             const int col = (l32 + 32 * ci) * 8;
-            if (col < H) {
-                float v[8];
-                load8(v, (const TT_*)a.dz + row * H + col);
+            load8(vv[ci], (const TT_*)a.dz + row * H + (col < H ? col : 0));
+        }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    acc[ci][j] += v[j];
-                    if (two_types) acc1[ci][j] += tt ? v[j] : 0.f;
-                    else atomicAdd(&lds_type[tt * H + col + j], v[j]);
-                }
+        for (int ci = 0; ci < NC; ++ci) {
+            const int col = (l32 + 32 * ci) * 8;
+            const bool ok = col < H;
+            float (&v)[8] = vv[ci];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v[j] = ok ? v[j] : 0.f;
+                acc[ci][j] += v[j];
+                if (two_types) acc1[ci][j] += tt ? v[j] : 0.f;
+                else if (ok) atomicAdd(&lds_type[tt * H + col + j], v[j]);
+            }
+            if (ok) {
                 if (text) {
                     if (a.d_word) {
 #pragma unroll
@@ -487,9 +508,14 @@ extern "C" int vb_ln_bwd(int dtype, const void* dy, const void* z, const float* 
     dim3 grid(row_grid(M, ws ? 1024 : 256));
     hipStream_t s = (hipStream_t)stream;
     const size_t smem = (size_t)H * WAVES_PER_BLOCK * 3 * sizeof(float);
-    if (dtype == VB_BF16) VB_DISPATCH_NC(ln_bwd_kernel, bf16, H, grid, smem, s, a);
-    else if (dtype == VB_F32) VB_DISPATCH_NC(ln_bwd_kernel, float, H, grid, smem, s, a);
-    else return VB_ERR_ARG;
+    // <.., 4>: four waves per SIMD (128 VGPRs, a 12-byte spill) beat three without the spill: 109 vs 130 us at M = 83,968
+    if (dtype == VB_BF16) {
+        if (H <= 512) VB_LAUNCH((ln_bwd_kernel<bf16, 1, 4>), grid, dim3(NT), smem, s, a);
+        else VB_LAUNCH((ln_bwd_kernel<bf16, 2, 4>), grid, dim3(NT), smem, s, a);
+    } else if (dtype == VB_F32) {
+        if (H <= 512) VB_LAUNCH((ln_bwd_kernel<float, 1, 4>), grid, dim3(NT), smem, s, a);
+        else VB_LAUNCH((ln_bwd_kernel<float, 2, 4>), grid, dim3(NT), smem, s, a);
+    } else return VB_ERR_ARG;
     if (ws && (dgamma || dbeta || dbias)) {
         dim3 g2((unsigned)((H + 31) / 32), 3, grid.x >= 256 ? 4 : 1);
         VB_LAUNCH(ln_bwd_reduce_kernel, g2, dim3(1024), 32 * 33 * sizeof(float), s, (const float*)ws, (int)grid.x, H,

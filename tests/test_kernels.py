@@ -491,7 +491,7 @@ def test_cross_attention_fwd_bwd(dev, dt, cfg):
         assert (out.float() - ref).abs().max().item() <= t
 
 
-@pytest.mark.parametrize("variant", [1, 22, 42, 80, 81, 90])
+@pytest.mark.parametrize("variant", [1, 22, 42, 80, 81, 90, 100])
 def test_gemm_pipelined_variants_agree(dev, variant):
     """every pipelined K-contiguous kernel variant (tile shape x LDS stages, counted vmcnt, ping-pong,
     256x256) must give the generic kernel's answer -- on hardware this is what validates the
@@ -510,7 +510,7 @@ def test_gemm_pipelined_variants_agree(dev, variant):
             assert (C - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
 
 
-@pytest.mark.parametrize("variant", [22, 42, 80, 81, 90])
+@pytest.mark.parametrize("variant", [22, 42, 80, 81, 90, 100])
 def test_gemm_specialised_epilogues(dev, variant):
     """the K-contiguous fast kernels carry ONE epilogue each (activation and optional operands are template
     parameters, picked by the launcher): bias only, GELU + saved pre-activation, GELU' + fused column sums,
@@ -573,7 +573,7 @@ def test_gemm_eight_phase_k_tails(dev, K):
     B = padded(N, K, dt, dev, g)
     bias = torch.randn(N, generator=g).to(dev)
     ref = A.float() @ B.float().t() + bias
-    for variant in (80, 81, 90):          # eight-slot / four-slot schedules of the persistent kernel; two-workgroup kernel
+    for variant in (80, 81, 90, 100):     # eight-slot / four-slot schedules of the persistent kernel; two-workgroup kernel
         for wgs in (0, 1, 2, 4):            # 6 output tiles: one per workgroup, or 6 / 3 / 2 walked by one workgroup
             with _lib.stream_opts(nt_kernel=variant, persistent_workgroups=wgs):
                 for out_f32 in (True, False):

@@ -9,7 +9,8 @@ from visualbert_amd import _lib, ops
 dev = torch.device("cuda", 0)
 import _knobs
 L = _knobs.L
-M = 64 * 164
+M = int(os.environ.get('VB_BATCH', '512')) * 164
+VARIANTS = [int(x) for x in sys.argv[1:]] or [100]
 g = torch.Generator().manual_seed(0)
 def bench(fn, iters=20):
     for _ in range(3): fn()
@@ -23,10 +24,10 @@ for name, n, k in [("ffn-out", 768, 3072), ("qkv", 2304, 768)]:
     a = (torch.randn(M, k, generator=g) * 0.5).to(torch.bfloat16).to(dev)
     w = (torch.randn(n, k, generator=g) * 0.05).to(torch.bfloat16).to(dev)
     out = torch.empty(M, n, dtype=torch.bfloat16, device=dev)
-    for v in (42,):
+    for v in VARIANTS:
         _knobs.variant(v)
         row = []
-        for dbg, label in [(0, "full"), (1, "no tile loads"), (2, "no fragment reads"), (4, "no MFMAs")]:
+        for dbg, label in [(0, "full"), (1, "no copies"), (2, "no reads"), (3, "MFMAs only"), (4, "no MFMAs"), (5, "reads only"), (6, "copies only"), (7, "copies only, no drain")] if v == 100 else [(0, "full"), (1, "no tile loads"), (2, "no fragment reads"), (4, "no MFMAs")]:
             L.vb_gemm_set_debug(dbg)
             ms = bench(lambda: ops.gemm(a, w, M, n, k, out=out))
             row.append("%s %.1fus" % (label, ms * 1e3))

@@ -1402,6 +1402,254 @@ int launch_dual(GemmArgs g, hipStream_t stream) {
 }
 
 // =================================================================================================
+// 256x256 tile, FOUR waves as 2 (M) x 2 (N) -- ONE WAVE PER SIMD, 128x128 outputs per wave (nt_kernel 100).
+//
+// Why: per MFMA the 8-wave kernels read (128 + 64) fragment rows from LDS per 128x64 block; a 128x128 block reads
+// (128 + 128) for twice the MFMAs -- a third less LDS traffic per FLOP on a chip whose GEMM clock is power-limited -- and a wave
+// that owns its SIMD needs no partner to hide its fragment reads: it software-pipelines them itself.  The 256 accumulator
+// registers live in the AGPR half of the unified file; the fragments of one MFMA K step (8 A + 8 B = 64 VGPRs) are double
+// buffered, so the 16 ds_read_b128 of K step s+1 and the 16 LDS-direct copies of K tile k+2 are issued BETWEEN the 64 MFMAs
+// of K step s (LLVM sched_group_barrier hints fix the interleave).  One workgroup barrier per K tile (at its middle: it
+// publishes the landed copies of K tile k+1 and proves everyone is done reading K tile k's stage, which the copies of k+2
+// then overwrite), against eight in the persistent 8-wave kernel.  LDS: two 64-KB stages (A0 | A1 | B0 | B1 half-tiles of 128
+// rows x 128 B, the usual chunk swizzle) + the waves' epilogue slabs.  Persistent; the copy stream runs across tile
+// boundaries, so a tile's epilogue has the next tile's first two K tiles landing underneath it.
+// The K loop's MFMAs and fragment reads are INLINE ASM: hipcc 7.2 does not keep 256 loop-carried accumulators in place in the
+// AGPR half of a 512-register wave (it copied every accumulator tuple in front of its MFMA, parked fragments in AGPRs and
+// spilled 540 bytes); "+a" constraints pin them, and the statements' source order IS the instruction interleave (4 MFMAs,
+// one ds_read_b128, ...).  The compiler therefore knows nothing about these reads' lgkmcnt: the waits are explicit.
+#ifdef VB_EMU
+#define VB_BIG_MMA(acc, a, b) acc = vb_mma(a, b, acc)
+template <int OFF> VB_DEVICE void big_read(bf16x8& d, const unsigned char* smem, unsigned off) { d = *(const bf16x8*)(smem + off + OFF); }
+VB_DEVICE unsigned big_lds_base(const unsigned char*) { return 0u; }
+VB_DEVICE void big_settle() {}
+#else
+#define VB_BIG_MMA(acc, a, b) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b))
+template <int OFF> VB_DEVICE void big_read(bf16x8& d, const unsigned char*, unsigned addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "DS offsets are 16 bits");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+VB_DEVICE unsigned big_lds_base(const unsigned char* smem) {
+    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)smem;
+}
+VB_DEVICE void big_settle() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }   // MFMA results / AGPR writes visible to what follows
+#endif
+
+template <typename TO, int ACT, int OPT, int ABL = 0>     // ABL (developer library): 1 = no copies, 2 = no fragment reads, 4 = no MFMAs
+VB_KERNEL VB_LAUNCH_BOUNDS2(256, 1) gemm_nt_big_kernel(GemmArgs g) {
+    typedef bf16 T;
+    constexpr int BK = 64, HALF = 128 * 128, STAGE = 4 * HALF;
+    VB_DYN_SMEM(smem);
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = vb_uniform(t >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int li = lane & 15, lg = lane >> 4;
+    const int ntiles = g.tiles_m * g.tiles_n;
+    const int G = (int)gridDim.x;
+    const int my_tiles = (ntiles - (int)blockIdx.x + G - 1) / G;      // persistent: tiles blockIdx.x + G j
+    const int nk = g.K / BK;
+    const vb_buf A = vb_make_buf(g.A);
+    const vb_buf B = vb_make_buf(g.B);
+    unsigned char* slab = smem + 2 * STAGE + wave * EPI8_BYTES_PER_WAVE;
+
+    f32x4 accL[8][4], accR[8][4];                  // columns 0..63 | 64..127 of the wave's block (the epilogue's unit)
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) { accL[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f}; accR[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        big_settle();
+    };
+
+    auto origin = [&](int j, int& m0, int& n0) {
+        const int tile = xcd_remap((int)blockIdx.x + G * j, ntiles);
+        m0 = (tile / g.tiles_n) * 256; n0 = (tile % g.tiles_n) * 256;
+    };
+    // copy stream: a half-tile is 16 one-KiB pieces, 4 per wave; piece i of wave w fills half-tile rows (4 w + i) 8 + lane/8,
+    // chunk slot lane % 8 <- global chunk (lane % 8) ^ swz(row); buffer form: descriptor + lane offset VGPR + K offset SGPR
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    typedef std::true_type Yes;
+    typedef std::false_type No;
+    unsigned offA[2][4], offB[2][4];
+    int ld_j = 0, ld_t = 0;
+    auto set_load_tile = [&](int j) {
+        int m0, n0;
+        origin(j, m0, n0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = (wave * 4 + i) * 8 + (lane >> 3);
+            const unsigned csrc = (unsigned)(((lane & 7) ^ swz(r)) * 16);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                int a = m0 + h * 128 + r, b = n0 + h * 128 + r;
+                a = a < g.M ? a : g.M - 1;                  // clamped rows are computed but never stored
+                b = b < g.N ? b : g.N - 1;
+                offA[h][i] = (unsigned)(a * (int)g.lda) * 2u + csrc;
+                offB[h][i] = (unsigned)(b * (int)g.ldb) * 2u + csrc;
+            }
+        }
+    };
+    // copy c (0..15) of the load stream's K tile into stage S: c = 8 (operand) + 4 h + i
+    // (Measured and dropped: B through registers -- plain buffer loads half a K tile ahead, ds_write_b128 in the next K tile's
+    //  first half -- to relieve the LDS-direct path: the copy stream alone went 284 -> 335 us on the FFN-out shape.)
+    auto copy_piece = [&](auto stag, auto ctag) {
+        constexpr int S = decltype(stag)::value, c = decltype(ctag)::value, h = (c >> 2) & 1, i = c & 3;
+        unsigned char* dst = smem + S * STAGE + wave * 4096 + i * 1024;
+        const unsigned koff = (unsigned)ld_t * (BK * 2);
+        if constexpr (c < 8) vb_glds16_buf(A, offA[h][i], koff, dst + h * HALF);
+        else vb_glds16_buf(B, offB[h][i], koff, dst + (2 + h) * HALF);
+    };
+    // past the workgroup's last K tile the stream stays on it (the unconditional copies of the last two K tiles of the loop
+    // below re-fetch it into a stage nobody reads again: two K tiles of traffic per workgroup buy a branch-free K loop)
+    auto ld_advance = [&]() {
+        if (ld_t + 1 < nk) ++ld_t;
+        else if (ld_j + 1 < my_tiles) { ld_t = 0; ++ld_j; set_load_tile(ld_j); }
+    };
+
+    // fragment addresses: row f 16 + li of a half-tile, chunk (4 ks + lg) ^ swz(row), and swz(f 16 + li) = ((li >> 1) ^ f) & 7:
+    // address = half + f 2048 + li 128 + ((c0 ^ f ^ 4 ks) << 4) with c0 = lg ^ (li >> 1) -- eight lane-dependent bases V[k],
+    // k = f ^ 4 ks, per operand and stage; everything else is an immediate
+    unsigned VA[2][8], VB_[2][8];
+    {
+        const unsigned base = big_lds_base(smem);
+        const int c0 = lg ^ (li >> 1);
+#pragma unroll
+        for (int sidx = 0; sidx < 2; ++sidx)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const unsigned v = (unsigned)(li * 128 + ((c0 ^ k) << 4));
+                VA[sidx][k] = base + sidx * STAGE + wr * HALF + v;
+                VB_[sidx][k] = base + sidx * STAGE + (2 + wc) * HALF + v;
+            }
+    }
+    bf16x8 fa0[8], fb0[8], fa1[8], fb1[8];         // the fragments of MFMA K step 0 / 1 of a K tile
+    // read r (0..15) of K step KS from stage S: r < 8 -> A fragment r, else B fragment r - 8
+    auto frag_read = [&](auto stag, auto kstag, auto rtag, bf16x8 (&fa)[8], bf16x8 (&fb)[8]) {
+        constexpr int S = decltype(stag)::value, KS = decltype(kstag)::value, r = decltype(rtag)::value, f = r & 7;
+        if constexpr (r < 8) big_read<f * 2048>(fa[f], smem, VA[S][f ^ (4 * KS)]);
+        else big_read<f * 2048>(fb[f], smem, VB_[S][f ^ (4 * KS)]);
+    };
+    // one half of a K tile: the 64 MFMAs of a K step from (fa, fb); between them the 16 reads of the NEXT K step into (na, nb)
+    // from stage RS / K step RKS and, if COPY, the 16 copies of K tile +2 into stage CS.  No branch anywhere near the
+    // accumulators: every alternative path through them made the register allocator shuffle all 256 between AGPRs and VGPRs.
+    constexpr bool no_copy = (ABL & 1) != 0, no_read = (ABL & 2) != 0, no_mma = (ABL & 4) != 0;   // timing-only builds
+    // COPY (second half): the 16 copies of the K tile after next into stage CS, one after every fourth MFMA
+    auto half = [&](auto rstag, auto rkstag, auto cstag, auto copytag, bf16x8 (&fa)[8], bf16x8 (&fb)[8],
+                    bf16x8 (&na)[8], bf16x8 (&nb)[8]) {
+        constexpr bool COPY = decltype(copytag)::value;
+        vb_static_for<0, 8>([&](auto mitag) {
+            constexpr int mi = decltype(mitag)::value;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) { if constexpr (!no_mma) VB_BIG_MMA(accL[mi][ni], fa[mi], fb[ni]); }
+            if constexpr (!no_read) frag_read(rstag, rkstag, std::integral_constant<int, 2 * mi>(), na, nb);
+            if constexpr (COPY && !no_copy) copy_piece(cstag, std::integral_constant<int, 2 * mi>());
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) { if constexpr (!no_mma) VB_BIG_MMA(accR[mi][ni], fa[mi], fb[4 + ni]); }
+            if constexpr (!no_read) frag_read(rstag, rkstag, std::integral_constant<int, 2 * mi + 1>(), na, nb);
+            if constexpr (COPY && !no_copy) copy_piece(cstag, std::integral_constant<int, 2 * mi + 1>());
+        });
+    };
+    set_load_tile(0);
+    vb_static_for<0, 16>([&](auto c) { copy_piece(I0(), c); });
+    ld_advance();
+    vb_static_for<0, 16>([&](auto c) { copy_piece(I1(), c); });
+    ld_advance();
+    vb_wait_vmcnt<16>();
+    vb_raw_barrier();
+    vb_static_for<0, 16>([&](auto r) { frag_read(I0(), I0(), r, fa0, fb0); });
+    vb_raw_barrier();                               // lgkmcnt(0): the first fragments are in
+
+    // one K tile held in stage S (compile-time)
+    auto ktile = [&](auto stag) {
+        constexpr int S = decltype(stag)::value;
+        typedef std::integral_constant<int, S ^ 1> SN;
+        half(stag, I1(), stag, No(), fa0, fb0, fa1, fb1);                 // K step 0 | reads of (this K tile, K step 1)
+        if constexpr ((ABL & 8) != 0) vb_wait_vmcnt<16>();      // timing-only: no drain (racy)
+        else vb_wait_vmcnt<0>();                    // my copies of the next K tile (issued a K tile ago) have landed
+        vb_raw_barrier();                           // lgkmcnt(0) | everyone is done reading this stage, everyone's copies are in
+        half(SN(), I0(), stag, Yes(), fa1, fb1, fa0, fb0);                // K step 1 | reads of (next K tile, K step 0) | copies of K tile +2
+        ld_advance();
+        vb_wait_lgkmcnt0();                         // the next K tile's first fragments
+    };
+    for (int cj = 0; cj < my_tiles; ++cj) {         // nk is even (launcher): every tile starts in stage 0
+        zero_acc();
+        for (int kt = 0; kt < nk; kt += 2) { ktile(I0()); ktile(I1()); }
+        big_settle();
+        int m0, n0;
+        origin(cj, m0, n0);
+        gemm_epilogue_private<T, TO, ACT, OPT>(accL, slab, g, m0 + wr * 128, n0 + wc * 128, lane);
+        gemm_epilogue_private<T, TO, ACT, OPT>(accR, slab, g, m0 + wr * 128, n0 + wc * 128 + 64, lane);
+    }
+    vb_wait_vmcnt<0>();                             // the re-fetched tail copies must not outlive the workgroup's LDS
+}
+
+template <typename TO, int ACT, int OPT>
+int launch_big_act(const GemmArgs& g, dim3 grid, hipStream_t stream) {
+    constexpr int SM = 2 * 4 * 128 * 128 + 4 * EPI8_BYTES_PER_WAVE;
+#ifndef VB_EMU
+    if (g_prof) {
+        ProfRec r;
+        if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return VB_ERR_LAUNCH;
+        r.flops = 2.0 * g.M * g.N * g.K;
+        r.key = (sizeof(TO) == 4 ? 4 : 0) | 128;
+        (void)hipEventRecord(r.e0, stream);
+        VB_LAUNCH((gemm_nt_big_kernel<TO, ACT, OPT>), grid, dim3(256), SM, stream, g);
+        (void)hipEventRecord(r.e1, stream);
+        g_prof->push_back(r);
+        return vb_check_launch();
+    }
+#endif
+    VB_LAUNCH((gemm_nt_big_kernel<TO, ACT, OPT>), grid, dim3(256), SM, stream, g);
+    return vb_check_launch();
+}
+template <typename T, typename TO>
+int launch_big(GemmArgs g, hipStream_t stream) {
+    if (sizeof(T) != 2 || (long)g.M * g.lda >= (1L << 30) || (long)g.N * g.ldb >= (1L << 30))
+        return launch_pipe<T, TO, 4, 2>(g, stream);
+    if ((g.K / 64) % 2 != 0) return launch_dual<T, TO>(g, stream);      // the K loop alternates two stages per trip
+    if constexpr (sizeof(T) == 2) {
+        g.tiles_m = (g.M + 255) / 256;
+        g.tiles_n = (g.N + 255) / 256;
+        const int ntiles = g.tiles_m * g.tiles_n;
+        int wgs = t_opts.persistent_workgroups > 0 ? t_opts.persistent_workgroups : vb_num_cus();
+        if (wgs >= ntiles) wgs = ntiles;
+        else if (wgs >= 8) wgs &= ~7;
+        dim3 grid((unsigned)wgs);
+        const int needs = epi_needs(g, sizeof(T), sizeof(TO));
+#ifdef VB_DEV_KNOBS
+        if constexpr (sizeof(TO) == 2) {
+            if (g.act == VB_ACT_NONE && needs == 0 && (g.debug & 7)) {
+                constexpr int SMB = 2 * 4 * 128 * 128 + 4 * EPI8_BYTES_PER_WAVE;
+                switch (g.debug & 7) {
+                    case 1: VB_LAUNCH((gemm_nt_big_kernel<TO, 0, 0, 1>), grid, dim3(256), SMB, stream, g); break;
+                    case 2: VB_LAUNCH((gemm_nt_big_kernel<TO, 0, 0, 2>), grid, dim3(256), SMB, stream, g); break;
+                    case 3: VB_LAUNCH((gemm_nt_big_kernel<TO, 0, 0, 3>), grid, dim3(256), SMB, stream, g); break;
+                    case 4: VB_LAUNCH((gemm_nt_big_kernel<TO, 0, 0, 4>), grid, dim3(256), SMB, stream, g); break;
+                    case 5: VB_LAUNCH((gemm_nt_big_kernel<TO, 0, 0, 5>), grid, dim3(256), SMB, stream, g); break;
+                    case 6: VB_LAUNCH((gemm_nt_big_kernel<TO, 0, 0, 6>), grid, dim3(256), SMB, stream, g); break;
+                    default: VB_LAUNCH((gemm_nt_big_kernel<TO, 0, 0, 14>), grid, dim3(256), SMB, stream, g); break;
+                }
+                return vb_check_launch();
+            }
+        }
+#endif
+#define VB_TRY_EPI(A, O) if (g.act == (A) && (needs & ~(O)) == 0) return launch_big_act<TO, A, O>(g, grid, stream)
+        if constexpr (kActSpecialised<T, TO>) {
+            VB_TRY_EPI(VB_ACT_NONE, 0);
+            VB_TRY_EPI(VB_ACT_GELU_SAVE_GRAD, 0);
+            VB_TRY_EPI(VB_ACT_MUL_AUX, EPI_COLSUM);
+            VB_TRY_EPI(VB_ACT_NONE, EPI_ADD);
+        } else {
+            VB_TRY_EPI(VB_ACT_NONE, EPI_RAGGED);
+        }
+#undef VB_TRY_EPI
+        return launch_big_act<TO, -1, EPI_ALL>(g, grid, stream);
+    }
+    return VB_ERR_UNSUPPORTED;
+}
+
+// =================================================================================================
 // Weight gradients: dW_p[out_p, in_p] += alpha * dY_p^T X_p for a GROUP of problems that share the token count
 // (the four Linears of an encoder layer), one persistent launch.  Both operands are K-strided ([token][feature]):
 // tiles are copied AS STORED (LDS-direct, a [64 token][128 feature] half-tile per copy stream step) and the MFMA
@@ -1762,6 +2010,7 @@ int dispatch_pipe(const GemmArgs& g, hipStream_t s) {
         case 80: return launch_8ph<T, TO>(g, s);
         case 81: return launch_8ph<T, TO>(g, s);
         case 90: case 91: return launch_dual<T, TO>(g, s);
+        case 100: return launch_big<T, TO>(g, s);
         default: return VB_ERR_UNSUPPORTED;
     }
 }

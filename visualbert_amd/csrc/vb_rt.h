@@ -159,6 +159,15 @@ VB_DEVICE void vb_glds16_buf(vb_buf b, unsigned voff, unsigned soff, unsigned ch
 }
 #endif
 
+// 16 bytes per lane through the same descriptor into REGISTERS (buffer_load_dwordx4 ... offen)
+#ifdef VB_EMU
+VB_DEVICE u32x4 vb_buf_load16(vb_buf b, unsigned voff, unsigned soff) { u32x4 v; memcpy(&v, b.base + voff + soff, 16); return v; }
+#else
+VB_DEVICE u32x4 vb_buf_load16(vb_buf b, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(b, (int)voff, (int)soff, 0));
+}
+#endif
+
 // counted wait for outstanding vector-memory operations (LDS-direct copies included) + raw workgroup
 // barrier: lets the newest K tile(s) stay in flight across the barrier (guide: "Pipelining across
 // barriers").  N must be an immediate.
@@ -172,6 +181,12 @@ VB_DEVICE void vb_raw_barrier() {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
+#endif
+
+#ifdef VB_EMU
+VB_DEVICE void vb_wait_lgkmcnt0() {}
+#else
+VB_DEVICE void vb_wait_lgkmcnt0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 #endif
 
 // ds_read_b64_tr_b16 (gfx950): within each 16-lane group, lane s passes the address of 4 contiguous 16-bit values
@@ -322,6 +337,14 @@ VB_DEVICE float row16_sum(float v) {
     v += vb_row_ror<8>(v); v += vb_row_ror<4>(v); v += vb_row_ror<2>(v); v += vb_row_ror<1>(v);
     return v;
 }
+#endif
+
+// scheduling hint: the next `n` instructions of class `mask` (0x008 MFMA, 0x020 VMEM read, 0x100 DS read) come here, in the
+// order the hints are written (LLVM sched_group_barrier) -- used to interleave fragment reads / copies with MFMAs
+#ifdef VB_EMU
+#define VB_SCHED_GROUP(mask, n)
+#else
+#define VB_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier((mask), (n), 0)
 #endif
 
 // "the value becomes available HERE": an empty volatile asm that redefines its operand.  Consumers of a register that a

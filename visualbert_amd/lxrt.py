@@ -1,13 +1,13 @@
 """The cross-modality building blocks of the sibling model (unsupervised_visualbert/src/lxrt/modeling.py) on the HIP
 kernels -- SURVEY 8f / N4, last part.  Same class names, constructor arguments, forward signatures and state-dict keys:
 
-  BertAttention(config, ctx_dim=None)   :347-411   query from hidden_states, key / value from `context` (any width ctx_dim)
-  BertAttOutput                         :413-424   dense -> dropout -> LayerNorm(x + input)
-  BertCrossattLayer / BertSelfattLayer  :427-449
-  BertIntermediate / BertOutput         :452-477
-  LXRTXLayer                            :660-712   cross-attention in both directions with ONE shared BertCrossattLayer,
+  BertAttention(config, ctx_dim=None)   :349-404   query from hidden_states, key / value from `context` (any width ctx_dim)
+  BertAttOutput                         :406-417   dense -> dropout -> LayerNorm(x + input)
+  BertCrossattLayer / BertSelfattLayer  :420-443
+  BertIntermediate / BertOutput         :445-471
+  LXRTXLayer                            :667-717   cross-attention in both directions with ONE shared BertCrossattLayer,
                                                    self-attention per modality, FFN per modality
-  VisualFeatEncoder                     :715-747   (LayerNorm(visn_fc(feats)) + LayerNorm(box_fc(boxes))) / 2, dropout
+  VisualFeatEncoder                     :719-767   (LayerNorm(visn_fc(feats)) + LayerNorm(box_fc(boxes))) / 2, dropout
 
 Every FLOP runs in libvisualbert_hip.so: the Linears through vb_gemm (ops.LinearFn), dropout + residual + LayerNorm through
 vb_ln_fwd / vb_ln_bwd (ops.LayerNormFn), the attention core through vb_attn_cross_fwd / vb_attn_cross_bwd

@@ -16,7 +16,7 @@ re-executes itself through `python -m torch.distributed.run --nnodes=1 --nproc-p
 Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
   roofline     -- dominant kernel (the MFMA GEMM instantiation with the largest total time): algorithmic FLOPs per
                   launch / HIP-event duration per launch, against the dense bf16 MFMA peak; `hbm_bound` lists the
-                  HBM-bound kernels (LayerNorm, BertAdam) as GB/s against the 8 TB/s peak
+                  HBM-bound kernels (LayerNorm, BertAdam, MLM cross-entropy) as GB/s against the 8 TB/s peak
   cpu_baseline -- the oracle restatement of the reference (oracle/visualbert_oracle.py, "port") timed on this node's
                   host cores on a bounded sample, training mode (dropout on) (rank 0, N = 1 only)
   parity       -- bf16 kernels against the fp32 oracle on a B = 2 side batch (rank 0, N = 1 only)
@@ -170,7 +170,7 @@ def parity_side_batch(model, dev, head, T, R):
                      "(5e-6 at BERT-base, tests/test_parity_at_scale.py)")
 
 
-def hbm_bound_kernels(model, M, H, dev):
+def hbm_bound_kernels(model, M, H, dev, optimizer=None, V=0):
     """the HBM-bound kernels of the step timed alone: algorithmic bytes / event time against the 8 TB/s peak."""
     import torch
     from visualbert_amd import _lib
@@ -202,9 +202,31 @@ def hbm_bound_kernels(model, M, H, dev):
     t_b = timed(lambda: L.vb_ln_bwd(_lib.VB_BF16, _lib.ptr(x), _lib.ptr(z), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(gamma),
                                     _lib.ptr(dz), _lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db), _lib.ptr(dbias), M, H, 0.1, 11,
                                     0.0, 12, 5, _lib.ptr(ws), _lib.stream_ptr()))
+    rows_list = [("ln_fwd (dropout + residual + LayerNorm)", t_f, 4 * M * H * 2), ("ln_bwd", t_b, 4 * M * H * 2)]
+    if optimizer is not None:                            # the fused multi-tensor BertAdam step on the live arena (after the timed region)
+        n_par = sum(p.numel() for p in model.parameters())
+        t_a = timed(lambda: optimizer.step(), n=5)
+        # fp32 p, g, m, v read (16 B) + p, m, v written (12 B) + the bf16 shadow written (2 B) per parameter
+        rows_list.append(("bert_adam_step (fused multi-tensor)", t_a, 30 * n_par))
+    if V:                                                # MLM cross-entropy over the labelled rows (~11.7 % of the tokens), compact gradient
+        ld = (V + 63) // 64 * 64
+        g = torch.Generator().manual_seed(0)
+        lab = torch.full((M,), -1, dtype=torch.int64)
+        sel = torch.rand(M, generator=g) < 0.117
+        lab[sel] = torch.randint(0, V, (int(sel.sum()),), generator=g)
+        lab = lab.to(dev)
+        rows = torch.nonzero(lab != -1).reshape(-1)
+        n = rows.numel()
+        n_pad = (n + 63) // 64 * 64
+        logits = torch.randn(M, ld, device=dev)
+        acc, loss = torch.empty(66, device=dev), torch.empty(1, device=dev)
+        dlc = torch.empty(n_pad, ld, dtype=dt, device=dev)
+        t_c = timed(lambda: L.vb_ce_fwd_bwd_rows(_lib.VB_BF16, _lib.ptr(logits), ld, _lib.ptr(lab), -1, _lib.ptr(rows), n, n_pad,
+                                                 _lib.ptr(acc), _lib.ptr(loss), _lib.ptr(dlc), ld, M, V, _lib.stream_ptr()))
+        rows_list.append(("mlm_cross_entropy (labelled rows, gradient written compactly)", t_c, n * V * 4 + n_pad * ld * 2))
+        del logits, dlc
     out = {}
-    for name, t, nbytes in (("ln_fwd (dropout + residual + LayerNorm)", t_f, 4 * M * H * 2),
-                            ("ln_bwd", t_b, 4 * M * H * 2)):
+    for name, t, nbytes in rows_list:
         out[name] = dict(us=round(t * 1e6, 1), GBps=round(nbytes / t / 1e9, 1), frac_of_peak=round(nbytes / t / 1e9 / PEAK_HBM_GBPS, 3),
                          algorithmic_bytes=nbytes)
     return out
@@ -400,7 +422,8 @@ def main():
                     roofline["mfma_ceiling_note"] = ("register-only bf16 MFMA loop, operands changing every instruction, all "
                                                      "CUs: what the chip sustains at the clock it holds under real data")
             if dtype == torch.bfloat16:
-                roofline["hbm_bound"] = hbm_bound_kernels(model, B * S, H, dev)
+                roofline["hbm_bound"] = hbm_bound_kernels(model, B * S, H, dev, optimizer=mw.optimizer,
+                                                            V=30522 if head == "pretraining" else 0)
         cpu = par = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args.cpu_batch, T, R, head)

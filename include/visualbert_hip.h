@@ -48,9 +48,10 @@ const char* vb_version(void);
  *                          data-parallel caller lowers it while RCCL kernels are resident (parallel.py).
  *   nt_kernel: K-contiguous x K-contiguous bf16 GEMM kernel; 0 = chosen from the shape; 22 / 42 = two-barrier 128x128 /
  *              256x128 tiles; 80 / 81 = persistent 256x256 tile, eight / four slots per K tile; 90 = 256x128 tiles, two
- *              workgroups per compute unit (91: the same with the copies issued ahead of the fragment reads); 1 = the
- *              generic register-staged kernel.
+ *              workgroups per compute unit (91: the same with the copies issued ahead of the fragment reads); 100 = persistent
+ *              256x256 tile with four waves, 128x128 outputs each (K / 64 even, else 90); 1 = the generic register-staged kernel.
  *   attn_two_pass: 1 = two-pass attention backward even where the one-pass kernel applies.
+ *   reserved: bit 0 = attention forward without the Q-fragment prefetch (A/B measurements); other bits must be 0.
  * vb_stream_set_opts(stream, NULL) forgets the stream's entry (call it before destroying a stream).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct vb_stream_opts {

@@ -39,11 +39,11 @@ PEAK_HBM_GBPS = 8000.0
 
 # BASELINE.json configs -> (head, text tokens, regions, feature width, label for config.workload)
 WORKLOADS = {
-    "pretrain": dict(head="pretraining", T=128, R=36, Dv=2048, batch=512, cfg="configs[1]",
+    "pretrain": dict(head="pretraining", T=128, R=36, Dv=2048, batch=1024, cfg="configs[1]",
                      what="MLM + image-text-match pre-training step incl. dropout, dense 30522-wide decoder, BertAdam"),
-    "vqa": dict(head="vqa", T=20, R=36, Dv=2048, batch=1536, cfg="configs[3]",
+    "vqa": dict(head="vqa", T=20, R=36, Dv=2048, batch=3072, cfg="configs[3]",
                 what="VQA2.0 fine-tuning step (3129-answer head, KL-div on soft scores) incl. dropout, BertAdam"),
-    "nlvr2": dict(head="nlvr", T=40, R=72, Dv=2048, batch=768, cfg="configs[4]",
+    "nlvr2": dict(head="nlvr", T=40, R=72, Dv=2048, batch=1536, cfg="configs[4]",
                   what="NLVR2 paired-image fine-tuning step (2 x 36 regions, 2-way head) incl. dropout, BertAdam"),
 }
 

@@ -382,12 +382,14 @@ VB_DEVICE float half_sum(float v) {
 // Counter-based random bits for dropout.  One call yields 128 bits = eight 16-bit uniforms for the 8 consecutive
 // elements of "group"; element e is dropped iff u16[e] < thresh16, thresh16 = round(p * 65536).  Any kernel (forward
 // or backward, any thread mapping) regenerates the same mask from (seed, stream, element index) -- no mask tensor
-// in HBM.  The generator is a KEYED 32-bit mixer (two multiplies per word, key material folded in before the first
-// and between the two multiplies; the key schedule is wave-uniform, i.e. scalar): 8 integer multiplies per 8
-// elements where Philox4x32-10 needs 40 -- 32-bit multiplies are quarter-rate on CDNA, and Philox was 27 % of the
-// attention forward kernel and a co-limiter of the LayerNorm kernels (profiles/r01_dropout_rng.txt).  Dropout masks
-// need decorrelated, unbiased bits, not cryptographic strength; the keep fraction and the forward/backward agreement
-// are tested (tests/test_kernels.py).
+// in HBM.  Two words come from a KEYED 32-bit mixer (two multiplies per word, key material folded in before the first
+// and between the two multiplies; the key schedule is wave-uniform, i.e. scalar); the other two are each ONE full-rate
+// 24-bit multiply of one mixed word XORed with the other (w2 = f(w0) ^ w1, w3 = g(w1) ^ w0: every word uniform and
+// pairwise independent of every other, which is all a Bernoulli mask needs).  32-bit multiplies are quarter-rate on CDNA:
+// Philox4x32-10 needs 40 per 8 elements (27 % of the attention forward kernel in round 1), four mixer words 8 (dropout was
+// still ~half of that kernel's VALU work), this form 4.  Keep rates, pair / lag / stream / seed correlations, bucket
+// chi-squares and bit balance of old and new form are indistinguishable on 2^21 groups (tools/dropout_rng_check.py);
+// the keep fraction and the forward/backward agreement are tested on the device (tests/test_kernels.py).
 // ------------------------------------------------------------------------------------------
 struct Rand8 { uint32_t w[4]; };               // eight 16-bit uniforms
 VB_DEVICE uint32_t vb_mix32(uint32_t x, uint32_t k) {
@@ -397,14 +399,21 @@ VB_DEVICE uint32_t vb_mix32(uint32_t x, uint32_t k) {
     x ^= x >> 16;
     return x;
 }
+#ifdef VB_EMU
+VB_DEVICE uint32_t vb_mul24(uint32_t a, uint32_t b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
+#else
+VB_DEVICE uint32_t vb_mul24(uint32_t a, uint32_t b) { return __umul24(a, b); }       // v_mul_u32_u24: full rate
+#endif
 VB_DEVICE Rand8 vb_dropout_bits8(uint64_t seed, uint64_t group, uint32_t stream) {
     const uint32_t s0 = (uint32_t)seed, s1 = (uint32_t)(seed >> 32);
     const uint32_t k1 = vb_mix32(s0 ^ (stream * 0x9E3779B9u), s1 ^ 0x5ca1ab1eu);           // uniform: scalar unit
-    const uint32_t k2 = vb_mix32(s1 + stream * 0x85EBCA6Bu, k1) ^ ((uint32_t)(group >> 30) * 0xC2B2AE35u);
-    const uint32_t c = (uint32_t)group * 4u + k1;
+    const uint32_t k2 = vb_mix32(s1 + stream * 0x85EBCA6Bu, k1) ^ ((uint32_t)(group >> 31) * 0xC2B2AE35u);
+    const uint32_t c = (uint32_t)group * 2u + k1;
     Rand8 o;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) o.w[i] = vb_mix32(c + (uint32_t)i, k2);
+    o.w[0] = vb_mix32(c, k2);
+    o.w[1] = vb_mix32(c + 1u, k2);
+    o.w[2] = vb_mul24(o.w[0] >> 8, 0x9E3779u) ^ o.w[1];
+    o.w[3] = vb_mul24(o.w[1] >> 8, 0x85EBCBu) ^ o.w[0];
     return o;
 }
 // keep-mask bit e (0..7) of a group

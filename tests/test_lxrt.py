@@ -46,6 +46,9 @@ def test_fp32_lxrt_blocks_match_reference_golden(dev):
     assert maxdiff(lang.grad.cpu(), g["grad_in/lang"]) < 1e-3 and maxdiff(feats.grad.cpu(), g["grad_in/feats"]) < 1e-3
     for n, gr in grads.items():
         ref = torch.as_tensor(g["grad/" + n])
+        if n.endswith("key.bias"):              # d/d(key bias) is identically 0 (softmax shift invariance): rounding noise on both sides
+            assert float(gr.norm()) < 1e-5, n
+            continue
         assert float((gr - ref).norm()) <= 2e-3 * float(ref.norm()) + 1e-6, n
 
 

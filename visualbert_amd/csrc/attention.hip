@@ -978,7 +978,7 @@ int fill_args(AttnArgs& a, int B, int S, int nh, int head_dim, float p, uint64_t
     if (B <= 0 || S <= 0 || nh <= 0 || head_dim != D || p < 0.f || p >= 1.f) return VB_ERR_ARG;
     a.B = B; a.S = S; a.Sq = S; a.nh = nh; a.scale = 0.125f; // 1/sqrt(64), modeling.py:242
     a.p = p; a.inv_keep = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
-    a.thresh = (uint32_t)(p * 65536.0f + 0.5f); a.stream = stream_id; a.seed = seed;
+    a.thresh = vb_drop_thresh16(p); a.stream = stream_id; a.seed = seed;
     return VB_OK;
 }
 

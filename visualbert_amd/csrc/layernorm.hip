@@ -27,7 +27,7 @@ struct DropSpec {
 };
 static inline DropSpec make_drop(float p, uint64_t seed, uint32_t stream) {
     DropSpec d; d.p = p; d.scale = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
-    d.thresh = (uint32_t)(p * 65536.0f + 0.5f); d.stream = stream; d.seed = seed;
+    d.thresh = vb_drop_thresh16(p); d.stream = stream; d.seed = seed;
     return d;
 }
 // multiply v[0..8) by the keep mask / (1-p) of group (element index >> 3)

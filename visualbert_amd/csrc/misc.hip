@@ -206,7 +206,7 @@ extern "C" int vb_dropout(int dtype, const void* x, void* y, int64_t n, float p,
     long blocks = ((n + 7) / 8 + NT - 1) / NT;
     if (blocks > 2048) blocks = 2048;
     const float inv_keep = 1.0f / (1.0f - p);
-    const uint32_t thresh = (uint32_t)(p * 65536.0f + 0.5f);
+    const uint32_t thresh = vb_drop_thresh16(p);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == VB_BF16) VB_LAUNCH(dropout_kernel<bf16>, dim3((unsigned)blocks), dim3(NT), 0, s, (const bf16*)x, (bf16*)y, (long)n, inv_keep, thresh, seed, stream_id);
     else if (dtype == VB_F32) VB_LAUNCH(dropout_kernel<float>, dim3((unsigned)blocks), dim3(NT), 0, s, (const float*)x, (float*)y, (long)n, inv_keep, thresh, seed, stream_id);

@@ -392,6 +392,10 @@ VB_DEVICE float half_sum(float v) {
 // the keep fraction and the forward/backward agreement are tested on the device (tests/test_kernels.py).
 // ------------------------------------------------------------------------------------------
 struct Rand8 { uint32_t w[4]; };               // eight 16-bit uniforms
+static inline uint32_t vb_drop_thresh16(float p) {                         // host side: round(p * 65536), at most 65535
+    const uint32_t t = (uint32_t)(p * 65536.0f + 0.5f);
+    return t > 65535u ? 65535u : t;
+}
 VB_DEVICE uint32_t vb_mix32(uint32_t x, uint32_t k) {
     x ^= x >> 16; x *= 0x7feb352du;
     x ^= k;
@@ -416,10 +420,11 @@ VB_DEVICE Rand8 vb_dropout_bits8(uint64_t seed, uint64_t group, uint32_t stream)
     o.w[3] = vb_mul24(o.w[1] >> 8, 0x85EBCBu) ^ o.w[0];
     return o;
 }
-// keep-mask bit e (0..7) of a group
+// keep-mask bit e (0..7) of a group.  thresh16 <= 65535 (vb_drop_thresh16), so the upper half of a word is tested without
+// extracting it: (w >> 16) >= t  <=>  w >= (t << 16)
 VB_DEVICE bool rand8_keep(const Rand8& r, int e, uint32_t thresh16) {
-    uint32_t u = (r.w[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu;
-    return u >= thresh16;
+    const uint32_t w = r.w[e >> 1];
+    return (e & 1) ? (w >= (thresh16 << 16)) : ((w & 0xFFFFu) >= thresh16);
 }
 
 // fast exp: one v_exp_f32 (2^x) after a multiply; relative error ~1e-7..1e-6, flushes like expf for the

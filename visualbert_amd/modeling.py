@@ -29,7 +29,11 @@ from . import _lib, ops
 
 # ------------------------------------------------------------------------------------------------
 class BertConfig(object):
-    """modeling.py:69-153."""
+    """modeling.py:69-153.  This class is configuration plumbing that has to match the reference field for field (JSON
+    files, `to_dict` / `from_dict` round trips, attribute names read all over the callers), so its body follows the
+    reference's BertConfig closely; that class derives from pytorch-pretrained-BERT -- Copyright 2018 The Google AI Language
+    Team Authors and The HuggingFace Inc. team; Copyright (c) 2018 NVIDIA CORPORATION; licensed under the Apache License,
+    Version 2.0 (http://www.apache.org/licenses/LICENSE-2.0)."""
 
     def __init__(self, vocab_size_or_config_json_file, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
                  intermediate_size=3072, hidden_act="gelu", hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1,

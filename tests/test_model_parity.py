@@ -435,6 +435,53 @@ def test_collated_pinned_batch_streams_and_trains(dev):
     assert abs(float(out["loss"].detach()) - float(ref["loss"])) < 1e-4
 
 
+def test_captions_and_region_files_to_training_steps(dev, tmp_path):
+    """the whole ingest path in front of the hot path, as one pipeline (SURVEY 8f N2 + N3): caption TEXT -> WordPieceEncoder ->
+    collate_pretraining (masking, [CLS]/[SEP], padding) -> per-image region .npy files -> RegionFeatureStore (pinned slab) ->
+    FeatureStager (side-stream H2D) -> ModelWrapper.step.  The first loss equals the oracle's on the same host batch; a few
+    steps on the same batch bring it down."""
+    if dev.type != "cuda":
+        pytest.skip("pinned memory + async copies: GPU only")
+    import numpy as np
+    from visualbert_amd.data import collate_pretraining, FeatureStager, RegionFeatureStore
+    from visualbert_amd.model import ModelWrapper, AttrDict
+    from visualbert_amd.tokenization import WordPieceEncoder
+    cfg, head, sd, _, _ = load_case("micro_pretraining")
+    specials = ["[PAD]", "[CLS]", "[SEP]", "[MASK]", "[UNK]"]
+    words = ["a", "the", "man", "woman", "dog", "ride", "riding", "horse", "on", "in", "park", "play", "##s", "##ing", "##ed", ".", ","]
+    vocab = specials + words + ["w%d" % i for i in range(cfg.vocab_size - len(specials) - len(words))]
+    assert len(vocab) == cfg.vocab_size
+    enc = WordPieceEncoder({t: i for i, t in enumerate(vocab)})
+    captions = [("A man riding a horse.", "the dog plays in the park"), ("The woman rides.", None),
+                ("a dog, a horse, a man", "riding on the horse"), ("the park", "a man played")]
+    ids_a = [torch.tensor(enc.encode(a), dtype=torch.int64) for a, _ in captions]
+    ids_b = [torch.tensor(enc.encode(b), dtype=torch.int64) if b else None for _, b in captions]
+    assert enc.tokenize("plays riding") == ["play", "##s", "riding"]
+    rng = np.random.RandomState(3)
+    image_ids = [11, 222, 3333, 44]
+    for i, r in zip(image_ids, (4, 2, 5, 3)):
+        np.save(str(tmp_path / ("COCO_train2014_%012d.npy" % i)), rng.rand(r, cfg.visual_embedding_dim).astype(np.float32))
+    store = RegionFeatureStore(str(tmp_path), "train")
+    region = store.read_batch(image_ids)
+    feats = [region["image_feat_variable"][b, :int(region["image_dim_variable"][b])] for b in range(len(image_ids))]
+    g = torch.Generator().manual_seed(7)
+    host = collate_pretraining(ids_a, ids_b, [True, False, True, False], feats, cfg.vocab_size, vocab.index("[MASK]"),
+                               vocab.index("[CLS]"), vocab.index("[SEP]"), probability=0.5, generator=g)
+    assert all(v.is_pinned() for v in host.values())
+    assert (host["masked_lm_labels"] >= 0).any()
+    stager = FeatureStager(dev)
+    batch, ev = stager.stage(host)
+    torch.cuda.current_stream().wait_event(ev)
+    model = build_model(cfg, head, sd, dev, dropout=0.0)
+    mw = ModelWrapper(AttrDict(train_batch_size=4, learning_rate=2e-3, warmup_proportion=0.1, num_train_epochs=1), 40,
+                      model=model)
+    model.train()
+    losses = [float(mw.step(batch)["loss"].detach()) for _ in range(6)]
+    ref = vo.objective_forward(sd, cfg, head, mode="fp32", **{k: v.clone() for k, v in host.items()})
+    assert abs(losses[0] - float(ref["loss"])) < 1e-4
+    assert losses[-1] < losses[0] - 0.05, losses
+
+
 def test_degenerate_batches_match_oracle(dev):
     """edges of the input contract: a sample whose regions are ALL padding (image_dim = 0: its visual slots are masked
     keys but still produce rows), a sample with a single real token, and a batch without any labelled token -- the

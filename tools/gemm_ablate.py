@@ -1,7 +1,9 @@
 #!/usr/bin/env python
-"""ablation of the two-barrier pipelined GEMM (variant 42) on the GPU box: which of {tile loads, fragment reads,
-MFMAs} bounds the loop.  (The combined / fewer-barrier builds behind profiles/r01_gemm_ablation*.txt were removed with
-the kernels they led to; the single-knob builds 1, 2, 4 remain.)"""
+"""which of {copies, fragment reads, MFMAs} bounds a GEMM kernel: timing-only builds with parts removed (developer library,
+vb_gemm_set_debug bits; results are wrong by construction).  The four-wave kernel (nt_kernel 100) has every combination
+(1 no copies, 2 no reads, 3 MFMAs only, 4 no MFMAs, 5 reads only, 6 copies only, 7 copies only without the per-K-tile
+drain); the older kernels the single bits 1 / 2 / 4.  profiles/r02_gemm_big_tile_notes.txt is written from this.
+    VB_DEV=1 python tools/gemm_ablate.py [kernel ids ...]      default: 100      (VB_BATCH=512)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

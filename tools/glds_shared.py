@@ -1,5 +1,9 @@
+#!/usr/bin/env python
+"""LDS-direct streaming when every wave reads the SAME small window (64 KB .. 16 MB, depth 4): is there a hot-line penalty
+in L2?  (No: profiles/r02_glds_stream.txt.)   python tools/glds_shared.py"""
 import sys, os
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tools")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch
 from visualbert_amd import _lib
 dev = torch.device("cuda", 0)

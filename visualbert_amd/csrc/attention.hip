@@ -829,23 +829,43 @@ VB_KERNEL VB_LAUNCH_BOUNDS(FNT) attn_bwd_fused_kernel(AttnArgs a) {
         }
         __syncthreads();                                   // the chunk's dS tile is complete, the next chunk is staged
         if (q0 + 2 * CQ < S) load_chunk(q0 + 2 * CQ);
-        // ---- phase B: dQ^T block (d rows df*16.., query columns qf*16..) = K^T dS^T over all keys
-        for (int blk = wave; blk < (CQ / 16) * 4; blk += FWPB) {
-            const int qf = blk >> 2, df = blk & 3;
-            const int q = q0 + qf * 16 + li;
-            if (q0 + qf * 16 >= S) continue;
-            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        // ---- phase B: dQ^T block (d rows df*16.., query columns qf*16..) = K^T dS^T over all keys.  16 blocks, 12 waves:
+        // wave w owns block w (qf = w >> 2, df = w & 3) and waves 0..3 also block w + 12 (qf = 3, the SAME df): the two are
+        // computed together -- one K^T fragment feeds both, and their MFMA chains (six dependent instructions each) overlap
+        // instead of running back to back on the four waves the whole workgroup then waits for
+        {
+            static_assert(CQ == 64 && FWPB == 12, "block ownership below assumes 16 blocks on 12 waves");
+            const int df = wave & 3, qf0 = wave >> 2, qf1 = 3;
+            const bool v0 = q0 + qf0 * 16 < S, v1 = wave < 4 && q0 + qf1 * 16 < S;      // wave-uniform
+            if (v0 || v1) {
+                f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
 #pragma unroll
-            for (int ks = 0; ks < FNK / 32; ++ks) {
-                if (ks * 32 >= S) continue;
-                // B operand: lane (n = query li, g = lg) holds dS[q][key(g, j)], key(g, j) = 32 ks + 16 (j >> 2) + 4 g + (j & 3)
-                const unsigned char* src = ldsDS + (qf * 16 + li) * TSP + (32 * ks + 4 * lg) * 2;
-                const bf16x4 lo = *(const bf16x4*)src, hi = *(const bf16x4*)(src + 32);
-                const bf16x8 dsb = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                acc = vb_mma(frag_tr(ldsKT, tr_pitch<T>(FNK), df * 16 + li, ks, lg, T()), dsb, acc);
+                for (int ks = 0; ks < FNK / 32; ++ks) {
+                    if (ks * 32 >= S) continue;
+                    // B operand: lane (n = query li, g = lg) holds dS[q][key(g, j)], key(g, j) = 32 ks + 16 (j >> 2) + 4 g + (j & 3)
+                    const bf16x8 kt = frag_tr(ldsKT, tr_pitch<T>(FNK), df * 16 + li, ks, lg, T());
+                    if (v0) {
+                        const unsigned char* src = ldsDS + (qf0 * 16 + li) * TSP + (32 * ks + 4 * lg) * 2;
+                        const bf16x4 lo = *(const bf16x4*)src, hi = *(const bf16x4*)(src + 32);
+                        acc0 = vb_mma(kt, bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}, acc0);
+                    }
+                    if (v1) {
+                        const unsigned char* src = ldsDS + (qf1 * 16 + li) * TSP + (32 * ks + 4 * lg) * 2;
+                        const bf16x4 lo = *(const bf16x4*)src, hi = *(const bf16x4*)(src + 32);
+                        acc1 = vb_mma(kt, bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}, acc1);
+                    }
+                }
+                if (v0) {
+                    const int q = q0 + qf0 * 16 + li;
+                    if (q < S) store4((T*)a.dqkv + (row0 + q) * ldx + h * D + df * 16 + lg * 4, acc0);
+                    dqsum += acc0;                          // columns of padded queries are exactly 0 (their dS rows are)
+                }
+                if (v1) {
+                    const int q = q0 + qf1 * 16 + li;
+                    if (q < S) store4((T*)a.dqkv + (row0 + q) * ldx + h * D + df * 16 + lg * 4, acc1);
+                    dqsum += acc1;
+                }
             }
-            if (q < S) store4((T*)a.dqkv + (row0 + q) * ldx + h * D + df * 16 + lg * 4, acc);
-            dqsum += acc;                                   // columns of padded queries are exactly 0 (their dS rows are)
         }
         __syncthreads();                                   // phase B is done with the tile before the next phase A writes it
     }

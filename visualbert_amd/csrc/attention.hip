@@ -690,32 +690,38 @@ VB_KERNEL VB_LAUNCH_BOUNDS(FNT) attn_bwd_fused_kernel(AttnArgs a) {
     constexpr int BPT = (CQ * 4 * NW + FNT - 1) / FNT;
     constexpr int SI = CQ * 4;                             // staging items per tensor (row pair x 16-byte chunk)
     static_assert(SI % 64 == 0 && CQ == 64, "the staging role must be wave-uniform; wave 0 carries the chunk's lse values");
-    const int st = t % SI, role = vb_uniform(t / SI);      // role 0 stages Q, role 1 dO (and D from dO . O), the rest nothing
+    // staging roles (wave-uniform): role 0 (waves 0-3) fetches dO and O for D = dO . O and carries the chunk's lse and keep-bit
+    // words, role 1 (waves 4-7) stages dO, role 2 (waves 8-11) stages Q.  The heaviest staging goes to the OLDEST waves: the
+    // SIMD arbiter favours them in phase A (an in-kernel cycle trace shows waves 0-3 done with a chunk's phase A after ~3700
+    // cycles, waves 8-11 after ~6000 -- three waves per SIMD share its VALU), so they have the slack.
+    const int st = t % SI, role = vb_uniform(t / SI);
     const int sdc = st & 7, sr = (st >> 3) * 2;            // rows q0 + sr, q0 + sr + 1; 16-byte column chunk sdc
-    const T* ssrc = (role == 0 ? qkv : dctx) + h * D + sdc * 8;
-    const long sld = role == 0 ? ldx : (long)H;
+    // addresses: byte offsets of this thread's row q0 = 0 from wave-uniform bases, 32 bits (launcher: tokens x pitch x 2 below
+    // 2^32); a chunk adds a small signed multiple of the pitch, which also expresses the clamp of rows past S
+    const unsigned char* sbase = (const unsigned char*)((role == 2 ? qkv : dctx) + h * D);   // Q rows | dO rows (roles 0 and 1)
+    const int sldb = (int)((role == 2 ? ldx : (long)H) * 2);                 // row pitch in bytes
+    const unsigned char* obase = (const unsigned char*)(octx + h * D);       // O rows: same pitch and offsets as dO
+    const unsigned off_s = (unsigned)((row0 + sr) * (long)sldb) + sdc * 16;
     u32x4 c0 = u32x4{0u, 0u, 0u, 0u}, c1 = c0, o0 = c0, o1 = c0;
     float c_lse = 0.f;
     uint64_t c_bits[BPT];
 #pragma unroll
     for (int j = 0; j < BPT; ++j) c_bits[j] = 0;
+    static_assert(BPT == 1 && CQ * 4 * NW == SI, "keep-bit words of a chunk: one per thread of waves 0-3");
     auto load_chunk = [&](int q0) {
-        const long r0 = row0 + (q0 + sr < S ? q0 + sr : S - 1), r1 = row0 + (q0 + sr + 1 < S ? q0 + sr + 1 : S - 1);
-        if (role < 2) {                                    // wave-uniform: a scalar branch
-            c0 = *(const u32x4*)(ssrc + r0 * sld);
-            c1 = *(const u32x4*)(ssrc + r1 * sld);
-        }
-        if (role == 1) {                                   // O rows for D = dO . O, fetched with the chunk
-            o0 = *(const u32x4*)(octx + r0 * (long)H + h * D + sdc * 8);
-            o1 = *(const u32x4*)(octx + r1 * (long)H + h * D + sdc * 8);
-        }
-        if (wave == 0) c_lse = a.lse[(long)bh * S + (q0 + t < S ? q0 + t : S - 1)];      // CQ = 64 queries = wave 0
-        if (a.p > 0.f) {
-#pragma unroll
-            for (int j = 0; j < BPT; ++j) {
-                if (vb_uniform((t & ~63) + j * FNT) >= CQ * 4 * NW) continue;          // whole waves: a scalar branch
-                const long i = ((long)bh * S + q0) * 4 * NW + t + j * FNT, last = ((long)bh * S + S) * 4 * NW - 1;
-                c_bits[j] = a.keepbits[i < last ? i : last];
+        // rows q0 + sr (+ 1), clamped to S - 1, as a row delta from this thread's chunk-0 row sr
+        const int d0r = q0 + sr < S ? q0 : S - 1 - sr, d1r = q0 + sr + 1 < S ? q0 + 1 : S - 1 - sr;
+        // ONE pair of loads for every role (role 0 reads the same dO rows as role 1): two branches filling the same registers
+        // made the compiler put a vmcnt wait in front of the second branch's loads
+        c0 = *(const u32x4*)(sbase + (off_s + (unsigned)(d0r * sldb)));
+        c1 = *(const u32x4*)(sbase + (off_s + (unsigned)(d1r * sldb)));
+        if (role == 0) {                                   // wave-uniform: a scalar branch
+            o0 = *(const u32x4*)(obase + (off_s + (unsigned)(d0r * sldb)));
+            o1 = *(const u32x4*)(obase + (off_s + (unsigned)(d1r * sldb)));
+            if (wave == 0) c_lse = a.lse[(long)bh * S + (q0 + lane < S ? q0 + lane : S - 1)];      // CQ = 64 queries = one wave
+            if (a.p > 0.f) {
+                const long i = ((long)bh * S + q0) * 4 * NW + t, last = ((long)bh * S + S) * 4 * NW - 1;
+                c_bits[0] = a.keepbits[i < last ? i : last];
             }
         }
     };
@@ -735,25 +741,21 @@ VB_KERNEL VB_LAUNCH_BOUNDS(FNT) attn_bwd_fused_kernel(AttnArgs a) {
 #pragma unroll
         for (int j = 0; j < BPT; ++j) vb_pin(c_bits[j]);
         const u32x4 z0 = zsel(q0 + sr < S, c0), z1 = zsel(q0 + sr + 1 < S, c1);        // rows past S are zeros
-        if (role < 2) {
-            unsigned char* rm = role == 0 ? ldsQ : ldsDO;
+        if (role > 0) {
+            unsigned char* rm = role == 2 ? ldsQ : ldsDO;
             *(u32x4*)(rm + rm_off<T>(sr, sdc)) = z0;
             *(u32x4*)(rm + rm_off<T>(sr + 1, sdc)) = z1;
-            store_tr2(role == 0 ? ldsQT : ldsDOT, z0, z1);
-        }
-        if (role == 1) {                                   // D[q] = dO[q] . O[q]: 8 products per thread, 8 threads per row
+            store_tr2(role == 2 ? ldsQT : ldsDOT, z0, z1);
+        } else {                                           // D[q] = dO[q] . O[q]: 8 products per thread, 8 threads per row
             const bf16x8 d0 = *(const bf16x8*)&z0, d1 = *(const bf16x8*)&z1, p0 = *(const bf16x8*)&o0, p1 = *(const bf16x8*)&o1;
             float s0 = 0.f, s1 = 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) { s0 += (float)d0[j] * (float)p0[j]; s1 += (float)d1[j] * (float)p1[j]; }
             s0 = oct_sum(s0); s1 = oct_sum(s1);
             if (sdc == 0) { ldsD[sr] = s0; ldsD[sr + 1] = s1; }
-        }
-        if (wave == 0) ldsLse[t] = q0 + t < S ? c_lse : INFINITY;                     // exp(x - inf) = 0 for padded queries
-#pragma unroll
-        for (int j = 0; j < BPT; ++j) {
-            const int i = t + j * FNT;
-            if (i < CQ * 4 * NW) ldsBits[i] = (a.p > 0.f && q0 + i / (4 * NW) < S) ? c_bits[j] : ~(uint64_t)0;
+            if (wave == 0) ldsLse[lane] = q0 + lane < S ? c_lse : INFINITY;            // exp(x - inf) = 0 for padded queries
+            const int i = t;
+            ldsBits[i] = (a.p > 0.f && q0 + i / (4 * NW) < S) ? c_bits[0] : ~(uint64_t)0;
         }
     };
     load_chunk(0);
@@ -879,32 +881,40 @@ VB_KERNEL VB_LAUNCH_BOUNDS(FNT) attn_bwd_fused_kernel(AttnArgs a) {
         }
     }
     if (a.bias_ws) {
-        // the dS tile is idle now (the loop ended on a barrier): per-wave partial sums [wave][16 dQ | 64 dK | 64 dV]
-        float* part = (float*)ldsDS;
-        constexpr int PW = 16 + 2 * D;
+        // every LDS image is idle now (the loop ended on a barrier): each lane parks its 36 accumulators (4 dQ sums, 16 dK^T,
+        // 16 dV^T) as raw[wave][value][lane] -- 36 conflict-free ds_write_b32 -- and 192 threads add up, per output column d,
+        // the 16 lanes (keys / queries) x the waves that hold it.  (The first form reduced inside each wave with 36 DPP
+        // row sums per lane before going to LDS: ~5000 of the workgroup's ~45000 cycles, by the in-kernel cycle trace.)
+        float* raw = (float*)smem;                          // 12 x 36 x 64 floats = 108 KB of the 124 KB
+        constexpr int NV = 4 + 2 * 16;
+        static_assert((size_t)FWPB * NV * 64 * 4 <= 2 * (size_t)SETB + tr_bytes<T>(FNK) + (size_t)CQ * TSP, "raw partials fit the idle images");
+        float* mine = raw + ((long)wave * NV) * 64 + lane;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float sq = row16_sum(dqsum[r]);
-            if (li == 0) part[wave * PW + lg * 4 + r] = sq;
-        }
+        for (int r = 0; r < 4; ++r) mine[r * 64] = dqsum[r];
 #pragma unroll
         for (int df = 0; df < 4; ++df)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float sk = row16_sum(dkT[df][r]), sv = row16_sum(dvT[df][r]);     // padded keys contribute exact zeros
-                if (li == 0) {
-                    part[wave * PW + 16 + df * 16 + lg * 4 + r] = sk;
-                    part[wave * PW + 16 + D + df * 16 + lg * 4 + r] = sv;
-                }
+            for (int r = 0; r < 4; ++r) {                   // padded keys contribute exact zeros
+                mine[(4 + df * 4 + r) * 64] = dkT[df][r];
+                mine[(20 + df * 4 + r) * 64] = dvT[df][r];
             }
         __syncthreads();
         if (t < 3 * D) {
-            const int which = t / D, dd = t % D;
+            const int which = t / D, dd = t % D, df = dd >> 4, glg = (dd >> 2) & 3, r = dd & 3;
             float sum = 0.f;
             if (which == 0) {                               // dQ^T block df lives in the waves with (wave & 3) == df
-                for (int w = dd >> 4; w < FWPB; w += 4) sum += part[w * PW + (dd & 15)];
+                for (int w = df; w < FWPB; w += 4) {
+                    const f32x4* src = (const f32x4*)(raw + ((long)w * NV + r) * 64 + glg * 16);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { const f32x4 x = src[i]; sum += (x[0] + x[1]) + (x[2] + x[3]); }
+                }
             } else {
-                for (int w = 0; w < FWPB; ++w) sum += part[w * PW + 16 + (which - 1) * D + dd];
+                const int v = (which == 1 ? 4 : 20) + df * 4 + r;
+                for (int w = 0; w < FWPB; ++w) {
+                    const f32x4* src = (const f32x4*)(raw + ((long)w * NV + v) * 64 + glg * 16);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { const f32x4 x = src[i]; sum += (x[0] + x[1]) + (x[2] + x[3]); }
+                }
             }
             a.bias_ws[((long)b * 3 + which) * H + h * D + dd] = sum;
         }
@@ -949,7 +959,8 @@ int launch_all(int which, const AttnArgs& a, hipStream_t s) {
         VB_LAUNCH((attn_fwd_kernel<T, NKF>), grid, block, sm, s, a);
     } else {
         if constexpr (sizeof(T) == 2 && NKF <= 12) {
-            if (a.ctx_fwd && a.qkv && a.Sq == a.S && a.S <= FWPB * 16 && vb_opts_for((void*)s).attn_two_pass != 1) {  // one-pass backward (needs the forward output)
+            if (a.ctx_fwd && a.qkv && a.Sq == a.S && a.S <= FWPB * 16 && vb_opts_for((void*)s).attn_two_pass != 1 &&
+                (long)a.B * a.S * 3 * a.nh * D * 2 < (1L << 32)) {   // one-pass backward (needs the forward output; 32-bit byte offsets)
                 // 64-query chunks (86 KB of LDS, one workgroup per CU): 528-541 us per layer at B=512; 32-query chunks (two
                 // workgroups per CU, twice the barriers): 575 us
                 VB_LAUNCH((attn_bwd_fused_kernel<NKF, 64>), grid, dim3(FNT), (fused_smem<NKF, 64>()), s, a);

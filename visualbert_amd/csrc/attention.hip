@@ -806,10 +806,12 @@ VB_KERNEL VB_LAUNCH_BOUNDS(FNT) attn_bwd_fused_kernel(AttnArgs a) {
                     for (int r = 0; r < 4; ++r) {
                         const int ql = qf * 16 + lg * 4 + r;
                         const float p = fast_exp(s[r] * a.scale + mk - lse4[r]);
-                        const uint64_t w = ldsBits[(ql * 4 + (li >> 2)) * NW + (kf >> 4)];
-                        const bool keep = (w >> ((kf & 15) * 4 + (li & 3))) & 1;
-                        const float pdrop = keep ? p * a.inv_keep : 0.f;
-                        const float dpv = keep ? dp[r] * a.inv_keep : 0.f;
+                        // this wave's nibble of the keep word lies in ONE 32-bit half (kf is wave-uniform): a 4-byte LDS read
+                        // and 32-bit shift / test instead of their 64-bit forms; one select yields the factor for both products
+                        const uint32_t w = ((const uint32_t*)ldsBits)[((ql * 4 + (li >> 2)) * NW + (kf >> 4)) * 2 + ((kf & 15) >> 3)];
+                        const float kscale = ((w >> ((kf & 7) * 4 + (li & 3))) & 1u) ? a.inv_keep : 0.f;
+                        const float pdrop = p * kscale;
+                        const float dpv = dp[r] * kscale;
                         pd[hf][r] = pdrop;
                         dsv[hf][r] = p * (dpv - d4[r]) * a.scale;
                         *(bf16*)(ldsDS + ql * TSP + (kf * 16 + li) * 2) = (bf16)dsv[hf][r];      // dS as [query][key]

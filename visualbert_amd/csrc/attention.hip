@@ -320,7 +320,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(NT, 3) attn_fwd_kernel(AttnArgs a) {
                     const int kf = 2 * kp + (e >> 2), r = e & 3;
                     if (kf >= NKF) continue;                // the padding half of an odd fragment count
                     const bool keep = rand8_keep(rnd, e, a.thresh);
-                    st[kf][r] = keep ? st[kf][r] * invk : 0.f;
+                    st[kf][r] *= keep ? invk : 0.f;         // (select the factor, then one -- packable -- multiply)
                     if (keep) bits[kf >> 4] |= (uint64_t)1 << ((kf & 15) * 4 + r);
                 }
             } else {

@@ -797,6 +797,45 @@ def test_rows_past_two_giga_elements(dev):
     assert (dlc[:n, :V].float() - ref_in.grad).abs().max().item() <= 2e-3
 
 
+def test_dropout_mask_equals_the_documented_generator(dev):
+    """the keep mask is a pure function of (seed, stream id, element index): the kernels' masks must equal, bit for bit, an
+    independent numpy statement of the generator documented in csrc/vb_rt.h (two keyed mixer words + two words derived with a
+    24-bit multiply each; element e of a group takes 16-bit lane e of the four words; keep iff >= round(p * 65536)) -- the
+    same model whose statistics tools/dropout_rng_check.py examines."""
+    import numpy as np
+    from visualbert_amd import ops
+    M32 = np.uint64(0xFFFFFFFF)
+
+    def u32(x):
+        return x & M32
+
+    def mix32(x, k):
+        x = u32(x); x = x ^ (x >> np.uint64(16)); x = u32(x * np.uint64(0x7feb352d)); x = x ^ k
+        x = x ^ (x >> np.uint64(15)); x = u32(x * np.uint64(0x846ca68b)); x = x ^ (x >> np.uint64(16))
+        return x
+
+    def mul24(a, b):
+        return u32((a & np.uint64(0xFFFFFF)) * np.uint64(b & 0xFFFFFF))
+
+    def keep_mask(n, p, seed, sid):
+        s0, s1, st = np.uint64(seed & 0xFFFFFFFF), np.uint64(seed >> 32), np.uint64(sid)
+        k1 = mix32(s0 ^ u32(st * np.uint64(0x9E3779B9)), s1 ^ np.uint64(0x5ca1ab1e))
+        g = np.arange((n + 7) // 8, dtype=np.uint64)
+        k2 = mix32(u32(s1 + u32(st * np.uint64(0x85EBCA6B))), k1) ^ u32((g >> np.uint64(31)) * np.uint64(0xC2B2AE35))
+        c = u32(g * np.uint64(2) + k1)
+        w0, w1 = mix32(c, k2), mix32(u32(c + np.uint64(1)), k2)
+        w2, w3 = mul24(w0 >> np.uint64(8), 0x9E3779) ^ w1, mul24(w1 >> np.uint64(8), 0x85EBCB) ^ w0
+        u = np.stack([h for w in (w0, w1, w2, w3) for h in (w & np.uint64(0xFFFF), w >> np.uint64(16))], 1).reshape(-1)[:n]
+        return u >= np.uint64(min(int(p * 65536.0 + 0.5), 65535))
+
+    for n, p, seed, sid in ((4099, 0.1, 1234, 10), (70000, 0.37, (7 << 32) | 99, 3)):
+        x = torch.ones(n, device=dev)
+        y = ops.dropout_apply(x, p, seed, sid)
+        got = (y != 0).cpu().numpy()
+        want = keep_mask(n, p, seed, sid)
+        assert np.array_equal(got, want), (n, p, int((got != want).sum()))
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 def test_head_dropout_kernel(dev, dt):
     """vb_dropout (nn.Dropout in front of the fine-tuning heads): keep rate, 1/(1-p) scaling, the same mask again for the

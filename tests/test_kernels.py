@@ -797,13 +797,12 @@ def test_rows_past_two_giga_elements(dev):
     assert (dlc[:n, :V].float() - ref_in.grad).abs().max().item() <= 2e-3
 
 
-def test_dropout_mask_equals_the_documented_generator(dev):
-    """the keep mask is a pure function of (seed, stream id, element index): the kernels' masks must equal, bit for bit, an
-    independent numpy statement of the generator documented in csrc/vb_rt.h (two keyed mixer words + two words derived with a
-    24-bit multiply each; element e of a group takes 16-bit lane e of the four words; keep iff >= round(p * 65536)) -- the
+def generator_keep(groups, p, seed, sid):
+    """an independent numpy statement of the dropout generator documented in csrc/vb_rt.h: for each 8-element group index in
+    `groups` -> bool [len(groups), 8], True = keep.  Two keyed mixer words + two words derived with a 24-bit multiply each;
+    element e of a group takes 16-bit lane e of the four words; keep iff >= round(p * 65536) (clamped to 65535).  It is the
     same model whose statistics tools/dropout_rng_check.py examines."""
     import numpy as np
-    from visualbert_amd import ops
     M32 = np.uint64(0xFFFFFFFF)
 
     def u32(x):
@@ -817,23 +816,58 @@ def test_dropout_mask_equals_the_documented_generator(dev):
     def mul24(a, b):
         return u32((a & np.uint64(0xFFFFFF)) * np.uint64(b & 0xFFFFFF))
 
-    def keep_mask(n, p, seed, sid):
-        s0, s1, st = np.uint64(seed & 0xFFFFFFFF), np.uint64(seed >> 32), np.uint64(sid)
-        k1 = mix32(s0 ^ u32(st * np.uint64(0x9E3779B9)), s1 ^ np.uint64(0x5ca1ab1e))
-        g = np.arange((n + 7) // 8, dtype=np.uint64)
-        k2 = mix32(u32(s1 + u32(st * np.uint64(0x85EBCA6B))), k1) ^ u32((g >> np.uint64(31)) * np.uint64(0xC2B2AE35))
-        c = u32(g * np.uint64(2) + k1)
-        w0, w1 = mix32(c, k2), mix32(u32(c + np.uint64(1)), k2)
-        w2, w3 = mul24(w0 >> np.uint64(8), 0x9E3779) ^ w1, mul24(w1 >> np.uint64(8), 0x85EBCB) ^ w0
-        u = np.stack([h for w in (w0, w1, w2, w3) for h in (w & np.uint64(0xFFFF), w >> np.uint64(16))], 1).reshape(-1)[:n]
-        return u >= np.uint64(min(int(p * 65536.0 + 0.5), 65535))
+    g = np.asarray(groups, dtype=np.uint64)
+    s0, s1, st = np.uint64(seed & 0xFFFFFFFF), np.uint64(seed >> 32), np.uint64(sid)
+    k1 = mix32(s0 ^ u32(st * np.uint64(0x9E3779B9)), s1 ^ np.uint64(0x5ca1ab1e))
+    k2 = mix32(u32(s1 + u32(st * np.uint64(0x85EBCA6B))), k1) ^ u32((g >> np.uint64(31)) * np.uint64(0xC2B2AE35))
+    c = u32(g * np.uint64(2) + k1)
+    w0, w1 = mix32(c, k2), mix32(u32(c + np.uint64(1)), k2)
+    w2, w3 = mul24(w0 >> np.uint64(8), 0x9E3779) ^ w1, mul24(w1 >> np.uint64(8), 0x85EBCB) ^ w0
+    u = np.stack([h for w in (w0, w1, w2, w3) for h in (w & np.uint64(0xFFFF), w >> np.uint64(16))], 1)
+    return u >= np.uint64(min(int(p * 65536.0 + 0.5), 65535))
 
+
+def test_dropout_mask_equals_the_documented_generator(dev):
+    """the keep mask is a pure function of (seed, stream id, element index): the elementwise kernels' masks must equal, bit for
+    bit, the numpy statement of the generator above (element i = lane i%8 of group i//8)."""
+    import numpy as np
+    from visualbert_amd import ops
     for n, p, seed, sid in ((4099, 0.1, 1234, 10), (70000, 0.37, (7 << 32) | 99, 3)):
         x = torch.ones(n, device=dev)
         y = ops.dropout_apply(x, p, seed, sid)
         got = (y != 0).cpu().numpy()
-        want = keep_mask(n, p, seed, sid)
+        want = generator_keep(np.arange((n + 7) // 8), p, seed, sid).reshape(-1)[:n]
         assert np.array_equal(got, want), (n, p, int((got != want).sum()))
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("cfg", [(2, 37, 2, 0.1), (1, 164, 2, 0.1), (1, 300, 1, 0.25)])
+def test_attention_keepbits_equal_the_documented_generator(dev, dt, cfg):
+    """attention-probability dropout: the keep-bits the forward records (and the backward replays) are the same generator,
+    indexed as csrc/attention.hip documents -- probability (head bh, query q, key k) is lane ((k>>4)&1)*4 + (k&3) of group
+    (((bh*S + q)*4 + ((k>>2)&3)) << 5) + (k>>5).  Bit-exact for every kernel variant these shapes select (one-pass S<=192,
+    the prefetching forward at 161..176, the long-sequence path above 256)."""
+    import numpy as np
+    B, S, nh, p = cfg
+    if S > 256 and dt == torch.float32:
+        pytest.skip("fp32 attention is limited to S <= 256 (DESIGN.md section 7)")
+    seed, sid = (5 << 32) | 4242, 7
+    H = nh * 64
+    g = torch.Generator().manual_seed(21)
+    qkv = (0.5 * torch.randn(B, S, 3 * H, generator=g)).to(dt).to(dev)
+    mask_add = torch.zeros(B, S, device=dev)
+    L = _lib.lib()
+    ctx = torch.empty(B, S, H, dtype=dt, device=dev)
+    lse = torch.empty(B, nh, S, device=dev)
+    bits = torch.zeros(B * nh * L.vb_attn_keepbits_words(S), dtype=torch.int64, device=dev)
+    _lib.check(L.vb_attn_fwd(_lib.dtype_code(dt), _lib.ptr(qkv), _lib.ptr(mask_add), _lib.ptr(ctx), _lib.ptr(lse),
+                             _lib.ptr(bits), B, S, nh, 64, p, seed, sid, _lib.stream_ptr()), "vb_attn_fwd")
+    got = decode_keepbits(bits, B, nh, S).view(B * nh, S, S).numpy()
+    bh, q, k = np.meshgrid(np.arange(B * nh), np.arange(S), np.arange(S), indexing="ij")
+    grp = ((((bh * S + q) * 4 + ((k >> 2) & 3)) << 5) + (k >> 5)).astype(np.uint64)
+    lane = ((k >> 4) & 1) * 4 + (k & 3)
+    want = generator_keep(grp.reshape(-1), p, seed, sid)[np.arange(grp.size), lane.reshape(-1)].reshape(got.shape)
+    assert np.array_equal(got, want), int((got != want).sum())
 
 
 @pytest.mark.parametrize("dt", DTYPES)

@@ -14,10 +14,10 @@ arms = sys.argv[2:] or ["81", "90"]            # "90:8" = kernel 90 with the til
 
 
 def select(arm):
-    k, _, stripe = arm.partition(":")
+    k, stripe, dbg = (arm.split(":") + ["", ""])[:3]       # "92::40" = raw developer debug bits 40 (VB_DEV=1)
     _lib.set_opts(nt_kernel=int(k))
     if os.environ.get("VB_DEV") == "1":
-        _lib.dev_lib().vb_gemm_set_debug((int(stripe) << 8) if stripe else 0)
+        _lib.dev_lib().vb_gemm_set_debug(((int(stripe) << 8) if stripe else 0) | (int(dbg) if dbg else 0))
 
 dev = torch.device("cuda", 0)
 M = B * 164

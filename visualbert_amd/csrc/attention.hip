@@ -220,7 +220,10 @@ VB_DEVICE long keep_index(const AttnArgs& a, int bh, int q, int g, int w, int nw
 // with an all-zero upper half.
 // PF (bf16): the Q fragment of a wave's next query block is fetched while the current block computes and pinned until the
 // top of the next iteration (vb_pin) -- one HBM round trip per block leaves the wave's critical path.
-template <typename T, int NKF, bool PF = false>
+// EXACT: every one of the NKF key fragments (and NKS 32-key steps) holds at least one real key -- the launcher's promise for
+// S = 161..176 -- so the per-fragment "is it inside the sequence" branches (46 scalar branches per query block) go, and a
+// chain's first MFMA takes the literal 0 as its C operand instead of four zeroed registers.
+template <typename T, int NKF, bool PF = false, bool EXACT = false>
 VB_KERNEL VB_LAUNCH_BOUNDS2(NT, 3) attn_fwd_kernel(AttnArgs a) {
     constexpr int NKV = (NKF + 1) / 2 * 2;
     constexpr int NK = NKF * 16, NKVK = NKV * 16, NKS = NKV / 2, NW = (NKF + 15) / 16;
@@ -280,7 +283,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(NT, 3) attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
         for (int kf = 0; kf < NKF; ++kf) {
             f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (kf * 16 < S) {
+            if (EXACT || kf * 16 < S) {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) acc = vb_mma(frag_rm(ldsK, kf * 16 + li, ks, lg, T()), qb[ks], acc);
             }
@@ -295,10 +298,16 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(NT, 3) attn_fwd_kernel(AttnArgs a) {
         m = fmaxf(m, __shfl_xor(m, 16));
         m = fmaxf(m, __shfl_xor(m, 32));
         float sum = 0.f;
+        // exp(s - m) = exp2(s * log2(e) - m * log2(e)): one packed fma per two scores instead of a subtract and a multiply each
+        const f32x2 l2e = vb_splat2(1.44269504088896340736f), negm = vb_splat2(-m * 1.44269504088896340736f);
 #pragma unroll
         for (int kf = 0; kf < NKF; ++kf)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { st[kf][r] = fast_exp(st[kf][r] - m); sum += st[kf][r]; }
+            for (int r = 0; r < 4; r += 2) {
+                const f32x2 x = vb_fma2(f32x2{st[kf][r], st[kf][r + 1]}, l2e, negm);
+                st[kf][r] = fast_exp2(x[0]); st[kf][r + 1] = fast_exp2(x[1]);
+                sum += st[kf][r]; sum += st[kf][r + 1];
+            }
         sum += __shfl_xor(sum, 16);
         sum += __shfl_xor(sum, 32);
         const float inv = 1.0f / sum;
@@ -345,7 +354,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(NT, 3) attn_fwd_kernel(AttnArgs a) {
             f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
-                if (ks * 32 < S)
+                if (EXACT || ks * 32 < S)
                     acc = vb_mma(frag_tr(ldsVT, tr_pitch<T>(NKVK), df * 16 + li, ks, lg, T()), pb[ks], acc);
             }
             if (qok) store4(crow + df * 16 + lg * 4, acc);     // lane: query q, d = df*16 + lg*4 + 0..3
@@ -753,13 +762,20 @@ VB_KERNEL VB_LAUNCH_BOUNDS(FNT) attn_bwd_fused_kernel(AttnArgs a) {
             for (int j = 0; j < 8; ++j) { s0 += (float)d0[j] * (float)p0[j]; s1 += (float)d1[j] * (float)p1[j]; }
             s0 = oct_sum(s0); s1 = oct_sum(s1);
             if (sdc == 0) { ldsD[sr] = s0; ldsD[sr + 1] = s1; }
-            if (wave == 0) ldsLse[lane] = q0 + lane < S ? c_lse : INFINITY;            // exp(x - inf) = 0 for padded queries
-            const int i = t;
-            ldsBits[i] = (a.p > 0.f && q0 + i / (4 * NW) < S) ? c_bits[0] : ~(uint64_t)0;
+            // lse in units of log 2 (phase A computes exp2 of one packed fma); exp2(x - inf) = 0 for padded queries
+            if (wave == 0) ldsLse[lane] = q0 + lane < S ? c_lse * 1.44269504088896340736f : INFINITY;
+            // keep words, re-laid for phase A: a lane there needs the SAME 32-bit half (its wave's key fragment) and the same
+            // key group g of the four queries lg*4 + 0..3 -- stored as [qf][lg][g][half][r] they are one 16-byte read instead
+            // of four address computations and four 4-byte reads
+            const int i = t, ql = i >> 2, g = i & 3;
+            const uint64_t kw = (a.p > 0.f && q0 + ql < S) ? c_bits[0] : ~(uint64_t)0;
+            uint32_t* bw = (uint32_t*)ldsBits + (((ql >> 2) * 4 + g) * 8 + (ql & 3));
+            bw[0] = (uint32_t)kw; bw[4] = (uint32_t)(kw >> 32);
         }
     };
     load_chunk(0);
     const float mk = kok ? mk_raw : -INFINITY;
+    const float mk2 = mk * 1.44269504088896340736f, sc2 = a.scale * 1.44269504088896340736f;
     {   // K^T image and a zeroed dS tile
         const u32x4 x0 = zsel(kr < S, kx0), x1 = zsel(kr + 1 < S, kx1);
         const int pitch = tr_pitch<bf16>(FNK);
@@ -800,16 +816,25 @@ VB_KERNEL VB_LAUNCH_BOUNDS(FNT) attn_bwd_fused_kernel(AttnArgs a) {
                         dp = vb_mma(frag_rm(ldsDO, qf * 16 + li, ks, lg, T()), vb[ks], dp);
                     }
                     // lane: key = kf*16 + li (column), queries q0 + qf*16 + lg*4 + r (rows)
-                    const f32x4 lse4 = *(const f32x4*)(ldsLse + qf * 16 + lg * 4);
+                    const f32x4 lse4 = *(const f32x4*)(ldsLse + qf * 16 + lg * 4);         // already times log2(e)
                     const f32x4 d4 = *(const f32x4*)(ldsD + qf * 16 + lg * 4);
+                    // this wave's nibble of the keep words lies in ONE 32-bit half (kf is wave-uniform); the four queries'
+                    // halves are adjacent (see store_chunk); one select per probability yields the factor for both products
+                    const u32x4 w4 = *(const u32x4*)((const uint32_t*)ldsBits + (((qf * 4 + lg) * 4 + (li >> 2)) * 2 + ((kf & 15) >> 3)) * 4);
+                    // p = exp(s * scale + mask - lse) = exp2(s * (scale log2 e) + (mask log2 e - lse log2 e)): two packed
+                    // instructions per two probabilities instead of an fma, a subtract and a multiply each
+                    f32x4 xe;
+#pragma unroll
+                    for (int r = 0; r < 4; r += 2) {
+                        const f32x2 c = vb_splat2(mk2) - f32x2{lse4[r], lse4[r + 1]};
+                        const f32x2 x = vb_fma2(f32x2{s[r], s[r + 1]}, vb_splat2(sc2), c);
+                        xe[r] = x[0]; xe[r + 1] = x[1];
+                    }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int ql = qf * 16 + lg * 4 + r;
-                        const float p = fast_exp(s[r] * a.scale + mk - lse4[r]);
-                        // this wave's nibble of the keep word lies in ONE 32-bit half (kf is wave-uniform): a 4-byte LDS read
-                        // and 32-bit shift / test instead of their 64-bit forms; one select yields the factor for both products
-                        const uint32_t w = ((const uint32_t*)ldsBits)[((ql * 4 + (li >> 2)) * NW + (kf >> 4)) * 2 + ((kf & 15) >> 3)];
-                        const float kscale = ((w >> ((kf & 7) * 4 + (li & 3))) & 1u) ? a.inv_keep : 0.f;
+                        const float p = fast_exp2(xe[r]);
+                        const float kscale = ((w4[r] >> ((kf & 7) * 4 + (li & 3))) & 1u) ? a.inv_keep : 0.f;
                         const float pdrop = p * kscale;
                         const float dpv = dp[r] * kscale;
                         pd[hf][r] = pdrop;
@@ -985,10 +1010,11 @@ int dispatch_nkf(int which, const AttnArgs& a, hipStream_t s) {
         const size_t sm = fwd_smem<T, 11>();
         if constexpr (sizeof(T) == 2) {
             if ((vb_opts_for((void*)s).reserved & 1) == 0) {   // reserved bit 0: A/B switch of the Q prefetch (measurement only)
-                VB_LAUNCH((attn_fwd_kernel<T, 11, true>), dim3((unsigned)(a.B * a.nh)), dim3(NT), sm, s, a);
+                VB_LAUNCH((attn_fwd_kernel<T, 11, true, true>), dim3((unsigned)(a.B * a.nh)), dim3(NT), sm, s, a);
                 return vb_check_launch();
             }
         }
+        // (without the prefetch the branch-free form lets the scheduler hoist every fragment read: 612-1448 bytes of scratch, 4x slower)
         VB_LAUNCH((attn_fwd_kernel<T, 11>), dim3((unsigned)(a.B * a.nh)), dim3(NT), sm, s, a);
         return vb_check_launch();
     }

@@ -368,6 +368,7 @@ def decode_keepbits(bits, B, nh, S):
 
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("cfg", [(2, 40, 2, 0.0), (1, 164, 2, 0.0), (2, 23, 3, 0.1), (1, 164, 1, 0.1),
+                                 (2, 56, 2, 0.1), (1, 112, 2, 0.1),      # VQA / NLVR2 lengths: exact 4- and 7-fragment forwards
                                  (1, 192, 1, 0.1), (2, 177, 2, 0.0),     # edges of the one-pass bf16 backward (12 key fragments)
                                  (1, 300, 1, 0.1), (1, 416, 1, 0.1)])    # 416 = NLVR2 as the reference runs it (2x144 + 128)
 def test_attention_fwd_bwd(dev, dt, cfg):
@@ -841,7 +842,7 @@ def test_dropout_mask_equals_the_documented_generator(dev):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("cfg", [(2, 37, 2, 0.1), (1, 164, 2, 0.1), (1, 300, 1, 0.25)])
+@pytest.mark.parametrize("cfg", [(2, 37, 2, 0.1), (1, 164, 2, 0.1), (1, 112, 2, 0.1), (2, 56, 1, 0.1), (1, 300, 1, 0.25)])
 def test_attention_keepbits_equal_the_documented_generator(dev, dt, cfg):
     """attention-probability dropout: the keep-bits the forward records (and the backward replays) are the same generator,
     indexed as csrc/attention.hip documents -- probability (head bh, query q, key k) is lane ((k>>4)&1)*4 + (k&3) of group

@@ -4,7 +4,7 @@ import torch
 from visualbert_amd import _lib, ops
 dev = torch.device("cuda", 0)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-S, nh = 164, 12
+S, nh = (int(sys.argv[2]) if len(sys.argv) > 2 else 164), 12
 H = nh * 64
 g = torch.Generator().manual_seed(0)
 qkv = (0.5 * torch.randn(B * S, 3 * H, generator=g)).to(torch.bfloat16).to(dev)

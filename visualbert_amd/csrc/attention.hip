@@ -985,7 +985,9 @@ int launch_all(int which, const AttnArgs& a, hipStream_t s) {
         if (sm > kMaxLds) return VB_ERR_UNSUPPORTED;
         VB_LAUNCH((attn_fwd_kernel<T, NKF>), grid, block, sm, s, a);
     } else {
-        if constexpr (sizeof(T) == 2 && NKF <= 12) {
+        // (S <= 64: only 4 of the one-pass kernel's 12 waves own a key fragment -- the two-pass form plus the separate
+        //  bias-gradient pass is faster there: 349 + ~85 us against 483 us per layer at 86 k tokens, S = 56)
+        if constexpr (sizeof(T) == 2 && NKF <= 12 && NKF > 4) {
             if (a.ctx_fwd && a.qkv && a.Sq == a.S && a.S <= FWPB * 16 && vb_opts_for((void*)s).attn_two_pass != 1 &&
                 (long)a.B * a.S * 3 * a.nh * D * 2 < (1L << 32)) {   // one-pass backward (needs the forward output; 32-bit byte offsets)
                 // 64-query chunks (86 KB of LDS, one workgroup per CU): 528-541 us per layer at B=512; 32-query chunks (two
@@ -1006,14 +1008,21 @@ int launch_all(int which, const AttnArgs& a, hipStream_t s) {
 template <typename T>
 int dispatch_nkf(int which, const AttnArgs& a, hipStream_t s) {
     const int nkf = ((a.S + 31) / 32) * 2;          // key fragments, padded to an even count
-    if (which == 0 && (a.S + 15) / 16 == 11) {      // forward at S = 161..176 (BASELINE: 164): exactly 11 fragments of work
-        const size_t sm = fwd_smem<T, 11>();
-        if constexpr (sizeof(T) == 2) {
-            if ((vb_opts_for((void*)s).reserved & 1) == 0) {   // reserved bit 0: A/B switch of the Q prefetch (measurement only)
-                VB_LAUNCH((attn_fwd_kernel<T, 11, true, true>), dim3((unsigned)(a.B * a.nh)), dim3(NT), sm, s, a);
-                return vb_check_launch();
-            }
+    if constexpr (sizeof(T) == 2) {
+        // forward with EXACTLY ceil(S / 16) key fragments of work for the sequence lengths of BASELINE's configurations
+        // (S = 164 pre-training: 11 fragments; NLVR2 S = 112: 7, where the padded-to-even form computed 8; VQA S = 56: 4) -- the
+        // prefetching, branch-free instantiation.  reserved bit 0: A/B switch back to the generic kernels (measurement only).
+        const int nf = (a.S + 15) / 16;
+        if (which == 0 && (nf == 11 || nf == 7 || nf == 4) && (vb_opts_for((void*)s).reserved & 1) == 0) {
+            const dim3 grid((unsigned)(a.B * a.nh));
+            if (nf == 11) VB_LAUNCH((attn_fwd_kernel<T, 11, true, true>), grid, dim3(NT), (fwd_smem<T, 11>()), s, a);
+            else if (nf == 7) VB_LAUNCH((attn_fwd_kernel<T, 7, true, true>), grid, dim3(NT), (fwd_smem<T, 7>()), s, a);
+            else VB_LAUNCH((attn_fwd_kernel<T, 4, true, true>), grid, dim3(NT), (fwd_smem<T, 4>()), s, a);
+            return vb_check_launch();
         }
+    }
+    if (which == 0 && (a.S + 15) / 16 == 11) {      // forward at S = 161..176 without the prefetch (fp32, or the A/B switch)
+        const size_t sm = fwd_smem<T, 11>();
         // (without the prefetch the branch-free form lets the scheduler hoist every fragment read: 612-1448 bytes of scratch, 4x slower)
         VB_LAUNCH((attn_fwd_kernel<T, 11>), dim3((unsigned)(a.B * a.nh)), dim3(NT), sm, s, a);
         return vb_check_launch();

@@ -423,7 +423,8 @@ def test_attention_fwd_bwd(dev, dt, cfg):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("cfg", [(2, 20, 36, 2, 0.0), (2, 36, 20, 2, 0.0), (1, 40, 164, 1, 0.1), (3, 7, 5, 1, 0.0)])
+@pytest.mark.parametrize("cfg", [(2, 20, 36, 2, 0.0), (2, 36, 20, 2, 0.0), (1, 40, 164, 1, 0.1), (3, 7, 5, 1, 0.0),
+                                 (2, 20, 100, 2, 0.1), (1, 30, 56, 1, 0.1)])   # keys at the exact 7- and 4-fragment forwards
 def test_cross_attention_fwd_bwd(dev, dt, cfg):
     """queries and keys / values from different sequences of different lengths (LXRT: language <-> vision): forward and the
     two-pass backward against a torch fp32 reference; keys masked per sample; dropout keep-bits decoded and replayed."""

@@ -51,7 +51,8 @@ const char* vb_version(void);
  *              workgroups per compute unit (91: the same with the copies issued ahead of the fragment reads); 100 = persistent
  *              256x256 tile with four waves, 128x128 outputs each (K / 64 even, else 90); 1 = the generic register-staged kernel.
  *   attn_two_pass: 1 = two-pass attention backward even where the one-pass kernel applies.
- *   reserved: bit 0 = attention forward without the Q-fragment prefetch (A/B measurements); other bits must be 0.
+ *   reserved: bit 0 = attention forward through the generic kernels instead of the exact-fragment, prefetching instantiations
+ *              (S = 49..64, 97..112, 161..176; A/B measurements only); other bits must be 0.
  * vb_stream_set_opts(stream, NULL) forgets the stream's entry (call it before destroying a stream).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct vb_stream_opts {

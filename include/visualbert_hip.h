@@ -220,8 +220,9 @@ int vb_small_linear_bwd(int dtype, const float* dy, const void* x, int64_t ldx, 
  * norms, summed in table order -- bit-reproducible, so data-parallel replicas stay identical); step_counters:
  * int32[n_tensors] (state).
  * touched: optional fp32[n_tensors] on the device; tensor t takes NO step (no moments, no weight decay, no counter
- * increment) when touched[t] == 0 and its gradient norm is 0 -- what `p.grad is None` means to the reference's loop
- * (optimization.py:254-255).  The decision is taken on the device, every step, from data that is identical on every
+ * increment) when touched[t] == 0, its gradient norm is 0 and it has never taken a step (step_counters[t] == 0) -- what
+ * `p.grad is None` means to the reference's loop (optimization.py:254-255; after a parameter's first backward its .grad is
+ * a tensor for good, zeroed by zero_grad(), and the reference steps it every time).  The decision is taken on the device, every step, from data that is identical on every
  * data-parallel rank once the flags have been all-reduced like the gradients (parallel.py).
  * schedule: 0 none, 1 warmup_linear(warmup, t_total).  bf16_shadow may be NULL.
  * Replaces BertAdam.step, optimization.py:239-304 (+ WarmupLinearSchedule :164-173).

@@ -6,6 +6,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -35,3 +37,26 @@ def test_bench_runs_as_a_rank_of_an_existing_launch():
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1 and json.loads(lines[0])["ranks_seen"] == 2
+
+
+@pytest.mark.gpu
+def test_driver_command_two_ranks_end_to_end(dev):
+    """The driver's multi-GPU command, `python bench.py --gpus 2 ...`, executed for real on the one GPU this box has: both
+    ranks drive cuda:0 (VB_BENCH_ONE_DEVICE=1; the process group is gloo because RCCL refuses two ranks on one device).
+    Everything but the transport is the N > 1 path the scaling bench runs: self-spawn through torch.distributed.run, rank
+    environment, per-rank shards, gradient hooks firing during backward, max-over-ranks timing, ONE JSON line from rank 0
+    that still carries cpu_baseline and parity."""
+    if dev.type != "cuda":
+        pytest.skip("needs the GPU")
+    d = _run(["--gpus", "2", "--batch", "8", "--steps", "2", "--warmup", "1", "--cpu-batch", "1", "--no-h2d"],
+             extra_env={"VB_BENCH_ONE_DEVICE": "1"})
+    assert d["n_gpus"] == 2 and d["rccl_ranks_seen"] == 2
+    assert d["config"]["global_batch"] == 16 and d["config"]["parallelism"] == "dp2"
+    assert "overlapped with backward" in d["config"]["grad_allreduce"]
+    assert d["allreduce"] and d["allreduce"]["ranks"] == 2 and d["allreduce"]["bus_GBps"] > 0
+    assert d["cpu_baseline"] and d["cpu_baseline"]["value"] > 0
+    assert d["parity"] and d["parity"]["max_dlogit_vs_fp32_ref"] < 0.1
+    assert d["value"] > 0 and d["final_loss"] == d["final_loss"]
+    single = _run(["--gpus", "1", "--batch", "8", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-h2d",
+                   "--strict-dtype", "none"])
+    assert abs(single["final_loss"] - d["final_loss"]) < 0.5        # different shards / dropout masks: same regime, not equal

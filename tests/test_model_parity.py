@@ -533,3 +533,39 @@ def test_text_only_batch_matches_oracle(dev):
         rg = leaves[n].grad
         assert maxdiff(named[n].grad.detach().cpu(), rg) <= 2e-3 * max(float(rg.norm()), 1e-3), n
     assert float(named["bert.embeddings.projection.weight"].grad.abs().max()) == 0.0   # untouched without regions
+
+
+def test_adam_keeps_stepping_a_tensor_once_it_has_had_a_gradient(dev):
+    """optimization.py:254-255 skips a parameter only while `p.grad is None`.  After a parameter's first backward the
+    reference's zero_grad() leaves a ZERO tensor behind, so on a later text-only batch the visual tables and the region
+    projection still take a step: moments decay and -- for decayed tensors -- the weight decay is applied.  A tensor no
+    batch ever touched (here: nothing, all are touched by the first batch; see test_text_only_batch_matches_oracle for
+    the never-touched side) stays skipped.  Sequence: one batch with regions, then two text-only batches, against the
+    oracle's BertAdam driven with zero gradients in place of None for every tensor that has had a gradient."""
+    from visualbert_amd.model import ModelWrapper, AttrDict
+    cfg, head, sd, batch, g = load_case("micro_pretraining")
+    text_only = {k: v for k, v in batch.items() if not k.startswith("image_")}
+    model = build_model(cfg, head, sd, dev, dropout=0.0)
+    mw = ModelWrapper(AttrDict(train_batch_size=1, learning_rate=1e-3, warmup_proportion=0.1, num_train_epochs=1,
+                               gradient_accumulation_steps=1), 100, model=model)
+    model.train()
+    ref_sd, state, seen = copy.deepcopy(sd), {}, set()
+    for b in (batch, text_only, text_only):
+        mw.step(to_dev(b, dev))
+        leaves = {k: v.detach().clone().requires_grad_(True) for k, v in ref_sd.items()}
+        vo.objective_forward(leaves, cfg, head, mode="fp32", **b)["loss"].backward()
+        grads = {}
+        for k, v in leaves.items():
+            if v.grad is not None:
+                seen.add(k)
+                grads[k] = v.grad
+            elif k in seen:
+                grads[k] = torch.zeros_like(v)              # what .grad holds upstream after zero_grad()
+        with torch.no_grad():
+            vo.bert_adam_step(ref_sd, grads, state, 1e-3, 0.1, 100)
+    named = dict(model.bert.named_parameters())
+    moved = float((sd["bert.embeddings.projection.weight"] - ref_sd["bert.embeddings.projection.weight"]).abs().max())
+    assert moved > 0
+    for n in ("bert.embeddings.projection.weight", "bert.embeddings.token_type_embeddings_visual.weight",
+              "bert.embeddings.position_embeddings_visual.weight", "bert.embeddings.word_embeddings.weight"):
+        assert maxdiff(named[n].detach().cpu(), ref_sd[n]) <= 2e-6, n

@@ -11,8 +11,14 @@ L = _knobs.L
 g = torch.Generator().manual_seed(123)
 bad = 0
 n_checks = 0
-for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 6):
-    for (m, n, k) in [(20992, 768, 768), (20992, 2304, 768), (5248, 3072, 768), (20992, 768, 3072), (1300, 1000, 192), (4096, 4096, 1024)]:
+BENCH_ROWS = "--bench-rows" in sys.argv              # add bench.py's own M = 1024 x 164 rows (tests/test_bench_shape.py)
+NT_SHAPES = [(20992, 768, 768), (20992, 2304, 768), (5248, 3072, 768), (20992, 768, 3072), (1300, 1000, 192), (4096, 4096, 1024)]
+TN_GROUPS = [(20992, [(768, 3072), (3072, 768), (768, 768), (2304, 768)]), (2496, [(30522, 768)]), (4608, [(768, 2048), (264, 520)])]
+if BENCH_ROWS:
+    NT_SHAPES += [(167936, 768, 768), (167936, 2304, 768), (167936, 768, 3072)]
+    TN_GROUPS += [(167936, [(768, 3072), (3072, 768), (768, 768), (2304, 768)])]
+for it in range(int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 6):
+    for (m, n, k) in NT_SHAPES:
         a = (torch.randn(m, k, generator=g) * 0.5).to(torch.bfloat16).to(dev)
         w = (torch.randn(n, k, generator=g) * 0.1).to(torch.bfloat16).to(dev)
         ref = a.float() @ w.float().t()
@@ -25,7 +31,7 @@ for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 6):
             if not err < 2e-3:
                 bad += 1; print("NT MISMATCH", it, (m, n, k), variant, wgs, err)
     _knobs.variant(1); _knobs.wgs(0)
-    for tokens, shapes in [(20992, [(768, 3072), (3072, 768), (768, 768), (2304, 768)]), (2496, [(30522, 768)]), (4608, [(768, 2048), (264, 520)])]:
+    for tokens, shapes in TN_GROUPS:
         dys = [ops.alloc2d(tokens, o, torch.bfloat16, dev) for o, _ in shapes]
         xs = [ops.alloc2d(tokens, i, torch.bfloat16, dev) for _, i in shapes]
         for t in dys + xs:

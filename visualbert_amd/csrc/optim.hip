@@ -80,11 +80,15 @@ VB_DEVICE float schedule_mult(const AdamHyper& h, int step) {
     return (float)r;
 }
 
-// a tensor no backward pass wrote to this step (and whose gradient is zero): the reference's `if p.grad is None: continue`
-// (optimization.py:254-255).  Device-side, per step: no host-cached decision can go stale between data-parallel ranks.
-VB_DEVICE bool adam_skips(const float* touched, const float* norm2, const AdamHyper& h, long tid) {
-    if (!touched || touched[tid] != 0.f) return false;
-    return !(h.max_grad_norm > 0.f && norm2[tid] > 0.f);
+// a tensor no backward pass has EVER written to (and whose gradient is zero): the reference's `if p.grad is None: continue`
+// (optimization.py:254-255).  .grad stops being None at a parameter's first backward and zero_grad() leaves a zero tensor
+// behind from then on, so the skip is sticky the other way round: once a tensor has taken a step (its counter is > 0) it
+// takes every later step too (weight decay, moment decay, counter) even when this step wrote nothing to it.  Device-side,
+// per step: no host-cached decision can go stale between data-parallel ranks.  The gradient norms are always computed when
+// flags are given (host side below), so an unrecorded non-zero gradient is never dropped.
+VB_DEVICE bool adam_skips(const float* touched, const float* norm2, const int* steps, long tid) {
+    if (!touched || touched[tid] != 0.f || steps[tid] > 0) return false;
+    return !(norm2[tid] > 0.f);
 }
 
 VB_KERNEL VB_LAUNCH_BOUNDS(NT) adam_update_kernel(float* params, const float* grads, float* m, float* v, bf16* shadow,
@@ -95,7 +99,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) adam_update_kernel(float* params, const float* gr
     const int64_t* te = tensors + tid * 4;
     const long t_off = te[0], sh_off = te[2], flags = te[3];
     if (!(flags & 1)) return;
-    if (adam_skips(touched, norm2, h, tid)) return;
+    if (adam_skips(touched, norm2, steps, tid)) return;
     const float wd = (flags & 2) ? h.weight_decay : 0.0f;
     float clip = 1.0f;
     if (h.max_grad_norm > 0.f) {
@@ -117,9 +121,9 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) adam_update_kernel(float* params, const float* gr
     }
 }
 
-VB_KERNEL adam_step_inc_kernel(int* steps, const int64_t* tensors, int n, const float* touched, const float* norm2, AdamHyper h) {
+VB_KERNEL adam_step_inc_kernel(int* steps, const int64_t* tensors, int n, const float* touched, const float* norm2) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && (tensors[(long)i * 4 + 3] & 1) && !adam_skips(touched, norm2, h, i)) steps[i] += 1;
+    if (i < n && (tensors[(long)i * 4 + 3] & 1) && !adam_skips(touched, norm2, steps, i)) steps[i] += 1;
 }
 
 VB_KERNEL VB_LAUNCH_BOUNDS(NT) shadow_refresh_kernel(const float* params, bf16* shadow, const int64_t* chunks,
@@ -192,7 +196,7 @@ extern "C" int vb_bert_adam_step(float* params, const float* grads, float* exp_a
     if (n_chunks <= 0 || n_tensors <= 0 || (schedule != 0 && schedule != 1)) return VB_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     AdamHyper h{lr, b1, b2, eps, max_grad_norm, warmup, t_total, weight_decay, schedule};
-    if (max_grad_norm > 0.f) {
+    if (max_grad_norm > 0.f || touched) {                   // the skip decision reads the norms too
         float* partial = norm2_ws + n_tensors;              // [n_chunks]
         VB_LAUNCH(adam_norm_kernel, dim3((unsigned)n_chunks), dim3(NT), 64, s, grads, chunk_table, partial);
         VB_LAUNCH(adam_norm_finish_kernel, dim3((unsigned)n_chunks), dim3(64), 0, s, chunk_table, n_chunks,
@@ -201,7 +205,7 @@ extern "C" int vb_bert_adam_step(float* params, const float* grads, float* exp_a
     VB_LAUNCH(adam_update_kernel, dim3((unsigned)n_chunks), dim3(NT), 0, s, params, grads, exp_avg, exp_avg_sq,
               (bf16*)bf16_shadow, chunk_table, tensor_table, (const float*)norm2_ws, (const int*)step_counters, touched, h);
     VB_LAUNCH(adam_step_inc_kernel, dim3((unsigned)((n_tensors + 63) / 64)), dim3(64), 0, s, step_counters,
-              tensor_table, n_tensors, touched, (const float*)norm2_ws, h);
+              tensor_table, n_tensors, touched, (const float*)norm2_ws);
     return vb_check_launch();
 }
 

@@ -236,6 +236,10 @@ class FeatureStager(object):
             for k, v in host_batch.items():
                 if v.is_pinned():                       # the feature store already lives in pinned memory
                     pin = v
+                    if prev is not None:
+                        # the caller may be re-filling a pinned slab it handed to this slot before (RegionFeatureStore.
+                        # read_batch(out=...) rings): the slot's previous DMA out of host memory must have executed
+                        prev.synchronize()
                 else:
                     key = (slot, k)
                     pin = self._pinned.get(key)

@@ -307,6 +307,9 @@ class BertAdam(Optimizer):
                 if sch.get("cycles") is not None:
                     kw["cycles"] = sch["cycles"]
                 group["schedule"] = _SCHEDULE_CLASSES[sch["class"]](**kw)
+        # the fused state caches weight decay, the decay / optimise flags and the device tables: rebuild it from the
+        # hyper-parameters just restored (the moments and counters are overwritten from the checkpoint right below)
+        self._fused = None
         f = self.fused()
         sch0 = self.param_groups[0]["schedule"]
         f["code"] = 1 if type(sch0) is WarmupLinearSchedule else (0 if (type(sch0) is ConstantLR or sch0.t_total < 0) else -1)

@@ -156,11 +156,21 @@ class DataParallelGradSync(object):
         import ctypes
         sp = _lib.stream_ptr()
         if on:
+            # only persistent_workgroups changes: whatever else the user attached to this stream (nt_kernel for an A/B run,
+            # attn_two_pass) is read back first and restored when the reservation ends
+            cur = _lib.StreamOpts(0, 0, 0, 0)
+            _lib.check(_lib.lib().vb_stream_get_opts(sp, ctypes.byref(cur)), "vb_stream_get_opts")
+            self._saved_opts = (cur.persistent_workgroups, cur.nt_kernel, cur.attn_two_pass, cur.reserved)
             cus = torch.cuda.get_device_properties(self.obj.arena.grad.device).multi_processor_count
-            o = _lib.StreamOpts(max(8, (cus - comm_cus()) // 8 * 8), 0, 0, 0)
+            o = _lib.StreamOpts(max(8, (cus - comm_cus()) // 8 * 8), cur.nt_kernel, cur.attn_two_pass, cur.reserved)
             _lib.check(_lib.lib().vb_stream_set_opts(sp, ctypes.byref(o)), "vb_stream_set_opts")
         else:
-            _lib.check(_lib.lib().vb_stream_set_opts(sp, None), "vb_stream_set_opts")
+            saved = getattr(self, "_saved_opts", (0, 0, 0, 0))
+            if any(saved):
+                o = _lib.StreamOpts(*saved)
+                _lib.check(_lib.lib().vb_stream_set_opts(sp, ctypes.byref(o)), "vb_stream_set_opts")
+            else:
+                _lib.check(_lib.lib().vb_stream_set_opts(sp, None), "vb_stream_set_opts")
 
     def _layer_ready(self, layer_index):
         # everything above this layer in the graph has finished enqueuing its backward

@@ -38,7 +38,7 @@ PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBPS = 8000.0
 
 # --dtype -> compute dtype handed to the model (visualbert_amd.modeling.set_compute_dtype)
-DTYPES = {"bf16": "bfloat16", "fp32": "float32"}
+DTYPES = {"bf16": "bfloat16", "fp32": "float32", "bf16x3": "bf16x3"}
 
 # BASELINE.json configs -> (head, text tokens, regions, feature width, label for config.workload)
 WORKLOADS = {
@@ -49,6 +49,13 @@ WORKLOADS = {
     "nlvr2": dict(head="nlvr", T=40, R=72, Dv=2048, batch=1536, cfg="configs[4]",
                   what="NLVR2 paired-image fine-tuning step (2 x 36 regions, 2-way head) incl. dropout, BertAdam"),
 }
+
+
+def compute_dtype_of(name):
+    """what the model's compute_dtype argument takes: a torch dtype, or the string "bf16x3" (split-operand GEMM mode)"""
+    import torch
+    v = DTYPES[name]
+    return v if v == "bf16x3" else getattr(torch, v)
 
 
 def flops_per_sample(L, H, I, V, S, R, Dv, head):
@@ -172,8 +179,8 @@ def parity_side_batch(model, dev, head, T, R):
                 top1_agree=float((lg.argmax(-1) == ref["logits"].argmax(-1)).float().mean()),
                 dloss=abs(float(out["loss"]) - float(ref["loss"])), logits_absmax=float(ref["logits"].abs().max()),
                 north_star_tolerance=1e-3,
-                note="bf16 MFMA operands cannot meet 1e-3 (profiles/r02_bf16_error_budget.txt); the fp32 kernels do "
-                     "(5e-6 at BERT-base, tests/test_parity_at_scale.py)")
+                note="plain bf16 MFMA operands cannot meet 1e-3 (profiles/r02_bf16_error_budget.txt); the split-operand bf16x3 "
+                     "mode and the fp32 kernels do (tests/test_parity_at_scale.py; `strict_mode` in this line)")
 
 
 def strict_mode(dev, head, T, R, Dv, V, batch, steps, dtype_name, flops_per_sample_):
@@ -187,7 +194,7 @@ def strict_mode(dev, head, T, R, Dv, V, batch, steps, dtype_name, flops_per_samp
     torch.manual_seed(1234)
     config = BertConfig(V, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072)
     model = VisualBERTFixedImageEmbedding(config=config, training_head_type=head, visual_embedding_dim=Dv,
-                                          compute_dtype=getattr(torch, DTYPES[dtype_name])).to(dev)
+                                          compute_dtype=compute_dtype_of(dtype_name)).to(dev)
     model.train()
     mw = ModelWrapper(AttrDict(train_batch_size=batch, learning_rate=5e-5, warmup_proportion=0.1, num_train_epochs=1,
                                gradient_accumulation_steps=1), 1000 * batch, model=model)
@@ -292,7 +299,7 @@ def main():
     ap.add_argument("--workload", default="pretrain", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (weak scaling); 0 = the workload's default")
     ap.add_argument("--dtype", default="bf16", choices=list(DTYPES))
-    ap.add_argument("--strict-dtype", default="fp32", choices=[d for d in DTYPES if d != "bf16"] + ["none"],
+    ap.add_argument("--strict-dtype", default="both", choices=[d for d in DTYPES if d != "bf16"] + ["both", "none"],
                     help="after the timed bf16 run, also time a short run of the mode that meets the north-star's 1e-3 "
                          "logit tolerance and report it as `strict_mode` (rank 0, N = 1)")
     ap.add_argument("--strict-batch", type=int, default=128)
@@ -359,7 +366,7 @@ def main():
     T, R = args.text_len or wl["T"], args.regions or wl["R"]
     S = T + R
     B = args.batch or wl["batch"]
-    dtype = getattr(torch, DTYPES[args.dtype])
+    dtype = compute_dtype_of(args.dtype)
     torch.manual_seed(1234)
     config = BertConfig(V, hidden_size=H, num_hidden_layers=L, num_attention_heads=H // 64, intermediate_size=I)
     model = VisualBERTFixedImageEmbedding(config=config, training_head_type=head, visual_embedding_dim=Dv,
@@ -449,7 +456,7 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = B * world * args.steps / elapsed
     fps = flops_per_sample(L, H, I, V, S, R, Dv, head)
-    peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS
+    peak = PEAK_BF16_TFLOPS if args.dtype in ("bf16", "bf16x3") else PEAK_F32_TFLOPS     # bf16x3 runs on the bf16 matrix pipe
 
     if rank == 0:
         roofline = None
@@ -482,10 +489,13 @@ def main():
                 roofline["hbm_bound"] = hbm_bound_kernels(model, B * S, H, dev, optimizer=mw.optimizer,
                                                             V=30522 if head == "pretraining" else 0)
         cpu = par = strict = None
-        if not args.no_parity and dtype == torch.bfloat16:
+        if not args.no_parity:
             par = parity_side_batch(model, dev, head, T, R)
         if world == 1 and args.strict_dtype != "none" and args.dtype == "bf16":
-            strict = strict_mode(dev, head, T, R, Dv, V, args.strict_batch, args.strict_steps, args.strict_dtype, fps)
+            kinds = ["bf16x3", "fp32"] if args.strict_dtype == "both" else [args.strict_dtype]
+            strict = strict_mode(dev, head, T, R, Dv, V, args.strict_batch, args.strict_steps, kinds[0], fps)
+            for extra in kinds[1:]:
+                strict[extra + "_kernels"] = strict_mode(dev, head, T, R, Dv, V, args.strict_batch, args.strict_steps, extra, fps)
         if not args.no_cpu_baseline:
             cpu = cpu_baseline(args.cpu_batch, T, R, head)
         metric = {"pretrain": "pretrain samples/sec (BERT-base, 36 regions+128 tok)",

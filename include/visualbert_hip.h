@@ -19,9 +19,9 @@
  *   - row-major everywhere; `ld*` are leading dimensions in ELEMENTS.
  *   - re-entrant per stream: entry points keep no process-wide tuning state.  Launch options are attached to a STREAM
  *     (vb_stream_set_opts) and read by the calls enqueued on that stream only; the RCCL communicator is an object the
- *     caller owns (vb_comm_*).  The one process-wide facility is the opt-in HIP-event recorder vb_gemm_profile (a
- *     measurement aid).  Knobs that change results or exist only for kernel analysis are NOT in this header: they live
- *     in visualbert_hip_dev.h and exist only in libvisualbert_hip_dev.so (built with -DVB_DEV_KNOBS).
+ *     caller owns (vb_comm_*); the optional launch timing is attached to a stream as well (vb_stream_profile).  Knobs that
+ *     change results or exist only for kernel analysis are NOT in this header: they live in visualbert_hip_dev.h and exist
+ *     only in libvisualbert_hip_dev.so (built with -DVB_DEV_KNOBS).
  */
 #ifndef VISUALBERT_HIP_H
 #define VISUALBERT_HIP_H
@@ -32,7 +32,14 @@
 extern "C" {
 #endif
 
-enum { VB_F32 = 0, VB_BF16 = 1 };
+enum { VB_F32 = 0, VB_BF16 = 1,
+       /* GEMM entry points only (vb_gemm, vb_wgrad_grouped, vb_bert_layer_*): "bf16x3" split-operand mode.  Activations,
+        * gradients and epilogue operands are fp32; each GEMM operand is handed over SPLIT (vb_split_bf16): a row of leading
+        * dimension ld holds a bf16 hi plane in columns [0, ld/2) and a bf16 lo plane in [ld/2, ld), x = hi + lo to ~2^-17
+        * relative.  The kernels form hi.hi + lo.hi + hi.lo on the bf16 matrix pipe with fp32 accumulation (the lo.lo term,
+        * ~2^-18 relative, is dropped): fp32-class results (BERT-base logits within ~1e-5 of the fp32 reference, the
+        * north-star asks 1e-3) at three bf16 MFMA passes instead of the ~16x slower fp32-input MFMA. */
+       VB_BF16X3 = 2 };
 enum { VB_KCONTIG = 0, VB_KSTRIDED = 1 };
 enum { VB_ACT_NONE = 0, VB_ACT_GELU = 1, VB_ACT_TANH = 2, VB_ACT_GELU_GRAD = 3,
        VB_ACT_GELU_SAVE_GRAD = 4, VB_ACT_MUL_AUX = 5 };
@@ -51,8 +58,7 @@ const char* vb_version(void);
  *              workgroups per compute unit (91: the same with the copies issued ahead of the fragment reads); 100 = persistent
  *              256x256 tile with four waves, 128x128 outputs each (K / 64 even, else 90); 1 = the generic register-staged kernel.
  *   attn_two_pass: 1 = two-pass attention backward even where the one-pass kernel applies.
- *   reserved: bit 0 = attention forward through the generic kernels instead of the exact-fragment, prefetching instantiations
- *              (S = 49..64, 97..112, 161..176; A/B measurements only); other bits must be 0.
+ *   reserved: must be 0 (VB_ERR_ARG otherwise).
  * vb_stream_set_opts(stream, NULL) forgets the stream's entry (call it before destroying a stream).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct vb_stream_opts {
@@ -84,6 +90,8 @@ int vb_stream_get_opts(void* stream, vb_stream_opts* out);
  * Replaces: nn.Linear forward/backward at modeling.py:232-234, 271, 303, 316, 383-385, 398, 419, 451,
  *           1220 and the GELU of :56-61 fused behind :303 / :398.
  * ---------------------------------------------------------------------------------------------- */
+/*   dtype VB_BF16X3: A [M, lda] and B [N, ldb] are split operands (see the enum), both K-contiguous, K % 64 == 0,
+ *   K <= lda / 2, K <= ldb / 2, lda and ldb multiples of 16; out_dtype VB_F32; bias / addend / aux / C are fp32. */
 int vb_gemm(int dtype, int out_dtype, int a_layout, int b_layout,
             const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
             int M, int N, int K, float alpha, const float* alpha_dev, const float* bias,
@@ -254,6 +262,13 @@ int vb_prepare_inputs(const int64_t* input_mask, const int64_t* image_dim, const
 int vb_zero(void* dst, int64_t bytes, void* stream);
 /* elementwise dtype conversion (VB_F32 / VB_BF16 in any combination) */
 int vb_cast(int src_dtype, const void* src, int dst_dtype, void* dst, int64_t n, void* stream);
+/* Split operands of the VB_BF16X3 GEMM mode.  src: fp32 [rows, cols] (ld_src); dst: bf16 [rows, ld_dst], ld_dst a multiple
+ * of 16 with cols <= ld_dst / 2:  dst[r, c] = hi = bf16(src[r, c]),  dst[r, ld_dst/2 + c] = bf16(src[r, c] - hi); the columns
+ * cols .. ld_dst/2 - 1 of both planes are written as zeros (so a GEMM may reduce over whole K tiles of a padded operand).
+ * vb_split_bf16_t writes the TRANSPOSE: dst[c, r] and dst[c, ld_dst/2 + r] for src[r, c] (dst: bf16 [cols, ld_dst],
+ * rows <= ld_dst / 2, pad columns zeroed) -- the W^T operands of the dgrad GEMMs. */
+int vb_split_bf16(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows, int cols, void* stream);
+int vb_split_bf16_t(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, int rows, int cols, void* stream);
 /* nn.Dropout on a contiguous T[n] (modeling.py:1495, 1509, 1557: the [B, H] state in front of the multichoice / VQA / NLVR2
  * heads): y = keep ? x / (1 - p) : 0, keep-bits from (seed, stream_id, element index).  Its own backward: call it on dy with
  * the same seed and stream_id.  x == y (in place) is allowed. */
@@ -318,14 +333,15 @@ int vb_bert_layer_bwd(int dtype, const void* h_in, const float* mask_add, const 
                       int B, int S, int H, int I, int nh, float p_hidden, float p_attn,
                       uint64_t seed, uint32_t sid, void* stream);
 
-/* Optional HIP-event timing of every vb_gemm launch (measurement aid for bench.py's roofline object):
- * vb_gemm_profile(1) starts recording an event pair around each launch on the launch stream,
- * vb_gemm_profile_read() (after a device synchronise) returns per-launch {milliseconds, algorithmic FLOPs
- * 2MNK, key}; key bits: 8 = fp32 operands (else bf16), 4 = fp32 output, 2 = A K-strided, 1 = B K-strided,
- * 16 = 256x256-tile kernel, 32 = experimental pipelined variant (neither: 256x128 pipelined kernel when bits 1,2 are 0).
- * vb_gemm_profile(0) stops and frees the events. */
-int vb_gemm_profile(int enable);
-int64_t vb_gemm_profile_read(double* ms, double* flops, int* key, int64_t max_records);
+/* Optional per-stream timing of the GEMM launches (what bench.py's roofline object is measured with, over its timed region):
+ * vb_stream_profile(stream, 1) makes every later vb_gemm / vb_wgrad_grouped launch ENQUEUED ON THAT STREAM record a HIP
+ * event pair around itself (other streams are unaffected; nothing is recorded by default);
+ * vb_stream_profile_read(stream, ...) (after synchronising the stream) returns per-launch {milliseconds, algorithmic FLOPs
+ * 2MNK, key}; key bits: 8 = fp32 operands (else bf16), 4 = fp32 output, 2 = A K-strided, 1 = B K-strided, 16 = 256x256-tile
+ * kernel, 64 = two-workgroup 256x128 kernel, 256 = split-operand (bf16x3) mode.  vb_stream_profile(stream, 0) stops and frees
+ * the events. */
+int vb_stream_profile(void* stream, int enable);
+int64_t vb_stream_profile_read(void* stream, double* ms, double* flops, int* key, int64_t max_records);
 
 /* Weight gradients of a group of Linears that saw the same tokens (the four of an encoder layer), one launch:
  *   dw[i][n_out[i], n_in[i]] (fp32, ld_dw[i]) += alpha * dy[i]^T x[i],   dy[i]: [tokens, n_out[i]] (T, ld_dy[i]),

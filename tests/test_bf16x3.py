@@ -1,0 +1,181 @@
+"""The split-operand GEMM mode ("bf16x3", VB_BF16X3 in include/visualbert_hip.h): fp32 activations, every GEMM operand
+split into bf16 hi | lo planes, hi.hi + lo.hi + hi.lo on the bf16 matrix pipe with fp32 accumulation.  This is the mode
+that meets BASELINE.json's "logits within 1e-3" on the MFMA path the north-star names (plain bf16 operands cannot:
+profiles/r02_bf16_error_budget.txt) -- so the bounds here are fp32-class, not bf16-class:
+
+  * vb_split_bf16 / vb_split_bf16_t: hi + lo reproduces x to 2^-16 relative, planes and zero padding where the ABI says;
+  * vb_gemm(VB_BF16X3): every kernel that carries the mode (generic, two-barrier 128 / 256-row tiles, two-workgroup 256x128)
+    with every epilogue the training step uses, split-K, ragged N, against fp64 -- relative error <= 3e-5 of max|ref|
+    (plain bf16 operands: ~4e-3);
+  * vb_wgrad_grouped(VB_BF16X3), the dgrad through split W^T, the ops.gemm fallbacks to the exact fp32 kernels;
+The whole model in this mode against the goldens of the REAL reference: tests/test_model_parity.py (every micro case is run
+with mode = fp32 AND mode = bf16x3 at the same bounds) and tests/test_parity_at_scale.py (BERT-base, BASELINE configs 1 / 3 / 4).
+Reference lines replaced: the nn.Linear calls of pytorch_pretrained_bert/modeling.py:232-234, 271, 303, 316, 383-385, 398,
+419, 1220 and their autograd."""
+import ctypes
+import math
+
+import pytest
+import torch
+
+from visualbert_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def split(dev, x, half=None):
+    rows, cols = x.shape
+    half = half or (cols + 7) // 8 * 8
+    buf = torch.full((rows, 2 * half), 9.0, dtype=torch.bfloat16, device=dev)
+    _lib.check(_lib.lib().vb_split_bf16(_lib.ptr(x), x.stride(0), _lib.ptr(buf), 2 * half, rows, cols, _lib.stream_ptr()),
+               "vb_split_bf16")
+    return buf
+
+
+def gemm_x3(dev, A, B, M, N, K, bias=None, act=0, addend=None, aux_in=None, aux_out=None, acc=None, alpha=1.0,
+            alpha_dev=None, colsum=None):
+    """A [M, K], B [N, K] fp32 -> C fp32 through vb_gemm(VB_BF16X3) on freshly split operands"""
+    L = _lib.lib()
+    As, Bs = split(dev, A), split(dev, B)
+    C = acc if acc is not None else torch.full((M, N), 7.0, dtype=torch.float32, device=dev)
+    aux = aux_in if aux_in is not None else aux_out
+    rc = L.vb_gemm(_lib.VB_BF16X3, _lib.VB_F32, 0, 0, _lib.ptr(As), As.stride(0), _lib.ptr(Bs), Bs.stride(0), _lib.ptr(C),
+                   C.stride(0), M, N, K, alpha, _lib.ptr(alpha_dev), _lib.ptr(bias), _lib.ptr(addend),
+                   addend.stride(0) if addend is not None else 0, act, _lib.ptr(aux_in), _lib.ptr(aux_out),
+                   aux.stride(0) if aux is not None else 0, 1 if acc is not None else 0, _lib.ptr(colsum), _lib.stream_ptr())
+    _lib.check(rc, "vb_gemm(bf16x3)")
+    return C
+
+
+def test_split_planes_reconstruct_the_input(dev):
+    g = torch.Generator().manual_seed(1)
+    x = (torch.randn(37, 100, generator=g) * torch.logspace(-6, 4, 100)).to(dev)       # ten decades of magnitude
+    x[3, 5] = 0.0
+    half = 104
+    buf = split(dev, x)
+    hi, lo = buf[:, :100].float(), buf[:, half:half + 100].float()
+    assert torch.equal(hi, x.to(torch.bfloat16).float())                               # hi is the RNE bf16 of x
+    err = (hi + lo - x).abs()
+    assert bool((err <= 2.0 ** -16 * x.abs()).all())                                   # 16 significand bits survive
+    assert float(buf[:, 100:half].float().abs().max()) == 0.0 and float(buf[:, half + 100:].float().abs().max()) == 0.0
+    # transposed form, zero padded to 64 rows of the source per plane
+    L = _lib.lib()
+    ldt = 2 * 64
+    bt = torch.full((100, ldt), 9.0, dtype=torch.bfloat16, device=dev)
+    _lib.check(L.vb_split_bf16_t(_lib.ptr(x), x.stride(0), _lib.ptr(bt), ldt, 37, 100, _lib.stream_ptr()), "vb_split_bf16_t")
+    assert torch.equal(bt[:, :37].float(), hi.t()) and torch.equal(bt[:, 64:64 + 37].float(), lo.t())
+    assert float(bt[:, 37:64].float().abs().max()) == 0.0 and float(bt[:, 64 + 37:].float().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("variant", [0, 1, 22, 42, 90])
+def test_gemm_bf16x3_epilogues_against_fp64(dev, variant):
+    """variant: vb_stream_opts.nt_kernel (0 = chosen from the shape, 1 = generic register-staged kernel, 22 / 42 = the
+    two-barrier LDS-direct kernels, 90 = two workgroups per CU)"""
+    M, N, K = 530, 392, 192
+    g = torch.Generator().manual_seed(20 + variant)
+    A = (torch.randn(M, K, generator=g) * 0.5).to(dev)
+    B = (torch.randn(N, K, generator=g) * 0.2).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    base = (A.double() @ B.double().t())
+    lim = lambda ref: 3e-5 * max(1.0, float(ref.abs().max()))
+    gprime = lambda x: 0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
+    with _lib.stream_opts(nt_kernel=variant):
+        C = gemm_x3(dev, A, B, M, N, K, bias=bias)
+        ref = base + bias.double()
+        assert float((C.double() - ref).abs().max()) <= lim(ref)
+        # what plain bf16 operands give on the same problem: two orders of magnitude more
+        err_bf16 = float(((A.to(torch.bfloat16).double() @ B.to(torch.bfloat16).double().t()) - base).abs().max())
+        assert err_bf16 > 30 * float((C.double() - ref).abs().max())
+        # FFN-in forward: bias + GELU, GELU' saved (fp32)
+        aux = torch.zeros(M, N, device=dev)
+        C = gemm_x3(dev, A, B, M, N, K, bias=bias, act=_lib.VB_ACT_GELU_SAVE_GRAD, aux_out=aux)
+        assert float((C.double() - torch.nn.functional.gelu(ref)).abs().max()) <= 2 * lim(ref)      # A&S erf: 1.5e-7 abs
+        assert float((aux.double() - gprime(ref)).abs().max()) <= 2 * lim(ref)
+        aux.zero_()
+        C = gemm_x3(dev, A, B, M, N, K, bias=bias, act=_lib.VB_ACT_GELU, aux_out=aux)
+        assert float((aux.double() - ref).abs().max()) <= lim(ref)
+        # FFN-out dgrad: x saved GELU' + column sums
+        pre = torch.randn(M, N, generator=g).to(dev)
+        cs = torch.ones(N, device=dev)
+        C = gemm_x3(dev, A, B, M, N, K, act=_lib.VB_ACT_MUL_AUX, aux_in=pre, colsum=cs)
+        ref2 = base * pre.double()
+        assert float((C.double() - ref2).abs().max()) <= lim(ref2)
+        assert float((cs.double() - (1.0 + ref2.sum(0))).abs().max()) <= 1e-4 * max(1.0, float(ref2.sum(0).abs().max()))
+        # residual addend; accumulate with alpha on the device
+        add_t = torch.randn(M, N, generator=g).to(dev)
+        C = gemm_x3(dev, A, B, M, N, K, addend=add_t)
+        assert float((C.double() - (base + add_t.double())).abs().max()) <= lim(base)
+        acc = torch.randn(M, N, generator=g).to(dev)
+        acc0 = acc.double().clone()
+        ad = torch.tensor([0.5], device=dev)
+        C = gemm_x3(dev, A, B, M, N, K, acc=acc, alpha=2.0, alpha_dev=ad)
+        assert float((C.double() - (acc0 + base)).abs().max()) <= lim(base)
+        # ragged N (the vocabulary-sized decoder, the 3129 VQA answers)
+        Nr = N - 5
+        C = gemm_x3(dev, A, B[:Nr].contiguous(), M, Nr, K, bias=bias[:Nr].contiguous())
+        assert float((C.double() - ref[:, :Nr]).abs().max()) <= lim(ref)
+
+
+def test_gemm_bf16x3_split_k_accumulates(dev):
+    """few output tiles, long reduction, fp32 accumulator: the launcher slices K (here over the 3 x K/64 virtual tiles of the
+    split-operand loop) and adds the partial tiles with atomics -- the MLM decoder's dgrad over the labelled rows"""
+    M, N, K = 128, 128, 1024
+    g = torch.Generator().manual_seed(5)
+    A = (torch.randn(M, K, generator=g) * 0.5).to(dev)
+    B = (torch.randn(N, K, generator=g) * 0.2).to(dev)
+    acc = torch.zeros(M, N, device=dev)
+    C = gemm_x3(dev, A, B, M, N, K, acc=acc)
+    ref = A.double() @ B.double().t()
+    assert float((C.double() - ref).abs().max()) <= 3e-5 * float(ref.abs().max())
+
+
+def test_gemm_bf16x3_rejects_what_it_cannot_split(dev):
+    L = _lib.lib()
+    A = torch.zeros(64, 2 * 96, dtype=torch.bfloat16, device=dev)
+    C = torch.zeros(64, 64, device=dev)
+    args = lambda K, al, ld: (_lib.VB_BF16X3, _lib.VB_F32, al, 0, _lib.ptr(A), ld, _lib.ptr(A), ld, _lib.ptr(C), 64, 64, 64, K, 1.0,
+                              None, None, None, 0, 0, None, None, 0, 0, None, _lib.stream_ptr())
+    assert L.vb_gemm(*args(96, 0, 192)) == -3          # K not a whole number of 64-wide tiles
+    assert L.vb_gemm(*args(64, 1, 192)) == -3          # K-strided operand
+    assert L.vb_gemm(*args(128, 0, 192)) == -3         # K > ld / 2: no room for the lo plane
+    assert L.vb_gemm(*args(64, 0, 192)) == 0
+
+
+@pytest.mark.parametrize("tokens", [192, 100])
+def test_wgrad_and_dgrad_through_split_operands(dev, tokens):
+    """ops.linear_wgrad / linear_dgrad under x3_scope: 192 tokens take the grouped transposing-read kernel three times
+    (hi.hi, lo.hi, hi.lo planes), 100 tokens its register-staged fallback; the dgrad reads the split W^T shadow; a reduction
+    length that is not a multiple of 64 (the 3129-answer VQA head) silently takes the exact fp32 kernels."""
+    from visualbert_amd import ops
+    g = torch.Generator().manual_seed(tokens)
+    n_out, n_in = 136, 128
+    dy = (torch.randn(tokens, n_out, generator=g) * 0.1).to(dev)
+    x = (torch.randn(tokens, n_in, generator=g) * 0.5).to(dev)
+    w = torch.nn.Parameter((torch.randn(n_out, n_in, generator=g) * 0.2).to(dev))
+    with ops.x3_scope(True):
+        dw = torch.zeros(n_out, n_in, device=dev)
+        ops.linear_wgrad(dy, x, dw)
+        ref = dy.double().t() @ x.double()
+        assert float((dw.double() - ref).abs().max()) <= 3e-5 * float(ref.abs().max())
+        # dgrad dx = dy W: n_out = 136 is not a multiple of 64 -> fp32 kernels on the master weight (exact to fp32 round-off)
+        dx = ops.linear_dgrad(dy, ops.weight_for(w, torch.float32), wt=ops.weight_t_for(w, torch.float32))
+        refx = dy.double() @ w.detach().double()
+        assert float((dx.double() - refx).abs().max()) <= 2e-6 * float(refx.abs().max())
+        # forward y = x W^T through the cached split weight; the cache follows in-place updates of the parameter
+        y = ops.linear_fwd(x, ops.weight_for(w, torch.float32), None)
+        refy = x.double() @ w.detach().double().t()
+        assert float((y.double() - refy).abs().max()) <= 3e-5 * float(refy.abs().max())
+        with torch.no_grad():
+            w.mul_(2.0)
+        y2 = ops.linear_fwd(x, ops.weight_for(w, torch.float32), None)
+        assert float((y2.double() - 2 * refy).abs().max()) <= 6e-5 * float(refy.abs().max())
+        # a 64-multiple reduction takes the split W^T: [n_in, 2 * 128]
+        w2 = torch.nn.Parameter((torch.randn(128, n_in, generator=g) * 0.2).to(dev))
+        dy2 = (torch.randn(tokens, 128, generator=g) * 0.1).to(dev)
+        wt = ops.weight_t_for(w2, torch.float32)
+        assert isinstance(wt, ops.SplitOperand) and wt.buf.shape == (n_in, 256)
+        dx2 = ops.linear_dgrad(dy2, ops.weight_for(w2, torch.float32), wt=wt)
+        refx2 = dy2.double() @ w2.detach().double()
+        assert float((dx2.double() - refx2).abs().max()) <= 3e-5 * float(refx2.abs().max())
+    # outside the scope the same calls are plain fp32
+    assert not isinstance(ops.weight_for(w, torch.float32), ops.SplitOperand)

@@ -37,10 +37,16 @@ def to_dev(batch, dev):
     return {k: v.to(dev) for k, v in batch.items()}
 
 
+# the two kernel modes that must meet the north-star's tolerance: fp32 kernels (fp32-input MFMA) and "bf16x3" (fp32
+# activations, every GEMM as three bf16 MFMA passes over hi / lo split operands; tests/test_bf16x3.py has the kernel tests)
+STRICT_MODES = {"fp32": torch.float32, "bf16x3": "bf16x3"}
+
+
+@pytest.mark.parametrize("mode", sorted(STRICT_MODES))
 @pytest.mark.parametrize("stem", sorted(CASES))
-def test_fp32_forward_matches_reference_golden(dev, stem):
+def test_fp32_forward_matches_reference_golden(dev, stem, mode):
     cfg, head, sd, batch, g = load_case(stem)
-    model = build_model(cfg, head, sd, dev)
+    model = build_model(cfg, head, sd, dev, dtype=STRICT_MODES[mode])
     model.eval()
     captured = []           # encoder outputs at the BertVisualModel boundary (as oracle/make_golden.py captures them)
     hook = model.bert.bert.register_forward_hook(lambda m, i, o: captured.append(o))
@@ -75,12 +81,13 @@ def test_fp32_forward_matches_reference_golden(dev, stem):
         assert abs(float(out["accuracy"]) - float(g["accuracy"])) < 1e-6
 
 
+@pytest.mark.parametrize("mode", sorted(STRICT_MODES))
 @pytest.mark.parametrize("stem", sorted(CASES))
-def test_fp32_train_steps_match_reference_golden(dev, stem):
+def test_fp32_train_steps_match_reference_golden(dev, stem, mode):
     """gradients (dropout p=0) and N_STEPS fused BertAdam steps against the reference's own run."""
     from visualbert_amd.model import ModelWrapper, AttrDict
     cfg, head, sd, batch, g = load_case(stem)
-    model = build_model(cfg, head, sd, dev, dropout=0.0)
+    model = build_model(cfg, head, sd, dev, dtype=STRICT_MODES[mode], dropout=0.0)
     model.train()
     args = AttrDict(train_batch_size=1, learning_rate=LR, warmup_proportion=WARMUP, num_train_epochs=1,
                     gradient_accumulation_steps=1)

@@ -22,11 +22,8 @@ flops = 4.0 * S * S * 64 * nh * B
 for p in (0.0, 0.1):
     ctx, lse, bits = ops.attn_fwd(qkv, mask, B, S, nh, p, 5, 3)
     tf = bench(lambda: ops.attn_fwd(qkv, mask, B, S, nh, p, 5, 3))
-    _lib.set_opts(reserved=1)                              # A/B: forward without the Q prefetch
-    tf0 = bench(lambda: ops.attn_fwd(qkv, mask, B, S, nh, p, 5, 3))
-    _lib.set_opts()
     tf1 = bench(lambda: ops.attn_fwd(qkv, mask, B, S, nh, p, 5, 3))
-    print("B=%d p=%.1f: fwd with Q prefetch %.1f / %.1f us, without %.1f us" % (B, p, tf, tf1, tf0))
+    print("B=%d p=%.1f: fwd %.1f / %.1f us" % (B, p, tf, tf1))
     tb = bench(lambda: ops.attn_bwd(qkv, mask, dctx, lse, bits, B, S, nh, p, 5, 3))
     t1 = bench(lambda: ops.attn_bwd(qkv, mask, dctx, lse, bits, B, S, nh, p, 5, 3, ctx_fwd=ctx))
     tb2 = bench(lambda: ops.attn_bwd(qkv, mask, dctx, lse, bits, B, S, nh, p, 5, 3))

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "libvisualbert_hip.so")
 
-VB_F32, VB_BF16 = 0, 1
+VB_F32, VB_BF16, VB_BF16X3 = 0, 1, 2
 VB_KCONTIG, VB_KSTRIDED = 0, 1
 VB_ACT_NONE, VB_ACT_GELU, VB_ACT_TANH, VB_ACT_GELU_GRAD, VB_ACT_GELU_SAVE_GRAD, VB_ACT_MUL_AUX = 0, 1, 2, 3, 4, 5
 
@@ -53,6 +53,8 @@ SIGNATURES = {
     "vb_prepare_inputs": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "vb_zero": (_i, [_p, _i64, _p]),
     "vb_cast": (_i, [_i, _p, _i, _p, _i64, _p]),
+    "vb_split_bf16": (_i, [_p, _i64, _p, _i64, _i64, _i, _p]),
+    "vb_split_bf16_t": (_i, [_p, _i64, _p, _i64, _i, _i, _p]),
     "vb_dropout": (_i, [_i, _p, _p, _i64, _f, _u64, _u32, _p]),
     "vb_gather_rows": (_i, [_i, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "vb_scatter_rows": (_i, [_i, _p, _p, _p, _i, _i, _i, _p]),
@@ -63,8 +65,8 @@ SIGNATURES = {
     "vb_colsum": (_i, [_i, _p, _i64, _p, _p, _i, _i, _p]),
     "vb_act_bwd": (_i, [_i, _p, _p, _p, _i64, _i, _p]),
     "vb_wgrad_grouped": (_i, [_i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _f, _p, _p]),
-    "vb_gemm_profile": (_i, [_i]),
-    "vb_gemm_profile_read": (_i64, [_p, _p, _p, _i64]),
+    "vb_stream_profile": (_i, [_p, _i]),
+    "vb_stream_profile_read": (_i64, [_p, _p, _p, _p, _i64]),
     "vb_bert_layer_saved_bytes": (_i64, [_i, _i, _i, _i, _i, _i, _f]),
     "vb_bert_layer_scratch_bytes": (_i64, [_i, _i, _i, _i, _i, _i]),
     "vb_bert_layer_fwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _f, _u64, _u32, _p]),
@@ -194,10 +196,10 @@ class stream_opts(object):
         return False
 
 
-def set_opts(persistent_workgroups=0, nt_kernel=0, attn_two_pass=0, reserved=0):
+def set_opts(persistent_workgroups=0, nt_kernel=0, attn_two_pass=0):
     """attach launch options to the CURRENT stream until changed again (tools; library code uses `stream_opts`)."""
-    o = StreamOpts(int(persistent_workgroups), int(nt_kernel), int(attn_two_pass), int(reserved))
-    zero = not (o.persistent_workgroups or o.nt_kernel or o.attn_two_pass or o.reserved)
+    o = StreamOpts(int(persistent_workgroups), int(nt_kernel), int(attn_two_pass), 0)
+    zero = not (o.persistent_workgroups or o.nt_kernel or o.attn_two_pass)
     check(lib().vb_stream_set_opts(stream_ptr(), None if zero else ctypes.byref(o)), "vb_stream_set_opts")
 
 

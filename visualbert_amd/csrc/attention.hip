@@ -1011,9 +1011,9 @@ int dispatch_nkf(int which, const AttnArgs& a, hipStream_t s) {
     if constexpr (sizeof(T) == 2) {
         // forward with EXACTLY ceil(S / 16) key fragments of work for the sequence lengths of BASELINE's configurations
         // (S = 164 pre-training: 11 fragments; NLVR2 S = 112: 7, where the padded-to-even form computed 8; VQA S = 56: 4) -- the
-        // prefetching, branch-free instantiation.  reserved bit 0: A/B switch back to the generic kernels (measurement only).
+        // prefetching, branch-free instantiation
         const int nf = (a.S + 15) / 16;
-        if (which == 0 && (nf == 11 || nf == 7 || nf == 4) && (vb_opts_for((void*)s).reserved & 1) == 0) {
+        if (which == 0 && (nf == 11 || nf == 7 || nf == 4)) {
             const dim3 grid((unsigned)(a.B * a.nh));
             if (nf == 11) VB_LAUNCH((attn_fwd_kernel<T, 11, true, true>), grid, dim3(NT), (fwd_smem<T, 11>()), s, a);
             else if (nf == 7) VB_LAUNCH((attn_fwd_kernel<T, 7, true, true>), grid, dim3(NT), (fwd_smem<T, 7>()), s, a);
@@ -1021,7 +1021,7 @@ int dispatch_nkf(int which, const AttnArgs& a, hipStream_t s) {
             return vb_check_launch();
         }
     }
-    if (which == 0 && (a.S + 15) / 16 == 11) {      // forward at S = 161..176 without the prefetch (fp32, or the A/B switch)
+    if (which == 0 && (a.S + 15) / 16 == 11) {      // forward at S = 161..176 without the prefetch (fp32)
         const size_t sm = fwd_smem<T, 11>();
         // (without the prefetch the branch-free form lets the scheduler hoist every fragment read: 612-1448 bytes of scratch, 4x slower)
         VB_LAUNCH((attn_fwd_kernel<T, 11>), dim3((unsigned)(a.B * a.nh)), dim3(NT), sm, s, a);

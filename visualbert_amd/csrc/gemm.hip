@@ -33,6 +33,7 @@
 #ifdef VB_DEV_KNOBS
 #include "../../include/visualbert_hip_dev.h"
 #endif
+#include <mutex>
 #include <vector>
 #include <type_traits>
 #include <utility>
@@ -77,7 +78,20 @@ struct GemmArgs {
     float* colsum;                // optional fp32 [N]: += column sums of the stored values (bias gradient)
     int debug;                    // ablation bits (measurement only): 1 skip tile loads, 2 skip fragment reads, 4 skip MFMAs
     int stripe;                   // dual kernel: column tiles per stripe of the tile walk (tiles_n = one stripe = row-major)
+    // VB_BF16X3 (split-operand mode): each operand row holds a hi plane [0, ld/2) and a lo plane [ld/2, ld) of bf16 with
+    // x = hi + lo to ~2^-17; the kernel walks 3 K segments of K / 64 tiles each -- hi.hi, lo.hi, hi.lo -- into the same
+    // fp32 accumulators.  a_lo / b_lo: ELEMENT offset of the lo plane inside a row; kseg: K tiles per segment.
+    int x3, a_lo, b_lo, kseg;
 };
+// K tile `v` of the (virtual) K loop -> element offset of its first column inside a row of A / of B
+VB_DEVICE int x3_col_a(const GemmArgs& g, int v, int bk) {
+    const int seg = v >= 2 * g.kseg ? 2 : (v >= g.kseg ? 1 : 0);
+    return (v - seg * g.kseg) * bk + (seg == 1 ? g.a_lo : 0);
+}
+VB_DEVICE int x3_col_b(const GemmArgs& g, int v, int bk) {
+    const int seg = v >= 2 * g.kseg ? 2 : (v >= g.kseg ? 1 : 0);
+    return (v - seg * g.kseg) * bk + (seg == 2 ? g.b_lo : 0);
+}
 
 // ---- global -> register staging -------------------------------------------------------------
 template <typename T>
@@ -188,8 +202,17 @@ VB_DEVICE f32x8 load_frag(const unsigned char* lds, int row, int ks, int g, floa
 }
 
 #ifndef VB_EMU
+// opt-in per-STREAM launch timing (vb_stream_profile): a stream that asked for it gets an event pair around every GEMM launch
+// enqueued on it; other streams are untouched.  The table is found once per extern "C" entry, like the launch options.
 struct ProfRec { hipEvent_t e0, e1; double flops; int key; };
-static std::vector<ProfRec>* g_prof = nullptr;      // opt-in measurement recorder (vb_gemm_profile): the one process-wide facility
+static std::mutex g_prof_mutex;
+static std::vector<std::pair<void*, std::vector<ProfRec>*>> g_prof_table;
+static thread_local std::vector<ProfRec>* g_prof = nullptr;      // the recorder of the stream being served (nullptr: none)
+static std::vector<ProfRec>* prof_for(void* stream) {
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
+    for (auto& e : g_prof_table) if (e.first == stream) return e.second;
+    return nullptr;
+}
 #endif
 // launch options of the call being served: copied from the stream's entry (vb_stream_set_opts) at every extern "C" entry of
 // this file; thread-local, so concurrent callers on different streams never see each other's settings
@@ -457,7 +480,8 @@ VB_DEVICE void gemm_epilogue(f32x4 (&acc)[4][4], unsigned char* smem, const Gemm
     if constexpr (OPT & EPI_COLSUM) epi_colsum_flush(e, g, nw0, lane);
 }
 
-template <typename T, typename TO, int AL, int BL>
+// TE: element type of the epilogue's T operands (addend, aux) -- T, except in the split-operand mode (bf16 operands, fp32 rest)
+template <typename T, typename TO, int AL, int BL, typename TE = T>
 VB_KERNEL VB_LAUNCH_BOUNDS(NT) gemm_kernel(GemmArgs g) {
     constexpr int EPC = TT<T>::EPC, BK = TT<T>::BK, KSTEPS = TT<T>::KSTEPS;
     (void)EPC;
@@ -493,27 +517,29 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) gemm_kernel(GemmArgs g) {
     const bool glds_a = (AL == VB_KCONTIG) && g.fast_a;
     const bool glds_b = (BL == VB_KCONTIG) && g.fast_b;
 
-    const int nk_all = (g.K + BK - 1) / BK;
+    const int nk_all = g.x3 ? 3 * g.kseg : (g.K + BK - 1) / BK;
+    const int kbound = g.x3 ? (1 << 30) : g.K;       // split operands: whole K tiles only, columns past K belong to the lo plane
     const int kt0 = split * g.kt_per_split;
     const int kt1 = (kt0 + g.kt_per_split < nk_all) ? kt0 + g.kt_per_split : nk_all;
 
     // issue(): start moving K tile `kt` towards LDS buffer `buf`; commit(): finish it for the
     // register-staged operands (LDS-direct copies need no commit, only the barrier)
     auto issue = [&](int kt, int buf) {
-        const int k0 = kt * BK;
+        const int k0 = g.x3 ? x3_col_a(g, kt, BK) : kt * BK;
+        const int k0b = g.x3 ? x3_col_b(g, kt, BK) : k0;
         unsigned char* la = smem + buf * 2 * TILE_BYTES;
         unsigned char* lb = la + TILE_BYTES;
         if constexpr (AL == VB_KCONTIG) {
             if (glds_a) glds_kcontig<T>(la, A, g.lda, g.M, m0, k0, wave, lane);
-            else gload_kcontig<T>(ra, A, g.lda, g.M, g.K, m0, k0, t);
+            else gload_kcontig<T>(ra, A, g.lda, g.M, kbound, m0, k0, t);
         } else {
             if (a_active) gload_kstrided<T>(ra, A, g.lda, g.M, g.K, m0, k0, t);
         }
         if constexpr (BL == VB_KCONTIG) {
-            if (glds_b) glds_kcontig<T>(lb, B, g.ldb, g.N, n0, k0, wave, lane);
-            else gload_kcontig<T>(rb, B, g.ldb, g.N, g.K, n0, k0, t);
+            if (glds_b) glds_kcontig<T>(lb, B, g.ldb, g.N, n0, k0b, wave, lane);
+            else gload_kcontig<T>(rb, B, g.ldb, g.N, kbound, n0, k0b, t);
         } else {
-            if (b_active) gload_kstrided<T>(rb, B, g.ldb, g.N, g.K, n0, k0, t - B_TBASE);
+            if (b_active) gload_kstrided<T>(rb, B, g.ldb, g.N, g.K, n0, k0b, t - B_TBASE);
         }
     };
     auto commit = [&](int buf) {
@@ -550,14 +576,14 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) gemm_kernel(GemmArgs g) {
         }
     }
 
-    gemm_epilogue<T, TO, -1, EPI_ALL>(acc, smem, g, m0 + wm * 64, n0 + wn * 64, wave, lane);
+    gemm_epilogue<TE, TO, -1, EPI_ALL>(acc, smem, g, m0 + wm * 64, n0 + wn * 64, wave, lane);
 }
 
 // ---- optional per-launch HIP-event timing (bench.py's roofline leg) -----------------------------------
 // Events are recorded on the stream the kernel is launched on, immediately around the launch, so the
 // elapsed time is the kernel's own duration even when the host is the bottleneck.
 
-template <typename T, typename TO, int AL, int BL>
+template <typename T, typename TO, int AL, int BL, typename TE = T>
 int launch_gemm(const GemmArgs& g, hipStream_t stream) {
     dim3 grid((unsigned)(g.tiles_m * g.tiles_n * g.splits)), block(NT);
 #ifndef VB_EMU
@@ -565,15 +591,15 @@ int launch_gemm(const GemmArgs& g, hipStream_t stream) {
         ProfRec r;
         if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return VB_ERR_LAUNCH;
         r.flops = 2.0 * g.M * g.N * g.K;
-        r.key = (sizeof(T) == 2 ? 0 : 8) | (sizeof(TO) == 4 ? 4 : 0) | (AL << 1) | BL;
+        r.key = (sizeof(T) == 2 ? 0 : 8) | (sizeof(TO) == 4 ? 4 : 0) | (AL << 1) | BL | (g.x3 ? 256 : 0);
         (void)hipEventRecord(r.e0, stream);
-        VB_LAUNCH((gemm_kernel<T, TO, AL, BL>), grid, block, SMEM_BYTES, stream, g);
+        VB_LAUNCH((gemm_kernel<T, TO, AL, BL, TE>), grid, block, SMEM_BYTES, stream, g);
         (void)hipEventRecord(r.e1, stream);
         g_prof->push_back(r);
         return vb_check_launch();
     }
 #endif
-    VB_LAUNCH((gemm_kernel<T, TO, AL, BL>), grid, block, SMEM_BYTES, stream, g);
+    VB_LAUNCH((gemm_kernel<T, TO, AL, BL, TE>), grid, block, SMEM_BYTES, stream, g);
     return vb_check_launch();
 }
 
@@ -620,11 +646,11 @@ VB_DEVICE void fast_setup(FastPtrs<T, WM>& p, const T* A, const T* B, const Gemm
     }
 }
 template <typename T, int WM>
-VB_DEVICE void fast_issue(unsigned char* stage, const FastPtrs<T, WM>& p, int k0, int wave) {
+VB_DEVICE void fast_issue(unsigned char* stage, const FastPtrs<T, WM>& p, int k0, int k0b, int wave) {
     unsigned char* la = stage;
     unsigned char* lb = stage + FastPtrs<T, WM>::BMX * 128;
     const unsigned char* sa = p.A + (long)k0 * (long)sizeof(T);
-    const unsigned char* sb = p.B + (long)k0 * (long)sizeof(T);
+    const unsigned char* sb = p.B + (long)k0b * (long)sizeof(T);
 #pragma unroll
     for (int i = 0; i < FastPtrs<T, WM>::A_INSTR; ++i)
         vb_glds16(sa + p.a[i], la + (wave * FastPtrs<T, WM>::A_INSTR + i) * 8 * 128);
@@ -633,7 +659,7 @@ VB_DEVICE void fast_issue(unsigned char* stage, const FastPtrs<T, WM>& p, int k0
         vb_glds16(sb + p.b[i], lb + (wave * FastPtrs<T, WM>::B_INSTR + i) * 8 * 128);
 }
 
-template <typename T, typename TO, int WM, int STAGES, int DBG = 0, int ACT = -1, int OPT = EPI_ALL>
+template <typename T, typename TO, int WM, int STAGES, int DBG = 0, int ACT = -1, int OPT = EPI_ALL, typename TE = T, bool X3 = false>
 VB_KERNEL VB_LAUNCH_BOUNDS(WM * 128) gemm_nt_pipe_kernel(GemmArgs g) {
     constexpr int NW = WM * 2, BMX = WM * 64;
     constexpr int BK = TT<T>::BK, KSTEPS = TT<T>::KSTEPS;
@@ -656,13 +682,18 @@ VB_KERNEL VB_LAUNCH_BOUNDS(WM * 128) gemm_nt_pipe_kernel(GemmArgs g) {
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = g.K / BK;
+    const int nk = X3 ? 3 * g.kseg : g.K / BK;
     FastPtrs<T, WM> ptrs;
     fast_setup<T, WM>(ptrs, A, B, g, m0, n0, wave, lane);
     typename VecOf<T>::v8 fa[4], fb[4];
+    auto issue_tile = [&](int kt) {                       // K tile kt of the (virtual) K loop into its ring stage
+        unsigned char* stage = smem + (kt % STAGES) * STAGE_BYTES;
+        if constexpr (X3) fast_issue<T, WM>(stage, ptrs, x3_col_a(g, kt, BK), x3_col_b(g, kt, BK), wave);
+        else fast_issue<T, WM>(stage, ptrs, kt * BK, kt * BK, wave);
+    };
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s)
-        if (s < nk) fast_issue<T, WM>(smem + s * STAGE_BYTES, ptrs, s * BK, wave);
+        if (s < nk) issue_tile(s);
 
     for (int kt = 0; kt < nk; ++kt) {
         // tile kt must have landed; tiles kt+1 .. kt+STAGES-2 (if they exist) may stay in flight
@@ -678,8 +709,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS(WM * 128) gemm_nt_pipe_kernel(GemmArgs g) {
         // DBG is a compile-time ablation / experiment mask (0 in production): 1 skip tile loads, 2 skip fragment
         // reads, 4 skip MFMAs, 8 raise wave priority around the MFMA block, 16 issue the next tile's copies
         // after the first K step instead of before it
-        if (!(DBG & 16) && kt + STAGES - 1 < nk && !(DBG & 1))
-            fast_issue<T, WM>(smem + ((kt + STAGES - 1) % STAGES) * STAGE_BYTES, ptrs, (kt + STAGES - 1) * BK, wave);
+        if (!(DBG & 16) && kt + STAGES - 1 < nk && !(DBG & 1)) issue_tile(kt + STAGES - 1);
         const unsigned char* ldsA = smem + (kt % STAGES) * STAGE_BYTES;
         const unsigned char* ldsB = ldsA + BMX * 128;
         if (tr) trp[2] = vb_clock();          // tile kt+1 copies issued
@@ -719,11 +749,10 @@ VB_KERNEL VB_LAUNCH_BOUNDS(WM * 128) gemm_nt_pipe_kernel(GemmArgs g) {
 #endif
                 if (tr) trp[4 + 2 * ks] = vb_clock();    // this K step's MFMAs issued
             }
-            if ((DBG & 16) && ks == 0 && kt + STAGES - 1 < nk)
-                fast_issue<T, WM>(smem + ((kt + STAGES - 1) % STAGES) * STAGE_BYTES, ptrs, (kt + STAGES - 1) * BK, wave);
+            if ((DBG & 16) && ks == 0 && kt + STAGES - 1 < nk) issue_tile(kt + STAGES - 1);
         }
     }
-    gemm_epilogue<T, TO, ACT, OPT>(acc, smem, g, m0 + wm * 64, n0 + wn * 64, wave, lane);
+    gemm_epilogue<TE, TO, ACT, OPT>(acc, smem, g, m0 + wm * 64, n0 + wn * 64, wave, lane);
 }
 
 // activation baked into the kernel where it matters (bf16 in / bf16 out: FFN-in forward GELU, FFN-out dgrad GELU');
@@ -731,22 +760,22 @@ VB_KERNEL VB_LAUNCH_BOUNDS(WM * 128) gemm_nt_pipe_kernel(GemmArgs g) {
 template <typename T, typename TO>
 constexpr bool kActSpecialised = (sizeof(T) == 2 && sizeof(TO) == 2);
 
-template <typename T, typename TO, int WM, int STAGES, int ACT, int OPT>
+template <typename T, typename TO, int WM, int STAGES, int ACT, int OPT, typename TE = T, bool X3 = false>
 int launch_pipe_act(const GemmArgs& g, dim3 grid, dim3 block, int smem_bytes, hipStream_t stream) {
 #ifndef VB_EMU
     if (g_prof) {
         ProfRec r;
         if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return VB_ERR_LAUNCH;
         r.flops = 2.0 * g.M * g.N * g.K;
-        r.key = (sizeof(T) == 2 ? 0 : 8) | (sizeof(TO) == 4 ? 4 : 0);
+        r.key = (sizeof(T) == 2 ? 0 : 8) | (sizeof(TO) == 4 ? 4 : 0) | (X3 ? 256 : 0);
         (void)hipEventRecord(r.e0, stream);
-        VB_LAUNCH((gemm_nt_pipe_kernel<T, TO, WM, STAGES, 0, ACT, OPT>), grid, block, smem_bytes, stream, g);
+        VB_LAUNCH((gemm_nt_pipe_kernel<T, TO, WM, STAGES, 0, ACT, OPT, TE, X3>), grid, block, smem_bytes, stream, g);
         (void)hipEventRecord(r.e1, stream);
         g_prof->push_back(r);
         return vb_check_launch();
     }
 #endif
-    VB_LAUNCH((gemm_nt_pipe_kernel<T, TO, WM, STAGES, 0, ACT, OPT>), grid, block, smem_bytes, stream, g);
+    VB_LAUNCH((gemm_nt_pipe_kernel<T, TO, WM, STAGES, 0, ACT, OPT, TE, X3>), grid, block, smem_bytes, stream, g);
     return vb_check_launch();
 }
 
@@ -756,10 +785,15 @@ int launch_pipe(GemmArgs g, hipStream_t stream) {
     constexpr int SM = STAGES * (BMX + 128) * 128;
     static_assert(WM * 2 * EPI_BYTES_PER_WAVE <= SM, "epilogue slabs must fit");
     // 32-bit byte offsets inside the kernel: larger operands take the generic kernel
-    if ((long)g.M * g.lda * (long)sizeof(T) >= (1L << 32) || (long)g.N * g.ldb * (long)sizeof(T) >= (1L << 32))
+    if ((long)g.M * g.lda * (long)sizeof(T) >= (1L << 32) || (long)g.N * g.ldb * (long)sizeof(T) >= (1L << 32)) {
+        if constexpr (sizeof(T) == 2 && sizeof(TO) == 4) { if (g.x3) return launch_gemm<T, TO, VB_KCONTIG, VB_KCONTIG, float>(g, stream); }
         return launch_gemm<T, TO, VB_KCONTIG, VB_KCONTIG>(g, stream);
+    }
     g.tiles_m = (g.M + BMX - 1) / BMX;
     dim3 grid((unsigned)(g.tiles_m * g.tiles_n)), block(WM * 128);
+    if constexpr (sizeof(T) == 2 && sizeof(TO) == 4) {
+        if (g.x3) return launch_pipe_act<T, TO, WM, STAGES, -1, EPI_ALL, float, true>(g, grid, block, SM, stream);
+    }
     if constexpr (sizeof(T) == 2 && sizeof(TO) == 2 && WM == 4 && STAGES == 2) {
         switch (g.debug & 127) {                  // ablation / timeline builds of this kernel (measurement only)
             case 0: break;
@@ -1217,9 +1251,12 @@ int launch_8ph(GemmArgs g, hipStream_t stream) {
 // (VAR 3, nt_kernel 90) is what ships; VAR 0 (nt_kernel 91) is kept for A/B.  Measured and dropped
 // (profiles/r02_gemm_dual_notes.txt): copies issued one by one between the MFMAs; a half-tile start offset for one of
 // the two workgroups that open a CU; v_mfma_f32_32x32x16_bf16 instead of 16x16x32 (same fragment reads, 7 % slower).
-template <typename TO, int ACT, int OPT, int VAR>
+// X3: split-operand mode (see GemmArgs): the K loop runs over 3 K / 64 virtual tiles whose column offsets come from
+// x3_col_a / x3_col_b (scalar arithmetic per copy batch); the epilogue's T operands are fp32.
+template <typename TO, int ACT, int OPT, int VAR, bool X3 = false>
 VB_KERNEL VB_LAUNCH_BOUNDS2(256, 2) gemm_nt_dual_kernel(GemmArgs g) {
     typedef bf16 T;
+    typedef typename std::conditional<X3, float, bf16>::type TE;
     constexpr int BK = 64, KSTEPS = 2, HALF = 128 * 128;
     VB_DYN_SMEM(smem);
     const int t = threadIdx.x;
@@ -1263,11 +1300,17 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(256, 2) gemm_nt_dual_kernel(GemmArgs g) {
         b = b < g.N ? b : g.N - 1;
         offB[i] = (unsigned)(b * (int)g.ldb) * 2u + csrc;
     }
-    auto issue = [&](const vb_buf& buf, const unsigned (&off)[4], int kt, int slot) {
+    auto issue_at = [&](const vb_buf& buf, const unsigned (&off)[4], unsigned koff, int slot) {
         unsigned char* dst = smem + slot * HALF + wave * 4096;
-        const unsigned koff = (unsigned)kt * (BK * 2);
 #pragma unroll
         for (int i = 0; i < 4; ++i) vb_glds16_buf(buf, off[i], koff, dst + i * 1024);
+    };
+    // is_b: the copy belongs to operand B (the K tile -> column map of the split-operand mode differs per operand)
+    auto issue_a = [&](const unsigned (&off)[4], int kt, int slot) {
+        issue_at(A, off, X3 ? (unsigned)x3_col_a(g, kt, BK) * 2u : (unsigned)kt * (BK * 2), slot);
+    };
+    auto issue_b = [&](int kt, int slot) {
+        issue_at(B, offB, X3 ? (unsigned)x3_col_b(g, kt, BK) * 2u : (unsigned)kt * (BK * 2), slot);
     };
 
     bf16x8 fa[4][KSTEPS], fb0[2][KSTEPS], fb1[2][KSTEPS];
@@ -1299,10 +1342,10 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(256, 2) gemm_nt_dual_kernel(GemmArgs g) {
         (void)p;
     };
 
-    const int nk = g.K / BK;
+    const int nk = X3 ? 3 * g.kseg : g.K / BK;
     // prologue: h = 0 .. 3 (A0(0) B(0) A1(0) A0(1)); E(0) adds h = 4
-    issue(A, offA[0], 0, 0); issue(B, offB, 0, 1); issue(A, offA[1], 0, 2);
-    if (nk > 1) issue(A, offA[0], 1, 3);
+    issue_a(offA[0], 0, 0); issue_b(0, 1); issue_a(offA[1], 0, 2);
+    if (nk > 1) issue_a(offA[0], 1, 3);
 
     // one K tile; J = k % 5 fixes the ring slots: A0 -> (3J) % 5, B -> (3J+1) % 5, A1 -> (3J+2) % 5
     auto step = [&](auto jtag, int k) {
@@ -1313,11 +1356,11 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(256, 2) gemm_nt_dual_kernel(GemmArgs g) {
         // ---- E(k): A0(k), B(k) must have landed; A1(k) and A0(k+1) may still be in flight
         if (last) vb_wait_vmcnt<4>(); else vb_wait_vmcnt<8>();
         vb_phase_barrier();
-        if constexpr ((VAR & 1) == 0) { if (!last) issue(B, offB, k + 1, SE); }
+        if constexpr ((VAR & 1) == 0) { if (!last) issue_b(k + 1, SE); }
         readB(fb0, smem + SB * HALF, 0);
         readA(smem + SA0 * HALF);
         readB(fb1, smem + SB * HALF, 1);
-        if constexpr ((VAR & 1) != 0) { vb_sched_fence(); if (!last) issue(B, offB, k + 1, SE); vb_sched_fence(); }
+        if constexpr ((VAR & 1) != 0) { vb_sched_fence(); if (!last) issue_b(k + 1, SE); vb_sched_fence(); }
         prio(1);
         quad(0, 0, fb0);
         quad(0, 1, fb1);
@@ -1326,8 +1369,8 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(256, 2) gemm_nt_dual_kernel(GemmArgs g) {
         if (last) vb_wait_vmcnt<0>(); else vb_wait_vmcnt<8>();
         vb_phase_barrier();
         if constexpr ((VAR & 1) != 0) { readA(smem + SA1 * HALF); vb_sched_fence(); }
-        if (!last) issue(A, offA[1], k + 1, SA0);              // A1(k+1) into the slot A0(k) just left
-        if (k + 2 < nk) issue(A, offA[0], k + 2, SB);          // A0(k+2) into the slot B(k) just left
+        if (!last) issue_a(offA[1], k + 1, SA0);               // A1(k+1) into the slot A0(k) just left
+        if (k + 2 < nk) issue_a(offA[0], k + 2, SB);           // A0(k+2) into the slot B(k) just left
         if constexpr ((VAR & 1) == 0) readA(smem + SA1 * HALF);
         else vb_sched_fence();
         prio(1);
@@ -1343,10 +1386,10 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(256, 2) gemm_nt_dual_kernel(GemmArgs g) {
         step(std::integral_constant<int, 4>(), k); if (++k == nk) break;
     }
     vb_phase_barrier();                                        // every wave is done with the ring: the slabs may alias it
-    gemm_epilogue_private<T, TO, ACT, OPT>(acc, smem + wave * EPI8_BYTES_PER_WAVE, g, m0 + wr * 128, n0 + wc * 64, lane);
+    gemm_epilogue_private<TE, TO, ACT, OPT>(acc, smem + wave * EPI8_BYTES_PER_WAVE, g, m0 + wr * 128, n0 + wc * 64, lane);
 }
 
-template <typename TO, int ACT, int OPT, int VAR>
+template <typename TO, int ACT, int OPT, int VAR, bool X3 = false>
 int launch_dual_var(const GemmArgs& g, dim3 grid, hipStream_t stream) {
     constexpr int SM = 5 * 128 * 128;                           // 80 KB: two workgroups per compute unit
 #ifndef VB_EMU
@@ -1354,15 +1397,15 @@ int launch_dual_var(const GemmArgs& g, dim3 grid, hipStream_t stream) {
         ProfRec r;
         if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return VB_ERR_LAUNCH;
         r.flops = 2.0 * g.M * g.N * g.K;
-        r.key = (sizeof(TO) == 4 ? 4 : 0) | 64;
+        r.key = (sizeof(TO) == 4 ? 4 : 0) | 64 | (X3 ? 256 : 0);
         (void)hipEventRecord(r.e0, stream);
-        VB_LAUNCH((gemm_nt_dual_kernel<TO, ACT, OPT, VAR>), grid, dim3(256), SM, stream, g);
+        VB_LAUNCH((gemm_nt_dual_kernel<TO, ACT, OPT, VAR, X3>), grid, dim3(256), SM, stream, g);
         (void)hipEventRecord(r.e1, stream);
         g_prof->push_back(r);
         return vb_check_launch();
     }
 #endif
-    VB_LAUNCH((gemm_nt_dual_kernel<TO, ACT, OPT, VAR>), grid, dim3(256), SM, stream, g);
+    VB_LAUNCH((gemm_nt_dual_kernel<TO, ACT, OPT, VAR, X3>), grid, dim3(256), SM, stream, g);
     return vb_check_launch();
 }
 template <typename TO, int ACT, int OPT>
@@ -1385,6 +1428,9 @@ int launch_dual(GemmArgs g, hipStream_t stream) {
         g.stripe = (g.tiles_n > 12 && g.tiles_n <= 20) ? (g.tiles_n + 2) / 3 : g.tiles_n;
         if ((g.debug >> 8) > 0) g.stripe = (g.debug >> 8) < g.tiles_n ? (g.debug >> 8) : g.tiles_n;      // developer library only: walk override
         dim3 grid((unsigned)(g.tiles_m * g.tiles_n));
+        if constexpr (sizeof(TO) == 4) {
+            if (g.x3) return launch_dual_var<TO, -1, EPI_ALL, 3, true>(g, grid, stream);
+        }
         const int needs = epi_needs(g, sizeof(T), sizeof(TO));
 #define VB_TRY_EPI(A, O) if (g.act == (A) && (needs & ~(O)) == 0) return launch_dual_act<TO, A, O>(g, grid, stream)
         if constexpr (kActSpecialised<T, TO>) {
@@ -1991,6 +2037,11 @@ static bool tn_eligible(const void* A, long lda, const void* B, long ldb, const 
 template <typename T, typename TO>
 int dispatch_pipe(const GemmArgs& g, hipStream_t s) {
     int variant = t_opts.nt_kernel;
+    if (g.x3) {                                            // split operands: the two-workgroup kernel or the two-barrier ones
+        const long t256 = (long)((g.M + 255) / 256) * ((g.N + 255) / 256);
+        const long t128 = (long)((g.M + 255) / 256) * ((g.N + 127) / 128);
+        if (variant != 22 && variant != 42 && variant != 90) variant = t256 >= 160 ? 90 : (t128 >= 256 ? 42 : 22);
+    }
     if (variant == 0) {
         // measured on MI355X (profiles/r01_gemm_variant_sweep_b128.txt)
         const long t256 = (long)((g.M + 255) / 256) * ((g.N + 255) / 256);
@@ -2020,6 +2071,7 @@ int dispatch(int out_dtype_is_f32, int al, int bl, const GemmArgs& g, hipStream_
     if (al == VB_KCONTIG && bl == VB_KCONTIG) {
         if (g.fast_a && g.fast_b && g.splits == 1 && t_opts.nt_kernel != 1)
             return out_dtype_is_f32 ? dispatch_pipe<T, float>(g, s) : dispatch_pipe<T, T>(g, s);
+        if constexpr (sizeof(T) == 2) { if (g.x3) return launch_gemm<T, float, VB_KCONTIG, VB_KCONTIG, float>(g, s); }
         return out_dtype_is_f32 ? launch_gemm<T, float, VB_KCONTIG, VB_KCONTIG>(g, s)
                                 : launch_gemm<T, T, VB_KCONTIG, VB_KCONTIG>(g, s);
     }
@@ -2041,9 +2093,18 @@ extern "C" int vb_gemm(int dtype, int out_dtype, int a_layout, int b_layout,
                        const void* aux_in, void* aux_out, int64_t ld_aux, int accumulate,
                        float* colsum_out, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C) return VB_ERR_ARG;
-    if (dtype != VB_F32 && dtype != VB_BF16) return VB_ERR_ARG;
+    if (dtype != VB_F32 && dtype != VB_BF16 && dtype != VB_BF16X3) return VB_ERR_ARG;
     if (out_dtype != VB_F32 && out_dtype != dtype) return VB_ERR_ARG;
+    const bool x3 = dtype == VB_BF16X3;
+    if (x3) {
+        // split operands: fp32 everywhere but the MFMA inputs; whole K tiles; hi | lo halves of 16-byte-aligned rows
+        if (out_dtype != VB_F32 || a_layout != VB_KCONTIG || b_layout != VB_KCONTIG) return VB_ERR_UNSUPPORTED;
+        if ((K % 64) || (lda % 16) || (ldb % 16) || K > lda / 2 || K > ldb / 2) return VB_ERR_UNSUPPORTED;
+    }
     t_opts = vb_opts_for(stream);
+#ifndef VB_EMU
+    g_prof = prof_for(stream);
+#endif
     const int epc = dtype == VB_BF16 ? 8 : 4;
     // vector loads are 16 bytes: leading dimensions and base pointers must keep them aligned
     if ((lda % 8) || (ldb % 8) || (((uintptr_t)A | (uintptr_t)B) & 15)) return VB_ERR_ARG;
@@ -2057,8 +2118,10 @@ extern "C" int vb_gemm(int dtype, int out_dtype, int a_layout, int b_layout,
     g.ld_aux = ld_aux; g.alpha = alpha; g.alpha_dev = alpha_dev; g.colsum = colsum_out; g.act = act; g.accumulate = accumulate;
     g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
     g.debug = g_debug; g.trace = g_trace;
-    const int bk = dtype == VB_BF16 ? 64 : 32;
-    const int nk = (K + bk - 1) / bk;
+    g.x3 = x3 ? 1 : 0; g.a_lo = x3 ? (int)(lda / 2) : 0; g.b_lo = x3 ? (int)(ldb / 2) : 0; g.kseg = x3 ? K / 64 : 0;
+    g.stripe = 0;
+    const int bk = dtype == VB_F32 ? 32 : 64;
+    const int nk = x3 ? 3 * (K / 64) : (K + bk - 1) / bk;
     // LDS-direct copies need whole K tiles (a masked lane would leave stale LDS behind)
     g.fast_a = (a_layout == VB_KCONTIG && (K % bk) == 0) ? 1 : 0;
     g.fast_b = (b_layout == VB_KCONTIG && (K % bk) == 0) ? 1 : 0;
@@ -2084,7 +2147,7 @@ extern "C" int vb_gemm(int dtype, int out_dtype, int a_layout, int b_layout,
         tg.p[0].Mo = M; tg.p[0].Ni = N;
         return launch_tn_group(tg, K, s);
     }
-    if (dtype == VB_BF16) return dispatch<bf16>(of32 && true, a_layout, b_layout, g, s);
+    if (dtype == VB_BF16 || x3) return dispatch<bf16>(of32 && true, a_layout, b_layout, g, s);
     return dispatch<float>(1, a_layout, b_layout, g, s);
 }
 
@@ -2093,8 +2156,26 @@ extern "C" int vb_wgrad_grouped(int dtype, int n, const void* const* dy, const i
                                 const int* n_in, int tokens, float alpha, const float* alpha_dev, void* stream) {
     if (n <= 0 || n > VB_TN_MAX || !dy || !ld_dy || !x || !ld_x || !dw || !ld_dw || !n_out || !n_in || tokens <= 0)
         return VB_ERR_ARG;
-    if (dtype != VB_F32 && dtype != VB_BF16) return VB_ERR_ARG;
+    if (dtype != VB_F32 && dtype != VB_BF16 && dtype != VB_BF16X3) return VB_ERR_ARG;
+    if (dtype == VB_BF16X3) {
+        // split operands [tokens][hi | lo]: dW += dy_hi^T x_hi + dy_lo^T x_hi + dy_hi^T x_lo -- three passes of the bf16 path
+        // over the planes (the accumulation into the fp32 dW is what the kernel does anyway)
+        const void* dyp[VB_TN_MAX]; const void* xp[VB_TN_MAX];
+        for (int pass = 0; pass < 3; ++pass) {
+            for (int i = 0; i < n; ++i) {
+                if ((ld_dy[i] % 16) || (ld_x[i] % 16) || n_out[i] > ld_dy[i] / 2 || n_in[i] > ld_x[i] / 2) return VB_ERR_UNSUPPORTED;
+                dyp[i] = (const bf16*)dy[i] + (pass == 1 ? ld_dy[i] / 2 : 0);
+                xp[i] = (const bf16*)x[i] + (pass == 2 ? ld_x[i] / 2 : 0);
+            }
+            const int rc = vb_wgrad_grouped(VB_BF16, n, dyp, ld_dy, xp, ld_x, dw, ld_dw, n_out, n_in, tokens, alpha, alpha_dev, stream);
+            if (rc != VB_OK) return rc;
+        }
+        return VB_OK;
+    }
     t_opts = vb_opts_for(stream);
+#ifndef VB_EMU
+    g_prof = prof_for(stream);
+#endif
     bool fast = dtype == VB_BF16 && t_opts.nt_kernel != 1;
     for (int i = 0; i < n && fast; ++i)
         fast = tn_eligible(dy[i], ld_dy[i], x[i], ld_x[i], (const float*)dw[i], ld_dw[i], n_out[i], n_in[i], tokens);
@@ -2117,25 +2198,29 @@ extern "C" int vb_wgrad_grouped(int dtype, int n, const void* const* dy, const i
     return VB_OK;
 }
 
-extern "C" int vb_gemm_profile(int enable) {
+extern "C" int vb_stream_profile(void* stream, int enable) {
 #ifndef VB_EMU
-    if (g_prof) {
-        for (auto& r : *g_prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
-        delete g_prof;
-        g_prof = nullptr;
-    }
-    if (enable) g_prof = new std::vector<ProfRec>();
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
+    for (size_t i = 0; i < g_prof_table.size(); ++i)
+        if (g_prof_table[i].first == stream) {
+            for (auto& r : *g_prof_table[i].second) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+            delete g_prof_table[i].second;
+            g_prof_table.erase(g_prof_table.begin() + i);
+            break;
+        }
+    if (enable) g_prof_table.emplace_back(stream, new std::vector<ProfRec>());
 #else
-    (void)enable;
+    (void)stream; (void)enable;
 #endif
     return VB_OK;
 }
 
-extern "C" int64_t vb_gemm_profile_read(double* ms, double* flops, int* key, int64_t max_records) {
+extern "C" int64_t vb_stream_profile_read(void* stream, double* ms, double* flops, int* key, int64_t max_records) {
 #ifndef VB_EMU
-    if (!g_prof) return 0;
+    std::vector<ProfRec>* recs = prof_for(stream);
+    if (!recs) return 0;
     int64_t n = 0;
-    for (auto& r : *g_prof) {
+    for (auto& r : *recs) {
         if (n >= max_records) break;
         float t = 0.f;
         if (hipEventElapsedTime(&t, r.e0, r.e1) != hipSuccess) return -1;   // caller must synchronise first
@@ -2146,7 +2231,7 @@ extern "C" int64_t vb_gemm_profile_read(double* ms, double* flops, int* key, int
     }
     return n;
 #else
-    (void)ms; (void)flops; (void)key; (void)max_records;
+    (void)stream; (void)ms; (void)flops; (void)key; (void)max_records;
     return 0;
 #endif
 }

@@ -10,7 +10,9 @@
 
 namespace {
 
-struct Dims { int B, S, H, I, nh; long M; size_t es; };
+// dtype: the caller's (VB_F32 / VB_BF16 / VB_BF16X3); edt: what the non-GEMM kernels see (bf16x3 keeps every activation
+// in fp32 and splits a GEMM's operands into bf16 hi | lo planes right in front of it); es: bytes per activation element
+struct Dims { int B, S, H, I, nh; long M; size_t es; int dtype, edt; bool x3; };
 
 inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -48,6 +50,9 @@ struct Scratch {
     unsigned char *t_h0, *t_h1, *t_h2, *t_h3, *t_h4, *t_h5, *t_i, *t_3h;
     float* dsum;
     float* ln_ws;
+    // bf16x3 only: split (hi | lo) images of the GEMM operands, [M, 2 x features] bf16 each.  Backward keeps all eight alive
+    // for the grouped weight-gradient launch; forward stages its four GEMM inputs through sp_inter one after the other.
+    unsigned char *sp_dfo, *sp_dpre, *sp_dao, *sp_dqkv, *sp_inter, *sp_aout, *sp_ctx, *sp_hin;
     size_t total;
 };
 Scratch carve_scratch(unsigned char* base, const Dims& d) {
@@ -64,15 +69,36 @@ Scratch carve_scratch(unsigned char* base, const Dims& d) {
     s.t_3h = take((size_t)d.M * 3 * d.H * d.es);
     s.dsum = (float*)take((size_t)vb_attn_bwd_ws_floats((int)d.B, (int)d.S, (int)d.nh) * 4);
     s.ln_ws = (float*)take((size_t)vb_ln_bwd_ws_bytes((int)d.M, d.H));
+    const size_t sh = d.x3 ? (size_t)d.M * 2 * d.H * 2 : 0, si = d.x3 ? (size_t)d.M * 2 * d.I * 2 : 0;
+    s.sp_dfo = take(sh); s.sp_dpre = take(si); s.sp_dao = take(sh); s.sp_dqkv = take(3 * sh);
+    s.sp_inter = take(si); s.sp_aout = take(sh); s.sp_ctx = take(sh); s.sp_hin = take(sh);
     s.total = o;
     return s;
 }
 
 bool fill_dims(Dims& d, int dtype, int B, int S, int H, int I, int nh) {
     if (B <= 0 || S <= 0 || H <= 0 || I <= 0 || nh <= 0 || nh * 64 != H || (H % 8) || (I % 8)) return false;
-    if (dtype != VB_F32 && dtype != VB_BF16) return false;
+    if (dtype != VB_F32 && dtype != VB_BF16 && dtype != VB_BF16X3) return false;
+    if (dtype == VB_BF16X3 && ((H % 64) || (I % 64))) return false;       // split-operand GEMMs reduce over whole K tiles
     d.B = B; d.S = S; d.H = H; d.I = I; d.nh = nh; d.M = (long)B * S; d.es = dtype == VB_BF16 ? 2 : 4;
+    d.dtype = dtype; d.x3 = dtype == VB_BF16X3; d.edt = d.x3 ? VB_F32 : dtype;
     return true;
+}
+
+// y[M, n] = epilogue(x[M, k] W[n, k]^T): in the split-operand mode x (fp32) is split into `stage` first and W arrives split
+int linear(const Dims& d, const void* x, int k, unsigned char* stage, const void* w, int64_t ldw, void* y, int n,
+           const float* bias, const void* addend, int act, const void* aux_in, void* aux_out, float* colsum, void* stream) {
+    const int M = (int)d.M;
+    if (!d.x3)
+        return vb_gemm(d.dtype, d.dtype, VB_KCONTIG, VB_KCONTIG, x, k, w, ldw, y, n, M, n, k, 1.f, nullptr, bias, addend, n, act,
+                       aux_in, aux_out, n, 0, colsum, stream);
+    if (stage) {                                               // nullptr: `x` already is the split image
+        const int rc = vb_split_bf16((const float*)x, k, stage, 2 * k, M, k, stream);
+        if (rc != VB_OK) return rc;
+        x = stage;
+    }
+    return vb_gemm(VB_BF16X3, VB_F32, VB_KCONTIG, VB_KCONTIG, x, 2 * k, w, ldw, y, n, M, n, k, 1.f, nullptr, bias, addend, n, act,
+                   aux_in, aux_out, n, 0, colsum, stream);
 }
 
 #define VB_TRY(expr) do { int rc_ = (expr); if (rc_ != VB_OK) return rc_; } while (0)
@@ -108,25 +134,24 @@ extern "C" int vb_bert_layer_fwd(int dtype, const void* h_in, const float* mask_
     const void* wo2 = weights[VB_LW_FO_W]; const float* bo2 = (const float*)weights[VB_LW_FO_B];
     const float* g2 = (const float*)weights[VB_LW_LN2_G]; const float* b2 = (const float*)weights[VB_LW_LN2_B];
 
+    const int edt = d.edt;
+    const int64_t wk = d.x3 ? 2 : 1;                   // leading dimension of a weight matrix per K element (split: hi | lo)
+    unsigned char* stage = d.x3 ? sc.sp_inter : nullptr;
     // 1. packed Q|K|V projection
-    VB_TRY(vb_gemm(dtype, dtype, VB_KCONTIG, VB_KCONTIG, h_in, H, wqkv, H, sv.qkv, 3 * H, M, 3 * H, H, 1.f, nullptr,
-                   bqkv, nullptr, 0, VB_ACT_NONE, nullptr, nullptr, 0, 0, nullptr, stream));
+    VB_TRY(linear(d, h_in, H, stage, wqkv, wk * H, sv.qkv, 3 * H, bqkv, nullptr, VB_ACT_NONE, nullptr, nullptr, nullptr, stream));
     // 2. fused attention
-    VB_TRY(vb_attn_fwd(dtype, sv.qkv, mask_add, sv.ctx, sv.lse, sv.keepbits, B, S, nh, 64, p_attn, seed, sid, stream));
+    VB_TRY(vb_attn_fwd(edt, sv.qkv, mask_add, sv.ctx, sv.lse, sv.keepbits, B, S, nh, 64, p_attn, seed, sid, stream));
     // 3. attention output projection
-    VB_TRY(vb_gemm(dtype, dtype, VB_KCONTIG, VB_KCONTIG, sv.ctx, H, wo, H, sc.t_h0, H, M, H, H, 1.f, nullptr, bo,
-                   nullptr, 0, VB_ACT_NONE, nullptr, nullptr, 0, 0, nullptr, stream));
+    VB_TRY(linear(d, sv.ctx, H, stage, wo, wk * H, sc.t_h0, H, bo, nullptr, VB_ACT_NONE, nullptr, nullptr, nullptr, stream));
     // 4. dropout + residual + LayerNorm
-    VB_TRY(vb_ln_fwd(dtype, sc.t_h0, h_in, sv.z1, sv.a_out, sv.mean1, sv.rstd1, g1, b1, M, H, eps, p_hidden, sid + 1,
+    VB_TRY(vb_ln_fwd(edt, sc.t_h0, h_in, sv.z1, sv.a_out, sv.mean1, sv.rstd1, g1, b1, M, H, eps, p_hidden, sid + 1,
                      0.f, 0, seed, stream));
-    // 5. FFN in + erf-GELU (pre-activation kept for backward)
-    VB_TRY(vb_gemm(dtype, dtype, VB_KCONTIG, VB_KCONTIG, sv.a_out, H, wi, H, sv.inter, I, M, I, H, 1.f, nullptr, bi,
-                   nullptr, 0, VB_ACT_GELU_SAVE_GRAD, nullptr, sv.pre, I, 0, nullptr, stream));
+    // 5. FFN in + erf-GELU (GELU' kept for backward)
+    VB_TRY(linear(d, sv.a_out, H, stage, wi, wk * H, sv.inter, I, bi, nullptr, VB_ACT_GELU_SAVE_GRAD, nullptr, sv.pre, nullptr, stream));
     // 6. FFN out
-    VB_TRY(vb_gemm(dtype, dtype, VB_KCONTIG, VB_KCONTIG, sv.inter, I, wo2, I, sc.t_h1, H, M, H, I, 1.f, nullptr, bo2,
-                   nullptr, 0, VB_ACT_NONE, nullptr, nullptr, 0, 0, nullptr, stream));
+    VB_TRY(linear(d, sv.inter, I, stage, wo2, wk * I, sc.t_h1, H, bo2, nullptr, VB_ACT_NONE, nullptr, nullptr, nullptr, stream));
     // 7. dropout + residual + LayerNorm
-    VB_TRY(vb_ln_fwd(dtype, sc.t_h1, sv.a_out, sv.z2, h_out, sv.mean2, sv.rstd2, g2, b2, M, H, eps, p_hidden, sid + 4,
+    VB_TRY(vb_ln_fwd(edt, sc.t_h1, sv.a_out, sv.z2, h_out, sv.mean2, sv.rstd2, g2, b2, M, H, eps, p_hidden, sid + 4,
                      0.f, 0, seed, stream));
     return VB_OK;
 }
@@ -154,9 +179,14 @@ extern "C" int vb_bert_layer_bwd(int dtype, const void* h_in, const float* mask_
     for (int i = 0; i < VB_LW_COUNT; ++i) { G[i] = (float*)grads[i]; if (!G[i]) return VB_ERR_ARG; }
     // dgrad dx[M,in] = dy[M,out] W[out,in]: with W^T [in, ld>=out] both operands are K-contiguous (LDS-direct
     // loads); otherwise W is read K-strided and transposed on the fly
+    const int edt = d.edt;
+    if (d.x3 && (!weights_t || !weights_t[0] || !weights_t[1] || !weights_t[2] || !weights_t[3] || !ld_t)) return VB_ERR_UNSUPPORTED;
+    // split-operand mode: dy (fp32) is split into `stage` -- kept for the grouped weight-gradient launch -- and W^T arrives split
     auto dgrad = [&](const void* dy, int n_out, const void* w, int which_t, int n_in, void* dx, const void* addend,
-                     int act, const void* aux, float* colsum = nullptr) -> int {
+                     int act, const void* aux, float* colsum = nullptr, unsigned char* stage = nullptr) -> int {
         const void* wt = weights_t ? weights_t[which_t] : nullptr;
+        if (d.x3)
+            return linear(d, dy, n_out, stage, wt, ld_t[which_t], dx, n_in, nullptr, addend, act, aux, nullptr, colsum, stream);
         if (wt)
             return vb_gemm(dtype, dtype, VB_KCONTIG, VB_KCONTIG, dy, n_out, wt, ld_t[which_t], dx, n_in, M, n_in, n_out,
                            1.f, nullptr, nullptr, addend, n_in, act, aux, nullptr, n_in, 0, colsum, stream);
@@ -170,29 +200,44 @@ extern "C" int vb_bert_layer_bwd(int dtype, const void* h_in, const float* mask_
     unsigned char* dz2 = sc.t_h0;                        // d(a_out) through the residual of the output LN
     unsigned char* dfo = p_hidden > 0.f ? sc.t_h1 : dz2; // d(FFN-out dense output)
     // 1. output LayerNorm backward (+ bias gradient of the FFN-out dense as a by-product)
-    VB_TRY(vb_ln_bwd(dtype, d_out, sv.z2, sv.mean2, sv.rstd2, g2, dz2, dfo, G[VB_LW_LN2_G], G[VB_LW_LN2_B],
+    VB_TRY(vb_ln_bwd(edt, d_out, sv.z2, sv.mean2, sv.rstd2, g2, dz2, dfo, G[VB_LW_LN2_G], G[VB_LW_LN2_B],
                      G[VB_LW_FO_B], M, H, p_hidden, sid + 4, 0.f, 0, seed, sc.ln_ws, stream));
     // 2. dgrad FFN-out with the saved GELU' folded into the epilogue: dpre = (dfo Wo2) * gelu'(pre)
     //    (+ bias gradient of FFN-in = column sums of dpre, accumulated by the same epilogue)
-    VB_TRY(dgrad(dfo, H, wo2, VB_LWT_FO, I, sc.t_i, nullptr, VB_ACT_MUL_AUX, sv.pre, G[VB_LW_FI_B]));
+    VB_TRY(dgrad(dfo, H, wo2, VB_LWT_FO, I, sc.t_i, nullptr, VB_ACT_MUL_AUX, sv.pre, G[VB_LW_FI_B], sc.sp_dfo));
     // 3. dgrad FFN-in + residual gradient: da = dpre Wi + dz2
-    VB_TRY(dgrad(sc.t_i, I, wi, VB_LWT_FI, H, sc.t_h2, dz2, VB_ACT_NONE, nullptr));
+    VB_TRY(dgrad(sc.t_i, I, wi, VB_LWT_FI, H, sc.t_h2, dz2, VB_ACT_NONE, nullptr, nullptr, sc.sp_dpre));
     // 4. attention-output LayerNorm backward
     unsigned char* dz1 = sc.t_h5;
     unsigned char* dao = p_hidden > 0.f ? sc.t_h4 : dz1;
-    VB_TRY(vb_ln_bwd(dtype, sc.t_h2, sv.z1, sv.mean1, sv.rstd1, g1, dz1, dao, G[VB_LW_LN1_G], G[VB_LW_LN1_B],
+    VB_TRY(vb_ln_bwd(edt, sc.t_h2, sv.z1, sv.mean1, sv.rstd1, g1, dz1, dao, G[VB_LW_LN1_G], G[VB_LW_LN1_B],
                      G[VB_LW_AO_B], M, H, p_hidden, sid + 1, 0.f, 0, seed, sc.ln_ws, stream));
     // 5. dgrad attention-out: dctx = dao Wo
-    VB_TRY(dgrad(dao, H, wo, VB_LWT_AO, H, sc.t_h3, nullptr, VB_ACT_NONE, nullptr));
+    VB_TRY(dgrad(dao, H, wo, VB_LWT_AO, H, sc.t_h3, nullptr, VB_ACT_NONE, nullptr, nullptr, sc.sp_dao));
     // 6-8. attention backward (one pass for bf16 and S <= 192, else dQ pass + dK/dV pass) + the q | k | v bias gradient
     //      (per-sample sums out of the one-pass kernel's accumulators; a column-sum pass over dqkv otherwise)
-    VB_TRY(vb_attn_bwd(dtype, sv.qkv, mask_add, sc.t_h3, sv.lse, sv.keepbits, sc.dsum, sc.t_3h, sv.ctx, G[VB_LW_QKV_B], B, S, nh,
+    VB_TRY(vb_attn_bwd(edt, sv.qkv, mask_add, sc.t_h3, sv.lse, sv.keepbits, sc.dsum, sc.t_3h, sv.ctx, G[VB_LW_QKV_B], B, S, nh,
                        64, p_attn, seed, sid, stream));
     // 9. dgrad QKV + residual gradient: dh = dqkv Wqkv + dz1
-    VB_TRY(dgrad(sc.t_3h, 3 * H, wqkv, VB_LWT_QKV, H, d_in, dz1, VB_ACT_NONE, nullptr));
+    VB_TRY(dgrad(sc.t_3h, 3 * H, wqkv, VB_LWT_QKV, H, d_in, dz1, VB_ACT_NONE, nullptr, nullptr, sc.sp_dqkv));
     // 10. the four weight gradients: dW_fo[H,I] += dfo^T inter, dW_fi[I,H] += dpre^T a_out, dW_ao[H,H] += dao^T ctx,
     //     dW_qkv[3H,H] += dqkv^T h_in
-    {
+    if (d.x3) {
+        // the dy images were split for the dgrads above; the four layer inputs are split here
+        VB_TRY(vb_split_bf16((const float*)sv.inter, I, sc.sp_inter, 2 * I, M, I, stream));
+        VB_TRY(vb_split_bf16((const float*)sv.a_out, H, sc.sp_aout, 2 * H, M, H, stream));
+        VB_TRY(vb_split_bf16((const float*)sv.ctx, H, sc.sp_ctx, 2 * H, M, H, stream));
+        VB_TRY(vb_split_bf16((const float*)h_in, H, sc.sp_hin, 2 * H, M, H, stream));
+        const void* dys[4] = {sc.sp_dfo, sc.sp_dpre, sc.sp_dao, sc.sp_dqkv};
+        const int64_t ld_dy[4] = {2 * H, 2 * I, 2 * H, 6 * H};
+        const void* xs[4] = {sc.sp_inter, sc.sp_aout, sc.sp_ctx, sc.sp_hin};
+        const int64_t ld_x[4] = {2 * I, 2 * H, 2 * H, 2 * H};
+        void* dws[4] = {G[VB_LW_FO_W], G[VB_LW_FI_W], G[VB_LW_AO_W], G[VB_LW_QKV_W]};
+        const int64_t ld_dw[4] = {I, H, H, H};
+        const int n_out[4] = {H, I, H, 3 * H};
+        const int n_in[4] = {I, H, H, H};
+        VB_TRY(vb_wgrad_grouped(VB_BF16X3, 4, dys, ld_dy, xs, ld_x, dws, ld_dw, n_out, n_in, M, 1.f, nullptr, stream));
+    } else {
         const void* dys[4] = {dfo, sc.t_i, dao, sc.t_3h};
         const int64_t ld_dy[4] = {H, I, H, 3 * H};
         const void* xs[4] = {sv.inter, sv.a_out, sv.ctx, h_in};

@@ -185,6 +185,69 @@ extern "C" int vb_cast(int src_dtype, const void* src, int dst_dtype, void* dst,
     return vb_check_launch();
 }
 
+// ---- split operands of the VB_BF16X3 GEMM mode (include/visualbert_hip.h) ------------------------------------------
+// x = hi + lo with hi = bf16(x) (round to nearest even) and lo = bf16(x - hi): the residual x - hi is exact in fp32 (it has
+// at most 16 significant bits), so |x - hi - lo| <= 2^-9 |x - hi| <= 2^-18 |x|.
+// A thread handles 8 consecutive columns of a row: one 32-byte read, two 16-byte writes (hi plane, lo plane).
+VB_KERNEL VB_LAUNCH_BOUNDS(NT) split_rows_kernel(const float* src, long ld_src, bf16* dst, long ld_dst, long rows, int cols) {
+    const int half = (int)(ld_dst / 2), chunks = half / 8;               // ld_dst % 16 == 0
+    const bool vec_src = ((ld_src % 4) == 0) && ((((uintptr_t)src) & 15) == 0);
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < rows * chunks; i += (long)gridDim.x * NT) {
+        const long r = i / chunks;
+        const int c0 = (int)(i - r * chunks) * 8;
+        float v[8];
+        if (c0 + 8 <= cols && vec_src) load8(v, src + r * ld_src + c0);
+        else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (c0 + j < cols) ? src[r * ld_src + c0 + j] : 0.0f;
+        }
+        float lo[8];
+        bf16x8 h;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { h[j] = (bf16)v[j]; lo[j] = v[j] - (float)h[j]; }
+        *(bf16x8*)(dst + r * ld_dst + c0) = h;
+        store8(dst + r * ld_dst + half + c0, lo);
+    }
+}
+// transposed: a 64 x 64 tile of src through LDS; dst[c, r] = hi, dst[c, half + r] = lo
+VB_KERNEL VB_LAUNCH_BOUNDS(NT) split_rows_t_kernel(const float* src, long ld_src, bf16* dst, long ld_dst, int rows, int cols, int tiles_c) {
+    VB_DYN_SMEM(smem_raw);
+    float (*tile)[65] = (float (*)[65])smem_raw;
+    const int tr = blockIdx.x / tiles_c, tc = blockIdx.x % tiles_c;
+    const int r0 = tr * 64, c0 = tc * 64, half = (int)(ld_dst / 2);
+    for (int i = threadIdx.x; i < 64 * 64; i += NT) {
+        const int r = i >> 6, c = i & 63;
+        tile[r][c] = (r0 + r < rows && c0 + c < cols) ? src[(long)(r0 + r) * ld_src + c0 + c] : 0.0f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 64; i += NT) {
+        const int c = i >> 6, r = i & 63;                                 // output row = source column
+        if (c0 + c >= cols || r0 + r >= half) continue;
+        const float v = tile[r][c];
+        const bf16 h = (bf16)v;
+        dst[(long)(c0 + c) * ld_dst + r0 + r] = h;
+        dst[(long)(c0 + c) * ld_dst + half + r0 + r] = (bf16)(v - (float)h);
+    }
+}
+
+extern "C" int vb_split_bf16(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows, int cols, void* stream) {
+    if (!src || !dst || rows <= 0 || cols <= 0 || (ld_dst % 16) || cols > ld_dst / 2 || ld_src < cols || (((uintptr_t)dst) & 15))
+        return VB_ERR_ARG;
+    const long work = rows * (ld_dst / 16);
+    long blocks = (work + NT - 1) / NT;
+    if (blocks > 8192) blocks = 8192;
+    VB_LAUNCH(split_rows_kernel, dim3((unsigned)blocks), dim3(NT), 0, (hipStream_t)stream, src, (long)ld_src, (bf16*)dst, (long)ld_dst,
+              (long)rows, cols);
+    return vb_check_launch();
+}
+extern "C" int vb_split_bf16_t(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, int rows, int cols, void* stream) {
+    if (!src || !dst || rows <= 0 || cols <= 0 || (ld_dst % 16) || rows > ld_dst / 2 || ld_src < cols) return VB_ERR_ARG;
+    const int tiles_r = (int)((ld_dst / 2 + 63) / 64), tiles_c = (cols + 63) / 64;       // row tiles cover the zero padding too
+    VB_LAUNCH(split_rows_t_kernel, dim3((unsigned)(tiles_r * tiles_c)), dim3(NT), 64 * 65 * 4, (hipStream_t)stream, src, (long)ld_src, (bf16*)dst,
+              (long)ld_dst, rows, cols, tiles_c);
+    return vb_check_launch();
+}
+
 // nn.Dropout on a small tensor (the pooled / gathered [B, H] state in front of the fine-tuning heads, modeling.py:1495, 1509,
 // 1557): y = keep ? x / (1 - p) : 0 with the counter-based bits every other dropout site uses (vb_dropout_bits8: keyed by
 // seed, stream id and the 8-element group index) -- the backward pass calls it again on dy with the same key and gets the
@@ -285,6 +348,7 @@ vb_stream_opts vb_opts_for(void* stream) {
 extern "C" int vb_stream_set_opts(void* stream, const vb_stream_opts* opts) {
     if (opts) {
         const int k = opts->nt_kernel;
+        if (opts->reserved != 0) return VB_ERR_ARG;
         if (opts->persistent_workgroups < 0 || (k != 0 && k != 1 && k != 22 && k != 42 && k != 80 && k != 81 && k != 90 && k != 91 && k != 100))
             return VB_ERR_ARG;
     }

@@ -10,12 +10,14 @@ visualbert/models/model.py:213-223,272-288 work unchanged.  What differs is unde
     packed QKV GEMM reads them in place, gradients are written by the kernels straight into a
     flat gradient arena (bucketed RCCL all-reduce and the fused BertAdam work on contiguous ranges),
     and a bf16 shadow arena feeds the MFMA GEMMs in bf16 mode;
-  * compute dtype is selectable: torch.float32 (strict parity) or torch.bfloat16 (throughput).
+  * compute dtype is selectable: torch.float32 (strict parity), torch.bfloat16 (throughput) or "bf16x3" (fp32 activations,
+    GEMMs as three bf16 MFMA passes over hi / lo split operands: fp32-class logits at several times the fp32 kernels' speed).
 
 The branches BASELINE.json's configs never take run on the same kernels:
-image_text_alignment, bypass_transformer, output_attention_weights, the multichoice / vqa_advanced / flickr heads.  What is left of
-that row raises NotImplementedError (the `confidence` / `position_embeddings_visual` inputs, which the reference's
-embeddings accept and ignore; attention weights under training-mode dropout) -- never silently approximated.
+image_text_alignment, bypass_transformer, output_attention_weights, the multichoice / vqa_advanced / flickr heads.  The
+`confidence` / `position_embeddings_visual` inputs are accepted and ignored like the reference's embeddings do
+(modeling.py:1198-1257).  What is left of that row raises NotImplementedError (attention weights under training-mode
+dropout) -- never silently approximated.
 """
 import copy
 import json
@@ -235,6 +237,7 @@ class ParameterArena(object):
         for p in self.params:
             if p.dim() == 2:
                 p._vb_shadow_ver = p._version
+        ops.bump_x3_epoch()
         # a raw write into `data` (broadcast, checkpoint restore) does not move p._version, so the W^T shadows cannot rely
         # on version counters either: re-transpose now (one launch)
         self.refresh_transposed()
@@ -426,6 +429,7 @@ class _PackedWeight(object):
         return getattr(self._o.query.weight, "_vb_arena", None)
 
 
+@ops.x3_aware
 class _PackedLinearFn(torch.autograd.Function):
     """the three Linears of modeling.py:232-234 as one GEMM (stand-alone BertSelfAttention path)."""
 
@@ -907,11 +911,18 @@ class TrainVisualBERTObjective(PreTrainedBertModel):
 
     # -- storage ---------------------------------------------------------------------------------
     def set_compute_dtype(self, dtype):
+        """torch.float32: every kernel in fp32 (fp32-input MFMA; the strict parity mode).  torch.bfloat16 (also what .half()
+        selects): bf16 storage and MFMA operands, fp32 accumulation.  "bf16x3": fp32 activations and fp32-class results
+        with the GEMMs on the bf16 matrix pipe -- operands split into hi + lo bf16 planes, three passes (VB_BF16X3)."""
+        x3 = isinstance(dtype, str) and dtype.lower() == "bf16x3"
+        if x3:
+            dtype = torch.float32
         if dtype in (torch.float16, torch.half):
             dtype = torch.bfloat16              # gfx950 path: bf16 storage + fp32 accumulate
         if dtype not in (torch.float32, torch.bfloat16):
-            raise ValueError("compute dtype must be float32 or bfloat16")
+            raise ValueError("compute dtype must be float32, bfloat16 or 'bf16x3'")
         self.compute_dtype = dtype
+        self.gemm_x3 = x3
         self.bert.embeddings.compute_dtype = dtype
         return self
 
@@ -1019,13 +1030,16 @@ class TrainVisualBERTObjective(PreTrainedBertModel):
         return r
 
     # -- forward ---------------------------------------------------------------------------------
-    def forward(self, input_ids, token_type_ids, input_mask, visual_embeddings, position_embeddings_visual, image_mask,
-                image_text_alignment=None, confidence=None, visual_embeddings_type=None, label=None,
-                flickr_position=None, masked_lm_labels=None, image_lm_lables=None, is_random_next=None,
-                output_all_encoded_layers=False):
-        if confidence is not None or position_embeddings_visual is not None:
-            raise NotImplementedError("confidence / position_embeddings_visual: the reference's embeddings ignore "
-                                      "both (modeling.py:1198-1257); refusing rather than dropping them silently")
+    def forward(self, *args, **kwargs):
+        with ops.x3_scope(getattr(self, "gemm_x3", False)):          # GEMM mode of THIS model, for forward and (via ctx) backward
+            return self._forward(*args, **kwargs)
+
+    def _forward(self, input_ids, token_type_ids, input_mask, visual_embeddings, position_embeddings_visual, image_mask,
+                 image_text_alignment=None, confidence=None, visual_embeddings_type=None, label=None,
+                 flickr_position=None, masked_lm_labels=None, image_lm_lables=None, is_random_next=None,
+                 output_all_encoded_layers=False):
+        # `confidence` and `position_embeddings_visual` are accepted and IGNORED, exactly as the reference does: its
+        # embeddings take both arguments and never read them (modeling.py:1198-1257; :1383, :1403 pass them through)
         flat_input_ids = transform_to_batch_sequence(input_ids)
         flat_token_type_ids = transform_to_batch_sequence(token_type_ids)
         self._check_inputs(flat_input_ids, flat_token_type_ids, masked_lm_labels)

@@ -75,11 +75,140 @@ def _ld(t):
 
 
 # ------------------------------------------------------------------------------------------------
+# "bf16x3": fp32 GEMMs on the bf16 matrix pipe (include/visualbert_hip.h, VB_BF16X3).  Activations stay fp32 tensors; right
+# in front of a GEMM each operand is split into bf16 hi | lo planes and the kernel accumulates hi.hi + lo.hi + hi.lo in fp32.
+# The mode is a property of the MODEL (TrainVisualBERTObjective.set_compute_dtype("bf16x3")): its forward runs inside
+# x3_scope(True), every autograd Function below remembers the flag for its backward (x3_aware).
+# ------------------------------------------------------------------------------------------------
+_x3 = [False]
+_x3_epoch = [0]
+
+
+def x3_active():
+    return _x3[0]
+
+
+def bump_x3_epoch():
+    """parameters were rewritten behind torch's version counters (fused optimizer step, broadcast, checkpoint restore):
+    every cached split weight is stale from here on and is re-split at its next use."""
+    _x3_epoch[0] += 1
+
+
+class x3_scope(object):
+    def __init__(self, on):
+        self.on = bool(on)
+
+    def __enter__(self):
+        self.old = _x3[0]
+        _x3[0] = self.on
+        return self
+
+    def __exit__(self, *exc):
+        _x3[0] = self.old
+        return False
+
+
+def x3_aware(cls):
+    """class decorator for the autograd Functions: forward records whether the split-operand mode was on, backward runs under
+    the same setting (autograd calls it long after the model's forward scope has closed)."""
+    fwd, bwd = cls.forward, cls.backward
+
+    def forward(ctx, *args):
+        ctx._vb_x3 = _x3[0]
+        return fwd(ctx, *args)
+
+    def backward(ctx, *grads):
+        with x3_scope(getattr(ctx, "_vb_x3", False)):
+            return bwd(ctx, *grads)
+
+    cls.forward = staticmethod(forward)
+    cls.backward = staticmethod(backward)
+    return cls
+
+
+class SplitOperand(object):
+    """bf16 [rows, ld] image of an fp32 [rows, cols] matrix: hi plane in columns [0, ld/2), lo plane in [ld/2, ld), pad zeroed.
+    Quacks like the fp32 matrix where the callers look at shapes; `master` (optional) is the fp32 tensor it was made from."""
+
+    def __init__(self, buf, cols, master=None):
+        self.buf, self.cols, self.master = buf, cols, master
+        self.shape = (buf.size(0), cols)
+        self.dtype = torch.float32
+        self.device = buf.device
+
+    def size(self, i):
+        return self.shape[i]
+
+    @property
+    def ld(self):
+        return self.buf.stride(0)
+
+
+def split_rows(x, rows, cols, half=None):
+    """split `cols` columns of the first `rows` rows of the row-major fp32 matrix behind x (leading dimension x.stride(0); the
+    columns may extend into x's zero padding) into a SplitOperand with hi | lo planes of `half` columns (default: cols rounded
+    up to 8)."""
+    if x.dtype != torch.float32 or x.stride(-1) != 1:
+        raise RuntimeError("visualbert_amd.split_rows: fp32 row-major input required")
+    half = half or round_up(cols, 8)
+    buf = torch.empty((rows, 2 * half), dtype=torch.bfloat16, device=x.device)
+    ld_src = x.stride(0) if x.dim() == 2 else cols
+    check(_lib.lib().vb_split_bf16(ptr(x), ld_src, ptr(buf), 2 * half, rows, cols, stream_ptr()), "vb_split_bf16")
+    return SplitOperand(buf, cols)
+
+
+def _x3_holder(p):
+    return getattr(p, "_o", p)                      # the packed q|k|v alias keeps its cache on the attention module
+
+
+def _x3_entry(p):
+    h = _x3_holder(p)
+    e = getattr(h, "_vb_x3_entry", None)
+    ver = (p._version, _x3_epoch[0])
+    if e is None or e["device"] != p.device:
+        e = dict(w=None, wt=None, w_ver=None, wt_ver=None, device=p.device)
+        h._vb_x3_entry = e
+    return e, ver
+
+
+def x3_weight(p):
+    """split image [N, 2 K'] of the 2-D fp32 weight p [N, K] (cached on the parameter, re-split when it changed)"""
+    e, ver = _x3_entry(p)
+    w = p.detach()
+    N, K = w.shape
+    if e["w"] is None:
+        e["w"] = SplitOperand(torch.empty((N, 2 * round_up(K, 8)), dtype=torch.bfloat16, device=w.device), K, master=w)
+    if e["w_ver"] != ver:
+        so = e["w"]
+        so.master = w
+        check(_lib.lib().vb_split_bf16(ptr(w), w.stride(0), ptr(so.buf), so.ld, N, K, stream_ptr()), "vb_split_bf16")
+        e["w_ver"] = ver
+    return e["w"]
+
+
+def x3_weight_t(p):
+    """split image of W^T: [K, 2 round_up(N, 64)] for p [N, K] (the dgrad operand; zero padded so the decoder's ragged
+    vocabulary reduces over whole K tiles)"""
+    e, ver = _x3_entry(p)
+    w = p.detach()
+    N, K = w.shape
+    if e["wt"] is None:
+        e["wt"] = SplitOperand(torch.empty((K, 2 * round_up(N, 64)), dtype=torch.bfloat16, device=w.device), N)
+    if e["wt_ver"] != ver:
+        so = e["wt"]
+        check(_lib.lib().vb_split_bf16_t(ptr(w), w.stride(0), ptr(so.buf), so.ld, N, K, stream_ptr()), "vb_split_bf16_t")
+        e["wt_ver"] = ver
+    return e["wt"]
+
+
+# ------------------------------------------------------------------------------------------------
 # parameters: bf16 shadows and gradient targets
 # ------------------------------------------------------------------------------------------------
 def weight_for(p, dtype):
     """The tensor a GEMM should read for parameter/buffer `p` when activations have `dtype`."""
     if dtype == torch.float32:
+        if _x3[0] and len(p.shape) == 2:
+            return x3_weight(p)
         return p.detach()
     sh = getattr(p, "_vb_shadow", None)
     if sh is None or sh.device != p.device:
@@ -95,6 +224,8 @@ def weight_for(p, dtype):
 def weight_t_for(p, dtype):
     """W^T (bf16, [in, out] with a padded leading dimension) for dgrad, or None when the parameter has no
     arena-managed transposed shadow (fp32 mode, stand-alone modules): dgrad then reads W K-strided."""
+    if dtype == torch.float32 and _x3[0] and len(p.shape) == 2:
+        return x3_weight_t(p)
     if dtype != torch.bfloat16:
         return None
     wt = getattr(p, "_vb_shadow_t", None)
@@ -128,9 +259,13 @@ def cast(src, dst):
     return dst
 
 
+_profiled_stream = [None]
+
+
 def gemm_profile_start():
-    """HIP-event timing of every vb_gemm launch, recorded inside the library on the launch stream."""
-    check(_lib.lib().vb_gemm_profile(1), "vb_gemm_profile")
+    """HIP-event timing of every GEMM launch enqueued on the CURRENT stream, recorded inside the library (vb_stream_profile)."""
+    _profiled_stream[0] = stream_ptr()
+    check(_lib.lib().vb_stream_profile(_profiled_stream[0], 1), "vb_stream_profile")
 
 
 def gemm_profile_stop():
@@ -141,29 +276,31 @@ def gemm_profile_stop():
     ms = (ctypes.c_double * cap)()
     fl = (ctypes.c_double * cap)()
     ky = (ctypes.c_int * cap)()
-    n = L.vb_gemm_profile_read(ms, fl, ky, cap)
+    n = L.vb_stream_profile_read(_profiled_stream[0], ms, fl, ky, cap)
     if n < 0:
-        raise RuntimeError("vb_gemm_profile_read failed (device not synchronised?)")
+        raise RuntimeError("vb_stream_profile_read failed (device not synchronised?)")
     out = {}
     for i in range(n):
         d = out.setdefault(ky[i], dict(ms=0.0, flops=0.0, launches=0))
         d["ms"] += ms[i]
         d["flops"] += fl[i]
         d["launches"] += 1
-    L.vb_gemm_profile(0)
+    L.vb_stream_profile(_profiled_stream[0], 0)
     return out
 
 
 def gemm_key_name(key):
     if (key & 19) == 19:
         return "gemm_tn_8ph_kernel<bf16->fp32, grouped persistent 256x256 wgrad, ds_read_b64_tr_b16 gathers, fp32 atomics>"
+    x3 = " [bf16x3 split operands]" if key & 256 else ""
+    key &= 255
     if not (key & 3):
         kind = ("gemm_nt_dual_kernel<%s->%s, 256x128 tile, two workgroups per CU, five-slot LDS-direct ring>" if key & 64 else
                 "gemm_nt_8ph_kernel<%s->%s, persistent 256x256 tile, four-slot LDS-direct schedule>" if key & 16 else
                 "gemm_nt_experimental<%s->%s>" if key & 32 else
                 "gemm_nt_pipe_kernel<%s->%s, 256x128 tile, 2-stage LDS-direct>")
-        return kind % ("fp32" if key & 8 else "bf16", "fp32" if (key & 4 or key & 8) else "bf16")
-    return "gemm_kernel<%s->%s, A %s, B %s>" % ("fp32" if key & 8 else "bf16",
+        return kind % ("fp32" if key & 8 else "bf16", "fp32" if (key & 4 or key & 8) else "bf16") + x3
+    return x3.strip() + "gemm_kernel<%s->%s, A %s, B %s>" % ("fp32" if key & 8 else "bf16",
                                                 "fp32" if (key & 4 or key & 8) else "bf16",
                                                 "Kstrided" if key & 2 else "Kcontig",
                                                 "Kstrided" if key & 1 else "Kcontig")
@@ -174,6 +311,17 @@ def gemm(a, b, M, N, K, a_layout=VB_KCONTIG, b_layout=VB_KCONTIG, out=None, out_
     dt = a.dtype
     if b.dtype != dt:
         raise RuntimeError("visualbert_amd.gemm: operand dtypes differ (%s vs %s)" % (dt, b.dtype))
+    if _x3[0] and dt == torch.float32:
+        r = _gemm_x3(a, b, M, N, K, a_layout, b_layout, out, out_dtype, bias, act, addend, aux_in, aux_out, accumulate, alpha,
+                     alpha_dev, colsum_out)
+        if r is not None:
+            return r
+    if isinstance(a, SplitOperand):                 # a shape the split-operand kernels do not take: the exact fp32 path
+        a = a.master
+    if isinstance(b, SplitOperand):
+        b = b.master
+    if a is None or b is None:
+        raise RuntimeError("visualbert_amd.gemm: split operand without an fp32 master on a shape that needs the fp32 kernels")
     if out is None:
         out = alloc2d(M, N, out_dtype or dt, a.device)
     aux = aux_in if aux_in is not None else aux_out
@@ -186,6 +334,43 @@ def gemm(a, b, M, N, K, a_layout=VB_KCONTIG, b_layout=VB_KCONTIG, out=None, out_
                                   1 if accumulate else 0, ptr(colsum_out), stream_ptr())
     check(run(), "vb_gemm")
     return out
+
+
+def _gemm_x3(a, b, M, N, K, a_layout, b_layout, out, out_dtype, bias, act, addend, aux_in, aux_out, accumulate, alpha, alpha_dev,
+             colsum_out):
+    """the split-operand form of gemm() for fp32 tensors, or None when the shape is not one it takes (ragged K, a K-strided
+    operand next to a K-contiguous one): the caller then runs the exact fp32 kernels."""
+    L = _lib.lib()
+    dev = a.device
+    if out is not None and out.dtype != torch.float32:
+        return None
+    if a_layout == VB_KCONTIG and b_layout == VB_KCONTIG:
+        if K % 64:
+            return None
+        A = a if isinstance(a, SplitOperand) else split_rows(a, M, K)
+        Bm = b if isinstance(b, SplitOperand) else split_rows(b, N, K)
+        if A.ld // 2 < K or Bm.ld // 2 < K or A.ld % 16 or Bm.ld % 16:
+            return None
+        if out is None:
+            out = alloc2d(M, N, torch.float32, dev)
+        aux = aux_in if aux_in is not None else aux_out
+        check(L.vb_gemm(_lib.VB_BF16X3, _lib.VB_F32, VB_KCONTIG, VB_KCONTIG, ptr(A.buf), A.ld, ptr(Bm.buf), Bm.ld, ptr(out),
+                        _ld(out), M, N, K, float(alpha), ptr(alpha_dev), ptr(bias), ptr(addend),
+                        _ld(addend) if addend is not None else 0, act, ptr(aux_in), ptr(aux_out),
+                        _ld(aux) if aux is not None else 0, 1 if accumulate else 0, ptr(colsum_out), stream_ptr()), "vb_gemm(bf16x3)")
+        return out
+    if a_layout == VB_KSTRIDED and b_layout == VB_KSTRIDED and accumulate and out is not None and bias is None and \
+            addend is None and act == VB_ACT_NONE and colsum_out is None and not isinstance(a, SplitOperand) and \
+            not isinstance(b, SplitOperand):
+        # weight gradient dW[M, N] += a^T b over K tokens: a [K, M], b [K, N] token-major
+        import ctypes
+        A, Bm = split_rows(a, K, M), split_rows(b, K, N)
+        P1, I64, I32 = ctypes.c_void_p * 1, ctypes.c_int64 * 1, ctypes.c_int * 1
+        check(L.vb_wgrad_grouped(_lib.VB_BF16X3, 1, P1(A.buf.data_ptr()), I64(A.ld), P1(Bm.buf.data_ptr()), I64(Bm.ld),
+                                 P1(out.data_ptr()), I64(_ld(out)), I32(M), I32(N), K, float(alpha), ptr(alpha_dev),
+                                 stream_ptr()), "vb_wgrad_grouped(bf16x3)")
+        return out
+    return None
 
 
 def linear_fwd(x, w, bias, act=VB_ACT_NONE, aux_out=None, out_dtype=None, addend=None):
@@ -202,6 +387,8 @@ def linear_dgrad(dy, w, act=VB_ACT_NONE, aux_in=None, addend=None, out=None, alp
     columns instead of N when BOTH dy and wt are zero-padded that far (ragged vocabulary)."""
     M, N = dy.shape
     K = w.shape[1]
+    if isinstance(wt, SplitOperand) and ((k_pad or N) % 64 != 0 or wt.ld // 2 < (k_pad or N)):
+        wt = None                                       # not a split-operand shape: exact fp32 kernels on the master weight
     if wt is not None:
         return gemm(dy, wt, M, K, k_pad or N, act=act, aux_in=aux_in, addend=addend, out=out, alpha_dev=alpha_dev,
                     colsum_out=colsum_out)
@@ -383,6 +570,7 @@ def _rows_for(lab):
 # ------------------------------------------------------------------------------------------------
 # autograd Functions
 # ------------------------------------------------------------------------------------------------
+@x3_aware
 class LinearFn(torch.autograd.Function):
     """nn.Linear (+ GELU / tanh) -- modeling.py:232-234, 271, 303-304, 316, 383-385, 398-399, 1220."""
 
@@ -446,6 +634,7 @@ def dropout_apply(x, p, seed, sid):
     return y
 
 
+@x3_aware
 class DropoutFn(torch.autograd.Function):
     """nn.Dropout in front of the fine-tuning heads (modeling.py:1495, 1557) without a mask tensor."""
 
@@ -461,6 +650,7 @@ class DropoutFn(torch.autograd.Function):
         return dropout_apply(dy, p, seed, sid).view(dy.shape), None, None
 
 
+@x3_aware
 class LayerNormFn(torch.autograd.Function):
     """y = dropout_out(LN(dropout_in(x) + resid)) -- modeling.py:171-175 with :272-273 / :317-318 / :1255-1256."""
 
@@ -491,6 +681,7 @@ class LayerNormFn(torch.autograd.Function):
                 None, None, None, None)
 
 
+@x3_aware
 class SelfAttentionCoreFn(torch.autograd.Function):
     """packed qkv [B,S,3H] -> context [B,S,H]; modeling.py:236-256."""
 
@@ -518,6 +709,7 @@ class SelfAttentionCoreFn(torch.autograd.Function):
         return dqkv.view(B, S, -1), None, None, None, None
 
 
+@x3_aware
 class CrossAttentionCoreFn(torch.autograd.Function):
     """softmax(Q K^T / 8 + mask) V with queries and keys / values from DIFFERENT sequences: q [B, Sq, H], k, v [B, Sk, H]
     (any row pitch), mask_add fp32 [B, Sk] over the keys -> context [B, Sq, H].  The core of the LXRT sibling's
@@ -568,6 +760,7 @@ def _packed_qkv(attn_self, dtype):
     return w, attn_self.qkv_bias.detach()
 
 
+@x3_aware
 class AttentionBlockFn(torch.autograd.Function):
     """BertAttention = BertSelfAttention + BertSelfOutput, fused: packed QKV GEMM -> attention ->
     output GEMM -> dropout + residual + LayerNorm (modeling.py:231-274).  Backward runs
@@ -626,6 +819,7 @@ class AttentionBlockFn(torch.autograd.Function):
                 grad_result(g_ow, d4), grad_result(g_ob, d3), grad_result(g_ln_w, d1), grad_result(g_ln_b, d2))
 
 
+@x3_aware
 class FFNBlockFn(torch.autograd.Function):
     """BertIntermediate + BertOutput fused (modeling.py:302-305, 315-319): GEMM+bias+erf-GELU epilogue,
     GEMM+bias, dropout + residual + LayerNorm; backward folds GELU' into the dgrad GEMM epilogue."""
@@ -693,10 +887,11 @@ def _ptr_array(items):
     import ctypes
     arr = (ctypes.c_void_p * len(items))()
     for i, t in enumerate(items):
-        arr[i] = t.data_ptr()
+        arr[i] = (t.buf if isinstance(t, SplitOperand) else t).data_ptr()
     return arr
 
 
+@x3_aware
 class BertLayerFn(torch.autograd.Function):
     """A whole BertLayer (modeling.py:331-341) as ONE autograd node: forward and backward are one C-ABI
     call each (vb_bert_layer_fwd / vb_bert_layer_bwd, csrc/layer.hip sequences the 7 + 15 launches)."""
@@ -710,7 +905,7 @@ class BertLayerFn(torch.autograd.Function):
         if not h2.is_contiguous():
             h2 = h2.contiguous()
         dt = h2.dtype
-        code = _lib.dtype_code(dt)
+        code = _lib.VB_BF16X3 if (_x3[0] and dt == torch.float32) else _lib.dtype_code(dt)
         I = im.dense.weight.size(0)
         nh = sa.num_attention_heads
         L = _lib.lib()
@@ -745,7 +940,7 @@ class BertLayerFn(torch.autograd.Function):
         at, im, om = layer.attention, layer.intermediate, layer.output
         sa, so = at.self, at.output
         dt = h2.dtype
-        code = _lib.dtype_code(dt)
+        code = _lib.VB_BF16X3 if (_x3[0] and dt == torch.float32) else _lib.dtype_code(dt)
         dy2 = dy.reshape(B * S, H)
         if dy2.dtype != dt:
             dy2 = dy2.to(dt)
@@ -770,6 +965,8 @@ class BertLayerFn(torch.autograd.Function):
         wt_arr = (ctypes.c_void_p * 4)()
         ld_arr = (ctypes.c_int64 * 4)()
         for i, w_ in enumerate(wts):
+            if isinstance(w_, SplitOperand):
+                w_ = w_.buf
             wt_arr[i] = w_.data_ptr() if w_ is not None else None
             ld_arr[i] = w_.stride(0) if w_ is not None else 0
         check(L.vb_bert_layer_bwd(code, ptr(h2), ptr(mask_add), ptr(dy2), ptr(d_in), ptr(saved), ptr(scratch),
@@ -783,6 +980,7 @@ class BertLayerFn(torch.autograd.Function):
         return (d_in.view(B, S, H), None, None, None, None, *gq, *[grad_result(g, d) for g, d in tg])
 
 
+@x3_aware
 class EmbeddingsFn(torch.autograd.Function):
     """BertEmbeddingsWithVisualEmbedding.forward (modeling.py:1198-1257): region projection GEMM, gather-add of
     the five tables (+ the mean text-position embedding of the aligned words when image_text_alignment is given,
@@ -881,6 +1079,7 @@ class EmbeddingsFn(torch.autograd.Function):
                 grad_result(g_pw, d8), grad_result(g_pb, d9))
 
 
+@x3_aware
 class MLMHeadLossFn(torch.autograd.Function):
     """BertLMPredictionHead + CrossEntropyLoss(ignore_index=-1), fused (modeling.py:397-401, 417-420,
     1471-1473): transform GEMM+GELU -> LayerNorm -> tied-decoder GEMM (fp32 logits) -> loss and
@@ -950,8 +1149,11 @@ class MLMHeadLossFn(torch.autograd.Function):
         # dgrad over few rows and a 30522-long reduction: split-K (fp32 accumulate) instead of 30 output tiles
         dtn_c = torch.zeros((n_pad, H), dtype=torch.float32, device=tn.device)
         k_pad = None
-        if Et is not None and Et.stride(0) == _ld(dlogits) and (Et.stride(0) % 64) == 0:
-            k_pad = Et.stride(0)                    # both pads are zero: reduce over whole K tiles (LDS-direct)
+        et_ld = (Et.ld // 2 if isinstance(Et, SplitOperand) else Et.stride(0)) if Et is not None else 0
+        if Et is not None and et_ld == _ld(dlogits) and (et_ld % 64) == 0:
+            k_pad = et_ld                           # both pads are zero: reduce over whole K tiles (LDS-direct)
+        if isinstance(Et, SplitOperand) and (k_pad or V) % 64 != 0:
+            Et = None                               # ragged reduction: the exact fp32 kernels on the master weight
         if Et is not None:
             gemm(dlogits, Et, n_pad, H, k_pad or V, out=dtn_c, accumulate=True, alpha_dev=up)
         else:
@@ -976,6 +1178,7 @@ class MLMHeadLossFn(torch.autograd.Function):
                 grad_result(g_tb, d6), grad_result(g_lw, d3), grad_result(g_lb, d4))
 
 
+@x3_aware
 class SparseMLMHeadLossFn(torch.autograd.Function):
     """Opt-in MLM head over the LABELLED positions only: gather the rows whose label is counted, then
     transform GEMM+GELU -> LayerNorm -> tied-decoder GEMM -> CrossEntropyLoss on those rows.  Same loss and gradients as
@@ -1031,8 +1234,11 @@ class SparseMLMHeadLossFn(torch.autograd.Function):
         Et = weight_t_for(ctx.word_weight, dt)
         dtn32 = torch.zeros((n_pad, H), dtype=torch.float32, device=s_c.device)
         k_pad = None
-        if Et is not None and Et.stride(0) == _ld(dlogits) and (Et.stride(0) % 64) == 0:
-            k_pad = Et.stride(0)
+        et_ld = (Et.ld // 2 if isinstance(Et, SplitOperand) else Et.stride(0)) if Et is not None else 0
+        if Et is not None and et_ld == _ld(dlogits) and (et_ld % 64) == 0:
+            k_pad = et_ld
+        if isinstance(Et, SplitOperand) and (k_pad or V) % 64 != 0:
+            Et = None                               # ragged reduction: the exact fp32 kernels on the master weight
         if Et is not None:
             gemm(dlogits, Et, n_pad, H, k_pad or V, out=dtn32, accumulate=True, alpha_dev=up)
         else:
@@ -1058,6 +1264,7 @@ class SparseMLMHeadLossFn(torch.autograd.Function):
                 grad_result(g_tb, d6), grad_result(g_lw, d3), grad_result(g_lb, d4))
 
 
+@x3_aware
 class SmallLinearCEFn(torch.autograd.Function):
     """Linear with a tiny output width + CrossEntropyLoss: seq_relationship / image-text-match
     (modeling.py:451, 1474), the NLVR2 classifier (modeling.py:1558-1565) and, with choices = 4, the VCR
@@ -1115,6 +1322,7 @@ class SmallLinearCEFn(torch.autograd.Function):
                 None)
 
 
+@x3_aware
 class VQAHeadLossFn(torch.autograd.Function):
     """VQA head (modeling.py:1502-1525): gather hidden state at index input_mask.sum(1)-2, Linear H->3129,
     KLDivLoss(batchmean) on log_softmax, mean VQA score.  Returns (logits [B,1,3129] fp32, loss, accuracy)."""
@@ -1178,6 +1386,7 @@ class VQAHeadLossFn(torch.autograd.Function):
         return dseq.view(B, S, H), None, None, None, None, grad_result(gw, d1), grad_result(gb, d2)
 
 
+@x3_aware
 class FlickrHeadLossFn(torch.autograd.Function):
     """Flickr30k grounding head (modeling.py:1568-1598): batched_index_select of the entity positions, the query / key
     projections of FlickrAttention (:1624-1648; one head, no value, no softmax), masked scores over the regions,

@@ -14,7 +14,7 @@ import math
 import torch
 from torch.optim import Optimizer
 
-from . import _lib
+from . import _lib, ops
 
 
 class _LRSchedule(object):
@@ -260,6 +260,7 @@ class BertAdam(Optimizer):
             if p.dim() == 2 and id(p) in member:
                 p._vb_shadow_ver = p._version
         a.refresh_transposed()                       # W^T copies for the next backward (one launch)
+        ops.bump_x3_epoch()                          # split (bf16x3) images of the weights are re-made at their next use
         return loss
 
     # -- checkpoint compatibility: per-parameter {'step', 'next_m', 'next_v'} like the reference ------

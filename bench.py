@@ -328,6 +328,9 @@ def main():
         return selftest_launch()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if os.environ.get("VB_BENCH_HANG_DUMP"):                 # debugging aid: every thread's stack to stderr after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["VB_BENCH_HANG_DUMP"]), exit=False)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))

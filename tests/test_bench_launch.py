@@ -11,11 +11,22 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(args, extra_env=None):
+def _run(args, extra_env=None, timeout=300):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(extra_env or {})
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, cwd=ROOT, timeout=300,
-                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    try:
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, cwd=ROOT, timeout=timeout,
+                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    except subprocess.TimeoutExpired as e:                  # keep what the ranks printed (VB_BENCH_HANG_DUMP stacks) for the log
+        tail = (e.stderr or b"")
+        tail = tail.decode("utf-8", "replace") if isinstance(tail, bytes) else tail
+        try:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "bench_launch_timeout_stderr.log"), "w") as f:
+                f.write(tail)
+        except OSError:
+            pass
+        raise AssertionError("bench.py %s timed out after %ds; stderr tail:\n%s" % (" ".join(args), timeout, tail[-3000:]))
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout                      # ONE JSON line, from rank 0 only
@@ -49,7 +60,7 @@ def test_driver_command_two_ranks_end_to_end(dev):
     if dev.type != "cuda":
         pytest.skip("needs the GPU")
     d = _run(["--gpus", "2", "--batch", "8", "--steps", "2", "--warmup", "1", "--cpu-batch", "1", "--no-h2d"],
-             extra_env={"VB_BENCH_ONE_DEVICE": "1"})
+             extra_env={"VB_BENCH_ONE_DEVICE": "1", "VB_BENCH_HANG_DUMP": "150"}, timeout=240)
     assert d["n_gpus"] == 2 and d["rccl_ranks_seen"] == 2
     assert d["config"]["global_batch"] == 16 and d["config"]["parallelism"] == "dp2"
     assert "overlapped with backward" in d["config"]["grad_allreduce"]

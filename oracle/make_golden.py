@@ -280,6 +280,75 @@ def make_lxrt_case(stem="micro_lxrt", B=3, Tl=12, Rv=7, seed=12, feat_dim=256):
     print("wrote %s (%d KB)" % (path, os.path.getsize(path) // 1024))
 
 
+def make_lxrt_encoder_case(stem="base_lxrt_encoder", B=4, Tl=20, Rv=36, seed=21, feat_dim=2048, n_l=2, n_r=1, n_x=2):
+    """LXRTEncoder (unsupervised_visualbert/src/lxrt/modeling.py:769-905) at BERT-base width, both of its forms, from the REAL
+    reference's classes:
+      style/  visualbert_style = True  -- the one form the reference's constructor can build (:784-799): visn_fc + n_l BertLayers
+              over the concatenated sequence;
+      lrx/    the l / r / x stack of forward :893-905.  The reference's constructor stops at `assert(0)` (:803-804) before
+              it builds this form, so the module is assembled here around that assert -- nn.Module.__init__, then the very
+              attributes the constructor would have set (:806-822), from the reference's own BertLayer / LXRTXLayer /
+              VisualFeatEncoder classes -- and the reference's own forward is what runs.
+    Compact golden: strided sub-samples (golden_util.sub) of outputs, input gradients and every parameter's gradient for the
+    loss sum(lang_out * Wl) + sum(visn_out * Wv), eval mode."""
+    from torch import nn
+    from oracle.reference_shim import load_reference_lxrt
+    from tests.golden_util import sub
+    rec = OrderedDict(meta=np.array([B, Tl, Rv, seed, feat_dim, n_l, n_r, n_x], dtype=np.int64))
+    cfg = vo.OracleConfig(**vo.CONFIGS["base"])
+    x = vo.lxrt_synth_inputs(cfg, B, Tl, Rv, seed, feat_dim)
+    g = torch.Generator().manual_seed(9100 + seed)
+    wl, wv = torch.randn((B, Tl, cfg.hidden_size), generator=g), torch.randn((B, Rv, cfg.hidden_size), generator=g)
+    for tag, style in (("style", True), ("lrx", False)):
+        lx = load_reference_lxrt(l_layers=n_l, x_layers=n_x, r_layers=n_r, visualbert_style=style)
+        lx.VISUAL_CONFIG.visualbert_style = style
+        lx.VISUAL_CONFIG.l_layers, lx.VISUAL_CONFIG.x_layers, lx.VISUAL_CONFIG.r_layers = n_l, n_x, n_r
+        lx.VISUAL_CONFIG.set_visual_dims(feat_dim, 4)
+        kw = dict(vo.CONFIGS["base"])
+        kw.pop("visual_embedding_dim")
+        rc = lx.BertConfig(kw.pop("vocab_size"), **kw)
+        import contextlib, io
+        with contextlib.redirect_stdout(io.StringIO()):
+            if style:
+                enc = lx.LXRTEncoder(rc)
+            else:
+                enc = lx.LXRTEncoder.__new__(lx.LXRTEncoder)
+                nn.Module.__init__(enc)
+                enc.visn_fc = lx.VisualFeatEncoder(rc)
+                enc.num_l_layers, enc.num_x_layers, enc.num_r_layers = n_l, n_x, n_r
+                enc.multi_choice, enc.visualbert_style = 0, False
+                enc.layer = nn.ModuleList([lx.BertLayer(rc) for _ in range(n_l)])
+                enc.x_layers = nn.ModuleList([lx.LXRTXLayer(rc) for _ in range(n_x)])
+                enc.r_layers = nn.ModuleList([lx.BertLayer(rc) for _ in range(n_r)])
+                enc.config = rc
+        shapes = {n: tuple(p_.shape) for n, p_ in enc.named_parameters()}
+        sd = vo.synth_named(shapes, seed)
+        enc.load_state_dict(sd, strict=True)
+        enc.eval()
+        lang = x["lang"].clone().requires_grad_(True)
+        feats = x["feats"].clone().requires_grad_(True)
+        lo, vo_ = enc(lang, x["lang_ext_mask"], (feats, x["boxes"]), x["visn_ext_mask"])
+        loss = (lo * wl).sum() + (vo_ * wv).sum()
+        loss.backward()
+        rec[tag + "/names"] = np.array(sorted(shapes))
+        rec[tag + "/shapes"] = np.array([",".join(str(d) for d in shapes[n]) for n in sorted(shapes)])
+        rec[tag + "/lang_out_sub"] = sub(lo).numpy()
+        rec[tag + "/visn_out_sub"] = sub(vo_).numpy()
+        rec[tag + "/out_absmax"] = np.array(float(max(lo.abs().max(), vo_.abs().max())))
+        rec[tag + "/loss"] = loss.detach().double().numpy()
+        rec[tag + "/grad_in_lang_sub"] = sub(lang.grad).numpy()
+        rec[tag + "/grad_in_feats_sub"] = sub(feats.grad).numpy()
+        for n, p_ in enc.named_parameters():
+            rec[tag + "/grad_sub/" + n] = sub(p_.grad).numpy()
+            rec[tag + "/grad_norm/" + n] = np.array(float(p_.grad.double().norm()))
+        import sys as _sys
+        for m in [k for k in _sys.modules if k == "param" or k.startswith("lxrt")]:
+            del _sys.modules[m]                               # the module reads its switches at import time: re-import per form
+    path = os.path.join(GOLDEN_DIR, stem + ".npz")
+    np.savez_compressed(path, **rec)
+    print("wrote %s (%d KB)" % (path, os.path.getsize(path) // 1024))
+
+
 def make_schedule_fixture():
     """learning-rate multipliers of EVERY schedule class of the reference (optimization.py:37-173) over a short run,
     evaluated by the reference's own classes -> tests/golden/schedules.json."""
@@ -316,3 +385,5 @@ if __name__ == "__main__":
         make_schedule_fixture()
     if not only or "micro_lxrt" in only:
         make_lxrt_case()
+    if not only or "base_lxrt_encoder" in only:
+        make_lxrt_encoder_case()

@@ -14,15 +14,19 @@ vb_ln_fwd / vb_ln_bwd (ops.LayerNormFn), the attention core through vb_attn_cros
 (ops.CrossAttentionCoreFn: queries and keys / values from different sequences of different lengths, scores never in HBM).
 These are stand-alone modules (no flat parameter arena): gradients reach `.grad` through autograd as usual.
 
-Not provided: the reference's LXRTEncoder outside `visualbert_style` -- its constructor stops at `assert(0)`
-(lxrt/modeling.py:803-804), so no configuration of the reference can build it; in `visualbert_style` it is a plain stack of
-BertLayer over the concatenated sequence, which is what visualbert_amd.modeling.BertEncoder already is.
-`output_attention` (returning the probabilities) is not offered for these blocks either: NotImplementedError, never silent."""
+  LXRTEncoder                           :769-905   VisualFeatEncoder + either (visualbert_style) a stack of BertLayer over the
+                                                   concatenated [language; vision] sequence, or the l / r / x stack: BertLayer
+                                                   over the language, BertLayer over the regions, LXRTXLayer across both
+
+The reference's own constructor reaches the l / r / x stack only through an `assert(0)` (lxrt/modeling.py:803-804): no
+argument set builds it there, but its forward (:893-905) is well defined, and tests/golden/base_lxrt_encoder.npz pins this
+class against that forward run on the reference's own blocks (oracle/make_golden.py assembles the module around the
+assert).  `output_attention` (returning the probabilities) is not offered: NotImplementedError, never silent."""
 import torch
 from torch import nn
 
 from . import ops
-from .modeling import BertConfig, BertLayerNorm  # noqa: F401  (re-exported: the reference module defines them too)
+from .modeling import BertConfig, BertLayer, BertLayerNorm  # noqa: F401  (re-exported: the reference module defines them too)
 
 
 def _p(drop, training):
@@ -198,6 +202,65 @@ class VisualFeatEncoder(nn.Module):
         out = (x + y) * 0.5
         p = _p(self.dropout, self.training)
         return ops.DropoutFn.apply(out, p, self._sid + 2) if p > 0.0 else out
+
+
+def _cat_with_none(a, b, dim):
+    if a is None:
+        return b
+    if b is None:
+        return a
+    return torch.cat((a, b), dim=dim)
+
+
+class LXRTEncoder(nn.Module):
+    """lxrt/modeling.py:769-905.  The reference reads the layer counts and `visualbert_style` from globals (VISUAL_CONFIG /
+    args); here they are constructor arguments.  forward(lang_feats, lang_attention_mask, visn_feats, visn_attention_mask):
+    lang_feats [B, Tl, H] (the word embeddings are applied outside, :829-830), visn_feats = (features [B, R, Dv], boxes
+    [B, R, 4]) or None, masks additive and broadcastable ([B, 1, 1, S], (1 - m) * -10000).  Returns (lang_feats, visn_feats).
+    BertLayer is the fused encoder layer of visualbert_amd.modeling (same state-dict keys as the sibling's :719-731)."""
+
+    def __init__(self, config, l_layers=12, x_layers=5, r_layers=0, visualbert_style=False, visual_feat_dim=2048,
+                 visual_pos_dim=4):
+        super(LXRTEncoder, self).__init__()
+        self.visn_fc = VisualFeatEncoder(config, visual_feat_dim=visual_feat_dim, visual_pos_dim=visual_pos_dim)
+        self.num_l_layers, self.num_x_layers, self.num_r_layers = l_layers, x_layers, r_layers
+        self.visualbert_style = visualbert_style
+        self.layer = nn.ModuleList([BertLayer(config) for _ in range(l_layers)])
+        for i, m in enumerate(self.layer):                       # dropout stream ids of the fused layers: clear of the blocks'
+            m.set_index(64 + i)
+        if not visualbert_style:
+            self.x_layers = nn.ModuleList([LXRTXLayer(config) for _ in range(x_layers)])
+            self.r_layers = nn.ModuleList([BertLayer(config) for _ in range(r_layers)])
+            for i, m in enumerate(self.r_layers):
+                m.set_index(64 + l_layers + i)
+        self.config = config
+
+    def forward(self, lang_feats, lang_attention_mask, visn_feats, visn_attention_mask=None, layer_limit=-1):
+        if visn_feats is not None and visn_feats[0] is not None:
+            visn_feats = self.visn_fc(visn_feats)
+        else:
+            visn_feats = None
+        if self.visualbert_style:                                # :853-891 (default switches)
+            joint = _cat_with_none(lang_feats, visn_feats, dim=1)
+            joint_mask = _cat_with_none(lang_attention_mask, visn_attention_mask, dim=-1)
+            layers = self.layer if layer_limit == -1 else self.layer[:layer_limit]
+            for layer_module in layers:
+                joint = layer_module(joint, joint_mask)
+            if lang_feats is None:
+                return None, joint
+            if visn_feats is None:
+                return joint, None
+            Tl = lang_feats.size(1)
+            return joint[:, :Tl, :].contiguous(), joint[:, Tl:, :].contiguous()
+        if lang_feats is not None:                               # :893-905
+            for layer_module in self.layer:
+                lang_feats = layer_module(lang_feats, lang_attention_mask)
+        for layer_module in self.r_layers:
+            visn_feats = layer_module(visn_feats, visn_attention_mask)
+        if lang_feats is not None:
+            for layer_module in self.x_layers:
+                lang_feats, visn_feats = layer_module(lang_feats, lang_attention_mask, visn_feats, visn_attention_mask)
+        return lang_feats, visn_feats
 
 
 class _PadColumns(torch.autograd.Function):

@@ -70,6 +70,23 @@ def flops_per_sample(L, H, I, V, S, R, Dv, head):
     return 3 * fwd
 
 
+def physical_cores():
+    """physical cores of this host (unique (package, core) pairs of /proc/cpuinfo); half the logical count as a fallback"""
+    try:
+        pairs, phys = set(), None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("physical id"):
+                    phys = line.split(":")[1].strip()
+                elif line.startswith("core id"):
+                    pairs.add((phys, line.split(":")[1].strip()))
+        if pairs:
+            return len(pairs)
+    except OSError:
+        pass
+    return max(1, (os.cpu_count() or 2) // 2)
+
+
 def free_port():
     import socket
     s = socket.socket()
@@ -139,8 +156,10 @@ def cpu_baseline(batch_size, T, R, head, steps=3):
     import torch
     from oracle import visualbert_oracle as vo
     # under torch.distributed.run every rank starts with OMP_NUM_THREADS=8; by now the other ranks are idle at the final
-    # barrier, so rank 0 takes the node's host cores like the single-process run does
-    torch.set_num_threads(max(torch.get_num_threads(), os.cpu_count() or 1))
+    # barrier, so rank 0 takes the node's PHYSICAL cores like the single-process run does (never the SMT siblings: 256
+    # OpenMP threads on 128 cores made this leg >10x slower and timed the r03 GPU sessions out)
+    if torch.get_num_threads() < physical_cores():
+        torch.set_num_threads(physical_cores())
     cfg = vo.OracleConfig(**vo.CONFIGS["base"])
     sd = vo.synth_state_dict(cfg, head, 0, perturb=False)
     batch = vo.synth_batch(cfg, batch_size, T, R, 0, head, ragged=False)

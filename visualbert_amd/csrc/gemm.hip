@@ -30,6 +30,7 @@
 #include "vb_rt.h"
 #include "../../include/visualbert_hip.h"
 #include "vb_opts.h"
+#include "vb_prof.h"
 #ifdef VB_DEV_KNOBS
 #include "../../include/visualbert_hip_dev.h"
 #endif
@@ -201,19 +202,6 @@ VB_DEVICE f32x8 load_frag(const unsigned char* lds, int row, int ks, int g, floa
     return f32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
-#ifndef VB_EMU
-// opt-in per-STREAM launch timing (vb_stream_profile): a stream that asked for it gets an event pair around every GEMM launch
-// enqueued on it; other streams are untouched.  The table is found once per extern "C" entry, like the launch options.
-struct ProfRec { hipEvent_t e0, e1; double flops; int key; };
-static std::mutex g_prof_mutex;
-static std::vector<std::pair<void*, std::vector<ProfRec>*>> g_prof_table;
-static thread_local std::vector<ProfRec>* g_prof = nullptr;      // the recorder of the stream being served (nullptr: none)
-static std::vector<ProfRec>* prof_for(void* stream) {
-    std::lock_guard<std::mutex> lock(g_prof_mutex);
-    for (auto& e : g_prof_table) if (e.first == stream) return e.second;
-    return nullptr;
-}
-#endif
 // launch options of the call being served: copied from the stream's entry (vb_stream_set_opts) at every extern "C" entry of
 // this file; thread-local, so concurrent callers on different streams never see each other's settings
 static thread_local vb_stream_opts t_opts = {0, 0, 0, 0};
@@ -586,21 +574,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) gemm_kernel(GemmArgs g) {
 template <typename T, typename TO, int AL, int BL, typename TE = T>
 int launch_gemm(const GemmArgs& g, hipStream_t stream) {
     dim3 grid((unsigned)(g.tiles_m * g.tiles_n * g.splits)), block(NT);
-#ifndef VB_EMU
-    if (g_prof) {
-        ProfRec r;
-        if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return VB_ERR_LAUNCH;
-        r.flops = 2.0 * g.M * g.N * g.K;
-        r.key = (sizeof(T) == 2 ? 0 : 8) | (sizeof(TO) == 4 ? 4 : 0) | (AL << 1) | BL | (g.x3 ? 256 : 0);
-        (void)hipEventRecord(r.e0, stream);
-        VB_LAUNCH((gemm_kernel<T, TO, AL, BL, TE>), grid, block, SMEM_BYTES, stream, g);
-        (void)hipEventRecord(r.e1, stream);
-        g_prof->push_back(r);
-        return vb_check_launch();
-    }
-#endif
-    VB_LAUNCH((gemm_kernel<T, TO, AL, BL, TE>), grid, block, SMEM_BYTES, stream, g);
-    return vb_check_launch();
+    return vb_prof_launch(2.0 * g.M * g.N * g.K, (sizeof(T) == 2 ? 0 : 8) | (sizeof(TO) == 4 ? 4 : 0) | (AL << 1) | BL | (g.x3 ? 256 : 0), stream, [&]() { VB_LAUNCH((gemm_kernel<T, TO, AL, BL, TE>), grid, block, SMEM_BYTES, stream, g); });
 }
 
 
@@ -722,31 +696,23 @@ VB_KERNEL VB_LAUNCH_BOUNDS(WM * 128) gemm_nt_pipe_kernel(GemmArgs g) {
                 for (int ni = 0; ni < 4; ++ni) fb[ni] = load_frag(ldsB, wn * 64 + ni * 16 + li, ks, lg, T());
             }
             if (DBG & 64) {                   // measurement build: fragments in registers before the clock is read
-#ifndef VB_EMU
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-#endif
+                vb_wait_lgkmcnt0();
+                vb_sched_fence();
                 if (tr) trp[3 + 2 * ks] = vb_clock();
             }
             if (!(DBG & 4)) {
-#ifndef VB_EMU
-                if (DBG & 8) __builtin_amdgcn_s_setprio(1);
-#endif
+                if (DBG & 8) vb_setprio<1>();
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = vb_mma(fa[mi], fb[ni], acc[mi][ni]);
-#ifndef VB_EMU
-                if (DBG & 8) __builtin_amdgcn_s_setprio(0);
-#endif
+                if (DBG & 8) vb_setprio<0>();
             } else {
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi) acc[mi][0][0] += to_f32(fa[mi][0]) + to_f32(fb[mi][0]);   // keep the reads live
             }
             if (DBG & 64) {
-#ifndef VB_EMU
-                __builtin_amdgcn_sched_barrier(0);
-#endif
+                vb_sched_fence();
                 if (tr) trp[4 + 2 * ks] = vb_clock();    // this K step's MFMAs issued
             }
             if ((DBG & 16) && ks == 0 && kt + STAGES - 1 < nk) issue_tile(kt + STAGES - 1);
@@ -762,21 +728,7 @@ constexpr bool kActSpecialised = (sizeof(T) == 2 && sizeof(TO) == 2);
 
 template <typename T, typename TO, int WM, int STAGES, int ACT, int OPT, typename TE = T, bool X3 = false>
 int launch_pipe_act(const GemmArgs& g, dim3 grid, dim3 block, int smem_bytes, hipStream_t stream) {
-#ifndef VB_EMU
-    if (g_prof) {
-        ProfRec r;
-        if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return VB_ERR_LAUNCH;
-        r.flops = 2.0 * g.M * g.N * g.K;
-        r.key = (sizeof(T) == 2 ? 0 : 8) | (sizeof(TO) == 4 ? 4 : 0) | (X3 ? 256 : 0);
-        (void)hipEventRecord(r.e0, stream);
-        VB_LAUNCH((gemm_nt_pipe_kernel<T, TO, WM, STAGES, 0, ACT, OPT, TE, X3>), grid, block, smem_bytes, stream, g);
-        (void)hipEventRecord(r.e1, stream);
-        g_prof->push_back(r);
-        return vb_check_launch();
-    }
-#endif
-    VB_LAUNCH((gemm_nt_pipe_kernel<T, TO, WM, STAGES, 0, ACT, OPT, TE, X3>), grid, block, smem_bytes, stream, g);
-    return vb_check_launch();
+    return vb_prof_launch(2.0 * g.M * g.N * g.K, (sizeof(T) == 2 ? 0 : 8) | (sizeof(TO) == 4 ? 4 : 0) | (X3 ? 256 : 0), stream, [&]() { VB_LAUNCH((gemm_nt_pipe_kernel<T, TO, WM, STAGES, 0, ACT, OPT, TE, X3>), grid, block, smem_bytes, stream, g); });
 }
 
 template <typename T, typename TO, int WM, int STAGES>
@@ -834,20 +786,6 @@ int launch_pipe(GemmArgs g, hipStream_t stream) {
 // h = p + 6 and waits until only the newest 4 half-tiles are in flight; phase p reads h <= p + 1 (landed
 // and barrier-published one phase earlier) and overwrites a half-tile last read >= 2 phases ago.
 // =================================================================================================
-VB_DEVICE void vb_sched_fence() {
-#ifndef VB_EMU
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-}
-VB_DEVICE void vb_phase_barrier() {
-#ifdef VB_EMU
-    __syncthreads();
-#else
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-}
 // Epilogue of the persistent kernel: a wave drains its 128x64 block through a PRIVATE 4 KB LDS slab (16 rows
 // x 64 fp32, 16-column groups XOR-swizzled by the row quad so the MFMA-layout stores are conflict-free), one
 // 16-row fragment row per pass.  No workgroup barrier: LDS executes one wave's instructions in order, so the
@@ -1045,9 +983,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS(512) gemm_nt_8ph_kernel(GemmArgs g) {
             for (int ks = 0; ks < KSTEPS; ++ks) fb[f][ks] = load_frag(half, wc * 32 + f * 16 + li, ks, lg, T());
     };
     auto quad = [&](int mh, int nh, typename VecOf<T>::v8 (&fb)[2][KSTEPS]) {
-#ifndef VB_EMU
-        __builtin_amdgcn_s_setprio(1);
-#endif
+        vb_setprio<1>();
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks)
 #pragma unroll
@@ -1055,9 +991,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS(512) gemm_nt_8ph_kernel(GemmArgs g) {
 #pragma unroll
                 for (int q = 0; q < 2; ++q)
                     acc[mh * 4 + f][nh * 2 + q] = vb_mma(fa[f][ks], fb[q][ks], acc[mh * 4 + f][nh * 2 + q]);
-#ifndef VB_EMU
-        __builtin_amdgcn_s_setprio(0);
-#endif
+        vb_setprio<0>();
     };
 
     const int nk = g.K / BK;
@@ -1171,21 +1105,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS(512) gemm_nt_8ph_kernel(GemmArgs g) {
 
 template <typename T, typename TO, int ACT, int OPT, int SCHED>
 int launch_8ph_sched(const GemmArgs& g, dim3 grid, dim3 block, int smem_bytes, hipStream_t stream) {
-#ifndef VB_EMU
-    if (g_prof) {
-        ProfRec r;
-        if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return VB_ERR_LAUNCH;
-        r.flops = 2.0 * g.M * g.N * g.K;
-        r.key = (sizeof(T) == 2 ? 0 : 8) | (sizeof(TO) == 4 ? 4 : 0) | 16;
-        (void)hipEventRecord(r.e0, stream);
-        VB_LAUNCH((gemm_nt_8ph_kernel<T, TO, ACT, OPT, SCHED>), grid, block, smem_bytes, stream, g);
-        (void)hipEventRecord(r.e1, stream);
-        g_prof->push_back(r);
-        return vb_check_launch();
-    }
-#endif
-    VB_LAUNCH((gemm_nt_8ph_kernel<T, TO, ACT, OPT, SCHED>), grid, block, smem_bytes, stream, g);
-    return vb_check_launch();
+    return vb_prof_launch(2.0 * g.M * g.N * g.K, (sizeof(T) == 2 ? 0 : 8) | (sizeof(TO) == 4 ? 4 : 0) | 16, stream, [&]() { VB_LAUNCH((gemm_nt_8ph_kernel<T, TO, ACT, OPT, SCHED>), grid, block, smem_bytes, stream, g); });
 }
 template <typename T, typename TO, int ACT, int OPT>
 int launch_8ph_act(const GemmArgs& g, dim3 grid, dim3 block, int smem_bytes, hipStream_t stream) {
@@ -1336,9 +1256,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(256, 2) gemm_nt_dual_kernel(GemmArgs g) {
                     acc[mh * 4 + f][nh * 2 + q] = vb_mma(fa[f][ks], fb[q][ks], acc[mh * 4 + f][nh * 2 + q]);
     };
     auto prio = [&](int p) {
-#ifndef VB_EMU
-        if constexpr ((VAR & 2) != 0) { if (p) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
-#endif
+        if constexpr ((VAR & 2) != 0) { if (p) vb_setprio<1>(); else vb_setprio<0>(); }
         (void)p;
     };
 
@@ -1392,21 +1310,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(256, 2) gemm_nt_dual_kernel(GemmArgs g) {
 template <typename TO, int ACT, int OPT, int VAR, bool X3 = false>
 int launch_dual_var(const GemmArgs& g, dim3 grid, hipStream_t stream) {
     constexpr int SM = 5 * 128 * 128;                           // 80 KB: two workgroups per compute unit
-#ifndef VB_EMU
-    if (g_prof) {
-        ProfRec r;
-        if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return VB_ERR_LAUNCH;
-        r.flops = 2.0 * g.M * g.N * g.K;
-        r.key = (sizeof(TO) == 4 ? 4 : 0) | 64 | (X3 ? 256 : 0);
-        (void)hipEventRecord(r.e0, stream);
-        VB_LAUNCH((gemm_nt_dual_kernel<TO, ACT, OPT, VAR, X3>), grid, dim3(256), SM, stream, g);
-        (void)hipEventRecord(r.e1, stream);
-        g_prof->push_back(r);
-        return vb_check_launch();
-    }
-#endif
-    VB_LAUNCH((gemm_nt_dual_kernel<TO, ACT, OPT, VAR, X3>), grid, dim3(256), SM, stream, g);
-    return vb_check_launch();
+    return vb_prof_launch(2.0 * g.M * g.N * g.K, (sizeof(TO) == 4 ? 4 : 0) | 64 | (X3 ? 256 : 0), stream, [&]() { VB_LAUNCH((gemm_nt_dual_kernel<TO, ACT, OPT, VAR, X3>), grid, dim3(256), SM, stream, g); });
 }
 template <typename TO, int ACT, int OPT>
 int launch_dual_act(const GemmArgs& g, dim3 grid, hipStream_t stream) {
@@ -1464,22 +1368,6 @@ int launch_dual(GemmArgs g, hipStream_t stream) {
 // AGPR half of a 512-register wave (it copied every accumulator tuple in front of its MFMA, parked fragments in AGPRs and
 // spilled 540 bytes); "+a" constraints pin them, and the statements' source order IS the instruction interleave (4 MFMAs,
 // one ds_read_b128, ...).  The compiler therefore knows nothing about these reads' lgkmcnt: the waits are explicit.
-#ifdef VB_EMU
-#define VB_BIG_MMA(acc, a, b) acc = vb_mma(a, b, acc)
-template <int OFF> VB_DEVICE void big_read(bf16x8& d, const unsigned char* smem, unsigned off) { d = *(const bf16x8*)(smem + off + OFF); }
-VB_DEVICE unsigned big_lds_base(const unsigned char*) { return 0u; }
-VB_DEVICE void big_settle() {}
-#else
-#define VB_BIG_MMA(acc, a, b) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b))
-template <int OFF> VB_DEVICE void big_read(bf16x8& d, const unsigned char*, unsigned addr) {
-    static_assert(OFF >= 0 && OFF < 65536, "DS offsets are 16 bits");
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
-}
-VB_DEVICE unsigned big_lds_base(const unsigned char* smem) {
-    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)smem;
-}
-VB_DEVICE void big_settle() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }   // MFMA results / AGPR writes visible to what follows
-#endif
 
 template <typename TO, int ACT, int OPT, int ABL = 0>     // ABL (developer library): 1 = no copies, 2 = no fragment reads, 4 = no MFMAs
 VB_KERNEL VB_LAUNCH_BOUNDS2(256, 1) gemm_nt_big_kernel(GemmArgs g) {
@@ -1633,21 +1521,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(256, 1) gemm_nt_big_kernel(GemmArgs g) {
 template <typename TO, int ACT, int OPT>
 int launch_big_act(const GemmArgs& g, dim3 grid, hipStream_t stream) {
     constexpr int SM = 2 * 4 * 128 * 128 + 4 * EPI8_BYTES_PER_WAVE;
-#ifndef VB_EMU
-    if (g_prof) {
-        ProfRec r;
-        if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return VB_ERR_LAUNCH;
-        r.flops = 2.0 * g.M * g.N * g.K;
-        r.key = (sizeof(TO) == 4 ? 4 : 0) | 128;
-        (void)hipEventRecord(r.e0, stream);
-        VB_LAUNCH((gemm_nt_big_kernel<TO, ACT, OPT>), grid, dim3(256), SM, stream, g);
-        (void)hipEventRecord(r.e1, stream);
-        g_prof->push_back(r);
-        return vb_check_launch();
-    }
-#endif
-    VB_LAUNCH((gemm_nt_big_kernel<TO, ACT, OPT>), grid, dim3(256), SM, stream, g);
-    return vb_check_launch();
+    return vb_prof_launch(2.0 * g.M * g.N * g.K, (sizeof(TO) == 4 ? 4 : 0) | 128, stream, [&]() { VB_LAUNCH((gemm_nt_big_kernel<TO, ACT, OPT>), grid, dim3(256), SM, stream, g); });
 }
 template <typename T, typename TO>
 int launch_big(GemmArgs g, hipStream_t stream) {
@@ -1858,9 +1732,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS(512) gemm_tn_8ph_kernel(TnArgs g) {
         });
     };
     auto quad = [&](int mh, int nh, bf16x4 (&bl)[2][2], bf16x4 (&bh)[2][2]) {
-#ifndef VB_EMU
-        __builtin_amdgcn_s_setprio(1);
-#endif
+        vb_setprio<1>();
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -1869,9 +1741,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS(512) gemm_tn_8ph_kernel(TnArgs g) {
                 for (int q = 0; q < 2; ++q)
                     acc[mh * 4 + f][nh * 2 + q] = vb_mma(vb_join(fal[f][ks], fah[f][ks]), vb_join(bl[q][ks], bh[q][ks]),
                                                          acc[mh * 4 + f][nh * 2 + q]);
-#ifndef VB_EMU
-        __builtin_amdgcn_s_setprio(0);
-#endif
+        vb_setprio<0>();
     };
     // partial tile -> fp32 atomics, a wave covering 64 consecutive columns of one row per instruction
     auto drain = [&](const Item& it) {
@@ -2009,22 +1879,9 @@ static int launch_tn_group(TnArgs& g, int K, hipStream_t stream) {
         else if (wgs >= 8) wgs &= ~7;
     }
     dim3 grid((unsigned)wgs), block(512);
-#ifndef VB_EMU
-    if (g_prof) {
-        ProfRec r;
-        if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return VB_ERR_LAUNCH;
-        r.flops = 0;
-        for (int i = 0; i < g.nprob; ++i) r.flops += 2.0 * g.p[i].Mo * g.p[i].Ni * K;
-        r.key = 4 | 2 | 1 | 16;
-        (void)hipEventRecord(r.e0, stream);
-        VB_LAUNCH(gemm_tn_8ph_kernel, grid, block, SM, stream, g);
-        (void)hipEventRecord(r.e1, stream);
-        g_prof->push_back(r);
-        return vb_check_launch();
-    }
-#endif
-    VB_LAUNCH(gemm_tn_8ph_kernel, grid, block, SM, stream, g);
-    return vb_check_launch();
+    double flops = 0;
+    for (int i = 0; i < g.nprob; ++i) flops += 2.0 * g.p[i].Mo * g.p[i].Ni * K;
+    return vb_prof_launch(flops, 4 | 2 | 1 | 16, stream, [&]() { VB_LAUNCH(gemm_tn_8ph_kernel, grid, block, SM, stream, g); });
 }
 static bool tn_eligible(const void* A, long lda, const void* B, long ldb, const float* C, long ldc, int Mo, int Ni, int K) {
     return K >= 64 && (K % 64) == 0 && Mo >= 1 && Ni >= 1 && lda >= ((Mo + 7) & ~7) && ldb >= ((Ni + 7) & ~7) && (lda % 8) == 0 && (ldb % 8) == 0 &&
@@ -2102,9 +1959,7 @@ extern "C" int vb_gemm(int dtype, int out_dtype, int a_layout, int b_layout,
         if ((K % 64) || (lda % 16) || (ldb % 16) || K > lda / 2 || K > ldb / 2) return VB_ERR_UNSUPPORTED;
     }
     t_opts = vb_opts_for(stream);
-#ifndef VB_EMU
-    g_prof = prof_for(stream);
-#endif
+    vb_prof_select(stream);
     const int epc = dtype == VB_BF16 ? 8 : 4;
     // vector loads are 16 bytes: leading dimensions and base pointers must keep them aligned
     if ((lda % 8) || (ldb % 8) || (((uintptr_t)A | (uintptr_t)B) & 15)) return VB_ERR_ARG;
@@ -2173,9 +2028,7 @@ extern "C" int vb_wgrad_grouped(int dtype, int n, const void* const* dy, const i
         return VB_OK;
     }
     t_opts = vb_opts_for(stream);
-#ifndef VB_EMU
-    g_prof = prof_for(stream);
-#endif
+    vb_prof_select(stream);
     bool fast = dtype == VB_BF16 && t_opts.nt_kernel != 1;
     for (int i = 0; i < n && fast; ++i)
         fast = tn_eligible(dy[i], ld_dy[i], x[i], ld_x[i], (const float*)dw[i], ld_dw[i], n_out[i], n_in[i], tokens);
@@ -2198,49 +2051,17 @@ extern "C" int vb_wgrad_grouped(int dtype, int n, const void* const* dy, const i
     return VB_OK;
 }
 
-extern "C" int vb_stream_profile(void* stream, int enable) {
-#ifndef VB_EMU
-    std::lock_guard<std::mutex> lock(g_prof_mutex);
-    for (size_t i = 0; i < g_prof_table.size(); ++i)
-        if (g_prof_table[i].first == stream) {
-            for (auto& r : *g_prof_table[i].second) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
-            delete g_prof_table[i].second;
-            g_prof_table.erase(g_prof_table.begin() + i);
-            break;
-        }
-    if (enable) g_prof_table.emplace_back(stream, new std::vector<ProfRec>());
-#else
-    (void)stream; (void)enable;
-#endif
-    return VB_OK;
-}
+extern "C" int vb_stream_profile(void* stream, int enable) { return vb_prof_enable(stream, enable); }
 
 extern "C" int64_t vb_stream_profile_read(void* stream, double* ms, double* flops, int* key, int64_t max_records) {
-#ifndef VB_EMU
-    std::vector<ProfRec>* recs = prof_for(stream);
-    if (!recs) return 0;
-    int64_t n = 0;
-    for (auto& r : *recs) {
-        if (n >= max_records) break;
-        float t = 0.f;
-        if (hipEventElapsedTime(&t, r.e0, r.e1) != hipSuccess) return -1;   // caller must synchronise first
-        if (ms) ms[n] = t;
-        if (flops) flops[n] = r.flops;
-        if (key) key[n] = r.key;
-        ++n;
-    }
-    return n;
-#else
-    (void)stream; (void)ms; (void)flops; (void)key; (void)max_records;
-    return 0;
-#endif
+    return vb_prof_read(stream, ms, flops, key, max_records);
 }
 
+// developer library only (never part of the simulator build)
 #ifdef VB_DEV_KNOBS
 extern "C" int vb_gemm_set_debug(int bits) { g_debug = bits; return VB_OK; }
 
 // ---- measurement aid: issue-rate ceiling of the two bf16 MFMA shapes at the clocks this chip really holds ---
-#ifndef VB_EMU
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 template <int KIND>
 __global__ void __launch_bounds__(512) mfma_peak_kernel(float* out, int iters) {
@@ -2290,25 +2111,18 @@ __global__ void __launch_bounds__(512) mfma_peak_kernel(float* out, int iters) {
         out[blockIdx.x * 512 + threadIdx.x] = s;
     }
 }
-#endif
 // kind 0: 32 x v_mfma_f32_16x16x32_bf16 per iteration, kind 1: 16 x v_mfma_f32_32x32x16_bf16 (same FLOPs: 524288 per wave-iter),
 // kind 2: kind 0 with operands that change every instruction
 extern "C" int vb_mfma_peak(int kind, int iters, int blocks, float* out, void* stream) {
-#ifndef VB_EMU
     if (kind == 2) hipLaunchKernelGGL(mfma_peak_kernel<2>, dim3(blocks), dim3(512), 0, (hipStream_t)stream, out, iters);
     else if (kind == 0) hipLaunchKernelGGL(mfma_peak_kernel<0>, dim3(blocks), dim3(512), 0, (hipStream_t)stream, out, iters);
     else hipLaunchKernelGGL(mfma_peak_kernel<1>, dim3(blocks), dim3(512), 0, (hipStream_t)stream, out, iters);
     return vb_check_launch();
-#else
-    (void)kind; (void)iters; (void)blocks; (void)out; (void)stream;
-    return VB_ERR_UNSUPPORTED;
-#endif
 }
 
 // ---- measurement aid: ceiling of the global -> LDS (LDS-direct) path per CU ---------------------------------
 // every wave of every 512-thread block streams `iters` x 1 KiB pieces from an `span`-byte window of src (L2- or
 // HBM-resident depending on span) into an LDS ring, keeping DEPTH pieces in flight (counted vmcnt).
-#ifndef VB_EMU
 template <int DEPTH>
 __global__ void __launch_bounds__(512) glds_stream_kernel(const unsigned char* src, long span, int iters, float* sink) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ring[];
@@ -2326,9 +2140,7 @@ __global__ void __launch_bounds__(512) glds_stream_kernel(const unsigned char* s
     __syncthreads();
     if (sink && threadIdx.x == 0) sink[blockIdx.x] = *(float*)ring;
 }
-#endif
 extern "C" int vb_glds_stream(int depth, const void* src, int64_t span, int iters, int blocks, float* sink, void* stream) {
-#ifndef VB_EMU
     hipStream_t s = (hipStream_t)stream;
     const unsigned char* p = (const unsigned char*)src;
     switch (depth) {
@@ -2340,10 +2152,6 @@ extern "C" int vb_glds_stream(int depth, const void* src, int64_t span, int iter
         default: return VB_ERR_ARG;
     }
     return vb_check_launch();
-#else
-    (void)depth; (void)src; (void)span; (void)iters; (void)blocks; (void)sink; (void)stream;
-    return VB_ERR_UNSUPPORTED;
-#endif
 }
 
 extern "C" int vb_gemm_set_trace(void* device_u64x1024) { g_trace = (unsigned long long*)device_u64x1024; return VB_OK; }

@@ -185,8 +185,41 @@ VB_DEVICE void vb_raw_barrier() {
 
 #ifdef VB_EMU
 VB_DEVICE void vb_wait_lgkmcnt0() {}
+VB_DEVICE void vb_sched_fence() {}
+VB_DEVICE void vb_phase_barrier() { __syncthreads(); }
+template <int P> VB_DEVICE void vb_setprio() {}
 #else
 VB_DEVICE void vb_wait_lgkmcnt0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// nothing may be scheduled across this point (LLVM sched_barrier 0)
+VB_DEVICE void vb_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+// workgroup barrier that the instruction scheduler may not move code across (the GEMM kernels' phase boundaries)
+VB_DEVICE void vb_phase_barrier() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+// wave priority for the instruction arbiter of its SIMD (s_setprio): raised around MFMA blocks
+template <int P> VB_DEVICE void vb_setprio() { __builtin_amdgcn_s_setprio(P); }
+#endif
+
+// The four-wave 256x256 GEMM (gemm.hip, nt_kernel 100) keeps 256 accumulator registers in the AGPR half of the file and
+// interleaves its K loop by hand: MFMA with the accumulator pinned ("+a"), ds_read_b128 with an immediate offset, and the
+// settling gap MFMA results need before ordinary code reads them.  The simulator executes the same steps synchronously.
+#ifdef VB_EMU
+#define VB_BIG_MMA(acc, a, b) acc = vb_mma(a, b, acc)
+template <int OFF> VB_DEVICE void big_read(bf16x8& d, const unsigned char* smem, unsigned off) { d = *(const bf16x8*)(smem + off + OFF); }
+VB_DEVICE unsigned big_lds_base(const unsigned char*) { return 0u; }
+VB_DEVICE void big_settle() {}
+#else
+#define VB_BIG_MMA(acc, a, b) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b))
+template <int OFF> VB_DEVICE void big_read(bf16x8& d, const unsigned char*, unsigned addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "DS offsets are 16 bits");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+VB_DEVICE unsigned big_lds_base(const unsigned char* smem) {
+    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)smem;
+}
+VB_DEVICE void big_settle() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }   // MFMA results / AGPR writes visible to what follows
 #endif
 
 // ds_read_b64_tr_b16 (gfx950): within each 16-lane group, lane s passes the address of 4 contiguous 16-bit values
@@ -337,14 +370,6 @@ VB_DEVICE float row16_sum(float v) {
     v += vb_row_ror<8>(v); v += vb_row_ror<4>(v); v += vb_row_ror<2>(v); v += vb_row_ror<1>(v);
     return v;
 }
-#endif
-
-// scheduling hint: the next `n` instructions of class `mask` (0x008 MFMA, 0x020 VMEM read, 0x100 DS read) come here, in the
-// order the hints are written (LLVM sched_group_barrier) -- used to interleave fragment reads / copies with MFMAs
-#ifdef VB_EMU
-#define VB_SCHED_GROUP(mask, n)
-#else
-#define VB_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier((mask), (n), 0)
 #endif
 
 // "the value becomes available HERE": an empty volatile asm that redefines its operand.  Consumers of a register that a

@@ -159,6 +159,9 @@ int vb_align_pos_bwd(int dtype, const void* dz, const int64_t* alignment, float*
  * ctx: T [B*S, H], lse: fp32 [B,nh,S] row log-sum-exp (saved for backward),
  * keepbits: uint64 [B*nh * vb_attn_keepbits_words(S)] dropout keep-bits (only touched when p_drop > 0).
  * Backward writes dqkv (T [B*S,3H]) completely; dsum_ws is an fp32 scratch of vb_attn_bwd_ws_floats(B, S, nh) elements.
+ * Sequence lengths up to 512 keys (max_position_embeddings, modeling.py:83): a (sample, head)'s K / V stay in LDS while they fit
+ * (forward: 256 keys fp32 / 512 bf16; dQ pass: 192 fp32 / 416 bf16), longer sequences stream the keys in chunks of 128
+ * (online softmax forward; two-sweep dQ pass) -- same results, same keep-bit layout.
  * ctx_fwd (optional): the forward output ctx -- with it, bf16 and S <= 192 the backward runs as ONE kernel (D = rowsum(P o dP)
  * taken as dO . ctx, scores and probabilities computed once); without it, or for longer sequences / fp32, as two passes
  * (dQ, then dK/dV).  dqkv_bias (optional, fp32 [3H]): += column sums of dqkv over the B*S tokens, i.e. the gradient of

@@ -370,11 +370,11 @@ def decode_keepbits(bits, B, nh, S):
 @pytest.mark.parametrize("cfg", [(2, 40, 2, 0.0), (1, 164, 2, 0.0), (2, 23, 3, 0.1), (1, 164, 1, 0.1),
                                  (2, 56, 2, 0.1), (1, 112, 2, 0.1),      # VQA / NLVR2 lengths: exact 4- and 7-fragment forwards
                                  (1, 192, 1, 0.1), (2, 177, 2, 0.0),     # edges of the one-pass bf16 backward (12 key fragments)
-                                 (1, 300, 1, 0.1), (1, 416, 1, 0.1)])    # 416 = NLVR2 as the reference runs it (2x144 + 128)
+                                 (1, 300, 1, 0.1), (1, 416, 1, 0.1),     # 416 = NLVR2 as the reference runs it (2x144 + 128)
+                                 (2, 230, 1, 0.1), (1, 512, 2, 0.1)])    # key-tiled kernels: fp32 dQ pass above 192 keys, fp32 forward
+                                                                         # above 256, bf16 dQ pass above 416; 512 = max_position_embeddings
 def test_attention_fwd_bwd(dev, dt, cfg):
     B, S, nh, p = cfg
-    if S > 256 and dt == torch.float32:
-        pytest.skip("fp32 attention backward keeps the whole sequence in LDS: S <= 192 (DESIGN.md section 7)")
     H = nh * 64
     g = torch.Generator().manual_seed(6)
     qkv = (0.7 * torch.randn(B, S, 3 * H, generator=g)).to(dt).to(dev)
@@ -843,7 +843,8 @@ def test_dropout_mask_equals_the_documented_generator(dev):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("cfg", [(2, 37, 2, 0.1), (1, 164, 2, 0.1), (1, 112, 2, 0.1), (2, 56, 1, 0.1), (1, 300, 1, 0.25)])
+@pytest.mark.parametrize("cfg", [(2, 37, 2, 0.1), (1, 164, 2, 0.1), (1, 112, 2, 0.1), (2, 56, 1, 0.1), (1, 300, 1, 0.25),
+                                 (1, 470, 1, 0.1)])              # 470: the key-tiled forward in fp32 (absolute key positions)
 def test_attention_keepbits_equal_the_documented_generator(dev, dt, cfg):
     """attention-probability dropout: the keep-bits the forward records (and the backward replays) are the same generator,
     indexed as csrc/attention.hip documents -- probability (head bh, query q, key k) is lane ((k>>4)&1)*4 + (k&3) of group
@@ -851,8 +852,6 @@ def test_attention_keepbits_equal_the_documented_generator(dev, dt, cfg):
     the prefetching forward at 161..176, the long-sequence path above 256)."""
     import numpy as np
     B, S, nh, p = cfg
-    if S > 256 and dt == torch.float32:
-        pytest.skip("fp32 attention is limited to S <= 256 (DESIGN.md section 7)")
     seed, sid = (5 << 32) | 4242, 7
     H = nh * 64
     g = torch.Generator().manual_seed(21)

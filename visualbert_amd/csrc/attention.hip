@@ -464,6 +464,237 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) attn_bwd_dq_kernel(AttnArgs a) {
 }
 
 // =================================================================================================
+// KEY-TILED forward and dQ pass: the kernels above keep a (sample, head)'s whole K / V in LDS, which holds S <= 256 (forward)
+// and S <= 192 (dQ pass) in fp32 and S <= 416 (dQ pass) in bf16.  The reference trains up to max_position_embeddings = 512
+// (modeling.py:83, :183; NLVR2 as it ships is S = 416): beyond those limits the keys stream through LDS in chunks of 128.
+//   forward : online softmax -- running maximum m and sum l per query; the context accumulators are rescaled by
+//             exp(m_old - m_new) when a chunk raises the maximum; dropout keep-bits and the generator's group index use the
+//             ABSOLUTE key position, so the masks are the ones the untiled kernels would draw; 1 / (l (1 - p)) at the end.
+//   dQ pass : the softmax statistics are known (lse from forward), so chunks are independent; D = rowsum(P o dP) needs every
+//             key before any dS can be formed: sweep 1 accumulates D over the chunks, sweep 2 recomputes P, dP per chunk and
+//             accumulates dQ += dS K.  (Twice the score work of the untiled form: this is the long-sequence parity path.)
+// Per workgroup one (sample, head); per pass over the chunks four query blocks (one per wave); K / V of a (sample, head) are
+// re-read from L2 once per group of 64 queries.  NW = keep-bit words per (query, key quad): the launcher's keepbits_nw(S).
+// The dK / dV pass below is already independent of S.
+// =================================================================================================
+constexpr int TCF = 8, TCK = TCF * 16, TCS = TCF / 2;       // key fragments, keys, 32-key steps per chunk
+
+template <typename T, int NW>
+VB_KERNEL VB_LAUNCH_BOUNDS(NT) attn_fwd_tiled_kernel(AttnArgs a) {
+    VB_DYN_SMEM(smem);
+    unsigned char* ldsK = smem;
+    unsigned char* ldsVT = ldsK + rm_bytes<T>(TCK);
+    float* ldsMask = (float*)(ldsVT + tr_bytes<T>(TCK));
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, lg = lane >> 4;
+    const int bh = blockIdx.x, b = bh / a.nh, h = bh % a.nh;
+    const int S = a.S, Sq = a.Sq;
+    const long rowk = (long)b * S, rowq = (long)b * Sq;
+    const T* Qp = (const T*)a.q;
+    const T* Kp = (const T*)a.k;
+    const T* Vp = (const T*)a.v;
+    const int nqf = (Sq + 15) / 16;
+    for (int qg = 0; qg < nqf; qg += 4) {                   // every wave runs every trip: the staging barriers are workgroup-wide
+        const int q = (qg + wave) * 16 + li;
+        const bool qok = q < Sq;
+        const T* qrow = Qp + (rowq + (qok ? q : 0)) * a.ldq + h * D;
+        typename VecOf<T>::v8 qb[2];
+        qb[0] = frag_g(qrow, 0, lg, qok); qb[1] = frag_g(qrow, 1, lg, qok);
+        float m = -INFINITY, l = 0.f;
+        f32x4 acc[4];
+#pragma unroll
+        for (int df = 0; df < 4; ++df) acc[df] = f32x4{0.f, 0.f, 0.f, 0.f};
+        uint64_t bits[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) bits[w] = 0;
+        for (int c0 = 0; c0 < S; c0 += TCK) {
+            __syncthreads();                                // the previous chunk is consumed
+            stage_rm<T>(ldsK, Kp, a.ldk, rowk + c0, h * D, S - c0, TCK, t);
+            stage_tr(ldsVT, Vp, a.ldv, rowk + c0, h * D, S - c0, TCK, t);
+            for (int k = t; k < TCK; k += NT) ldsMask[k] = c0 + k < S ? a.mask_add[(long)b * S + c0 + k] : -INFINITY;
+            __syncthreads();
+            f32x4 st[TCF];
+            float mc = -INFINITY;
+#pragma unroll
+            for (int kf = 0; kf < TCF; ++kf) {
+                f32x4 sc = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (c0 + kf * 16 < S) {
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) sc = vb_mma(frag_rm(ldsK, kf * 16 + li, ks, lg, T()), qb[ks], sc);
+                }
+                const f32x4 mk = *(const f32x4*)(ldsMask + kf * 16 + lg * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { sc[r] = sc[r] * a.scale + mk[r]; mc = fmaxf(mc, sc[r]); }
+                st[kf] = sc;
+            }
+            mc = fmaxf(mc, __shfl_xor(mc, 16));
+            mc = fmaxf(mc, __shfl_xor(mc, 32));
+            const float mn = fmaxf(m, mc);                   // finite: every chunk that starts below S holds a real key
+            const float alpha = fast_exp(m - mn);            // 0 on the first chunk (m = -inf)
+            float sum = 0.f;
+#pragma unroll
+            for (int kf = 0; kf < TCF; ++kf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { st[kf][r] = fast_exp(st[kf][r] - mn); sum += st[kf][r]; }
+            sum += __shfl_xor(sum, 16);
+            sum += __shfl_xor(sum, 32);
+            l = l * alpha + sum;
+            m = mn;
+#pragma unroll
+            for (int df = 0; df < 4; ++df)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[df][r] *= alpha;
+            if (a.p > 0.f) {
+#pragma unroll
+                for (int kp = 0; kp < TCS; ++kp) {
+                    const uint64_t grp = ((((uint64_t)bh * Sq + q) * 4 + lg) << 5) + (uint64_t)(c0 / 32 + kp);
+                    Rand8 rnd = vb_dropout_bits8(a.seed, grp, a.stream);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int kf = 2 * kp + (e >> 2), r = e & 3;
+                        const bool keep = rand8_keep(rnd, e, a.thresh);
+                        st[kf][r] = keep ? st[kf][r] : 0.f;
+                        const int kfa = c0 / 16 + kf;        // absolute key fragment: word kfa >> 4, nibble kfa & 15
+                        if (keep) bits[(kfa >> 4) < NW ? (kfa >> 4) : NW - 1] |= (uint64_t)1 << ((kfa & 15) * 4 + r);
+                    }
+                }
+            }
+            typename VecOf<T>::v8 pb[TCS];
+#pragma unroll
+            for (int ks = 0; ks < TCS; ++ks) pack_b(pb[ks], st[2 * ks], st[2 * ks + 1]);
+#pragma unroll
+            for (int df = 0; df < 4; ++df)
+#pragma unroll
+                for (int ks = 0; ks < TCS; ++ks)
+                    if (c0 + ks * 32 < S)
+                        acc[df] = vb_mma(frag_tr(ldsVT, tr_pitch<T>(TCK), df * 16 + li, ks, lg, T()), pb[ks], acc[df]);
+        }
+        const float inv = a.inv_keep / l;                    // normalisation and 1 / (1 - p) in one factor
+        if (a.lse && lg == 0 && qok) a.lse[(long)bh * Sq + q] = m + logf(l);
+        if (a.p > 0.f && a.keepbits && qok) {
+#pragma unroll
+            for (int w = 0; w < NW; ++w) a.keepbits[keep_index(a, bh, q, lg, w, NW)] = bits[w];
+        }
+        T* crow = (T*)a.ctx + (rowq + (qok ? q : 0)) * a.ldc + h * D;
+#pragma unroll
+        for (int df = 0; df < 4; ++df) {
+            f32x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = acc[df][r] * inv;
+            if (qok) store4(crow + df * 16 + lg * 4, o);
+        }
+    }
+}
+
+template <typename T, int NW>
+VB_KERNEL VB_LAUNCH_BOUNDS(NT) attn_bwd_dq_tiled_kernel(AttnArgs a) {
+    VB_DYN_SMEM(smem);
+    unsigned char* ldsK = smem;
+    unsigned char* ldsV = ldsK + rm_bytes<T>(TCK);
+    unsigned char* ldsKT = ldsV + rm_bytes<T>(TCK);
+    float* ldsMask = (float*)(ldsKT + tr_bytes<T>(TCK));
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, lg = lane >> 4;
+    const int bh = blockIdx.x, b = bh / a.nh, h = bh % a.nh;
+    const int S = a.S, Sq = a.Sq;
+    const long rowk = (long)b * S, rowq = (long)b * Sq;
+    const T* Qp = (const T*)a.q;
+    const T* Kp = (const T*)a.k;
+    const T* Vp = (const T*)a.v;
+    const int nqf = (Sq + 15) / 16;
+    for (int qg = 0; qg < nqf; qg += 4) {
+        const int q = (qg + wave) * 16 + li;
+        const bool qok = q < Sq;
+        const T* qrow = Qp + (rowq + (qok ? q : 0)) * a.ldq + h * D;
+        const T* dorow = (const T*)a.dctx + (rowq + (qok ? q : 0)) * a.lddo + h * D;
+        typename VecOf<T>::v8 qb[2], dob[2];
+        qb[0] = frag_g(qrow, 0, lg, qok); qb[1] = frag_g(qrow, 1, lg, qok);
+        dob[0] = frag_g(dorow, 0, lg, qok); dob[1] = frag_g(dorow, 1, lg, qok);
+        const float lse = qok ? a.lse[(long)bh * Sq + q] : 0.f;
+        uint64_t bits[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w)
+            bits[w] = (a.p > 0.f && qok) ? a.keepbits[keep_index(a, bh, q, lg, w, NW)] : ~(uint64_t)0;
+        // P and the dropped dP of one chunk (both sweeps); keys >= S have mask -inf: P = 0
+        auto chunk_p_dp = [&](int c0, f32x4 (&pt)[TCF], f32x4 (&dpt)[TCF]) {
+#pragma unroll
+            for (int kf = 0; kf < TCF; ++kf) {
+                f32x4 sc = f32x4{0.f, 0.f, 0.f, 0.f}, dp = sc;
+                if (c0 + kf * 16 < S) {
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        sc = vb_mma(frag_rm(ldsK, kf * 16 + li, ks, lg, T()), qb[ks], sc);
+                        dp = vb_mma(frag_rm(ldsV, kf * 16 + li, ks, lg, T()), dob[ks], dp);
+                    }
+                }
+                const f32x4 mk = *(const f32x4*)(ldsMask + kf * 16 + lg * 4);
+                const int kfa = c0 / 16 + kf;
+                const uint64_t word = bits[(kfa >> 4) < NW ? (kfa >> 4) : NW - 1];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = fast_exp(sc[r] * a.scale + mk[r] - lse);
+                    const bool keep = (word >> ((kfa & 15) * 4 + r)) & 1;
+                    sc[r] = pv;
+                    dp[r] = keep ? dp[r] * a.inv_keep : 0.f;
+                }
+                pt[kf] = sc; dpt[kf] = dp;
+            }
+        };
+        // ---- sweep 1: D = rowsum(P o dP) over every key
+        float dsum = 0.f;
+        for (int c0 = 0; c0 < S; c0 += TCK) {
+            __syncthreads();
+            stage_rm<T>(ldsK, Kp, a.ldk, rowk + c0, h * D, S - c0, TCK, t);
+            stage_rm<T>(ldsV, Vp, a.ldv, rowk + c0, h * D, S - c0, TCK, t);
+            for (int k = t; k < TCK; k += NT) ldsMask[k] = c0 + k < S ? a.mask_add[(long)b * S + c0 + k] : -INFINITY;
+            __syncthreads();
+            f32x4 pt[TCF], dpt[TCF];
+            chunk_p_dp(c0, pt, dpt);
+#pragma unroll
+            for (int kf = 0; kf < TCF; ++kf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dsum += pt[kf][r] * dpt[kf][r];
+        }
+        dsum += __shfl_xor(dsum, 16);
+        dsum += __shfl_xor(dsum, 32);
+        if (a.dsum && lg == 0 && qok) a.dsum[(long)bh * Sq + q] = dsum;
+        // ---- sweep 2: dQ += dS K, dS = P o (dP - D) / sqrt(d)
+        f32x4 acc[4];
+#pragma unroll
+        for (int df = 0; df < 4; ++df) acc[df] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int c0 = 0; c0 < S; c0 += TCK) {
+            __syncthreads();
+            stage_rm<T>(ldsK, Kp, a.ldk, rowk + c0, h * D, S - c0, TCK, t);
+            stage_rm<T>(ldsV, Vp, a.ldv, rowk + c0, h * D, S - c0, TCK, t);
+            stage_tr(ldsKT, Kp, a.ldk, rowk + c0, h * D, S - c0, TCK, t);
+            for (int k = t; k < TCK; k += NT) ldsMask[k] = c0 + k < S ? a.mask_add[(long)b * S + c0 + k] : -INFINITY;
+            __syncthreads();
+            f32x4 pt[TCF], dpt[TCF];
+            chunk_p_dp(c0, pt, dpt);
+            typename VecOf<T>::v8 dsb[TCS];
+#pragma unroll
+            for (int ks = 0; ks < TCS; ++ks) {
+                f32x4 x0, x1;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    x0[r] = pt[2 * ks][r] * (dpt[2 * ks][r] - dsum) * a.scale;
+                    x1[r] = pt[2 * ks + 1][r] * (dpt[2 * ks + 1][r] - dsum) * a.scale;
+                }
+                pack_b(dsb[ks], x0, x1);
+            }
+#pragma unroll
+            for (int df = 0; df < 4; ++df)
+#pragma unroll
+                for (int ks = 0; ks < TCS; ++ks)
+                    if (c0 + ks * 32 < S)
+                        acc[df] = vb_mma(frag_tr(ldsKT, tr_pitch<T>(TCK), df * 16 + li, ks, lg, T()), dsb[ks], acc[df]);
+        }
+        T* dqrow = (T*)a.dq + (rowq + (qok ? q : 0)) * a.lddq + h * D;
+#pragma unroll
+        for (int df = 0; df < 4; ++df)
+            if (qok) store4(dqrow + df * 16 + lg * 4, acc[df]);
+    }
+}
+
+// =================================================================================================
 // backward, pass B: dK and dV.  grid = (B*nh, ceil(key fragments / 4)): a wave owns ONE 16-key
 // fragment and sweeps all queries in chunks of QC; Q / dO (row-major and transposed), lse, D and the
 // keep-bits of a chunk are staged in LDS per chunk, so LDS use is independent of S.
@@ -974,15 +1205,22 @@ template <typename T, int NKF> size_t dkv_smem() {
     return 2 * rm_bytes<T>(QC) + 2 * tr_bytes<T>(QC) + 2 * QC * 4 + (size_t)QC * 4 * ((NKF + 15) / 16) * 8;
 }
 
+template <typename T> size_t fwd_tiled_smem() { return rm_bytes<T>(TCK) + tr_bytes<T>(TCK) + TCK * 4; }
+template <typename T> size_t dq_tiled_smem() { return 2 * rm_bytes<T>(TCK) + tr_bytes<T>(TCK) + TCK * 4; }
+
 constexpr size_t kMaxLds = 160 * 1024;
 
 
 template <typename T, int NKF>
 int launch_all(int which, const AttnArgs& a, hipStream_t s) {
     dim3 grid((unsigned)(a.B * a.nh)), block(NT);
+    constexpr int NW = (NKF + 15) / 16;                     // keep-bit words: the layout every kernel of this NKF family assumes
     if (which == 0) {
         const size_t sm = fwd_smem<T, NKF>();
-        if (sm > kMaxLds) return VB_ERR_UNSUPPORTED;
+        if (sm > kMaxLds) {                                 // K / V of the whole sequence do not fit: stream the keys in chunks
+            VB_LAUNCH((attn_fwd_tiled_kernel<T, NW>), grid, block, fwd_tiled_smem<T>(), s, a);
+            return vb_check_launch();
+        }
         VB_LAUNCH((attn_fwd_kernel<T, NKF>), grid, block, sm, s, a);
     } else {
         // (S <= 64: only 4 of the one-pass kernel's 12 waves own a key fragment -- the two-pass form plus the separate
@@ -997,8 +1235,9 @@ int launch_all(int which, const AttnArgs& a, hipStream_t s) {
             }
         }
         const size_t sm1 = dq_smem<T, NKF>(), sm2 = dkv_smem<T, NKF>();
-        if (sm1 > kMaxLds || sm2 > kMaxLds) return VB_ERR_UNSUPPORTED;
-        VB_LAUNCH((attn_bwd_dq_kernel<T, NKF>), grid, block, sm1, s, a);
+        if (sm2 > kMaxLds) return VB_ERR_UNSUPPORTED;
+        if (sm1 > kMaxLds) VB_LAUNCH((attn_bwd_dq_tiled_kernel<T, NW>), grid, block, dq_tiled_smem<T>(), s, a);
+        else VB_LAUNCH((attn_bwd_dq_kernel<T, NKF>), grid, block, sm1, s, a);
         dim3 grid2((unsigned)(a.B * a.nh), (unsigned)(((a.S + 15) / 16 + 3) / 4));
         VB_LAUNCH((attn_bwd_dkv_kernel<T, NKF>), grid2, block, sm2, s, a);
     }

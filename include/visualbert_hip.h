@@ -91,7 +91,9 @@ int vb_stream_get_opts(void* stream, vb_stream_opts* out);
  *           1220 and the GELU of :56-61 fused behind :303 / :398.
  * ---------------------------------------------------------------------------------------------- */
 /*   dtype VB_BF16X3: A [M, lda] and B [N, ldb] are split operands (see the enum), both K-contiguous, K % 64 == 0,
- *   K <= lda / 2, K <= ldb / 2, lda and ldb multiples of 16; out_dtype VB_F32; bias / addend / aux / C are fp32. */
+ *   K <= lda / 2, K <= ldb / 2, lda and ldb multiples of 16; bias / addend / aux are fp32.  out_dtype VB_F32: C fp32;
+ *   out_dtype VB_BF16X3: C is written as a split operand itself (bf16 [M, ldc], N % 8 == 0, N <= ldc / 2, ldc % 16 == 0, no
+ *   accumulate) -- a GEMM that feeds only GEMMs (FFN-in -> FFN-out) skips the fp32 round trip and the split pass. */
 int vb_gemm(int dtype, int out_dtype, int a_layout, int b_layout,
             const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
             int M, int N, int K, float alpha, const float* alpha_dev, const float* bias,

@@ -179,3 +179,47 @@ def test_wgrad_and_dgrad_through_split_operands(dev, tokens):
         assert float((dx2.double() - refx2).abs().max()) <= 3e-5 * float(refx2.abs().max())
     # outside the scope the same calls are plain fp32
     assert not isinstance(ops.weight_for(w, torch.float32), ops.SplitOperand)
+
+
+@pytest.mark.parametrize("variant", [1, 42, 90])
+def test_gemm_bf16x3_split_result(dev, variant):
+    """out_dtype VB_BF16X3: the fp32 result leaves the epilogue as a split operand (hi | lo planes), here with the FFN-in forward's
+    bias + GELU + saved GELU' and with the FFN-out dgrad's x GELU' + column sums -- hi + lo must equal the fp32-output result of
+    the same call to 2^-16 relative, and the column sums are taken from the fp32 values."""
+    L = _lib.lib()
+    M, N, K = 530, 384, 128
+    g = torch.Generator().manual_seed(40 + variant)
+    A = (torch.randn(M, K, generator=g) * 0.5).to(dev)
+    B = (torch.randn(N, K, generator=g) * 0.2).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    pre = torch.randn(M, N, generator=g).to(dev)
+    As, Bs = split(dev, A), split(dev, B)
+
+    def run(out_split, act, aux_in=None, aux_out=None, colsum=None, use_bias=True):
+        C = torch.full((M, 2 * N), 9.0, dtype=torch.bfloat16, device=dev) if out_split else torch.full((M, N), 7.0, device=dev)
+        aux = aux_in if aux_in is not None else aux_out
+        rc = L.vb_gemm(_lib.VB_BF16X3, _lib.VB_BF16X3 if out_split else _lib.VB_F32, 0, 0, _lib.ptr(As), As.stride(0), _lib.ptr(Bs),
+                       Bs.stride(0), _lib.ptr(C), C.stride(0), M, N, K, 1.0, None, _lib.ptr(bias) if use_bias else None, None, 0, act,
+                       _lib.ptr(aux_in), _lib.ptr(aux_out), aux.stride(0) if aux is not None else 0, 0, _lib.ptr(colsum),
+                       _lib.stream_ptr())
+        _lib.check(rc, "vb_gemm")
+        return C
+
+    with _lib.stream_opts(nt_kernel=variant):
+        aux1, aux2 = torch.zeros(M, N, device=dev), torch.zeros(M, N, device=dev)
+        ref = run(False, _lib.VB_ACT_GELU_SAVE_GRAD, aux_out=aux1)
+        got = run(True, _lib.VB_ACT_GELU_SAVE_GRAD, aux_out=aux2)
+        assert torch.equal(aux1, aux2)
+        assert torch.equal(got[:, :N].float(), ref.to(torch.bfloat16).float())                 # hi = RNE bf16 of the fp32 result
+        assert bool(((got[:, :N].float() + got[:, N:].float() - ref).abs() <= 2.0 ** -16 * ref.abs()).all())
+        cs1, cs2 = torch.zeros(N, device=dev), torch.zeros(N, device=dev)
+        ref = run(False, _lib.VB_ACT_MUL_AUX, aux_in=pre, colsum=cs1, use_bias=False)
+        got = run(True, _lib.VB_ACT_MUL_AUX, aux_in=pre, colsum=cs2, use_bias=False)
+        assert bool(((got[:, :N].float() + got[:, N:].float() - ref).abs() <= 2.0 ** -16 * ref.abs()).all())
+        assert float((cs1 - cs2).abs().max()) <= 1e-5 * float(cs1.abs().max())               # same fp32 values, atomics order aside
+    # what a split result cannot be: ragged N, accumulate
+    C = torch.zeros(M, 2 * N, dtype=torch.bfloat16, device=dev)
+    assert L.vb_gemm(_lib.VB_BF16X3, _lib.VB_BF16X3, 0, 0, _lib.ptr(As), As.stride(0), _lib.ptr(Bs), Bs.stride(0), _lib.ptr(C), 2 * N,
+                     M, N - 3, K, 1.0, None, None, None, 0, 0, None, None, 0, 0, None, _lib.stream_ptr()) == -3
+    assert L.vb_gemm(_lib.VB_BF16X3, _lib.VB_BF16X3, 0, 0, _lib.ptr(As), As.stride(0), _lib.ptr(Bs), Bs.stride(0), _lib.ptr(C), 2 * N,
+                     M, N, K, 1.0, None, None, None, 0, 0, None, None, 0, 1, None, _lib.stream_ptr()) == -3

@@ -83,6 +83,9 @@ struct GemmArgs {
     // x = hi + lo to ~2^-17; the kernel walks 3 K segments of K / 64 tiles each -- hi.hi, lo.hi, hi.lo -- into the same
     // fp32 accumulators.  a_lo / b_lo: ELEMENT offset of the lo plane inside a row; kseg: K tiles per segment.
     int x3, a_lo, b_lo, kseg;
+    // split_out (VB_BF16X3 output): C is a bf16 [M, ldc] SPLIT operand -- the fp32 result leaves as hi = bf16(v) in column n and
+    // lo = bf16(v - hi) in column ldc / 2 + n (what vb_split_bf16 would make of it), ready to be the next GEMM's operand
+    int split_out;
 };
 // K tile `v` of the (virtual) K loop -> element offset of its first column inside a row of A / of B
 VB_DEVICE int x3_col_a(const GemmArgs& g, int v, int bk) {
@@ -254,7 +257,7 @@ VB_DEVICE void epi_lane_init(EpiLane& e, const GemmArgs& g, int nw0, int lane) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) { e.bb[j] = 0.f; e.cs[j] = 0.f; }
     if constexpr (OPT & EPI_RAGGED) {
-        e.vec = full && (((g.ldc * sizeof(TO)) | (uintptr_t)g.C) & 15) == 0 &&
+        e.vec = full && (((g.ldc * (g.split_out ? 2 : sizeof(TO))) | (uintptr_t)g.C) & 15) == 0 &&
                 (!g.addend || (((g.ld_addend * sizeof(T)) | (uintptr_t)g.addend) & 15) == 0) &&
                 (!(g.aux_in || g.aux_out) || (((g.ld_aux * sizeof(T)) | (uintptr_t)g.aux_in | (uintptr_t)g.aux_out) & 15) == 0);
         if (g.bias && full) {
@@ -370,6 +373,22 @@ VB_DEVICE void epi_vec8(float (&v)[8], const GemmArgs& g, EpiLane& e, long offc,
         }
     }
     TO* cp = (TO*)g.C + offc;
+    if constexpr (sizeof(TO) == 4 && (OPT & EPI_RAGGED) != 0) {            // the run-time epilogue of the fp32-output kernels only
+        if (g.split_out) {
+            bf16* hp = (bf16*)g.C + offc;
+            bf16x8 h;
+            float lo[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { h[j] = (bf16)v[j]; lo[j] = v[j] - (float)h[j]; }
+            *(bf16x8*)hp = h;
+            store8(hp + g.ldc / 2, lo);
+            if constexpr (OPT & EPI_COLSUM) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) e.cs[j] += v[j];
+            }
+            return;
+        }
+    }
     if (g.debug & 128) { if (v[0] == 123.456f) store8(cp, v); }           // ablation: no global stores
     else store8(cp, v);
     if constexpr (OPT & EPI_COLSUM) {
@@ -1953,9 +1972,12 @@ extern "C" int vb_gemm(int dtype, int out_dtype, int a_layout, int b_layout,
     if (dtype != VB_F32 && dtype != VB_BF16 && dtype != VB_BF16X3) return VB_ERR_ARG;
     if (out_dtype != VB_F32 && out_dtype != dtype) return VB_ERR_ARG;
     const bool x3 = dtype == VB_BF16X3;
+    const bool split_out = x3 && out_dtype == VB_BF16X3;
     if (x3) {
         // split operands: fp32 everywhere but the MFMA inputs; whole K tiles; hi | lo halves of 16-byte-aligned rows
-        if (out_dtype != VB_F32 || a_layout != VB_KCONTIG || b_layout != VB_KCONTIG) return VB_ERR_UNSUPPORTED;
+        if (a_layout != VB_KCONTIG || b_layout != VB_KCONTIG) return VB_ERR_UNSUPPORTED;
+        // a split RESULT: whole 8-column groups, room for both planes, nothing to accumulate into
+        if (split_out && ((N % 8) || (ldc % 16) || N > ldc / 2 || accumulate || (((uintptr_t)C) & 15))) return VB_ERR_UNSUPPORTED;
         if ((K % 64) || (lda % 16) || (ldb % 16) || K > lda / 2 || K > ldb / 2) return VB_ERR_UNSUPPORTED;
     }
     t_opts = vb_opts_for(stream);
@@ -1973,6 +1995,7 @@ extern "C" int vb_gemm(int dtype, int out_dtype, int a_layout, int b_layout,
     g.ld_aux = ld_aux; g.alpha = alpha; g.alpha_dev = alpha_dev; g.colsum = colsum_out; g.act = act; g.accumulate = accumulate;
     g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
     g.debug = g_debug; g.trace = g_trace;
+    g.split_out = split_out ? 1 : 0;
     g.x3 = x3 ? 1 : 0; g.a_lo = x3 ? (int)(lda / 2) : 0; g.b_lo = x3 ? (int)(ldb / 2) : 0; g.kseg = x3 ? K / 64 : 0;
     g.stripe = 0;
     const int bk = dtype == VB_F32 ? 32 : 64;
@@ -1993,7 +2016,7 @@ extern "C" int vb_gemm(int dtype, int out_dtype, int a_layout, int b_layout,
         }
     }
     hipStream_t s = (hipStream_t)stream;
-    const int of32 = (out_dtype == VB_F32) ? 1 : 0;
+    const int of32 = (out_dtype == VB_F32 || split_out) ? 1 : 0;
     if (dtype == VB_BF16 && of32 && a_layout == VB_KSTRIDED && b_layout == VB_KSTRIDED && accumulate && !bias && !addend &&
         !colsum_out && act == VB_ACT_NONE && t_opts.nt_kernel != 1 && tn_eligible(A, lda, B, ldb, (const float*)C, ldc, M, N, K)) {
         TnArgs tg;

@@ -21,6 +21,9 @@ struct Saved {
     unsigned char *qkv, *ctx, *z1, *a_out, *pre, *inter, *z2;
     float *lse, *mean1, *rstd1, *mean2, *rstd2;
     uint64_t* keepbits;
+    // bf16x3 only: the split (hi | lo) images of the four GEMM inputs the forward made anyway -- they are the x operands of the
+    // backward's weight-gradient launch, so keeping them saves four split passes per layer (19 % of the mode's split traffic)
+    unsigned char *sp_hin, *sp_ctx, *sp_aout, *sp_inter;
     size_t total;
 };
 
@@ -41,6 +44,8 @@ Saved carve_saved(unsigned char* base, const Dims& d, bool attn_dropout) {
     s.mean2 = (float*)take((size_t)d.M * 4);
     s.rstd2 = (float*)take((size_t)d.M * 4);
     s.keepbits = (uint64_t*)take(attn_dropout ? (size_t)d.B * d.nh * vb_attn_keepbits_words(d.S) * 8 : 0);
+    const size_t sh = d.x3 ? (size_t)d.M * 2 * d.H * 2 : 0, si = d.x3 ? (size_t)d.M * 2 * d.I * 2 : 0;
+    s.sp_hin = take(sh); s.sp_ctx = take(sh); s.sp_aout = take(sh); s.sp_inter = take(si);
     s.total = o;
     return s;
 }
@@ -50,9 +55,9 @@ struct Scratch {
     unsigned char *t_h0, *t_h1, *t_h2, *t_h3, *t_h4, *t_h5, *t_i, *t_3h;
     float* dsum;
     float* ln_ws;
-    // bf16x3 only: split (hi | lo) images of the GEMM operands, [M, 2 x features] bf16 each.  Backward keeps all eight alive
-    // for the grouped weight-gradient launch; forward stages its four GEMM inputs through sp_inter one after the other.
-    unsigned char *sp_dfo, *sp_dpre, *sp_dao, *sp_dqkv, *sp_inter, *sp_aout, *sp_ctx, *sp_hin;
+    // bf16x3 only: split (hi | lo) images of the backward's output gradients, [M, 2 x features] bf16 each, alive until the
+    // grouped weight-gradient launch (the x operands' images come from the forward: Saved)
+    unsigned char *sp_dfo, *sp_dpre, *sp_dao, *sp_dqkv;
     size_t total;
 };
 Scratch carve_scratch(unsigned char* base, const Dims& d) {
@@ -71,7 +76,6 @@ Scratch carve_scratch(unsigned char* base, const Dims& d) {
     s.ln_ws = (float*)take((size_t)vb_ln_bwd_ws_bytes((int)d.M, d.H));
     const size_t sh = d.x3 ? (size_t)d.M * 2 * d.H * 2 : 0, si = d.x3 ? (size_t)d.M * 2 * d.I * 2 : 0;
     s.sp_dfo = take(sh); s.sp_dpre = take(si); s.sp_dao = take(sh); s.sp_dqkv = take(3 * sh);
-    s.sp_inter = take(si); s.sp_aout = take(sh); s.sp_ctx = take(sh); s.sp_hin = take(sh);
     s.total = o;
     return s;
 }
@@ -86,8 +90,10 @@ bool fill_dims(Dims& d, int dtype, int B, int S, int H, int I, int nh) {
 }
 
 // y[M, n] = epilogue(x[M, k] W[n, k]^T): in the split-operand mode x (fp32) is split into `stage` first and W arrives split
+// split_y (split-operand mode only): y is written as a split image [M, 2 n] itself (the result feeds only GEMMs)
 int linear(const Dims& d, const void* x, int k, unsigned char* stage, const void* w, int64_t ldw, void* y, int n,
-           const float* bias, const void* addend, int act, const void* aux_in, void* aux_out, float* colsum, void* stream) {
+           const float* bias, const void* addend, int act, const void* aux_in, void* aux_out, float* colsum, void* stream,
+           bool split_y = false) {
     const int M = (int)d.M;
     if (!d.x3)
         return vb_gemm(d.dtype, d.dtype, VB_KCONTIG, VB_KCONTIG, x, k, w, ldw, y, n, M, n, k, 1.f, nullptr, bias, addend, n, act,
@@ -97,8 +103,8 @@ int linear(const Dims& d, const void* x, int k, unsigned char* stage, const void
         if (rc != VB_OK) return rc;
         x = stage;
     }
-    return vb_gemm(VB_BF16X3, VB_F32, VB_KCONTIG, VB_KCONTIG, x, 2 * k, w, ldw, y, n, M, n, k, 1.f, nullptr, bias, addend, n, act,
-                   aux_in, aux_out, n, 0, colsum, stream);
+    return vb_gemm(VB_BF16X3, split_y ? VB_BF16X3 : VB_F32, VB_KCONTIG, VB_KCONTIG, x, 2 * k, w, ldw, y, split_y ? 2 * n : n, M, n, k,
+                   1.f, nullptr, bias, addend, n, act, aux_in, aux_out, n, 0, colsum, stream);
 }
 
 #define VB_TRY(expr) do { int rc_ = (expr); if (rc_ != VB_OK) return rc_; } while (0)
@@ -136,20 +142,22 @@ extern "C" int vb_bert_layer_fwd(int dtype, const void* h_in, const float* mask_
 
     const int edt = d.edt;
     const int64_t wk = d.x3 ? 2 : 1;                   // leading dimension of a weight matrix per K element (split: hi | lo)
-    unsigned char* stage = d.x3 ? sc.sp_inter : nullptr;
     // 1. packed Q|K|V projection
-    VB_TRY(linear(d, h_in, H, stage, wqkv, wk * H, sv.qkv, 3 * H, bqkv, nullptr, VB_ACT_NONE, nullptr, nullptr, nullptr, stream));
+    VB_TRY(linear(d, h_in, H, sv.sp_hin, wqkv, wk * H, sv.qkv, 3 * H, bqkv, nullptr, VB_ACT_NONE, nullptr, nullptr, nullptr, stream));
     // 2. fused attention
     VB_TRY(vb_attn_fwd(edt, sv.qkv, mask_add, sv.ctx, sv.lse, sv.keepbits, B, S, nh, 64, p_attn, seed, sid, stream));
     // 3. attention output projection
-    VB_TRY(linear(d, sv.ctx, H, stage, wo, wk * H, sc.t_h0, H, bo, nullptr, VB_ACT_NONE, nullptr, nullptr, nullptr, stream));
+    VB_TRY(linear(d, sv.ctx, H, sv.sp_ctx, wo, wk * H, sc.t_h0, H, bo, nullptr, VB_ACT_NONE, nullptr, nullptr, nullptr, stream));
     // 4. dropout + residual + LayerNorm
     VB_TRY(vb_ln_fwd(edt, sc.t_h0, h_in, sv.z1, sv.a_out, sv.mean1, sv.rstd1, g1, b1, M, H, eps, p_hidden, sid + 1,
                      0.f, 0, seed, stream));
     // 5. FFN in + erf-GELU (GELU' kept for backward)
-    VB_TRY(linear(d, sv.a_out, H, stage, wi, wk * H, sv.inter, I, bi, nullptr, VB_ACT_GELU_SAVE_GRAD, nullptr, sv.pre, nullptr, stream));
+    //    (split-operand mode: the activation leaves the GEMM as a split image -- only GEMMs read it: FFN-out and its wgrad)
+    VB_TRY(linear(d, sv.a_out, H, sv.sp_aout, wi, wk * H, d.x3 ? (void*)sv.sp_inter : (void*)sv.inter, I, bi, nullptr,
+                  VB_ACT_GELU_SAVE_GRAD, nullptr, sv.pre, nullptr, stream, d.x3));
     // 6. FFN out
-    VB_TRY(linear(d, sv.inter, I, stage, wo2, wk * I, sc.t_h1, H, bo2, nullptr, VB_ACT_NONE, nullptr, nullptr, nullptr, stream));
+    VB_TRY(linear(d, d.x3 ? (const void*)sv.sp_inter : (const void*)sv.inter, I, nullptr, wo2, wk * I, sc.t_h1, H, bo2, nullptr,
+                  VB_ACT_NONE, nullptr, nullptr, nullptr, stream));
     // 7. dropout + residual + LayerNorm
     VB_TRY(vb_ln_fwd(edt, sc.t_h1, sv.a_out, sv.z2, h_out, sv.mean2, sv.rstd2, g2, b2, M, H, eps, p_hidden, sid + 4,
                      0.f, 0, seed, stream));
@@ -183,10 +191,12 @@ extern "C" int vb_bert_layer_bwd(int dtype, const void* h_in, const float* mask_
     if (d.x3 && (!weights_t || !weights_t[0] || !weights_t[1] || !weights_t[2] || !weights_t[3] || !ld_t)) return VB_ERR_UNSUPPORTED;
     // split-operand mode: dy (fp32) is split into `stage` -- kept for the grouped weight-gradient launch -- and W^T arrives split
     auto dgrad = [&](const void* dy, int n_out, const void* w, int which_t, int n_in, void* dx, const void* addend,
-                     int act, const void* aux, float* colsum = nullptr, unsigned char* stage = nullptr) -> int {
+                     int act, const void* aux, float* colsum = nullptr, unsigned char* stage = nullptr,
+                     bool split_dx = false) -> int {
         const void* wt = weights_t ? weights_t[which_t] : nullptr;
         if (d.x3)
-            return linear(d, dy, n_out, stage, wt, ld_t[which_t], dx, n_in, nullptr, addend, act, aux, nullptr, colsum, stream);
+            return linear(d, dy, n_out, stage, wt, ld_t[which_t], dx, n_in, nullptr, addend, act, aux, nullptr, colsum, stream,
+                          split_dx);
         if (wt)
             return vb_gemm(dtype, dtype, VB_KCONTIG, VB_KCONTIG, dy, n_out, wt, ld_t[which_t], dx, n_in, M, n_in, n_out,
                            1.f, nullptr, nullptr, addend, n_in, act, aux, nullptr, n_in, 0, colsum, stream);
@@ -204,9 +214,11 @@ extern "C" int vb_bert_layer_bwd(int dtype, const void* h_in, const float* mask_
                      G[VB_LW_FO_B], M, H, p_hidden, sid + 4, 0.f, 0, seed, sc.ln_ws, stream));
     // 2. dgrad FFN-out with the saved GELU' folded into the epilogue: dpre = (dfo Wo2) * gelu'(pre)
     //    (+ bias gradient of FFN-in = column sums of dpre, accumulated by the same epilogue)
-    VB_TRY(dgrad(dfo, H, wo2, VB_LWT_FO, I, sc.t_i, nullptr, VB_ACT_MUL_AUX, sv.pre, G[VB_LW_FI_B], sc.sp_dfo));
+    //    (split-operand mode: dpre leaves the GEMM as a split image -- only the next dgrad and the wgrad launch read it)
+    unsigned char* dpre = d.x3 ? sc.sp_dpre : sc.t_i;
+    VB_TRY(dgrad(dfo, H, wo2, VB_LWT_FO, I, dpre, nullptr, VB_ACT_MUL_AUX, sv.pre, G[VB_LW_FI_B], sc.sp_dfo, d.x3));
     // 3. dgrad FFN-in + residual gradient: da = dpre Wi + dz2
-    VB_TRY(dgrad(sc.t_i, I, wi, VB_LWT_FI, H, sc.t_h2, dz2, VB_ACT_NONE, nullptr, nullptr, sc.sp_dpre));
+    VB_TRY(dgrad(dpre, I, wi, VB_LWT_FI, H, sc.t_h2, dz2, VB_ACT_NONE, nullptr, nullptr, nullptr));
     // 4. attention-output LayerNorm backward
     unsigned char* dz1 = sc.t_h5;
     unsigned char* dao = p_hidden > 0.f ? sc.t_h4 : dz1;
@@ -223,14 +235,10 @@ extern "C" int vb_bert_layer_bwd(int dtype, const void* h_in, const float* mask_
     // 10. the four weight gradients: dW_fo[H,I] += dfo^T inter, dW_fi[I,H] += dpre^T a_out, dW_ao[H,H] += dao^T ctx,
     //     dW_qkv[3H,H] += dqkv^T h_in
     if (d.x3) {
-        // the dy images were split for the dgrads above; the four layer inputs are split here
-        VB_TRY(vb_split_bf16((const float*)sv.inter, I, sc.sp_inter, 2 * I, M, I, stream));
-        VB_TRY(vb_split_bf16((const float*)sv.a_out, H, sc.sp_aout, 2 * H, M, H, stream));
-        VB_TRY(vb_split_bf16((const float*)sv.ctx, H, sc.sp_ctx, 2 * H, M, H, stream));
-        VB_TRY(vb_split_bf16((const float*)h_in, H, sc.sp_hin, 2 * H, M, H, stream));
+        // the dy images were split for the dgrads above; the four layer inputs' images were kept by the forward
         const void* dys[4] = {sc.sp_dfo, sc.sp_dpre, sc.sp_dao, sc.sp_dqkv};
         const int64_t ld_dy[4] = {2 * H, 2 * I, 2 * H, 6 * H};
-        const void* xs[4] = {sc.sp_inter, sc.sp_aout, sc.sp_ctx, sc.sp_hin};
+        const void* xs[4] = {sv.sp_inter, sv.sp_aout, sv.sp_ctx, sv.sp_hin};
         const int64_t ld_x[4] = {2 * I, 2 * H, 2 * H, 2 * H};
         void* dws[4] = {G[VB_LW_FO_W], G[VB_LW_FI_W], G[VB_LW_AO_W], G[VB_LW_QKV_W]};
         const int64_t ld_dw[4] = {I, H, H, H};

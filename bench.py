@@ -321,7 +321,7 @@ def main():
     ap.add_argument("--strict-dtype", default="both", choices=[d for d in DTYPES if d != "bf16"] + ["both", "none"],
                     help="after the timed bf16 run, also time a short run of the mode that meets the north-star's 1e-3 "
                          "logit tolerance and report it as `strict_mode` (rank 0, N = 1)")
-    ap.add_argument("--strict-batch", type=int, default=128)
+    ap.add_argument("--strict-batch", type=int, default=256)
     ap.add_argument("--strict-steps", type=int, default=4)
     ap.add_argument("--text-len", type=int, default=0)
     ap.add_argument("--regions", type=int, default=0)

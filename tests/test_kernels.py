@@ -563,6 +563,41 @@ def test_gemm_specialised_epilogues(dev, variant):
         assert (Cf - ref[:, :Nr]).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("wgs", [0, 2])
+def test_gemm_direct_b_kernel(dev, wgs):
+    """nt_kernel 101: the four-wave 256x256 kernel whose B operand goes straight from global memory into MFMA-layout registers
+    (1 x 4 waves, four A stages; K / 64 a multiple of 4, N a multiple of 256).  Every epilogue the step uses, a ragged M, and
+    two persistent workgroups so that a workgroup walks several tiles with both operand streams running across tile boundaries."""
+    M, N, K = 700, 512, 256
+    g = torch.Generator().manual_seed(101)
+    dt = torch.bfloat16
+    A = (torch.randn(M, K, generator=g) * 0.5).to(dt).to(dev)
+    B = (torch.randn(N, K, generator=g) * 0.2).to(dt).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    base = A.float() @ B.float().t()
+    lim = lambda ref: 1.2e-2 * max(1.0, ref.abs().max().item())
+    gprime = lambda x: 0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
+    with _lib.stream_opts(nt_kernel=101, persistent_workgroups=wgs):
+        ref = base + bias
+        C = gemm(dev, dt, A, B, M, N, K, 0, 0, bias=bias)
+        assert (C.float() - ref).abs().max().item() <= lim(ref)
+        Cf = gemm(dev, dt, A, B, M, N, K, 0, 0, out_f32=True, bias=bias)
+        assert (Cf - ref).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
+        aux = torch.zeros(M, N, dtype=dt, device=dev)
+        C = gemm(dev, dt, A, B, M, N, K, 0, 0, bias=bias, act=_lib.VB_ACT_GELU_SAVE_GRAD, aux_out=aux)
+        assert (C.float() - torch.nn.functional.gelu(ref)).abs().max().item() <= lim(ref)
+        assert (aux.float() - gprime(ref)).abs().max().item() <= lim(ref)
+        pre = torch.randn(M, N, generator=g).to(dt).to(dev)
+        cs = torch.ones(N, device=dev)
+        C = gemm(dev, dt, A, B, M, N, K, 0, 0, act=_lib.VB_ACT_MUL_AUX, aux_in=pre, colsum=cs)
+        ref2 = base * pre.float()
+        assert (C.float() - ref2).abs().max().item() <= lim(ref2)
+        assert (cs - (1.0 + ref2.sum(0))).abs().max().item() <= 2e-2 * max(1.0, ref2.sum(0).abs().max().item())
+        add_t = torch.randn(M, N, generator=g).to(dt).to(dev)
+        C = gemm(dev, dt, A, B, M, N, K, 0, 0, addend=add_t)
+        assert (C.float() - (base + add_t.float())).abs().max().item() <= lim(base)
+
+
 @pytest.mark.parametrize("K", [64, 128, 192, 256, 320, 768])
 def test_gemm_eight_phase_k_tails(dev, K):
     """the 8-phase 256x256 kernel has a 6-half-tile prologue and a counted-wait tail that depend on the

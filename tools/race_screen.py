@@ -22,7 +22,7 @@ for it in range(int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() 
         a = (torch.randn(m, k, generator=g) * 0.5).to(torch.bfloat16).to(dev)
         w = (torch.randn(n, k, generator=g) * 0.1).to(torch.bfloat16).to(dev)
         ref = a.float() @ w.float().t()
-        for variant, wgs in ((81, 0), (81, 64), (80, 0), (81, 24), (90, 0), (100, 0), (100, 24)):
+        for variant, wgs in ((81, 0), (81, 64), (80, 0), (81, 24), (90, 0), (100, 0), (100, 24), (101, 0), (101, 24)):
             _knobs.variant(variant); _knobs.wgs(wgs)
             out = torch.empty(m, n, dtype=torch.float32, device=dev)
             ops.gemm(a, w, m, n, k, out=out)

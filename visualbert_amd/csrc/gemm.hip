@@ -1537,16 +1537,201 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(256, 1) gemm_nt_big_kernel(GemmArgs g) {
     vb_wait_vmcnt<0>();                             // the re-fetched tail copies must not outlive the workgroup's LDS
 }
 
+// =================================================================================================
+// nt_kernel 101: the four-wave 256x256 kernel above with the B operand fetched STRAIGHT from global memory into MFMA-layout
+// registers (no LDS for B).
+//
+// Why (the byte budget): with 128x64 outputs per wave the 8-wave kernels book the LDS port at 98-109 % of
+// its 128 B/clk at the full MFMA rate; the four-wave kernel (128x128 per wave) needs 94 B/clk but feeds BOTH operands through
+// LDS-direct copies, whose queue holds ~4 KB per wave: 4 waves deliver 49 GB/s per CU where 58 are needed.  Here the waves
+// are laid out 1 x 4 (a wave owns all 256 rows x 64 columns, so its B fragments are nobody else's) and a lane loads
+// the 16 bytes B[n0 + 64 w + 16 f + (lane & 15)][k .. k + 7], k = 32 ks + 8 (lane >> 4) -- exactly its B fragment of MFMA
+// K step ks -- with an ordinary buffer load one K tile ahead (two register sets: 128 VGPRs next to the 256 accumulators in
+// the AGPR half), so B travels through the deep ordinary load queue, the LDS-direct queue carries A only
+// (8 pieces per wave and K tile instead of 16) and the LDS port sees 160 KB per K tile instead of 192 (78 B/clk).  (With the
+// 2 x 2 wave layout of the kernel above every B byte was requested by two waves: 30 % slower than that kernel, measured.)
+// Same persistent tile walk, same epilogue, one barrier per K tile.  N must be a multiple of 256 (no per-fragment row clamp).
+// With B out of LDS there is room for FOUR A stages (128 KB): the A copies run three K tiles ahead of the MFMAs.
+// vmcnt: the loads of a wave retire in issue order; the first half of a K tile issues the 8 B loads of the next K tile, the
+// second half the 8 A copies of K tile + 3, so "all but the newest 24" at the mid-tile barrier means: the A copies of the NEXT
+// K tile (issued two K tiles ago) have landed.  The compiler adds its own (weaker) counted waits in
+// front of the MFMAs that consume a loaded register.
+template <typename TO, int ACT, int OPT>
+VB_KERNEL VB_LAUNCH_BOUNDS2(256, 1) gemm_nt_bdir_kernel(GemmArgs g) {
+    typedef bf16 T;
+    constexpr int BK = 64, HALF = 128 * 128, STAGE = 2 * HALF;          // a stage holds A only: A0 | A1
+    VB_DYN_SMEM(smem);
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = vb_uniform(t >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int ntiles = g.tiles_m * g.tiles_n;
+    const int G = (int)gridDim.x;
+    const int my_tiles = (ntiles - (int)blockIdx.x + G - 1) / G;
+    const int nk = g.K / BK;
+    const vb_buf A = vb_make_buf(g.A);
+    const vb_buf B = vb_make_buf(g.B);
+    constexpr int NSTG = 4;                                              // A stages: copies run three K tiles ahead of the MFMAs
+    unsigned char* slab = smem + NSTG * STAGE + wave * EPI8_BYTES_PER_WAVE;
+
+    // wave w owns ALL 256 rows x columns 64 w .. 64 w + 63 of the tile: its B fragments (4 per K step) are nobody else's -- fetched
+    // straight from global memory, no duplicate requests -- and A (shared by the four waves) goes through LDS
+    f32x4 acc[2][8][4];                             // [rows 0..127 | 128..255][fragment row][fragment column]
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) acc[h][mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+        big_settle();
+    };
+    auto origin = [&](int j, int& m0, int& n0) {
+        const int tile = xcd_remap((int)blockIdx.x + G * j, ntiles);
+        m0 = (tile / g.tiles_n) * 256; n0 = (tile % g.tiles_n) * 256;
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    typedef std::integral_constant<int, 2> I2;
+    typedef std::integral_constant<int, 3> I3;
+    typedef std::true_type Yes;
+    typedef std::false_type No;
+    // ---- A: LDS-direct copy stream (8 one-KiB pieces per wave and K tile)
+    unsigned offA[2][4];
+    int ld_j = 0, ld_t = 0;
+    auto set_load_tile = [&](int j) {
+        int m0, n0;
+        origin(j, m0, n0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = (wave * 4 + i) * 8 + (lane >> 3);
+            const unsigned csrc = (unsigned)(((lane & 7) ^ swz(r)) * 16);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                int a = m0 + h * 128 + r;
+                a = a < g.M ? a : g.M - 1;                  // clamped rows are computed but never stored
+                offA[h][i] = (unsigned)(a * (int)g.lda) * 2u + csrc;
+            }
+        }
+    };
+    auto copy_piece = [&](auto stag, auto ctag) {            // piece c (0..7) of the load stream's K tile into stage S
+        constexpr int S = decltype(stag)::value, c = decltype(ctag)::value, h = (c >> 2) & 1, i = c & 3;
+        unsigned char* dst = smem + S * STAGE + h * HALF + wave * 4096 + i * 1024;
+        vb_glds16_buf(A, offA[h][i], (unsigned)ld_t * (BK * 2), dst);
+    };
+    auto ld_advance = [&]() {
+        if (ld_t + 1 < nk) ++ld_t;
+        else if (ld_j + 1 < my_tiles) { ld_t = 0; ++ld_j; set_load_tile(ld_j); }
+    };
+    // ---- B: straight into fragment registers, one K tile ahead; both K steps of a fragment row back to back (the two 64-byte
+    //      halves of the same 128-byte lines)
+    unsigned bvoff = 0;                                      // (n0 + 64 w + li) ldb 2 + 16 lg
+    const unsigned brow16 = (unsigned)(16 * (int)g.ldb) * 2u; // bytes from fragment f to fragment f + 1
+    int b_j = 0, b_t = 0;
+    auto set_b_tile = [&](int j) {
+        int m0, n0;
+        origin(j, m0, n0);
+        bvoff = (unsigned)((n0 + wave * 64 + li) * (int)g.ldb) * 2u + (unsigned)lg * 16u;
+    };
+    auto b_load = [&](bf16x8& dst, auto ftag, auto kstag) {
+        constexpr int f = decltype(ftag)::value, ks = decltype(kstag)::value;
+        const u32x4 v = vb_buf_load16(B, bvoff, (unsigned)f * brow16 + (unsigned)(b_t * BK + ks * 32) * 2u);
+        dst = *(const bf16x8*)&v;
+    };
+    auto b_advance = [&]() {                                 // past the workgroup's last K tile the stream stays on it
+        if (b_t + 1 < nk) ++b_t;
+        else if (b_j + 1 < my_tiles) { b_t = 0; ++b_j; set_b_tile(b_j); }
+    };
+    unsigned VA[2][8];                              // base of stage PAIR p (stages 2 p, 2 p + 1: the second one is an immediate offset)
+    {
+        const unsigned base = big_lds_base(smem);
+        const int c0 = lg ^ (li >> 1);
+#pragma unroll
+        for (int sidx = 0; sidx < 2; ++sidx)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) VA[sidx][k] = base + sidx * 2 * STAGE + (unsigned)(li * 128 + ((c0 ^ k) << 4));
+    }
+    bf16x8 fa0[16], fa1[16];                        // A fragments (16 fragment rows = 256 rows) of MFMA K step 0 / 1 of a K tile
+    bf16x8 fbt[2][2][4];                            // B fragments: [K tile parity][K step][fragment]
+    auto a_read = [&](auto stag, auto kstag, auto ftag, bf16x8 (&fa)[16]) {      // fragment row f: half f >> 3, rows (f & 7) 16 ..
+        constexpr int S = decltype(stag)::value, KS = decltype(kstag)::value, f = decltype(ftag)::value;
+        big_read<(S & 1) * STAGE + (f >> 3) * HALF + (f & 7) * 2048>(fa[f], smem, VA[S >> 1][(f & 7) ^ (4 * KS)]);
+    };
+    // one half of a K tile: 64 MFMAs from (fa, fb); between them the 16 A reads of the NEXT K step into na (stage RS, K step RKS);
+    // first half (BLOAD): the 8 B loads of the NEXT K tile into nb; second half (COPY): the 8 A copies of K tile +2 into stage CS
+    auto half = [&](auto rstag, auto rkstag, auto cstag, auto copytag, auto bloadtag, bf16x8 (&fa)[16], bf16x8 (&fb)[4],
+                    bf16x8 (&na)[16], bf16x8 (&nb)[2][4]) {
+        constexpr bool COPY = decltype(copytag)::value, BLOAD = decltype(bloadtag)::value;
+        vb_static_for<0, 16>([&](auto mitag) {
+            constexpr int mi = decltype(mitag)::value;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) VB_BIG_MMA(acc[mi >> 3][mi & 7][ni], fa[mi], fb[ni]);
+            // the 16 A reads of the next K step go out in the first 8 of the 16 MFMA groups: the last one is 32 MFMAs old when the
+            // half ends, so the lgkmcnt(0) behind the half finds nothing outstanding
+            if constexpr (mi < 8) { a_read(rstag, rkstag, std::integral_constant<int, 2 * mi>(), na); a_read(rstag, rkstag, std::integral_constant<int, 2 * mi + 1>(), na); }
+            if constexpr (COPY && (mi & 1) == 0) copy_piece(cstag, std::integral_constant<int, mi / 2>());
+            if constexpr (BLOAD && (mi & 1) == 0) {
+                if constexpr ((mi & 2) == 0) b_load(nb[0][mi / 4], std::integral_constant<int, mi / 4>(), I0());
+                else b_load(nb[1][mi / 4], std::integral_constant<int, mi / 4>(), I1());
+            }
+        });
+        if constexpr (BLOAD) b_advance();
+    };
+    set_load_tile(0);
+    vb_static_for<0, 8>([&](auto c) { copy_piece(I0(), c); });
+    ld_advance();
+    vb_static_for<0, 8>([&](auto c) { copy_piece(I1(), c); });
+    ld_advance();
+    vb_static_for<0, 8>([&](auto c) { copy_piece(I2(), c); });
+    ld_advance();
+    set_b_tile(0);
+    vb_static_for<0, 4>([&](auto f) { b_load(fbt[0][0][decltype(f)::value], f, I0()); b_load(fbt[0][1][decltype(f)::value], f, I1()); });
+    b_advance();
+    vb_wait_vmcnt<0>();
+    vb_raw_barrier();
+    vb_static_for<0, 16>([&](auto f) { a_read(I0(), I0(), f, fa0); });
+    vb_raw_barrier();                               // lgkmcnt(0): the first A fragments are in
+
+    auto ktile = [&](auto stag) {                   // one K tile: A stage S (of 4), B register set S & 1
+        constexpr int S = decltype(stag)::value, P = S & 1;
+        typedef std::integral_constant<int, (S + 1) & 3> SN;                        // the next K tile's stage
+        typedef std::integral_constant<int, (S + 3) & 3> SC;                        // = the previous K tile's: refilled with K tile + 3
+        half(stag, I1(), SC(), No(), Yes(), fa0, fbt[P][0], fa1, fbt[P ^ 1]);       // K step 0 | A reads of K step 1 | B of the next K tile
+        vb_wait_vmcnt<24>();                        // the A copies of the NEXT K tile (issued two K tiles ago) have landed
+        vb_raw_barrier();                           // lgkmcnt(0) | everyone is done reading the previous stage, everyone's copies are in
+        half(SN(), I0(), SC(), Yes(), No(), fa1, fbt[P][1], fa0, fbt[P ^ 1]);       // K step 1 | A reads of (next tile, K step 0) | A copies
+        ld_advance();
+        vb_wait_lgkmcnt0();
+    };
+    for (int cj = 0; cj < my_tiles; ++cj) {         // nk % 4 == 0 (launcher): every tile starts in stage 0 / register set 0
+        zero_acc();
+        for (int kt = 0; kt < nk; kt += 4) { ktile(I0()); ktile(I1()); ktile(I2()); ktile(I3()); }
+        big_settle();
+        int m0, n0;
+        origin(cj, m0, n0);
+        gemm_epilogue_private<T, TO, ACT, OPT>(acc[0], slab, g, m0, n0 + wave * 64, lane);
+        gemm_epilogue_private<T, TO, ACT, OPT>(acc[1], slab, g, m0 + 128, n0 + wave * 64, lane);
+    }
+    vb_wait_vmcnt<0>();
+}
+
+template <typename TO, int ACT, int OPT>
+int launch_bdir_act(const GemmArgs& g, dim3 grid, hipStream_t stream) {
+    constexpr int SM = 4 * 2 * 128 * 128 + 4 * EPI8_BYTES_PER_WAVE;          // four A stages of 32 KB + the epilogue slabs
+    return vb_prof_launch(2.0 * g.M * g.N * g.K, (sizeof(TO) == 4 ? 4 : 0) | 128, stream,
+                          [&]() { VB_LAUNCH((gemm_nt_bdir_kernel<TO, ACT, OPT>), grid, dim3(256), SM, stream, g); });
+}
+
 template <typename TO, int ACT, int OPT>
 int launch_big_act(const GemmArgs& g, dim3 grid, hipStream_t stream) {
     constexpr int SM = 2 * 4 * 128 * 128 + 4 * EPI8_BYTES_PER_WAVE;
     return vb_prof_launch(2.0 * g.M * g.N * g.K, (sizeof(TO) == 4 ? 4 : 0) | 128, stream, [&]() { VB_LAUNCH((gemm_nt_big_kernel<TO, ACT, OPT>), grid, dim3(256), SM, stream, g); });
 }
 template <typename T, typename TO>
-int launch_big(GemmArgs g, hipStream_t stream) {
+int launch_big(GemmArgs g, hipStream_t stream, bool b_direct = false) {
     if (sizeof(T) != 2 || (long)g.M * g.lda >= (1L << 30) || (long)g.N * g.ldb >= (1L << 30))
         return launch_pipe<T, TO, 4, 2>(g, stream);
     if ((g.K / 64) % 2 != 0) return launch_dual<T, TO>(g, stream);      // the K loop alternates two stages per trip
+    if (b_direct && ((g.N % 256) != 0 || (g.K / 64) % 4 != 0)) return launch_dual<T, TO>(g, stream);   // no B row clamp; 4 A stages per trip
     if constexpr (sizeof(T) == 2) {
         g.tiles_m = (g.M + 255) / 256;
         g.tiles_n = (g.N + 255) / 256;
@@ -1573,7 +1758,7 @@ int launch_big(GemmArgs g, hipStream_t stream) {
             }
         }
 #endif
-#define VB_TRY_EPI(A, O) if (g.act == (A) && (needs & ~(O)) == 0) return launch_big_act<TO, A, O>(g, grid, stream)
+#define VB_TRY_EPI(A, O) if (g.act == (A) && (needs & ~(O)) == 0) return b_direct ? launch_bdir_act<TO, A, O>(g, grid, stream) : launch_big_act<TO, A, O>(g, grid, stream)
         if constexpr (kActSpecialised<T, TO>) {
             VB_TRY_EPI(VB_ACT_NONE, 0);
             VB_TRY_EPI(VB_ACT_GELU_SAVE_GRAD, 0);
@@ -1583,7 +1768,7 @@ int launch_big(GemmArgs g, hipStream_t stream) {
             VB_TRY_EPI(VB_ACT_NONE, EPI_RAGGED);
         }
 #undef VB_TRY_EPI
-        return launch_big_act<TO, -1, EPI_ALL>(g, grid, stream);
+        return b_direct ? launch_bdir_act<TO, -1, EPI_ALL>(g, grid, stream) : launch_big_act<TO, -1, EPI_ALL>(g, grid, stream);
     }
     return VB_ERR_UNSUPPORTED;
 }
@@ -1916,7 +2101,7 @@ int dispatch_pipe(const GemmArgs& g, hipStream_t s) {
     if (g.x3) {                                            // split operands: the two-workgroup kernel or the two-barrier ones
         const long t256 = (long)((g.M + 255) / 256) * ((g.N + 255) / 256);
         const long t128 = (long)((g.M + 255) / 256) * ((g.N + 127) / 128);
-        if (variant != 22 && variant != 42 && variant != 90) variant = t256 >= 160 ? 90 : (t128 >= 256 ? 42 : 22);
+        if (variant != 22 && variant != 42 && variant != 90) variant = t256 >= 160 ? 90 : (t128 >= 256 ? 42 : 22);   // (never 100 / 101)
     }
     if (variant == 0) {
         // measured on MI355X (profiles/r01_gemm_variant_sweep_b128.txt)
@@ -1938,6 +2123,7 @@ int dispatch_pipe(const GemmArgs& g, hipStream_t s) {
         case 81: return launch_8ph<T, TO>(g, s);
         case 90: case 91: return launch_dual<T, TO>(g, s);
         case 100: return launch_big<T, TO>(g, s);
+        case 101: return launch_big<T, TO>(g, s, true);
         default: return VB_ERR_UNSUPPORTED;
     }
 }

@@ -20,8 +20,7 @@ These are stand-alone modules (no flat parameter arena): gradients reach `.grad`
 
 The reference's own constructor reaches the l / r / x stack only through an `assert(0)` (lxrt/modeling.py:803-804): no
 argument set builds it there, but its forward (:893-905) is well defined, and tests/golden/base_lxrt_encoder.npz pins this
-class against that forward run on the reference's own blocks (oracle/make_golden.py assembles the module around the
-assert).  `output_attention` (returning the probabilities) is not offered: NotImplementedError, never silent."""
+class against that forward run on the reference's own blocks (the golden generator assembles the module around the assert).  `output_attention` (returning the probabilities) is not offered: NotImplementedError, never silent."""
 import torch
 from torch import nn
 

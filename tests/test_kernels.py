@@ -340,6 +340,13 @@ def test_embedding_fwd_bwd(dev, dt, B):
     assert torch.equal(dvp.view(B, R, H), dz[:, T:])
 
 
+# bf16 attention kernels against the fp32 restatement on the SAME bf16 inputs and the kernel's own keep-bits: 1.5 x the largest
+# error measured on MI355X over every configuration of test_attention_fwd_bwd (profiles/r03_parity_small.json,
+# attention_kernel_bf16: ctx <= 2.4e-3 absolute, dqkv <= 4.1e-3 of max |grad| -- round 2 asserted 3e-2 / 4e-2, wide enough to
+# hide a mis-scaled fragment; fp32 kernels: 2.5e-7 / 5.4e-7 measured, asserted at 2e-6 / 3e-6)
+ATTN_BF16_CTX, ATTN_BF16_DQKV = 3.6e-3, 6.2e-3
+
+
 def attn_ref(qkv, mask_add, nh, keep=None, p=0.0):
     """plain fp32 restatement of modeling.py:236-256 on packed qkv [B,S,3H]."""
     B, S, H3 = qkv.shape
@@ -398,8 +405,9 @@ def test_attention_fwd_bwd(dev, dt, cfg):
         assert abs(rate - (1 - p)) < 0.02, rate
     qr = qkv.float().detach().requires_grad_(True)
     ctx_r, lse_r = attn_ref(qr, mask_add, nh, keep, p)
-    t = tol(dt, 2e-5, 0.03)
-    assert (ctx.float() - ctx_r).abs().max().item() <= t, (ctx.float() - ctx_r).abs().max().item()
+    t = tol(dt, 2e-6, ATTN_BF16_CTX)
+    ctx_err = (ctx.float() - ctx_r).abs().max().item()
+    assert ctx_err <= t, ctx_err
     assert (lse - lse_r).abs().max().item() <= tol(dt, 2e-5, 2e-3)
     dctx = torch.randn(B, S, H, generator=g).to(dt).to(dev)
     ctx_r.backward(dctx.float())
@@ -416,7 +424,12 @@ def test_attention_fwd_bwd(dev, dt, cfg):
                                _lib.ptr(dbias) if with_bias else None, B, S, nh, 64, p, 77, 3, _lib.stream_ptr())
             _lib.check(rc, "vb_attn_bwd")
             err = (dqkv.float() - qr.grad).abs().max().item()
-            assert err <= tol(dt, 5e-5, 0.04) * max(1.0, gmax), (err, gmax, fwd_out is not None)
+            if dev.type == "cuda":
+                from golden_util import record
+                record("attention_kernel_%s" % ("bf16" if dt == torch.bfloat16 else "fp32"),
+                       "B%d_S%d_nh%d_p%g_%s" % (B, S, nh, p, "onepass" if fwd_out is not None else "twopass"),
+                       dict(ctx_err=ctx_err, dqkv_err_over_gmax=err / max(1.0, gmax), gmax=gmax))
+            assert err <= tol(dt, 3e-6, ATTN_BF16_DQKV) * max(1.0, gmax), (err, gmax, fwd_out is not None)
             if with_bias:
                 berr = (dbias - 2.0 - bias_ref).abs().max().item()
                 assert berr <= tol(dt, 2e-4, 0.04) * max(1.0, bias_ref.abs().max().item()), (berr, fwd_out is not None)
@@ -469,8 +482,8 @@ def test_cross_attention_fwd_bwd(dev, dt, cfg):
     if keep is not None:
         pr = pr * keep / (1 - p)
     ref = (pr @ heads(vr, Sk)).permute(0, 2, 1, 3).reshape(B, Sq, H)
-    t = tol(dt, 2e-5, 0.03)
-    assert (ctx.float().view(B, Sq, H) - ref).abs().max().item() <= t
+    t = tol(dt, 2e-6, ATTN_BF16_CTX)                    # the self-attention kernels' measured bounds (same kernels)
+    assert (ctx.float().view(B, Sq, H) - ref).abs().max().item() <= t * max(1.0, ref.abs().max().item())   # few keys: |ctx| up to ~3
     dctx = torch.randn(B, Sq, H, generator=g).to(dt).to(dev)
     ref.backward(dctx.float())
     dq = torch.full_like(q2, float("nan"))
@@ -483,7 +496,7 @@ def test_cross_attention_fwd_bwd(dev, dt, cfg):
                                    _lib.ptr(dk), dk.stride(0), _lib.ptr(dv), dv.stride(0), B, Sq, Sk, nh, 64, p, 99, 4,
                                    _lib.stream_ptr()), "vb_attn_cross_bwd")
     gm = max(qr.grad.abs().max().item(), kr.grad.abs().max().item(), vr.grad.abs().max().item(), 1.0)
-    lim = tol(dt, 5e-5, 0.04) * gm
+    lim = tol(dt, 3e-6, ATTN_BF16_DQKV) * gm
     assert (dq.float().view(B, Sq, H) - qr.grad).abs().max().item() <= lim
     assert (dk.float().reshape(B, Sk, H) - kr.grad).abs().max().item() <= lim
     assert (dv.float().reshape(B, Sk, H) - vr.grad).abs().max().item() <= lim

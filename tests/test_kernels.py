@@ -482,8 +482,10 @@ def test_cross_attention_fwd_bwd(dev, dt, cfg):
     if keep is not None:
         pr = pr * keep / (1 - p)
     ref = (pr @ heads(vr, Sk)).permute(0, 2, 1, 3).reshape(B, Sq, H)
-    t = tol(dt, 2e-6, ATTN_BF16_CTX)                    # the self-attention kernels' measured bounds (same kernels)
-    assert (ctx.float().view(B, Sq, H) - ref).abs().max().item() <= t * max(1.0, ref.abs().max().item())   # few keys: |ctx| up to ~3
+    # the self-attention kernels' measured bounds (same kernels); with a handful of keys nothing averages out: the bf16 rounding of
+    # the probabilities (2^-9 each) times max |v| ~ 3 is the error: 5.8e-3 measured at 5 keys
+    t = tol(dt, 2e-6, 9e-3 if Sk < 16 else ATTN_BF16_CTX)
+    assert (ctx.float().view(B, Sq, H) - ref).abs().max().item() <= t
     dctx = torch.randn(B, Sq, H, generator=g).to(dt).to(dev)
     ref.backward(dctx.float())
     dq = torch.full_like(q2, float("nan"))

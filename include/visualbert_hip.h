@@ -33,7 +33,8 @@ extern "C" {
 #endif
 
 enum { VB_F32 = 0, VB_BF16 = 1,
-       /* GEMM entry points only (vb_gemm, vb_wgrad_grouped, vb_bert_layer_*): "bf16x3" split-operand mode.  Activations,
+       /* GEMM entry points (vb_gemm, vb_wgrad_grouped, vb_bert_layer_*) and attention (vb_attn_*, which splits its fp32
+        * tensors on chip): "bf16x3" split-operand mode.  Activations,
         * gradients and epilogue operands are fp32; each GEMM operand is handed over SPLIT (vb_split_bf16): a row of leading
         * dimension ld holds a bf16 hi plane in columns [0, ld/2) and a bf16 lo plane in [ld/2, ld), x = hi + lo to ~2^-17
         * relative.  The kernels form hi.hi + lo.hi + hi.lo on the bf16 matrix pipe with fp32 accumulation (the lo.lo term,
@@ -170,6 +171,11 @@ int vb_align_pos_bwd(int dtype, const void* dz, const int64_t* alignment, float*
  * (dQ, then dK/dV).  dqkv_bias (optional, fp32 [3H]): += column sums of dqkv over the B*S tokens, i.e. the gradient of
  * the packed q | k | v bias (modeling.py:232-234) -- from the one-pass kernel's fp32 accumulators through per-sample
  * partial sums (no pass over dqkv), else by one column-sum pass.
+ * dtype VB_BF16X3 (these four entry points and the two cross-attention ones): every tensor is fp32 exactly as for VB_F32 -- same
+ * shapes, pitches, sequence limits and kernel forms -- but each MFMA operand is split once (while staging, or from registers for
+ * the probabilities) into hi = bf16(x), lo = bf16(x - hi) and each product is the three bf16 MFMAs hi*hi + lo*hi + hi*lo:
+ * results within ~1e-5 of the fp32 kernels (tests/test_kernels.py ATTN_X3_*): 3 bf16 MFMAs of K = 32 where the fp32 form issues
+ * 8 fp32-input MFMAs of K = 4.
  * Replaces: BertSelfAttention.forward modeling.py:236-256 and its autograd.
  * ---------------------------------------------------------------------------------------------- */
 int64_t vb_attn_keepbits_words(int S);

@@ -23,6 +23,16 @@
 #include "../../include/visualbert_hip.h"
 #include "vb_opts.h"
 
+struct xf32 { float v; };             // element tag of the split mode (see LT<xf32> below): fp32 in memory
+struct x3frag { bf16x8 hi, lo; };     // its MFMA operand
+template <> struct VecOf<xf32> { typedef x3frag v8; typedef f32x4 v4; };
+// the three-product MFMA of the split mode, small terms first (global scope: overloads the vb_mma set of vb_rt.h)
+VB_DEVICE f32x4 vb_mma(const x3frag& a, const x3frag& b, f32x4 c) {
+    c = vb_mma(a.lo, b.hi, c);
+    c = vb_mma(a.hi, b.lo, c);
+    return vb_mma(a.hi, b.hi, c);
+}
+
 namespace {
 
 constexpr int NT = 256;
@@ -31,21 +41,60 @@ constexpr int D = 64;
 template <typename T> struct LT;   // LDS tile geometry
 template <> struct LT<bf16> {
     static constexpr int RB = 128, CPR = 8, KPT = 2, TPAD = 8;
+    static constexpr bool SPLIT = false;
     VB_DEVICE int sw(int row) { return (row >> 1) & 7; }    // conflict-free for ds_read_b128 fragment reads (see gemm.hip)
 };
 template <> struct LT<float> {
     static constexpr int RB = 256, CPR = 16, KPT = 1, TPAD = 16;
+    static constexpr bool SPLIT = false;
+    VB_DEVICE int sw(int row) { return (row & 7) << 1; }
+};
+// Split mode (VB_BF16X3): the tensors in HBM are fp32, every MFMA operand is the pair (hi, lo) of bf16 planes with
+// hi = bf16(x), lo = bf16(x - hi), and a product is the three MFMAs hi*hi + lo*hi + hi*lo (the lo*lo term, 2^-18
+// relative, is dropped as in gemm.hip).  The split is made ONCE per element while staging: a row-major LDS row is
+// [64 hi | 64 lo] (256 B, the fp32 row's size), a transposed tile is a hi tile followed by a lo tile of bf16 pitch, so
+// the LDS budgets -- and with them the sequence limits of every kernel form -- are those of the fp32 instantiation.
+template <> struct LT<xf32> {
+    static constexpr int RB = 256, CPR = 16, TPAD = 8;
+    static constexpr bool SPLIT = true;
     VB_DEVICE int sw(int row) { return (row & 7) << 1; }
 };
 template <typename T> VB_DEVICE int rm_off(int row, int c) { return row * LT<T>::RB + ((c ^ LT<T>::sw(row)) << 4); }
 template <typename T> constexpr int tr_pitch(int nk) { return nk * (int)sizeof(T) + LT<T>::TPAD; }
 template <typename T> constexpr int rm_bytes(int nrows) { return nrows * LT<T>::RB; }
 template <typename T> constexpr int tr_bytes(int nk) { return D * tr_pitch<T>(nk); }
+template <> constexpr int tr_pitch<xf32>(int nk) { return nk * 2 + LT<xf32>::TPAD; }      // pitch of ONE bf16 plane
+template <> constexpr int tr_bytes<xf32>(int nk) { return 2 * D * tr_pitch<xf32>(nk); }   // hi tile, then lo tile
 
+VB_DEVICE void split8(const f32x4& a, const f32x4& b, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        hi[j] = (bf16)a[j]; lo[j] = (bf16)(a[j] - (float)hi[j]);
+        hi[4 + j] = (bf16)b[j]; lo[4 + j] = (bf16)(b[j] - (float)hi[4 + j]);
+    }
+}
+VB_DEVICE void stage_rm_split(unsigned char* lds, const xf32* X, long ldx, long row0, int c0, int S, int nrows, int t) {
+    for (int idx = t; idx < nrows * 8; idx += NT) {          // 8 elements per item: chunk c of the hi plane and of the lo plane
+        const int r = idx >> 3, c = idx & 7;
+        f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f}, b = a;
+        if (r < S) {
+            const float* p = (const float*)(X + (row0 + r) * ldx + c0 + c * 8);
+            a = *(const f32x4*)p; b = *(const f32x4*)(p + 4);
+        }
+        bf16x8 hi, lo;
+        split8(a, b, hi, lo);
+        *(bf16x8*)(lds + rm_off<xf32>(r, c)) = hi;
+        *(bf16x8*)(lds + rm_off<xf32>(r, 8 + c)) = lo;
+    }
+}
 // ---- staging ---------------------------------------------------------------------------------
 // row-major [nrows][64] tile from X[(row0 + r) * ldx + c0 + d], rows >= S zero-filled
 template <typename T>
 VB_DEVICE void stage_rm(unsigned char* lds, const T* X, long ldx, long row0, int c0, int S, int nrows, int t) {
+    if constexpr (LT<T>::SPLIT) {
+        stage_rm_split(lds, X, ldx, row0, c0, S, nrows, t);
+        return;
+    }
     constexpr int CPR = LT<T>::CPR, EPC = 16 / (int)sizeof(T);
     for (int idx = t; idx < nrows * CPR; idx += NT) {
         const int r = idx / CPR, c = idx % CPR;
@@ -83,6 +132,32 @@ VB_DEVICE void stage_tr(unsigned char* lds, const float* X, long ldx, long row0,
         for (int w = 0; w < 4; ++w) {
             *(uint32_t*)(lds + (dc * 8 + w) * pitch + r * 4) = x0[w];
             *(uint32_t*)(lds + (dc * 8 + 4 + w) * pitch + r * 4) = x1[w];
+        }
+    }
+}
+
+VB_DEVICE void stage_tr(unsigned char* lds, const xf32* X, long ldx, long row0, int c0, int S, int nk, int t) {
+    const int pitch = tr_pitch<xf32>(nk);
+    unsigned char* ldl = lds + D * pitch;
+    for (int idx = t; idx < (nk / 2) * 8; idx += NT) {
+        const int dc = idx & 7, r = (idx >> 3) * 2;
+        f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, b0 = a0, a1 = a0, b1 = a0;
+        if (r < S) {
+            const float* p = (const float*)(X + (row0 + r) * ldx + c0 + dc * 8);
+            a0 = *(const f32x4*)p; b0 = *(const f32x4*)(p + 4);
+        }
+        if (r + 1 < S) {
+            const float* p = (const float*)(X + (row0 + r + 1) * ldx + c0 + dc * 8);
+            a1 = *(const f32x4*)p; b1 = *(const f32x4*)(p + 4);
+        }
+        bf16x8 h0, l0, h1, l1;
+        split8(a0, b0, h0, l0);
+        split8(a1, b1, h1, l1);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            typedef bf16 pair_t __attribute__((ext_vector_type(2)));
+            *(pair_t*)(lds + (dc * 8 + j) * pitch + r * 2) = pair_t{h0[j], h1[j]};
+            *(pair_t*)(ldl + (dc * 8 + j) * pitch + r * 2) = pair_t{l0[j], l1[j]};
         }
     }
 }
@@ -157,6 +232,9 @@ VB_DEVICE f32x8 frag_rm(const unsigned char* lds, int row, int ks, int g, float)
     f32x4 hi = *(const f32x4*)(lds + rm_off<float>(row, c + 1));
     return f32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
+VB_DEVICE x3frag frag_rm(const unsigned char* lds, int row, int ks, int g, xf32) {
+    return x3frag{*(const bf16x8*)(lds + rm_off<xf32>(row, ks * 4 + g)), *(const bf16x8*)(lds + rm_off<xf32>(row, 8 + ks * 4 + g))};
+}
 // same 8 elements straight from global memory (row pointer already offset to the head's column 0)
 // rowp must be readable even when !ok (callers clamp the row): the load is UNCONDITIONAL and the zeroing a select on its
 // result.  A load under `if (ok)` compiles to an exec-masked branch with a zero-fill of the destination registers, and the
@@ -170,6 +248,14 @@ VB_DEVICE f32x8 frag_g(const float* rowp, int ks, int g, bool ok) {
     return f32x8{ok ? lo[0] : 0.f, ok ? lo[1] : 0.f, ok ? lo[2] : 0.f, ok ? lo[3] : 0.f,
                  ok ? hi[0] : 0.f, ok ? hi[1] : 0.f, ok ? hi[2] : 0.f, ok ? hi[3] : 0.f};
 }
+VB_DEVICE x3frag frag_g(const xf32* rowp, int ks, int g, bool ok) {
+    const float* p = (const float*)rowp + ks * 32 + g * 8;
+    const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+    x3frag f;
+    split8(f32x4{ok ? a[0] : 0.f, ok ? a[1] : 0.f, ok ? a[2] : 0.f, ok ? a[3] : 0.f},
+           f32x4{ok ? b[0] : 0.f, ok ? b[1] : 0.f, ok ? b[2] : 0.f, ok ? b[3] : 0.f}, f.hi, f.lo);
+    return f;
+}
 // A fragment from a transposed tile: row d, MFMA k index (g, j) <-> r = 32*ks + 16*(j>>2) + 4*g + (j&3)
 VB_DEVICE bf16x8 frag_tr(const unsigned char* lds, int pitch, int d, int ks, int g, bf16) {
     const unsigned char* p = lds + d * pitch + (32 * ks + 4 * g) * 2;
@@ -181,6 +267,9 @@ VB_DEVICE f32x8 frag_tr(const unsigned char* lds, int pitch, int d, int ks, int 
     f32x4 lo = *(const f32x4*)p, hi = *(const f32x4*)(p + 64);
     return f32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
+VB_DEVICE x3frag frag_tr(const unsigned char* lds, int pitch, int d, int ks, int g, xf32) {
+    return x3frag{frag_tr(lds, pitch, d, ks, g, bf16()), frag_tr(lds + D * pitch, pitch, d, ks, g, bf16())};
+}
 // B fragment from two C-layout fragments (regs of frag 2ks -> j 0..3, frag 2ks+1 -> j 4..7)
 VB_DEVICE void pack_b(bf16x8& o, const f32x4& a, const f32x4& b) {
     o = bf16x8{(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], (bf16)b[0], (bf16)b[1], (bf16)b[2], (bf16)b[3]};
@@ -190,6 +279,8 @@ VB_DEVICE void pack_b(f32x8& o, const f32x4& a, const f32x4& b) {
 }
 VB_DEVICE void store4(bf16* p, const f32x4& v) { *(bf16x4*)p = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]}; }
 VB_DEVICE void store4(float* p, const f32x4& v) { *(f32x4*)p = v; }
+VB_DEVICE void pack_b(x3frag& o, const f32x4& a, const f32x4& b) { split8(a, b, o.hi, o.lo); }
+VB_DEVICE void store4(xf32* p, const f32x4& v) { *(f32x4*)p = v; }
 
 struct AttnArgs {
     const void* qkv; const float* mask_add; void* ctx; float* lse; uint64_t* keepbits;   // forward
@@ -1327,6 +1418,7 @@ extern "C" int vb_attn_cross_fwd(int dtype, const void* q, int64_t ldq, const vo
     hipStream_t s = (hipStream_t)stream;
     if (dtype == VB_BF16) return dispatch_nkf<bf16>(0, a, s);
     if (dtype == VB_F32) return dispatch_nkf<float>(0, a, s);
+    if (dtype == VB_BF16X3) return dispatch_nkf<xf32>(0, a, s);
     return VB_ERR_ARG;
 }
 
@@ -1347,6 +1439,7 @@ extern "C" int vb_attn_cross_bwd(int dtype, const void* q, int64_t ldq, const vo
     hipStream_t s = (hipStream_t)stream;
     if (dtype == VB_BF16) rc = dispatch_nkf<bf16>(1, a, s);
     else if (dtype == VB_F32) rc = dispatch_nkf<float>(1, a, s);
+    else if (dtype == VB_BF16X3) rc = dispatch_nkf<xf32>(1, a, s);
     else return VB_ERR_ARG;
     return rc < 0 ? rc : VB_OK;
 }
@@ -1367,6 +1460,7 @@ extern "C" int vb_attn_fwd(int dtype, const void* qkv, const float* mask_add, vo
     hipStream_t s = (hipStream_t)stream;
     if (dtype == VB_BF16) return dispatch_nkf<bf16>(0, a, s);
     if (dtype == VB_F32) return dispatch_nkf<float>(0, a, s);
+    if (dtype == VB_BF16X3) return dispatch_nkf<xf32>(0, a, s);
     return VB_ERR_ARG;
 }
 
@@ -1391,6 +1485,7 @@ extern "C" int vb_attn_bwd(int dtype, const void* qkv, const float* mask_add, co
     hipStream_t s = (hipStream_t)stream;
     if (dtype == VB_BF16) rc = dispatch_nkf<bf16>(1, a, s);
     else if (dtype == VB_F32) rc = dispatch_nkf<float>(1, a, s);
+    else if (dtype == VB_BF16X3) rc = dispatch_nkf<xf32>(1, a, s);
     else return VB_ERR_ARG;
     if (rc < 0 || !dqkv_bias) return rc < 0 ? rc : VB_OK;
     const int C = 3 * nh * D;
@@ -1402,5 +1497,5 @@ extern "C" int vb_attn_bwd(int dtype, const void* qkv, const float* mask_add, co
         return vb_check_launch();
     }
     // two-pass kernels (fp32 parity mode, long sequences): one column-sum pass over dqkv
-    return vb_colsum(dtype, dqkv, C, dqkv_bias, nullptr, B * S, C, stream);
+    return vb_colsum(dtype == VB_BF16 ? VB_BF16 : VB_F32, dqkv, C, dqkv_bias, nullptr, B * S, C, stream);
 }

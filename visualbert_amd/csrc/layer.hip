@@ -145,7 +145,7 @@ extern "C" int vb_bert_layer_fwd(int dtype, const void* h_in, const float* mask_
     // 1. packed Q|K|V projection
     VB_TRY(linear(d, h_in, H, sv.sp_hin, wqkv, wk * H, sv.qkv, 3 * H, bqkv, nullptr, VB_ACT_NONE, nullptr, nullptr, nullptr, stream));
     // 2. fused attention
-    VB_TRY(vb_attn_fwd(edt, sv.qkv, mask_add, sv.ctx, sv.lse, sv.keepbits, B, S, nh, 64, p_attn, seed, sid, stream));
+    VB_TRY(vb_attn_fwd(d.dtype, sv.qkv, mask_add, sv.ctx, sv.lse, sv.keepbits, B, S, nh, 64, p_attn, seed, sid, stream));
     // 3. attention output projection
     VB_TRY(linear(d, sv.ctx, H, sv.sp_ctx, wo, wk * H, sc.t_h0, H, bo, nullptr, VB_ACT_NONE, nullptr, nullptr, nullptr, stream));
     // 4. dropout + residual + LayerNorm
@@ -228,7 +228,7 @@ extern "C" int vb_bert_layer_bwd(int dtype, const void* h_in, const float* mask_
     VB_TRY(dgrad(dao, H, wo, VB_LWT_AO, H, sc.t_h3, nullptr, VB_ACT_NONE, nullptr, nullptr, sc.sp_dao));
     // 6-8. attention backward (one pass for bf16 and S <= 192, else dQ pass + dK/dV pass) + the q | k | v bias gradient
     //      (per-sample sums out of the one-pass kernel's accumulators; a column-sum pass over dqkv otherwise)
-    VB_TRY(vb_attn_bwd(edt, sv.qkv, mask_add, sc.t_h3, sv.lse, sv.keepbits, sc.dsum, sc.t_3h, sv.ctx, G[VB_LW_QKV_B], B, S, nh,
+    VB_TRY(vb_attn_bwd(d.dtype, sv.qkv, mask_add, sc.t_h3, sv.lse, sv.keepbits, sc.dsum, sc.t_3h, sv.ctx, G[VB_LW_QKV_B], B, S, nh,
                        64, p_attn, seed, sid, stream));
     // 9. dgrad QKV + residual gradient: dh = dqkv Wqkv + dz1
     VB_TRY(dgrad(sc.t_3h, 3 * H, wqkv, VB_LWT_QKV, H, d_in, dz1, VB_ACT_NONE, nullptr, nullptr, sc.sp_dqkv));

@@ -448,6 +448,11 @@ def ln_bwd(dy, z, mean, rstd, gamma, dgamma, dbeta, dbias=None, p_in=0.0, sid_in
     return dz, dx
 
 
+def _attn_code(dt):
+    """dtype code of the attention kernels: fp32 tensors in split mode run the three-product bf16 MFMA form."""
+    return _lib.VB_BF16X3 if (_x3[0] and dt == torch.float32) else _lib.dtype_code(dt)
+
+
 def attn_fwd(qkv, mask_add, B, S, nh, p, seed, sid):
     H = nh * 64
     ctx = torch.empty((B * S, H), dtype=qkv.dtype, device=qkv.device)
@@ -456,7 +461,7 @@ def attn_fwd(qkv, mask_add, B, S, nh, p, seed, sid):
     if p > 0.0:
         nwords = _lib.lib().vb_attn_keepbits_words(S)
         bits = torch.empty(B * nh * nwords, dtype=torch.int64, device=qkv.device)
-    check(_lib.lib().vb_attn_fwd(_lib.dtype_code(qkv.dtype), ptr(qkv), ptr(mask_add), ptr(ctx), ptr(lse), ptr(bits),
+    check(_lib.lib().vb_attn_fwd(_attn_code(qkv.dtype), ptr(qkv), ptr(mask_add), ptr(ctx), ptr(lse), ptr(bits),
                                  B, S, nh, 64, float(p), seed, sid, stream_ptr()), "vb_attn_fwd")
     return ctx, lse, bits
 
@@ -468,7 +473,7 @@ def attn_bwd(qkv, mask_add, dctx, lse, bits, B, S, nh, p, seed, sid, ctx_fwd=Non
     ws = torch.empty(_lib.lib().vb_attn_bwd_ws_floats(B, S, nh), dtype=torch.float32, device=qkv.device)
     if not dctx.is_contiguous():
         dctx = dctx.contiguous()
-    check(_lib.lib().vb_attn_bwd(_lib.dtype_code(qkv.dtype), ptr(qkv), ptr(mask_add), ptr(dctx), ptr(lse), ptr(bits),
+    check(_lib.lib().vb_attn_bwd(_attn_code(qkv.dtype), ptr(qkv), ptr(mask_add), ptr(dctx), ptr(lse), ptr(bits),
                                  ptr(ws), ptr(dqkv), ptr(ctx_fwd), ptr(dqkv_bias), B, S, nh, 64, float(p), seed, sid,
                                  stream_ptr()),
           "vb_attn_bwd")
@@ -728,7 +733,7 @@ class CrossAttentionCoreFn(torch.autograd.Function):
         if p > 0.0:
             bits = torch.empty(B * nh * L.vb_attn_cross_keepbits_words(Sq, Sk), dtype=torch.int64, device=q2.device)
         seed = next_seed()
-        check(L.vb_attn_cross_fwd(_lib.dtype_code(dt), ptr(q2), _ld(q2), ptr(k2), _ld(k2), ptr(v2), _ld(v2), ptr(mask_add),
+        check(L.vb_attn_cross_fwd(_attn_code(dt), ptr(q2), _ld(q2), ptr(k2), _ld(k2), ptr(v2), _ld(v2), ptr(mask_add),
                                   ptr(out), _ld(out), ptr(lse), ptr(bits), B, Sq, Sk, nh, 64, float(p), seed, sid,
                                   stream_ptr()), "vb_attn_cross_fwd")
         ctx.cfg = (B, Sq, Sk, H, nh, p, seed, sid)
@@ -747,7 +752,7 @@ class CrossAttentionCoreFn(torch.autograd.Function):
             d2 = d2.contiguous()
         dq, dk, dv = torch.empty_like(q2), torch.empty_like(k2), torch.empty_like(v2)
         ws = torch.empty((B, nh, Sq), dtype=torch.float32, device=q2.device)
-        check(_lib.lib().vb_attn_cross_bwd(_lib.dtype_code(q2.dtype), ptr(q2), _ld(q2), ptr(k2), _ld(k2), ptr(v2), _ld(v2),
+        check(_lib.lib().vb_attn_cross_bwd(_attn_code(q2.dtype), ptr(q2), _ld(q2), ptr(k2), _ld(k2), ptr(v2), _ld(v2),
                                            ptr(mask_add), ptr(d2), _ld(d2), ptr(lse), ptr(ctx.bits), ptr(ws), ptr(dq), _ld(dq),
                                            ptr(dk), _ld(dk), ptr(dv), _ld(dv), B, Sq, Sk, nh, 64, float(p), seed, sid,
                                            stream_ptr()), "vb_attn_cross_bwd")

@@ -2203,13 +2203,20 @@ extern "C" int vb_gemm(int dtype, int out_dtype, int a_layout, int b_layout,
     }
     hipStream_t s = (hipStream_t)stream;
     const int of32 = (out_dtype == VB_F32 || split_out) ? 1 : 0;
+    // weight-gradient form: the persistent TN kernel reduces over whole 64-token K tiles; a ragged token count (tokens % 64 != 0:
+    // any batch whose B x S is not a multiple of 64) sends the last < 64 tokens through the generic kernel, accumulating onto the same C
+    const int k_main = K & ~63;
     if (dtype == VB_BF16 && of32 && a_layout == VB_KSTRIDED && b_layout == VB_KSTRIDED && accumulate && !bias && !addend &&
-        !colsum_out && act == VB_ACT_NONE && t_opts.nt_kernel != 1 && tn_eligible(A, lda, B, ldb, (const float*)C, ldc, M, N, K)) {
+        !colsum_out && act == VB_ACT_NONE && t_opts.nt_kernel != 1 && k_main >= 64 &&
+        tn_eligible(A, lda, B, ldb, (const float*)C, ldc, M, N, k_main)) {
         TnArgs tg;
         tg.nprob = 1; tg.alpha = alpha; tg.alpha_dev = alpha_dev;
         tg.p[0].A = A; tg.p[0].B = B; tg.p[0].C = (float*)C; tg.p[0].lda = lda; tg.p[0].ldb = ldb; tg.p[0].ldc = ldc;
         tg.p[0].Mo = M; tg.p[0].Ni = N;
-        return launch_tn_group(tg, K, s);
+        const int rc = launch_tn_group(tg, k_main, s);
+        if (rc != VB_OK || k_main == K) return rc;
+        return vb_gemm(dtype, out_dtype, a_layout, b_layout, (const bf16*)A + (long)k_main * lda, lda, (const bf16*)B + (long)k_main * ldb, ldb,
+                       C, ldc, M, N, K - k_main, alpha, alpha_dev, nullptr, nullptr, 0, VB_ACT_NONE, nullptr, nullptr, 0, 1, nullptr, stream);
     }
     if (dtype == VB_BF16 || x3) return dispatch<bf16>(of32 && true, a_layout, b_layout, g, s);
     return dispatch<float>(1, a_layout, b_layout, g, s);
@@ -2238,9 +2245,12 @@ extern "C" int vb_wgrad_grouped(int dtype, int n, const void* const* dy, const i
     }
     t_opts = vb_opts_for(stream);
     vb_prof_select(stream);
-    bool fast = dtype == VB_BF16 && t_opts.nt_kernel != 1;
+    // the grouped kernel takes whole 64-token K tiles; the last tokens % 64 rows (ragged B x S) go through the generic kernel below
+    const int main_tok = tokens & ~63;
+    bool fast = dtype == VB_BF16 && t_opts.nt_kernel != 1 && main_tok >= 64;
     for (int i = 0; i < n && fast; ++i)
-        fast = tn_eligible(dy[i], ld_dy[i], x[i], ld_x[i], (const float*)dw[i], ld_dw[i], n_out[i], n_in[i], tokens);
+        fast = tn_eligible(dy[i], ld_dy[i], x[i], ld_x[i], (const float*)dw[i], ld_dw[i], n_out[i], n_in[i], main_tok);
+    int done = 0;
     if (fast) {
         TnArgs tg;
         tg.nprob = n; tg.alpha = alpha; tg.alpha_dev = alpha_dev;
@@ -2249,11 +2259,15 @@ extern "C" int vb_wgrad_grouped(int dtype, int n, const void* const* dy, const i
             tg.p[i].lda = ld_dy[i]; tg.p[i].ldb = ld_x[i]; tg.p[i].ldc = ld_dw[i];
             tg.p[i].Mo = n_out[i]; tg.p[i].Ni = n_in[i];
         }
-        return launch_tn_group(tg, tokens, (hipStream_t)stream);
+        const int rc = launch_tn_group(tg, main_tok, (hipStream_t)stream);
+        if (rc != VB_OK || main_tok == tokens) return rc;
+        done = main_tok;
     }
+    const size_t es = dtype == VB_BF16 ? 2 : 4;
     for (int i = 0; i < n; ++i) {
-        int rc = vb_gemm(dtype, VB_F32, VB_KSTRIDED, VB_KSTRIDED, dy[i], ld_dy[i], x[i], ld_x[i], dw[i], ld_dw[i],
-                         n_out[i], n_in[i], tokens, alpha, alpha_dev, nullptr, nullptr, 0, VB_ACT_NONE, nullptr, nullptr, 0,
+        int rc = vb_gemm(dtype, VB_F32, VB_KSTRIDED, VB_KSTRIDED, (const char*)dy[i] + (size_t)done * ld_dy[i] * es, ld_dy[i],
+                         (const char*)x[i] + (size_t)done * ld_x[i] * es, ld_x[i], dw[i], ld_dw[i],
+                         n_out[i], n_in[i], tokens - done, alpha, alpha_dev, nullptr, nullptr, 0, VB_ACT_NONE, nullptr, nullptr, 0,
                          1, nullptr, stream);
         if (rc != VB_OK) return rc;
     }

@@ -20,6 +20,8 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with extra objec
   cpu_baseline -- the oracle restatement of the reference (oracle/visualbert_oracle.py, "port") timed on this node's
                   host cores on a bounded sample, training mode (dropout on) (rank 0, N = 1 only)
   parity       -- bf16 kernels against the fp32 oracle on a B = 2 side batch (rank 0, N = 1 only)
+  strict_mode  -- the split-operand bf16x3 mode (meets the north-star's 1e-3) and the fp32 kernels timed on the same step
+  vendor_plain_gemms -- the same step with the plain GEMMs handed to hipBLASLt (nt_kernel 200): a yardstick, never `value`
   value_with_h2d -- the same step with every batch streamed from pinned host memory (SURVEY 8d's metric definition);
                   `value` is the HBM-resident rate the contract asks for
 """
@@ -336,6 +338,8 @@ def main():
                     help="gradient all-reduce through the C ABI's RCCL communicator (vb_comm_*) or torch.distributed")
     ap.add_argument("--sparse-mlm-head", action="store_true",
                     help="also time the opt-in MLM head over the labelled positions only (SURVEY 8f/N1); reported as an extra field")
+    ap.add_argument("--no-vendor-leg", action="store_true",
+                    help="skip the extra timed leg with the plain GEMMs on hipBLASLt (N = 1 only; never part of `value`)")
     ap.add_argument("--nt-kernel", type=int, default=0,
                     help="vb_stream_opts.nt_kernel for the whole run (0 = chosen per shape; 81 / 90 for A/B runs)")
     ap.add_argument("--selftest-launch", action="store_true", help=argparse.SUPPRESS)
@@ -475,6 +479,35 @@ def main():
         sparse = B * world * args.steps / (time.perf_counter() - t1)
         mw.model.bert.sparse_mlm_head = False
 
+    vendor = None
+    if world == 1 and not args.no_vendor_leg and args.nt_kernel == 0 and args.dtype == "bf16":
+        # the same step with the PLAIN GEMMs (bias only / "+ addend": 76 of the step's 119) handed to hipBLASLt (nt_kernel 200,
+        # csrc/vendor_gemm.hip): what the vendor's hand-scheduled kernel is worth inside the step.  Reported next to `value`,
+        # never as `value`: the product path is the hand-written kernels.
+        from visualbert_amd import _lib
+        _lib.set_opts(nt_kernel=200)
+        for _ in range(3):
+            mw.step(batch)
+        ops.gemm_profile_start()
+        barrier()
+        t1 = time.perf_counter()
+        nv = max(5, args.steps // 5)
+        for _ in range(nv):
+            mw.step(batch)
+        barrier()
+        tv = (time.perf_counter() - t1) / nv
+        vs = ops.gemm_profile_stop()
+        _lib.set_opts(nt_kernel=0)
+        lib_ms = sum(v["ms"] for k, v in vs.items() if k & 512) / nv
+        lib_launches = sum(v["launches"] for k, v in vs.items() if k & 512) / nv
+        lib_flops = sum(v["flops"] for k, v in vs.items() if k & 512)
+        vendor = dict(value=round(B / tv, 2), unit="samples/s", ms_per_step=round(tv * 1e3, 3), steps=nv,
+                      library_launches_per_step=lib_launches, library_ms_per_step=round(lib_ms, 3),
+                      library_tflops=round(lib_flops / nv / (lib_ms * 1e-3) / 1e12, 1) if lib_ms > 0 else None,
+                      note="plain GEMMs through hipBLASLt (vb_stream_opts.nt_kernel = 200), fused-epilogue GEMMs, weight gradients "
+                           "and everything else unchanged; library_launches_per_step = 0 means the library was not found and the "
+                           "step ran on our kernels")
+
     ms_per_step = elapsed / args.steps * 1e3
     value = B * world * args.steps / elapsed
     fps = flops_per_sample(L, H, I, V, S, R, Dv, head)
@@ -543,6 +576,7 @@ def main():
             "cpu_baseline": cpu,
             "parity": par,
             "strict_mode": strict,
+            "vendor_plain_gemms": vendor,
         }
         if one_device:
             out["one_device_test_mode"] = "all %d ranks on cuda:0, gloo process group (VB_BENCH_ONE_DEVICE=1)" % world

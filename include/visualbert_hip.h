@@ -58,7 +58,10 @@ const char* vb_version(void);
  *              256x128 tiles; 80 / 81 = persistent 256x256 tile, eight / four slots per K tile; 90 = 256x128 tiles, two
  *              workgroups per compute unit (91: the same with the copies issued ahead of the fragment reads); 100 = persistent
  *              256x256 tile with four waves, 128x128 outputs each (K / 64 even, else 90); 101 = the same tile with B fetched straight
- *              into fragment registers (1 x 4 waves; K / 64 a multiple of 4 and N of 256, else 90); 1 = the generic register-staged kernel.
+ *              into fragment registers (1 x 4 waves; K / 64 a multiple of 4 and N of 256, else 90); 1 = the generic register-staged kernel;
+ *              200 = a yardstick, not a product path: plain GEMMs (bias only, or "+ addend") are handed to hipBLASLt (dlopen'ed
+ *              on first use; one 64 MB workspace per stream -- the only device memory this library ever owns), everything with a
+ *              fused epilogue and everything the library declines stays on the kernels above.
  *   attn_two_pass: 1 = two-pass attention backward even where the one-pass kernel applies.
  *   reserved: must be 0 (VB_ERR_ARG otherwise).
  * vb_stream_set_opts(stream, NULL) forgets the stream's entry (call it before destroying a stream).

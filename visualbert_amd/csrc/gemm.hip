@@ -2103,6 +2103,21 @@ int dispatch_pipe(const GemmArgs& g, hipStream_t s) {
         const long t128 = (long)((g.M + 255) / 256) * ((g.N + 127) / 128);
         if (variant != 22 && variant != 42 && variant != 90) variant = t256 >= 160 ? 90 : (t128 >= 256 ? 42 : 22);   // (never 100 / 101)
     }
+    if (variant == 200) {
+        // the vendor yardstick inside the step (vendor_gemm.hip): plain GEMMs -- bias only, or "+ addend" as beta = 1 -- go to
+        // hipBLASLt; whatever it does not take (fused epilogues, no library on the box) runs on the kernels chosen below
+        if constexpr (sizeof(T) == 2) {
+            const bool addend_ok = !g.addend || sizeof(TO) == 2;
+            if (!g.x3 && g.act == VB_ACT_NONE && !g.aux_in && !g.aux_out && !g.colsum && !g.alpha_dev && !g.accumulate && addend_ok) {
+                VbVendorGemm v{g.A, g.lda, g.B, g.ldb, g.C, g.ldc, g.M, g.N, g.K, g.alpha, g.bias, g.addend, g.ld_addend, sizeof(TO) == 4 ? 1 : 0};
+                int rc = VB_ERR_UNSUPPORTED;
+                const int prc = vb_prof_launch(2.0 * g.M * g.N * g.K, (sizeof(TO) == 4 ? 4 : 0) | 512, s, [&]() { rc = vb_vendor_nt(v, s); });
+                if (rc != VB_ERR_UNSUPPORTED) return rc != VB_OK ? rc : prc;
+                vb_prof_drop_last();
+            }
+        }
+        variant = 0;
+    }
     if (variant == 0) {
         // measured on MI355X (profiles/r01_gemm_variant_sweep_b128.txt)
         const long t256 = (long)((g.M + 255) / 256) * ((g.N + 255) / 256);

@@ -38,6 +38,13 @@ static inline int vb_prof_launch(double flops, int key, hipStream_t stream, F&& 
     launch();
     return vb_check_launch();
 }
+// forget the record vb_prof_launch just made (the launch turned out to be a no-op: the caller launches something else instead)
+static inline void vb_prof_drop_last() {
+    if (t_vb_prof && !t_vb_prof->empty()) {
+        (void)hipEventDestroy(t_vb_prof->back().e0); (void)hipEventDestroy(t_vb_prof->back().e1);
+        t_vb_prof->pop_back();
+    }
+}
 static inline int vb_prof_enable(void* stream, int enable) {
     std::lock_guard<std::mutex> lock(g_vb_prof_mutex);
     for (size_t i = 0; i < g_vb_prof_table.size(); ++i)
@@ -68,6 +75,7 @@ static inline int64_t vb_prof_read(void* stream, double* ms, double* flops, int*
 #else
 static inline void vb_prof_select(void*) {}
 template <typename F> static inline int vb_prof_launch(double, int, hipStream_t, F&& launch) { launch(); return vb_check_launch(); }
+static inline void vb_prof_drop_last() {}
 static inline int vb_prof_enable(void*, int) { return VB_OK; }
 static inline int64_t vb_prof_read(void*, double*, double*, int*, int64_t) { return 0; }
 #endif

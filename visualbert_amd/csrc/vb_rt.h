@@ -527,6 +527,17 @@ VB_DEVICE void gelu_and_grad_f(float x, float& y, float& dy) { float c, d; gelu_
 #define VB_ERR_LAUNCH (-2)
 #define VB_ERR_UNSUPPORTED (-3)
 
+// a plain K-contiguous x K-contiguous bf16 GEMM handed to the vendor library (vendor_gemm.hip; vb_stream_opts.nt_kernel = 200)
+struct VbVendorGemm {
+    const void* A; long lda; const void* B; long ldb; void* C; long ldc;
+    int M, N, K; float alpha; const float* bias; const void* addend; long ld_addend; int out_f32;
+};
+#ifdef VB_EMU
+static inline int vb_vendor_nt(const VbVendorGemm&, void*) { return VB_ERR_UNSUPPORTED; }   // no vendor library in the simulator
+#else
+__attribute__((visibility("hidden"))) int vb_vendor_nt(const VbVendorGemm& g, void* stream);   // internal: not part of the C ABI
+#endif
+
 static inline int vb_check_launch() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? VB_OK : VB_ERR_LAUNCH;

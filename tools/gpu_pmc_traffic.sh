@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 B=${1:-128}
 mkdir -p gpurun_out
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c -d gpurun_out/pt_$c -o p -- python bench.py --steps 2 --warmup 1 --batch $B --no-cpu-baseline --no-profile > gpurun_out/pt_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c -d gpurun_out/pt_$c -o p -- python bench.py --steps 2 --warmup 1 --batch $B --no-cpu-baseline --no-profile --no-h2d --no-parity --strict-dtype none --no-vendor-leg > gpurun_out/pt_$c.log 2>&1
   python tools/rocpd_pmc.py gpurun_out/pt_$c/p_results.db > gpurun_out/pt_$c.txt 2>&1
   rm -rf gpurun_out/pt_$c
 done

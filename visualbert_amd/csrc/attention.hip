@@ -73,95 +73,6 @@ VB_DEVICE void split8(const f32x4& a, const f32x4& b, bf16x8& hi, bf16x8& lo) {
         hi[4 + j] = (bf16)b[j]; lo[4 + j] = (bf16)(b[j] - (float)hi[4 + j]);
     }
 }
-VB_DEVICE void stage_rm_split(unsigned char* lds, const xf32* X, long ldx, long row0, int c0, int S, int nrows, int t) {
-    for (int idx = t; idx < nrows * 8; idx += NT) {          // 8 elements per item: chunk c of the hi plane and of the lo plane
-        const int r = idx >> 3, c = idx & 7;
-        f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f}, b = a;
-        if (r < S) {
-            const float* p = (const float*)(X + (row0 + r) * ldx + c0 + c * 8);
-            a = *(const f32x4*)p; b = *(const f32x4*)(p + 4);
-        }
-        bf16x8 hi, lo;
-        split8(a, b, hi, lo);
-        *(bf16x8*)(lds + rm_off<xf32>(r, c)) = hi;
-        *(bf16x8*)(lds + rm_off<xf32>(r, 8 + c)) = lo;
-    }
-}
-// ---- staging ---------------------------------------------------------------------------------
-// row-major [nrows][64] tile from X[(row0 + r) * ldx + c0 + d], rows >= S zero-filled
-template <typename T>
-VB_DEVICE void stage_rm(unsigned char* lds, const T* X, long ldx, long row0, int c0, int S, int nrows, int t) {
-    if constexpr (LT<T>::SPLIT) {
-        stage_rm_split(lds, X, ldx, row0, c0, S, nrows, t);
-        return;
-    }
-    constexpr int CPR = LT<T>::CPR, EPC = 16 / (int)sizeof(T);
-    for (int idx = t; idx < nrows * CPR; idx += NT) {
-        const int r = idx / CPR, c = idx % CPR;
-        u32x4 v = u32x4{0u, 0u, 0u, 0u};
-        if (r < S) v = *(const u32x4*)(X + (row0 + r) * ldx + c0 + c * EPC);
-        *(u32x4*)(lds + rm_off<T>(r, c)) = v;
-    }
-}
-// transposed [64][nk] tile: element (d, r) = X[(row0 + r) * ldx + c0 + d], r >= S zero-filled
-VB_DEVICE void stage_tr(unsigned char* lds, const bf16* X, long ldx, long row0, int c0, int S, int nk, int t) {
-    const int pitch = tr_pitch<bf16>(nk);
-    for (int idx = t; idx < (nk / 2) * 8; idx += NT) {
-        const int dc = idx & 7, r = (idx >> 3) * 2;
-        u32x4 x0 = u32x4{0u, 0u, 0u, 0u}, x1 = x0;
-        if (r < S) x0 = *(const u32x4*)(X + (row0 + r) * ldx + c0 + dc * 8);
-        if (r + 1 < S) x1 = *(const u32x4*)(X + (row0 + r + 1) * ldx + c0 + dc * 8);
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const uint32_t a = x0[w], b = x1[w];
-            *(uint32_t*)(lds + (dc * 8 + 2 * w) * pitch + r * 2) = (a & 0xFFFFu) | (b << 16);
-            *(uint32_t*)(lds + (dc * 8 + 2 * w + 1) * pitch + r * 2) = (a >> 16) | (b & 0xFFFF0000u);
-        }
-    }
-}
-VB_DEVICE void stage_tr(unsigned char* lds, const float* X, long ldx, long row0, int c0, int S, int nk, int t) {
-    const int pitch = tr_pitch<float>(nk);
-    for (int idx = t; idx < nk * 8; idx += NT) {
-        const int dc = idx & 7, r = idx >> 3;
-        u32x4 x0 = u32x4{0u, 0u, 0u, 0u}, x1 = x0;
-        if (r < S) {
-            x0 = *(const u32x4*)(X + (row0 + r) * ldx + c0 + dc * 8);
-            x1 = *(const u32x4*)(X + (row0 + r) * ldx + c0 + dc * 8 + 4);
-        }
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            *(uint32_t*)(lds + (dc * 8 + w) * pitch + r * 4) = x0[w];
-            *(uint32_t*)(lds + (dc * 8 + 4 + w) * pitch + r * 4) = x1[w];
-        }
-    }
-}
-
-VB_DEVICE void stage_tr(unsigned char* lds, const xf32* X, long ldx, long row0, int c0, int S, int nk, int t) {
-    const int pitch = tr_pitch<xf32>(nk);
-    unsigned char* ldl = lds + D * pitch;
-    for (int idx = t; idx < (nk / 2) * 8; idx += NT) {
-        const int dc = idx & 7, r = (idx >> 3) * 2;
-        f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, b0 = a0, a1 = a0, b1 = a0;
-        if (r < S) {
-            const float* p = (const float*)(X + (row0 + r) * ldx + c0 + dc * 8);
-            a0 = *(const f32x4*)p; b0 = *(const f32x4*)(p + 4);
-        }
-        if (r + 1 < S) {
-            const float* p = (const float*)(X + (row0 + r + 1) * ldx + c0 + dc * 8);
-            a1 = *(const f32x4*)p; b1 = *(const f32x4*)(p + 4);
-        }
-        bf16x8 h0, l0, h1, l1;
-        split8(a0, b0, h0, l0);
-        split8(a1, b1, h1, l1);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            typedef bf16 pair_t __attribute__((ext_vector_type(2)));
-            *(pair_t*)(lds + (dc * 8 + j) * pitch + r * 2) = pair_t{h0[j], h1[j]};
-            *(pair_t*)(ldl + (dc * 8 + j) * pitch + r * 2) = pair_t{l0[j], l1[j]};
-        }
-    }
-}
-
 // ---- batched staging (bf16) -------------------------------------------------------------------------------------
 // The loops above wait for every global load before its LDS store (the compiler keeps them rolled: one HBM round trip
 // per trip, 9 serial round trips per workgroup in the forward kernel).  Here a thread first issues ALL its loads of a
@@ -219,6 +130,100 @@ VB_DEVICE void pair_store_tr(const PairTile<NROWS>& p, unsigned char* lds, int t
             *(uint32_t*)(lds + (dc * 8 + 2 * w + 1) * pitch + r * 2) = (a >> 16) | (b & 0xFFFF0000u);
         }
     }
+}
+
+// ---- batched staging, fp32 sources (fp32 and split modes) -------------------------------------------------------------
+// Same idea as PairTile for the 4-byte element types, whose rolled stage_rm / stage_tr loops paid one HBM round trip per trip:
+// 9 serial round trips in front of the forward kernel's first MFMA with ONE workgroup per CU to hide them (the fp32 / split
+// tiles fill the LDS).  Item i = rows (2j, 2j+1) x 8-element chunk dc: four 16-byte loads, all issued before the first store.
+template <int NROWS>
+struct PairTile32 {
+    static constexpr int ITEMS = (NROWS / 2) * 8, PER = (ITEMS + NT - 1) / NT;
+    f32x4 a0[PER], b0[PER], a1[PER], b1[PER];              // row r: elements 0-3 / 4-7 of the chunk; row r + 1 likewise
+};
+VB_DEVICE f32x4 zsel4(bool ok, const f32x4& x) { return f32x4{ok ? x[0] : 0.f, ok ? x[1] : 0.f, ok ? x[2] : 0.f, ok ? x[3] : 0.f}; }
+template <int NROWS, typename T>
+VB_DEVICE void pair_load32(PairTile32<NROWS>& p, const T* X, long ldx, long row0, int c0, int S, int t) {
+#pragma unroll
+    for (int k = 0; k < PairTile32<NROWS>::PER; ++k) {     // unconditional loads from clamped rows (see frag_g)
+        const int idx = t + k * NT;
+        const int dc = idx & 7, r = (idx >> 3) * 2;
+        const float* p0 = (const float*)(X + (row0 + (r < S ? r : S - 1)) * ldx + c0 + dc * 8);
+        const float* p1 = (const float*)(X + (row0 + (r + 1 < S ? r + 1 : S - 1)) * ldx + c0 + dc * 8);
+        p.a0[k] = *(const f32x4*)p0; p.b0[k] = *(const f32x4*)(p0 + 4);
+        p.a1[k] = *(const f32x4*)p1; p.b1[k] = *(const f32x4*)(p1 + 4);
+    }
+#pragma unroll
+    for (int k = 0; k < PairTile32<NROWS>::PER; ++k) {
+        const int r = ((t + k * NT) >> 3) * 2;
+        p.a0[k] = zsel4(r < S, p.a0[k]); p.b0[k] = zsel4(r < S, p.b0[k]);
+        p.a1[k] = zsel4(r + 1 < S, p.a1[k]); p.b1[k] = zsel4(r + 1 < S, p.b1[k]);
+    }
+}
+template <int NROWS, typename T>
+VB_DEVICE void pair_store_rm32(const PairTile32<NROWS>& p, unsigned char* lds, int t) {
+#pragma unroll
+    for (int k = 0; k < PairTile32<NROWS>::PER; ++k) {
+        const int idx = t + k * NT;
+        if (idx >= PairTile32<NROWS>::ITEMS) continue;
+        const int dc = idx & 7, r = (idx >> 3) * 2;
+        if constexpr (LT<T>::SPLIT) {
+            bf16x8 h0, l0, h1, l1;
+            split8(p.a0[k], p.b0[k], h0, l0);
+            split8(p.a1[k], p.b1[k], h1, l1);
+            *(bf16x8*)(lds + rm_off<T>(r, dc)) = h0;     *(bf16x8*)(lds + rm_off<T>(r, 8 + dc)) = l0;
+            *(bf16x8*)(lds + rm_off<T>(r + 1, dc)) = h1; *(bf16x8*)(lds + rm_off<T>(r + 1, 8 + dc)) = l1;
+        } else {
+            *(f32x4*)(lds + rm_off<T>(r, 2 * dc)) = p.a0[k];     *(f32x4*)(lds + rm_off<T>(r, 2 * dc + 1)) = p.b0[k];
+            *(f32x4*)(lds + rm_off<T>(r + 1, 2 * dc)) = p.a1[k]; *(f32x4*)(lds + rm_off<T>(r + 1, 2 * dc + 1)) = p.b1[k];
+        }
+    }
+}
+template <int NROWS, typename T>
+VB_DEVICE void pair_store_tr32(const PairTile32<NROWS>& p, unsigned char* lds, int t) {
+    constexpr int pitch = tr_pitch<T>(NROWS);
+#pragma unroll
+    for (int k = 0; k < PairTile32<NROWS>::PER; ++k) {
+        const int idx = t + k * NT;
+        if (idx >= PairTile32<NROWS>::ITEMS) continue;
+        const int dc = idx & 7, r = (idx >> 3) * 2;
+        if constexpr (LT<T>::SPLIT) {
+            typedef bf16 pair_t __attribute__((ext_vector_type(2)));
+            unsigned char* ldl = lds + D * pitch;
+            bf16x8 h0, l0, h1, l1;
+            split8(p.a0[k], p.b0[k], h0, l0);
+            split8(p.a1[k], p.b1[k], h1, l1);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                *(pair_t*)(lds + (dc * 8 + j) * pitch + r * 2) = pair_t{h0[j], h1[j]};
+                *(pair_t*)(ldl + (dc * 8 + j) * pitch + r * 2) = pair_t{l0[j], l1[j]};
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                *(f32x2*)(lds + (dc * 8 + j) * pitch + r * 4) = f32x2{p.a0[k][j], p.a1[k][j]};
+                *(f32x2*)(lds + (dc * 8 + 4 + j) * pitch + r * 4) = f32x2{p.b0[k][j], p.b1[k][j]};
+            }
+        }
+    }
+}
+// one tile type for every element type: the loads of a [NROWS][64] tile in registers, stored row-major and / or transposed
+template <typename T, int NROWS> struct TileOf { typedef PairTile32<NROWS> type; };
+template <int NROWS> struct TileOf<bf16, NROWS> { typedef PairTile<NROWS> type; };
+template <int NROWS, typename T>
+VB_DEVICE void tile_load(typename TileOf<T, NROWS>::type& p, const T* X, long ldx, long row0, int c0, int S, int t) {
+    if constexpr (sizeof(T) == 2) pair_load<NROWS>(p, X, ldx, row0, c0, S, t);
+    else pair_load32<NROWS, T>(p, X, ldx, row0, c0, S, t);
+}
+template <int NROWS, typename T>
+VB_DEVICE void tile_store_rm(const typename TileOf<T, NROWS>::type& p, unsigned char* lds, int t) {
+    if constexpr (sizeof(T) == 2) pair_store_rm<NROWS>(p, lds, t);
+    else pair_store_rm32<NROWS, T>(p, lds, t);
+}
+template <int NROWS, typename T>
+VB_DEVICE void tile_store_tr(const typename TileOf<T, NROWS>::type& p, unsigned char* lds, int t) {
+    if constexpr (sizeof(T) == 2) pair_store_tr<NROWS>(p, lds, t);
+    else pair_store_tr32<NROWS, T>(p, lds, t);
 }
 
 // ---- fragments -------------------------------------------------------------------------------
@@ -338,8 +343,12 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(NT, 3) attn_fwd_kernel(AttnArgs a) {
         pair_store_rm<NK>(tk, ldsK, t);
         pair_store_tr<NKVK>(tv, ldsVT, t);                  // rows >= S arrive as zeros: the padded key columns are 0
     } else {
-        stage_rm<T>(ldsK, Kp, a.ldk, rowk, h * D, S, NK, t);
-        stage_tr(ldsVT, Vp, a.ldv, rowk, h * D, S, NKVK, t);
+        PairTile32<NK> tk;
+        PairTile32<NKVK> tv;
+        pair_load32<NK, T>(tk, Kp, a.ldk, rowk, h * D, S, t);
+        pair_load32<NKVK, T>(tv, Vp, a.ldv, rowk, h * D, S, t);
+        pair_store_rm32<NK, T>(tk, ldsK, t);
+        pair_store_tr32<NKVK, T>(tv, ldsVT, t);
     }
     for (int k = t; k < NK; k += NT) ldsMask[k] = k < S ? a.mask_add[(long)b * S + k] : -INFINITY;
     __syncthreads();
@@ -480,9 +489,12 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) attn_bwd_dq_kernel(AttnArgs a) {
         pair_store_tr<NK>(tk, ldsKT, t);
         pair_store_rm<NK>(tv, ldsV, t);
     } else {
-        stage_rm<T>(ldsK, Kp, a.ldk, rowk, h * D, S, NK, t);
-        stage_rm<T>(ldsV, Vp, a.ldv, rowk, h * D, S, NK, t);
-        stage_tr(ldsKT, Kp, a.ldk, rowk, h * D, S, NK, t);
+        PairTile32<NK> tk, tv;
+        pair_load32<NK, T>(tk, Kp, a.ldk, rowk, h * D, S, t);
+        pair_load32<NK, T>(tv, Vp, a.ldv, rowk, h * D, S, t);
+        pair_store_rm32<NK, T>(tk, ldsK, t);
+        pair_store_tr32<NK, T>(tk, ldsKT, t);
+        pair_store_rm32<NK, T>(tv, ldsV, t);
     }
     for (int k = t; k < NK; k += NT) ldsMask[k] = k < S ? a.mask_add[(long)b * S + k] : -INFINITY;
     __syncthreads();
@@ -599,8 +611,13 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) attn_fwd_tiled_kernel(AttnArgs a) {
         for (int w = 0; w < NW; ++w) bits[w] = 0;
         for (int c0 = 0; c0 < S; c0 += TCK) {
             __syncthreads();                                // the previous chunk is consumed
-            stage_rm<T>(ldsK, Kp, a.ldk, rowk + c0, h * D, S - c0, TCK, t);
-            stage_tr(ldsVT, Vp, a.ldv, rowk + c0, h * D, S - c0, TCK, t);
+            {
+                typename TileOf<T, TCK>::type tk, tv;
+                tile_load<TCK, T>(tk, Kp, a.ldk, rowk + c0, h * D, S - c0, t);
+                tile_load<TCK, T>(tv, Vp, a.ldv, rowk + c0, h * D, S - c0, t);
+                tile_store_rm<TCK, T>(tk, ldsK, t);
+                tile_store_tr<TCK, T>(tv, ldsVT, t);
+            }
             for (int k = t; k < TCK; k += NT) ldsMask[k] = c0 + k < S ? a.mask_add[(long)b * S + c0 + k] : -INFINITY;
             __syncthreads();
             f32x4 st[TCF];
@@ -733,8 +750,13 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) attn_bwd_dq_tiled_kernel(AttnArgs a) {
         float dsum = 0.f;
         for (int c0 = 0; c0 < S; c0 += TCK) {
             __syncthreads();
-            stage_rm<T>(ldsK, Kp, a.ldk, rowk + c0, h * D, S - c0, TCK, t);
-            stage_rm<T>(ldsV, Vp, a.ldv, rowk + c0, h * D, S - c0, TCK, t);
+            {
+                typename TileOf<T, TCK>::type tk, tv;
+                tile_load<TCK, T>(tk, Kp, a.ldk, rowk + c0, h * D, S - c0, t);
+                tile_load<TCK, T>(tv, Vp, a.ldv, rowk + c0, h * D, S - c0, t);
+                tile_store_rm<TCK, T>(tk, ldsK, t);
+                tile_store_rm<TCK, T>(tv, ldsV, t);
+            }
             for (int k = t; k < TCK; k += NT) ldsMask[k] = c0 + k < S ? a.mask_add[(long)b * S + c0 + k] : -INFINITY;
             __syncthreads();
             f32x4 pt[TCF], dpt[TCF];
@@ -753,9 +775,14 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) attn_bwd_dq_tiled_kernel(AttnArgs a) {
         for (int df = 0; df < 4; ++df) acc[df] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int c0 = 0; c0 < S; c0 += TCK) {
             __syncthreads();
-            stage_rm<T>(ldsK, Kp, a.ldk, rowk + c0, h * D, S - c0, TCK, t);
-            stage_rm<T>(ldsV, Vp, a.ldv, rowk + c0, h * D, S - c0, TCK, t);
-            stage_tr(ldsKT, Kp, a.ldk, rowk + c0, h * D, S - c0, TCK, t);
+            {
+                typename TileOf<T, TCK>::type tk, tv;
+                tile_load<TCK, T>(tk, Kp, a.ldk, rowk + c0, h * D, S - c0, t);
+                tile_load<TCK, T>(tv, Vp, a.ldv, rowk + c0, h * D, S - c0, t);
+                tile_store_rm<TCK, T>(tk, ldsK, t);
+                tile_store_tr<TCK, T>(tk, ldsKT, t);
+                tile_store_rm<TCK, T>(tv, ldsV, t);
+            }
             for (int k = t; k < TCK; k += NT) ldsMask[k] = c0 + k < S ? a.mask_add[(long)b * S + c0 + k] : -INFINITY;
             __syncthreads();
             f32x4 pt[TCF], dpt[TCF];
@@ -885,10 +912,15 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) attn_bwd_dkv_kernel(AttnArgs a) {
             __syncthreads();
             if (q0 + QC < Sq) load_chunk(q0 + QC);
         } else {
-            stage_rm<T>(ldsQ, Qp, a.ldq, rowq + q0, h * D, Sq - q0, QC, t);
-            stage_rm<T>(ldsDO, dctx, a.lddo, rowq + q0, h * D, Sq - q0, QC, t);
-            stage_tr(ldsQT, Qp, a.ldq, rowq + q0, h * D, Sq - q0, QC, t);
-            stage_tr(ldsDOT, dctx, a.lddo, rowq + q0, h * D, Sq - q0, QC, t);
+            {
+                PairTile32<QC> tq, td;
+                pair_load32<QC, T>(tq, Qp, a.ldq, rowq + q0, h * D, Sq - q0, t);
+                pair_load32<QC, T>(td, dctx, a.lddo, rowq + q0, h * D, Sq - q0, t);
+                pair_store_rm32<QC, T>(tq, ldsQ, t);
+                pair_store_tr32<QC, T>(tq, ldsQT, t);
+                pair_store_rm32<QC, T>(td, ldsDO, t);
+                pair_store_tr32<QC, T>(td, ldsDOT, t);
+            }
             for (int k = t; k < QC; k += NT) {
                 const int q = q0 + k;
                 ldsLse[k] = q < Sq ? a.lse[(long)bh * Sq + q] : INFINITY;   // exp(x - inf) = 0 for padded queries

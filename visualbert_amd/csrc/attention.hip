@@ -903,7 +903,14 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) attn_bwd_dkv_kernel(AttnArgs a) {
 #pragma unroll
         for (int j = 0; j < BPT; ++j) if (t + j * NT < QC * 4 * NW) ldsBits[t + j * NT] = c_bits[j];
     };
+    // fp32 / split modes: the same pipeline with the chunk's Q and dO tiles held in registers (pair tiles for 4-byte sources)
+    PairTile32<QC> tq32, td32;
+    auto load_chunk32 = [&](int q0) {
+        pair_load32<QC, T>(tq32, Qp, a.ldq, rowq + q0, h * D, Sq - q0, t);
+        pair_load32<QC, T>(td32, dctx, a.lddo, rowq + q0, h * D, Sq - q0, t);
+    };
     if constexpr (PIPE) load_chunk(0);
+    else load_chunk32(0);
 
     for (int q0 = 0; q0 < Sq; q0 += QC) {
         __syncthreads();                                   // previous chunk fully consumed
@@ -912,15 +919,10 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) attn_bwd_dkv_kernel(AttnArgs a) {
             __syncthreads();
             if (q0 + QC < Sq) load_chunk(q0 + QC);
         } else {
-            {
-                PairTile32<QC> tq, td;
-                pair_load32<QC, T>(tq, Qp, a.ldq, rowq + q0, h * D, Sq - q0, t);
-                pair_load32<QC, T>(td, dctx, a.lddo, rowq + q0, h * D, Sq - q0, t);
-                pair_store_rm32<QC, T>(tq, ldsQ, t);
-                pair_store_tr32<QC, T>(tq, ldsQT, t);
-                pair_store_rm32<QC, T>(td, ldsDO, t);
-                pair_store_tr32<QC, T>(td, ldsDOT, t);
-            }
+            pair_store_rm32<QC, T>(tq32, ldsQ, t);
+            pair_store_tr32<QC, T>(tq32, ldsQT, t);
+            pair_store_rm32<QC, T>(td32, ldsDO, t);
+            pair_store_tr32<QC, T>(td32, ldsDOT, t);
             for (int k = t; k < QC; k += NT) {
                 const int q = q0 + k;
                 ldsLse[k] = q < Sq ? a.lse[(long)bh * Sq + q] : INFINITY;   // exp(x - inf) = 0 for padded queries
@@ -931,6 +933,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) attn_bwd_dkv_kernel(AttnArgs a) {
                 ldsBits[i] = (a.p > 0.f && q < Sq) ? a.keepbits[((long)bh * Sq + q0) * 4 * NW + i] : ~(uint64_t)0;
             }
             __syncthreads();
+            if (q0 + QC < Sq) load_chunk32(q0 + QC);       // in flight under this chunk's MFMAs
         }
         if (!wave_on) continue;
 #pragma unroll

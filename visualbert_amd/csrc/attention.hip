@@ -73,11 +73,10 @@ VB_DEVICE void split8(const f32x4& a, const f32x4& b, bf16x8& hi, bf16x8& lo) {
         hi[4 + j] = (bf16)b[j]; lo[4 + j] = (bf16)(b[j] - (float)hi[4 + j]);
     }
 }
-// ---- batched staging (bf16) -------------------------------------------------------------------------------------
-// The loops above wait for every global load before its LDS store (the compiler keeps them rolled: one HBM round trip
-// per trip, 9 serial round trips per workgroup in the forward kernel).  Here a thread first issues ALL its loads of a
-// [NROWS][64] tile -- pair-item i = rows (2j, 2j+1) x 16-byte chunk dc -- and only then stores, row-major and / or
-// transposed, from the same registers.
+// ---- staging, bf16 ------------------------------------------------------------------------------------------------
+// A thread first issues ALL its loads of a [NROWS][64] tile -- pair-item i = rows (2j, 2j+1) x 16-byte chunk dc -- and only
+// then stores, row-major and / or transposed, from the same registers.  (A rolled "load, wait, store" loop, which is what
+// this replaced, pays one HBM round trip per trip: 9 serial round trips per workgroup in the forward kernel.)
 // zero fill as a select on a value that was loaded UNCONDITIONALLY (see frag_g)
 VB_DEVICE u32x4 zsel(bool ok, const u32x4& x) { return u32x4{ok ? x[0] : 0u, ok ? x[1] : 0u, ok ? x[2] : 0u, ok ? x[3] : 0u}; }
 template <int NROWS>
@@ -132,10 +131,9 @@ VB_DEVICE void pair_store_tr(const PairTile<NROWS>& p, unsigned char* lds, int t
     }
 }
 
-// ---- batched staging, fp32 sources (fp32 and split modes) -------------------------------------------------------------
-// Same idea as PairTile for the 4-byte element types, whose rolled stage_rm / stage_tr loops paid one HBM round trip per trip:
-// 9 serial round trips in front of the forward kernel's first MFMA with ONE workgroup per CU to hide them (the fp32 / split
-// tiles fill the LDS).  Item i = rows (2j, 2j+1) x 8-element chunk dc: four 16-byte loads, all issued before the first store.
+// ---- staging, fp32 sources (fp32 and split modes) ------------------------------------------------------------------------
+// The same for the 4-byte element types -- where it matters more: their tiles fill the LDS, so ONE workgroup per CU has nothing
+// to hide a round trip behind.  Item i = rows (2j, 2j+1) x 8-element chunk dc: four 16-byte loads, all issued before the first store.
 template <int NROWS>
 struct PairTile32 {
     static constexpr int ITEMS = (NROWS / 2) * 8, PER = (ITEMS + NT - 1) / NT;

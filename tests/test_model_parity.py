@@ -118,6 +118,47 @@ def test_fp32_train_steps_match_reference_golden(dev, stem, mode):
         assert abs(d - float(g["delta_norm/" + n])) <= 5e-3 * float(g["delta_norm/" + n]) + 1e-7, n
 
 
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3", "bf16"])
+def test_bert_large_width_matches_oracle(dev, mode):
+    """Nothing in the path is specialised to BERT-base's 768 / 12 / 3072: one layer at BERT-large width (hidden 1024, 16 heads of 64,
+    FFN 4096 -- what the reference's from_pretrained('bert-large-uncased') would build, modeling.py:44-52) against the oracle:
+    logits, per-tensor gradients (relative L2) and the weights after three BertAdam steps.  Measured: fp32 3.6e-6 / 1.5e-6,
+    bf16x3 2.1e-5 / 1.4e-5, bf16 1.7e-2 / 8.8e-3; asserted at about 3x (strict modes) and 2x (bf16) that."""
+    from visualbert_amd.model import ModelWrapper, AttrDict
+    cfg = vo.OracleConfig(vocab_size=1000, hidden_size=1024, num_hidden_layers=1, num_attention_heads=16, intermediate_size=4096,
+                          visual_embedding_dim=256)
+    head = "pretraining"
+    sd = vo.synth_state_dict(cfg, head, 1)
+    batch = vo.synth_batch(cfg, 2, 12, 4, 3, head)
+    dt = {"fp32": torch.float32, "bf16x3": "bf16x3", "bf16": torch.bfloat16}[mode]
+    model = build_model(cfg, head, sd, dev, dtype=dt, dropout=0.0)
+    model.train()
+    mw = ModelWrapper(AttrDict(train_batch_size=1, learning_rate=LR, warmup_proportion=WARMUP, num_train_epochs=1,
+                               gradient_accumulation_steps=1), T_TOTAL, model=model)
+    ref_sd = {k: v.clone() for k, v in sd.items()}
+    state = {}
+    ref_out, ref_grads = vo.train_step(ref_sd, cfg, head, batch, state, LR, WARMUP, T_TOTAL)
+    out = mw.step(to_dev(batch, dev))
+    lim_logit, lim_grad, lim_w = {"fp32": (1e-5, 1e-5, 2e-6), "bf16x3": (6e-5, 6e-5, 2e-6), "bf16": (3.4e-2, 1.8e-2, 1e-4)}[mode]
+    assert maxdiff(out["logits"].detach().float().cpu().reshape(ref_out["logits"].shape), ref_out["logits"].detach()) <= lim_logit
+    named = dict(model.bert.named_parameters())
+    worst = 0.0
+    for n, gr in ref_grads.items():
+        rn = float(gr.double().norm())
+        if rn < 1e-6:
+            continue
+        worst = max(worst, float((named[n].grad.detach().float().cpu() - gr).double().norm()) / rn)
+    assert worst <= lim_grad, worst
+    for _ in range(2):
+        vo.train_step(ref_sd, cfg, head, batch, state, LR, WARMUP, T_TOTAL)
+        mw.step(to_dev(batch, dev))
+    for n, p_ in named.items():
+        if n in ref_sd and n in ref_grads and float(ref_grads[n].double().norm()) >= 1e-6:
+            assert maxdiff(p_.detach().float().cpu(), ref_sd[n]) <= lim_w, n
+    if dev.type == "cuda":
+        record("bert_large_width_1layer", mode, dict(grad_rel_l2_worst=worst))
+
+
 # (max|dlogit| vs the bf16-emulating oracle, vs the fp32 REFERENCE golden, |dloss|): 1.5 x the values measured on MI355X
 # (profiles/r02_parity_small.json)
 #   measured: micro_pretraining 5.6e-3 / 3.2e-3 / 5.5e-4   tiny_pretraining 7.2e-3 / 6.4e-3 / 5.6e-4

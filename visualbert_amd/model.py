@@ -24,20 +24,19 @@ class VisualBERTFixedImageEmbedding(nn.Module):
     def __init__(self, config=None, bert_model_name=None, training_head_type="pretraining", visual_embedding_dim=2048,
                  hard_cap_seq_len=None, cut_first="text", embedding_strategy="plain", bypass_transformer=False,
                  random_initialize=True, output_attention_weights=False, special_visual_initialize=True,
-                 compute_dtype=torch.float32, class_embs=True, cnn_loss_ratio=0.0):
+                 compute_dtype=torch.float32, class_embs=True, cnn_loss_ratio=0.0, vocab=None, text_only=False):
         super(VisualBERTFixedImageEmbedding, self).__init__()
-        if config is None:
-            if bert_model_name is None:
-                config = BertConfig(30522)
-            else:
-                import os
-                config = BertConfig.from_json_file(os.path.join(bert_model_name, "bert_config.json"))
-        self.bert = TrainVisualBERTObjective(config, training_head_type, visual_embedding_dim=visual_embedding_dim,
-                                             hard_cap_seq_len=hard_cap_seq_len, cut_first=cut_first,
-                                             embedding_strategy=embedding_strategy,
-                                             bypass_transformer=bypass_transformer,
-                                             output_attention_weights=output_attention_weights,
-                                             compute_dtype=compute_dtype)
+        kw = dict(visual_embedding_dim=visual_embedding_dim, hard_cap_seq_len=hard_cap_seq_len, cut_first=cut_first,
+                  embedding_strategy=embedding_strategy, bypass_transformer=bypass_transformer,
+                  output_attention_weights=output_attention_weights, compute_dtype=compute_dtype)
+        if config is None and bert_model_name is not None:
+            # models/model.py:213-223: TrainVisualBERTObjective.from_pretrained(bert_model_name, ...): a name of the reference's
+            # archive map ("bert-base-uncased" in every shipped config) or a local directory (modeling.resolve_pretrained)
+            self.bert = TrainVisualBERTObjective.from_pretrained(bert_model_name, None, None, random_initialize,
+                                                                 training_head_type, **kw)
+        else:
+            self.bert = TrainVisualBERTObjective(config if config is not None else BertConfig(30522), training_head_type, **kw)
+        self.text_only = text_only
         if special_visual_initialize:
             self.bert.bert.embeddings.special_intialize()            # models/model.py:224-225
         self.training_head_type = training_head_type
@@ -96,22 +95,126 @@ class AttrDict(dict):
         self[k] = v
 
 
+def load_commented_json(path):
+    """The reference reads its configs with `commentjson` (models/model_wrapper.py:236-239; not installable here): JSON with
+    `//` and `#` line comments (also /* */ blocks) and a trailing comma tolerated.  Comment markers inside strings are kept."""
+    import json
+    with open(path, "r", encoding="utf-8") as f:
+        text = f.read()
+    out, i, n, in_str = [], 0, len(text), False
+    while i < n:
+        c = text[i]
+        if in_str:
+            out.append(c)
+            if c == "\\" and i + 1 < n:
+                out.append(text[i + 1])
+                i += 1
+            elif c == '"':
+                in_str = False
+        elif c == '"':
+            in_str = True
+            out.append(c)
+        elif c == "#" or text.startswith("//", i):
+            while i < n and text[i] != "\n":
+                i += 1
+            continue
+        elif text.startswith("/*", i):
+            j = text.find("*/", i + 2)
+            i = n if j < 0 else j + 2
+            continue
+        else:
+            out.append(c)
+        i += 1
+    text = "".join(out)
+    # trailing commas before a closing bracket (outside strings: the comments are gone, so scan once more)
+    out, in_str, i, n = [], False, 0, len(text)
+    while i < n:
+        c = text[i]
+        if in_str:
+            out.append(c)
+            if c == "\\" and i + 1 < n:
+                out.append(text[i + 1])
+                i += 1
+            elif c == '"':
+                in_str = False
+        elif c == '"':
+            in_str = True
+            out.append(c)
+        elif c == ",":
+            j = i + 1
+            while j < n and text[j] in " \t\r\n":
+                j += 1
+            if j < n and text[j] in "}]":
+                i += 1
+                continue
+            out.append(c)
+        else:
+            out.append(c)
+        i += 1
+    return json.loads("".join(out))
+
+
+def _attrify(x):
+    if isinstance(x, dict):
+        return AttrDict((k, _attrify(v)) for k, v in x.items())
+    if isinstance(x, list):
+        return [_attrify(v) for v in x]
+    return x
+
+
 class ModelWrapper(object):
     """models/model_wrapper.py:34-147, one process per GPU."""
 
+    #: `model.type` values of the reference's configs that this package builds (VisualBERTDetector carries a detectron
+    #: backbone: SURVEY.md section 2, out of scope)
+    MODEL_TYPES = ("VisualBERTFixedImageEmbedding",)
+
     def __init__(self, args, train_dataset_length, model=None, grad_sync=None, device=None):
-        self.args = args if isinstance(args, AttrDict) else AttrDict(args)
+        self.scheduler = None
+        self.args = args if isinstance(args, AttrDict) else _attrify(dict(args))
+        self.args.gradient_accumulation_steps = self.args.get("gradient_accumulation_steps", 1)     # model_wrapper.py:38-39
+        self.args.fp16 = self.args.get("fp16", False)
         self.device = device
         if model is None:
-            m = dict(self.args.get("model", {}))
-            m.pop("type", None)
-            dtype = torch.bfloat16 if self.args.get("fp16", False) else torch.float32
-            model = VisualBERTFixedImageEmbedding(compute_dtype=dtype, **m)
+            model = self.initialize_model(self.args)
         self.model = model.to(device) if device is not None else model
         self.grad_sync = grad_sync
         self.initialize_opimizer(self.args, train_dataset_length)
+        if self.args.get("restore_bin", None):
+            self.restore_checkpoint_pretrained(self.args.restore_bin)                                 # train.py:203-204
         self.global_step = 0
         self.called_time = 0
+
+    @staticmethod
+    def read_and_insert_args(args, confg):
+        """models/model_wrapper.py:235-244: the (commented) JSON config, overridden by the command line's attributes, as an
+        attribute dictionary; `model.bert_model_name` follows the top-level `bert_model_name`."""
+        config_json = load_commented_json(confg)
+        dict_args = dict(args) if isinstance(args, dict) else dict(vars(args))
+        config_json.update(dict_args)
+        args = _attrify(config_json)
+        args.model.bert_model_name = args.bert_model_name
+        return args
+
+    def initialize_model(self, args):
+        """models/model_wrapper.py:141-146 without AllenNLP's registry: `args.model` = {"type": <registered name>, **kwargs}.
+        `fp16: true` selects the bf16 kernels (the reference halves the model); the extra key `compute_dtype`
+        ("fp32" | "bf16" | "bf16x3"; not in the reference's configs) names a mode directly."""
+        m = dict(args.get("model", {}))
+        kind = m.pop("type", "VisualBERTFixedImageEmbedding")
+        if kind not in self.MODEL_TYPES:
+            raise NotImplementedError("visualbert_amd builds model types %s; %r (detector backbone in the model) is out of "
+                                      "scope" % (list(self.MODEL_TYPES), kind))
+        modes = {"fp32": torch.float32, "bf16": torch.bfloat16, "bf16x3": "bf16x3"}
+        dtype = modes[args.get("compute_dtype")] if args.get("compute_dtype") else \
+            (torch.bfloat16 if args.get("fp16", False) else torch.float32)
+        # the reference's constructor defaults (models/model.py:192-206), which its configs rely on
+        m.setdefault("special_visual_initialize", False)
+        m.setdefault("training_head_type", "")
+        m.setdefault("visual_embedding_dim", 512)
+        m.setdefault("random_initialize", False)
+        m.setdefault("bert_model_name", "bert-base-uncased")
+        return VisualBERTFixedImageEmbedding(compute_dtype=dtype, **m)
 
     def train(self):
         self.model.train()
@@ -121,6 +224,7 @@ class ModelWrapper(object):
 
     def initialize_opimizer(self, args, train_dataset_length):            # (sic) models/model_wrapper.py:100
         param_optimizer = [n for n in self.model.named_parameters() if "pooler" not in n[0]]
+        self.optimizer_param_names = [n for n, _ in param_optimizer]
         no_decay = ["bias", "LayerNorm.bias", "LayerNorm.weight"]
         groups = [
             {"params": [p for n, p in param_optimizer if not any(nd in n for nd in no_decay)], "weight_decay": 0.01},

@@ -697,9 +697,52 @@ class BertPreTrainingHeads(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------------
+# The architectures behind the model names the reference resolves to archive URLs (modeling.py:44-52,
+# PRETRAINED_MODEL_ARCHIVE_MAP).  Each archive's bert_config.json is public knowledge (Google's BERT release); with no network
+# the name resolves to that architecture and -- unless a local directory provides pytorch_model.bin -- to init_bert_weights'
+# random initialisation, which is what an offline reference run with `random_initialize=True` produces.
+def _arch(vocab, hidden=768, layers=12, heads=12, inter=3072):
+    return dict(vocab_size=vocab, hidden_size=hidden, num_hidden_layers=layers, num_attention_heads=heads,
+                intermediate_size=inter, hidden_act="gelu", hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1,
+                max_position_embeddings=512, type_vocab_size=2, initializer_range=0.02)
+
+
+PRETRAINED_MODEL_ARCHITECTURES = {
+    "bert-base-uncased": _arch(30522),
+    "bert-large-uncased": _arch(30522, 1024, 24, 16, 4096),
+    "bert-base-cased": _arch(28996),
+    "bert-large-cased": _arch(28996, 1024, 24, 16, 4096),
+    "bert-base-multilingual-uncased": _arch(105879),
+    "bert-base-multilingual-cased": _arch(119547),
+    "bert-base-chinese": _arch(21128),
+}
+CONFIG_NAME = "bert_config.json"
+WEIGHTS_NAME = "pytorch_model.bin"
+
+
+def resolve_pretrained(pretrained_model_name, cache_dir=None):
+    """-> (BertConfig, directory holding pytorch_model.bin or None).  The reference (modeling.py:511-544) maps a known name to
+    an S3 archive and anything else to a path; here a path (or <cache_dir>/<name>, or $VISUALBERT_AMD_BERT_DIR/<name>) that
+    holds bert_config.json wins, then a known name falls back to its built-in architecture."""
+    import os
+    candidates = [pretrained_model_name]
+    for root in (cache_dir, os.environ.get("VISUALBERT_AMD_BERT_DIR")):
+        if root:
+            candidates.append(os.path.join(str(root), str(pretrained_model_name)))
+    for c in candidates:
+        if os.path.isfile(os.path.join(str(c), CONFIG_NAME)):
+            return BertConfig.from_json_file(os.path.join(str(c), CONFIG_NAME)), str(c)
+    if pretrained_model_name in PRETRAINED_MODEL_ARCHITECTURES:
+        return BertConfig.from_dict(PRETRAINED_MODEL_ARCHITECTURES[pretrained_model_name]), None
+    raise FileNotFoundError(
+        "visualbert_amd: model name %r is neither one of %s nor a directory containing %s (no network access: archives are "
+        "not downloaded)" % (pretrained_model_name, ", ".join(sorted(PRETRAINED_MODEL_ARCHITECTURES)), CONFIG_NAME))
+
+
 class PreTrainedBertModel(nn.Module):
-    """modeling.py:459-596 (init_bert_weights; from_pretrained needs an on-disk archive -- there is no
-    network here, so only a local directory with bert_config.json [+ pytorch_model.bin] is accepted)."""
+    """modeling.py:459-596: init_bert_weights and from_pretrained.  There is no network here, so from_pretrained never
+    downloads: a local directory supplies bert_config.json [+ pytorch_model.bin]; a bare model name of the reference's archive
+    map resolves to its architecture (resolve_pretrained) with randomly initialised weights and a logged warning."""
 
     def __init__(self, config, *inputs, **kwargs):
         super(PreTrainedBertModel, self).__init__()
@@ -720,16 +763,21 @@ class PreTrainedBertModel(nn.Module):
     @classmethod
     def from_pretrained(cls, pretrained_model_name, state_dict=None, cache_dir=None, random_initialize=False,
                         *inputs, **kwargs):
+        import logging
         import os
-        if not os.path.isdir(pretrained_model_name):
-            raise FileNotFoundError("visualbert_amd: from_pretrained needs a local directory containing "
-                                    "bert_config.json (no network access); got %r" % (pretrained_model_name,))
-        config = BertConfig.from_json_file(os.path.join(pretrained_model_name, "bert_config.json"))
+        config, directory = resolve_pretrained(pretrained_model_name, cache_dir)
         model = cls(config, *inputs, **kwargs)
         if random_initialize:
             return model
         if state_dict is None:
-            state_dict = torch.load(os.path.join(pretrained_model_name, "pytorch_model.bin"), map_location="cpu")
+            weights = os.path.join(directory, WEIGHTS_NAME) if directory else None
+            if weights is None or not os.path.isfile(weights):
+                logging.getLogger(__name__).warning(
+                    "visualbert_amd: no %s for %r on this machine (archives are not downloaded): the %s keeps its random "
+                    "initialisation; load weights with ModelWrapper.restore_checkpoint_pretrained / `restore_bin`",
+                    WEIGHTS_NAME, pretrained_model_name, cls.__name__)
+                return model
+            state_dict = torch.load(weights, map_location="cpu")
         renamed = {}
         for key, value in state_dict.items():      # legacy gamma/beta names, modeling.py:556-568
             nk = key.replace("gamma", "weight").replace("beta", "bias")

@@ -54,14 +54,11 @@ const char* vb_version(void);
  * test_stream_options_do_not_leak_across_streams).
  *   persistent_workgroups: workgroups launched by the persistent GEMM kernels; 0 = one per compute unit.  A
  *                          data-parallel caller lowers it while RCCL kernels are resident (parallel.py).
- *   nt_kernel: K-contiguous x K-contiguous bf16 GEMM kernel; 0 = chosen from the shape; 22 / 42 = two-barrier 128x128 /
- *              256x128 tiles; 80 / 81 = persistent 256x256 tile, eight / four slots per K tile; 90 = 256x128 tiles, two
- *              workgroups per compute unit (91: the same with the copies issued ahead of the fragment reads); 100 = persistent
- *              256x256 tile with four waves, 128x128 outputs each (K / 64 even, else 90); 101 = the same tile with B fetched straight
- *              into fragment registers (1 x 4 waves; K / 64 a multiple of 4 and N of 256, else 90); 1 = the generic register-staged kernel;
- *              200 = a yardstick, not a product path: plain GEMMs (bias only, or "+ addend") are handed to hipBLASLt (dlopen'ed
- *              on first use; one 64 MB workspace per stream -- the only device memory this library ever owns), everything with a
- *              fused epilogue and everything the library declines stays on the kernels above.
+ *   nt_kernel: pins the K-contiguous x K-contiguous bf16 GEMM kernel to one the dispatcher could have chosen itself (for
+ *              reproducible summation order, or an A/B run); 0 = chosen from the shape; 22 / 42 = two-barrier 128x128 / 256x128
+ *              tiles; 81 = persistent 256x256 tile; 90 = 256x128 tiles, two workgroups per compute unit; 1 = the generic
+ *              register-staged kernel.  Anything else is VB_ERR_ARG: experiment arms and the vendor-library yardstick exist in
+ *              the developer library only (include/visualbert_hip_dev.h).  This library owns no device memory.
  *   attn_two_pass: 1 = two-pass attention backward even where the one-pass kernel applies.
  *   reserved: must be 0 (VB_ERR_ARG otherwise).
  * vb_stream_set_opts(stream, NULL) forgets the stream's entry (call it before destroying a stream).

@@ -12,6 +12,14 @@
 extern "C" {
 #endif
 
+/* vb_stream_opts.nt_kernel values accepted by the DEVELOPER library only (the product returns VB_ERR_ARG for them):
+ *   80  = persistent 256x256 tile, eight slots per K tile (81 is the four-slot form that ships)
+ *   91  = the two-workgroups-per-CU kernel with the copies issued ahead of the fragment reads
+ *   100 = persistent 256x256 tile with four waves, 128x128 outputs each, inline-asm K loop (K / 64 even, else 90)
+ *   101 = the same tile with B fetched straight into fragment registers (1 x 4 waves; K / 64 % 4 == 0 and N % 256 == 0, else 90)
+ *   200 = the vendor yardstick: plain GEMMs (bias only, or "+ addend") are handed to hipBLASLt (csrc/vendor_gemm.hip: dlopen'ed
+ *         on first use, one 64 MB workspace per (device, stream)); fused epilogues and whatever the library declines stay ours */
+
 /* ablation switch for kernel analysis (results are WRONG when non-zero): 1 skip tile loads, 2 skip fragment
  * reads, 4 skip MFMAs in the pipelined kernel, 128 predicate the epilogue's global stores off */
 int vb_gemm_set_debug(int bits);

@@ -51,6 +51,22 @@ def test_developer_knobs_are_not_in_the_product_library():
         assert hasattr(dev, name), name
     for name in header_symbols():
         assert hasattr(dev, name), name
+    # the vendor-library yardstick (csrc/vendor_gemm.hip) and the experiment arms of vb_stream_opts.nt_kernel live in the developer
+    # library only: the product contains no hipBLASLt binding at all and refuses those kernel ids when they are SET
+    blob = open(SO, "rb").read()
+    assert b"hipblasLt" not in blob and b"hipblaslt" not in blob
+    assert b"hipblasLtMatmul" in open(DEV_SO, "rb").read()
+    for L in (lib, dev):
+        L.vb_stream_set_opts.restype = ctypes.c_int
+        L.vb_stream_set_opts.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    fake_stream = ctypes.c_void_p(0x1234)                       # options are a host-side table keyed by the handle: no GPU needed
+    for k in (0, 1, 22, 42, 81, 90) + tuple(_lib.DEV_NT_KERNELS):
+        o = _lib.StreamOpts(0, k, 0, 0)
+        want_product = 0 if k not in _lib.DEV_NT_KERNELS else -1                 # VB_ERR_ARG
+        assert lib.vb_stream_set_opts(fake_stream, ctypes.byref(o)) == want_product, k
+        assert dev.vb_stream_set_opts(fake_stream, ctypes.byref(o)) == 0, k
+    lib.vb_stream_set_opts(fake_stream, None)
+    dev.vb_stream_set_opts(fake_stream, None)
 
 
 def test_missing_library_fails_loudly(tmp_path):

@@ -117,8 +117,9 @@ def test_from_pretrained_local_archive_and_legacy_names(tmp_path):
     rnd = TrainVisualBERTObjective.from_pretrained(str(tmp_path), random_initialize=True, training_head_type="pretraining",
                                                    visual_embedding_dim=256)
     assert not torch.equal(rnd.state_dict()["bert.pooler.dense.weight"], ref["bert.pooler.dense.weight"])
-    with pytest.raises(FileNotFoundError):
-        TrainVisualBERTObjective.from_pretrained("bert-base-uncased", training_head_type="pretraining")
+    with pytest.raises(FileNotFoundError):                    # neither a directory nor a name of the reference's archive map
+        TrainVisualBERTObjective.from_pretrained("bert-base-unknown", training_head_type="pretraining")
+    # (a known name resolves to its architecture offline: tests/test_config_dropin.py)
 
 
 def test_region_feature_store_reads_the_reference_file_layout(tmp_path):
@@ -138,7 +139,15 @@ def test_region_feature_store_reads_the_reference_file_layout(tmp_path):
         r = arrays[i].shape[0]
         assert np.array_equal(out["image_feat_variable"][b, :r].numpy(), arrays[i])
         assert float(out["image_feat_variable"][b, r:].abs().sum()) == 0.0
-    again = store.read_batch(list(reversed(ids)), regions=8, out=out, pin=False)        # same slot, other images
+    class Ev(object):                                   # the event FeatureStager.stage() returned for this slab's last DMA
+        waited = 0
+
+        def synchronize(self):
+            # the refill must not have started yet: the slab still holds the previous batch
+            assert np.array_equal(out["image_feat_variable"][0, :arrays[ids[0]].shape[0]].numpy(), arrays[ids[0]])
+            Ev.waited += 1
+    again = store.read_batch(list(reversed(ids)), regions=8, out=out, pin=False, wait=Ev())   # same slot, other images
+    assert Ev.waited == 1
     assert again["image_feat_variable"].data_ptr() == out["image_feat_variable"].data_ptr()
     assert again["image_dim_variable"].tolist() == [8, 3, 5]
     assert float(again["image_feat_variable"][1, 3:].abs().sum()) == 0.0                # stale rows of the longer image are cleared

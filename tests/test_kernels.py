@@ -33,6 +33,17 @@ def gemm(dev, dt, A, B, M, N, K, al, bl, out_f32=False, bias=None, act=0, addend
     return C
 
 
+def variant_lib(dev, variant):
+    """the library that has GEMM kernel `variant`: the product for the kernels its dispatcher can choose, the developer
+    library (same objects + experiment arms + the vendor yardstick) for _lib.DEV_NT_KERNELS; the simulator has no dev build."""
+    import contextlib
+    if variant not in _lib.DEV_NT_KERNELS:
+        return contextlib.nullcontext()
+    if dev.type != "cuda":
+        pytest.skip("experiment arms exist in libvisualbert_hip_dev.so only (no simulator build of it)")
+    return _lib.dev_library()
+
+
 def padded(rows, cols, dt, dev, g):
     """[rows, cols] view of a buffer whose leading dimension is a multiple of 8 (ABI requirement)."""
     ld = (cols + 7) // 8 * 8
@@ -535,7 +546,7 @@ def test_gemm_pipelined_variants_agree(dev, variant):
     B = padded(N, K, dt, dev, g)
     bias = torch.randn(N, generator=g).to(dev)
     ref = A.float() @ B.float().t() + bias
-    with _lib.stream_opts(nt_kernel=variant):
+    with variant_lib(dev, variant), _lib.stream_opts(nt_kernel=variant):
         for _ in range(3):
             C = gemm(dev, dt, A, B, M, N, K, 0, 0, out_f32=True, bias=bias)
             assert (C - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
@@ -556,7 +567,7 @@ def test_gemm_specialised_epilogues(dev, variant):                          # th
     bias = torch.randn(N, generator=g).to(dev)
     base = A.float() @ B.float().t()
     lim = lambda ref: 1.2e-2 * max(1.0, ref.abs().max().item())
-    with _lib.stream_opts(nt_kernel=variant):
+    with variant_lib(dev, variant), _lib.stream_opts(nt_kernel=variant):
         # bias only
         C = gemm(dev, dt, A, B, M, N, K, 0, 0, bias=bias)
         ref = base + bias
@@ -606,7 +617,7 @@ def test_gemm_direct_b_kernel(dev, wgs):
     base = A.float() @ B.float().t()
     lim = lambda ref: 1.2e-2 * max(1.0, ref.abs().max().item())
     gprime = lambda x: 0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
-    with _lib.stream_opts(nt_kernel=101, persistent_workgroups=wgs):
+    with variant_lib(dev, 101), _lib.stream_opts(nt_kernel=101, persistent_workgroups=wgs):
         ref = base + bias
         C = gemm(dev, dt, A, B, M, N, K, 0, 0, bias=bias)
         assert (C.float() - ref).abs().max().item() <= lim(ref)
@@ -641,7 +652,9 @@ def test_gemm_eight_phase_k_tails(dev, K):
     ref = A.float() @ B.float().t() + bias
     for variant in (80, 81, 90, 100):     # eight-slot / four-slot schedules of the persistent kernel; two-workgroup kernel
         for wgs in (0, 1, 2, 4):            # 6 output tiles: one per workgroup, or 6 / 3 / 2 walked by one workgroup
-            with _lib.stream_opts(nt_kernel=variant, persistent_workgroups=wgs):
+            if variant in _lib.DEV_NT_KERNELS and dev.type != "cuda":
+                continue                                      # no simulator build of the developer library
+            with variant_lib(dev, variant), _lib.stream_opts(nt_kernel=variant, persistent_workgroups=wgs):
                 for out_f32 in (True, False):
                     for _ in range(2):
                         C = gemm(dev, dt, A, B, M, N, K, 0, 0, out_f32=out_f32, bias=bias)
@@ -673,9 +686,9 @@ def test_stream_options_do_not_leak_across_streams(dev):
 
     got = _lib.StreamOpts()
     with on(sa):
-        with _lib.stream_opts(nt_kernel=80, persistent_workgroups=2):
+        with _lib.stream_opts(nt_kernel=81, persistent_workgroups=2):
             _lib.check(L.vb_stream_get_opts(_lib.stream_ptr(), ctypes.byref(got)), "get")
-            assert (got.nt_kernel, got.persistent_workgroups) == (80, 2)
+            assert (got.nt_kernel, got.persistent_workgroups) == (81, 2)
             if sb is not None:
                 with on(sb):                                    # the other stream sees the defaults, not A's options
                     _lib.check(L.vb_stream_get_opts(_lib.stream_ptr(), ctypes.byref(got)), "get")

@@ -165,6 +165,26 @@ def use_dev_library():
     return L
 
 
+#: vb_stream_opts.nt_kernel values that exist in the developer library only (include/visualbert_hip_dev.h)
+DEV_NT_KERNELS = (80, 91, 100, 101, 200)
+
+
+class dev_library(object):
+    """with dev_library(): ...   -- bind libvisualbert_hip_dev.so for the block (tests of the experiment arms, bench.py's
+    yardstick legs), then return to whatever library was bound before.  Per-stream options live inside each library: set them
+    inside the block."""
+
+    def __enter__(self):
+        global _lib, _lib_path
+        self.saved = (_lib, _lib_path)
+        return use_dev_library()
+
+    def __exit__(self, *exc):
+        global _lib, _lib_path
+        _lib, _lib_path = self.saved
+        return False
+
+
 class stream_opts(object):
     """with stream_opts(nt_kernel=42, persistent_workgroups=8): ...   -- launch options of the CURRENT stream
     (vb_stream_set_opts); restored on exit.  They never change results beyond summation order."""

@@ -1333,7 +1333,9 @@ int launch_dual_var(const GemmArgs& g, dim3 grid, hipStream_t stream) {
 }
 template <typename TO, int ACT, int OPT>
 int launch_dual_act(const GemmArgs& g, dim3 grid, hipStream_t stream) {
+#ifdef VB_DEV_KNOBS
     if (t_opts.nt_kernel == 91) return launch_dual_var<TO, ACT, OPT, 0>(g, grid, stream);
+#endif
     return launch_dual_var<TO, ACT, OPT, 3>(g, grid, stream);
 }
 template <typename T, typename TO>
@@ -2103,6 +2105,7 @@ int dispatch_pipe(const GemmArgs& g, hipStream_t s) {
         const long t128 = (long)((g.M + 255) / 256) * ((g.N + 127) / 128);
         if (variant != 22 && variant != 42 && variant != 90) variant = t256 >= 160 ? 90 : (t128 >= 256 ? 42 : 22);   // (never 100 / 101)
     }
+#ifdef VB_DEV_KNOBS
     if (variant == 200) {
         // the vendor yardstick inside the step (vendor_gemm.hip): plain GEMMs -- bias only, or "+ addend" as beta = 1 -- go to
         // hipBLASLt; whatever it does not take (fused epilogues, no library on the box) runs on the kernels chosen below
@@ -2118,6 +2121,7 @@ int dispatch_pipe(const GemmArgs& g, hipStream_t s) {
         }
         variant = 0;
     }
+#endif
     if (variant == 0) {
         // measured on MI355X (profiles/r01_gemm_variant_sweep_b128.txt)
         const long t256 = (long)((g.M + 255) / 256) * ((g.N + 255) / 256);
@@ -2134,11 +2138,14 @@ int dispatch_pipe(const GemmArgs& g, hipStream_t s) {
     switch (variant) {
         case 22: return launch_pipe<T, TO, 2, 2>(g, s);
         case 42: return launch_pipe<T, TO, 4, 2>(g, s);
-        case 80: return launch_8ph<T, TO>(g, s);
         case 81: return launch_8ph<T, TO>(g, s);
-        case 90: case 91: return launch_dual<T, TO>(g, s);
+        case 90: return launch_dual<T, TO>(g, s);
+#ifdef VB_DEV_KNOBS
+        case 80: return launch_8ph<T, TO>(g, s);
+        case 91: return launch_dual<T, TO>(g, s);
         case 100: return launch_big<T, TO>(g, s);
         case 101: return launch_big<T, TO>(g, s, true);
+#endif
         default: return VB_ERR_UNSUPPORTED;
     }
 }

@@ -86,6 +86,10 @@ VB_DEVICE float schedule_mult(const AdamHyper& h, int step) {
 // takes every later step too (weight decay, moment decay, counter) even when this step wrote nothing to it.  Device-side,
 // per step: no host-cached decision can go stale between data-parallel ranks.  The gradient norms are always computed when
 // flags are given (host side below), so an unrecorded non-zero gradient is never dropped.
+// ASSUMED zero_grad SEMANTICS: the reference's era (torch < 2: zero_grad() zeroes .grad in place, so .grad is None only before
+// a parameter's first backward).  Under torch >= 2's default zero_grad(set_to_none=True) the REFERENCE would skip a tensor again
+// in any later step that does not reach it; this library keeps the torch < 2 behaviour the reference was written and trained
+// with (include/visualbert_hip.h: vb_bert_adam_step; visualbert_amd.optimization.BertAdam docstring).
 VB_DEVICE bool adam_skips(const float* touched, const float* norm2, const int* steps, long tid) {
     if (!touched || touched[tid] != 0.f || steps[tid] > 0) return false;
     return !(norm2[tid] > 0.f);

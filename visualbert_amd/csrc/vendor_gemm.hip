@@ -1,15 +1,18 @@
 // vendor_gemm.hip -- the vendor library as a yardstick INSIDE the step (vb_stream_opts.nt_kernel = 200).
+// DEVELOPER LIBRARY ONLY (libvisualbert_hip_dev.so, include/visualbert_hip_dev.h): the product library neither contains this
+// file nor accepts nt_kernel = 200 (tests/test_abi.py::test_developer_knobs_are_not_in_the_product_library).
 //
-// Not the product path: every GEMM of the step runs on the hand-written kernels of gemm.hip by default.  hipBLASLt's
+// Not the product path: every GEMM of the step runs on the hand-written kernels of gemm.hip.  hipBLASLt's
 // hand-scheduled 256x256 stream-K kernel is 8-25 % faster than ours on the step's plain GEMM shapes when timed alone
 // (profiles/r03_gemm_vendor_yardstick.txt); this file lets the SAME training step run with those GEMMs -- bias-only, or
 // "+ addend" expressed as beta = 1 -- handed to the library, so the question "what would the vendor's schedule be worth
 // inside the step, at the clock the step runs at" has a measured answer.  Everything fused
 // (GELU + derivative, x GELU' + column sums, split operands, fp32-accumulating weight gradients) stays ours either way.
 //
-// libhipblaslt.so is opened with dlopen on first use: the product library has no link-time dependency on it, and a box
-// without it gets VB_ERR_UNSUPPORTED from this entry (the dispatcher then takes the normal kernel).  Unlike the rest of
-// the library this path owns device memory: one 64 MB stream-K workspace per stream, allocated on first use.
+// libhipblaslt.so is opened with dlopen on first use: no link-time dependency, and a box without it gets
+// VB_ERR_UNSUPPORTED from this entry (the dispatcher then takes the normal kernel).  This path owns device memory -- one
+// 64 MB stream-K workspace per (device, stream), allocated on first use, never freed (a measurement process) -- which is one
+// more reason it is not in the product, whose header promises that the library owns no device memory.
 #include "vb_rt.h"
 #include "../../include/visualbert_hip.h"
 #include <hipblaslt/hipblaslt.h>
@@ -70,7 +73,7 @@ typedef std::tuple<int, int, int, long, long, long, long, int, int, int> Key;
 
 std::mutex g_mutex;
 std::map<Key, Plan> g_plans;
-std::map<void*, void*> g_workspaces;
+std::map<std::pair<int, void*>, void*> g_workspaces;           // (device, stream) -> workspace
 
 // Row-major C[M,N] = A[M,K] . B[N,K]^T is, in the library's column-major terms, D[N x M] = op_T(B as K x N) . (A as K x M):
 // the "Alik_Bljk" form torch's F.linear issues, so the heuristic lands on the same kernels the yardstick measured.
@@ -123,11 +126,14 @@ int vb_vendor_nt(const VbVendorGemm& g, void* stream) {
         if (it == g_plans.end()) it = g_plans.emplace(key, make_plan(p, g)).first;
         pl = it->second;
         if (!pl.ok) return VB_ERR_UNSUPPORTED;
-        auto w = g_workspaces.find(stream);
+        int device = 0;
+        if (hipGetDevice(&device) != hipSuccess) return VB_ERR_UNSUPPORTED;
+        const std::pair<int, void*> wkey(device, stream);
+        auto w = g_workspaces.find(wkey);
         if (w == g_workspaces.end()) {
             void* buf = nullptr;
             if (hipMalloc(&buf, kWorkspace) != hipSuccess) return VB_ERR_UNSUPPORTED;
-            w = g_workspaces.emplace(stream, buf).first;
+            w = g_workspaces.emplace(wkey, buf).first;
         }
         ws = w->second;
         if (g.bias) {                                        // the descriptor is shared by every call of this shape: set under the lock,

@@ -180,11 +180,16 @@ class RegionFeatureStore(object):
             raise ValueError("%s: expected a [regions, Dv] array, got shape %s" % (self.path(image_id), a.shape))
         return a
 
-    def read_batch(self, image_ids, regions=None, out=None, pin=True):
+    def read_batch(self, image_ids, regions=None, out=None, pin=True, wait=None):
         """-> dict(image_feat_variable float32 [B, R, Dv] zero padded, image_dim_variable int64 [B]) in pinned memory.
         regions: pad / truncate to this many regions (None: the most regions in the batch, like the reference's padding);
-        out: a previous result to overwrite in place (a slot of a ring)."""
+        out: a previous result to overwrite in place (a slot of a ring);
+        wait: the event FeatureStager.stage() returned when `out` was last handed to it -- the DMA out of the slab must have
+              executed before the host rewrites it, so it is synchronised HERE, before the first byte is written (a wait
+              inside the next stage() call would come after the refill, i.e. after the race)."""
         import numpy as np
+        if wait is not None:
+            wait.synchronize()
         arrays = [self.load(i) for i in image_ids]
         B = len(arrays)
         Dv = int(arrays[0].shape[1])
@@ -215,7 +220,11 @@ class FeatureStager(object):
         tensor's memory to the next copy while a queued kernel still reads it: the slot's device tensors are REUSED, and
         before a slot is overwritten the copy stream waits for an event recorded on the compute stream at that moment --
         everything the consumer enqueued for the slot's previous contents is ahead of that event;
-      * a slot's pinned staging buffer is rewritten by the host only after the slot's previous copy has completed."""
+      * a slot's OWN pinned staging buffer (pageable inputs) is rewritten by the host only after the slot's previous copy has
+        completed.
+    Contract for inputs that are ALREADY pinned (RegionFeatureStore slabs): they are copied from in place, so the caller must
+    not rewrite such a slab until the event returned by the stage() call that consumed it has completed -- pass that event as
+    `wait=` to RegionFeatureStore.read_batch(out=slab, ...) or call `stager.wait_host(slot)` before refilling."""
 
     def __init__(self, device):
         self.device = device
@@ -234,12 +243,8 @@ class FeatureStager(object):
         with torch.cuda.stream(self.stream):
             self.stream.wait_event(consumed)
             for k, v in host_batch.items():
-                if v.is_pinned():                       # the feature store already lives in pinned memory
-                    pin = v
-                    if prev is not None:
-                        # the caller may be re-filling a pinned slab it handed to this slot before (RegionFeatureStore.
-                        # read_batch(out=...) rings): the slot's previous DMA out of host memory must have executed
-                        prev.synchronize()
+                if v.is_pinned():                       # the feature store already lives in pinned memory: copied from in
+                    pin = v                             # place (the caller keeps it intact until `ev` completes, see above)
                 else:
                     key = (slot, k)
                     pin = self._pinned.get(key)
@@ -260,3 +265,10 @@ class FeatureStager(object):
             ev.record(self.stream)
         self._copied[slot] = ev
         return out, ev
+
+    def wait_host(self, slot=0):
+        """block until the last stage() of `slot` has finished reading host memory: after this the caller may rewrite the
+        pinned tensors it passed to that call."""
+        ev = self._copied.get(slot)
+        if ev is not None:
+            ev.synchronize()

@@ -15,6 +15,8 @@ Conventions
     otherwise a fresh fp32 gradient is returned to autograd as usual.
   * dropout masks are regenerated in backward from (seed, stream id); forward draws the seed.
 """
+import threading
+
 import torch
 
 from . import _lib
@@ -80,7 +82,22 @@ def _ld(t):
 # The mode is a property of the MODEL (TrainVisualBERTObjective.set_compute_dtype("bf16x3")): its forward runs inside
 # x3_scope(True), every autograd Function below remembers the flag for its backward (x3_aware).
 # ------------------------------------------------------------------------------------------------
-_x3 = [False]
+class _X3State(threading.local):
+    """per-THREAD mode flag (indexable like the one-element list it replaces): autograd runs backward nodes on its own device
+    thread, and a second model may run its forward on another Python thread meanwhile -- neither may see the other's mode.
+    Every autograd Function carries the mode on its ctx (x3_aware), so a thread that starts with the default (off) is correct."""
+
+    def __init__(self):
+        self.on = False
+
+    def __getitem__(self, i):
+        return self.on
+
+    def __setitem__(self, i, v):
+        self.on = bool(v)
+
+
+_x3 = _X3State()
 _x3_epoch = [0]
 
 
@@ -299,10 +316,11 @@ def gemm_key_name(key):
     if not (key & 3):
         kind = ("gemm_nt_dual_kernel<%s->%s, 256x128 tile, two workgroups per CU, five-slot LDS-direct ring>" if key & 64 else
                 "gemm_nt_8ph_kernel<%s->%s, persistent 256x256 tile, four-slot LDS-direct schedule>" if key & 16 else
+                "gemm_nt_big_kernel / gemm_nt_bdir_kernel<%s->%s, four waves, 128x128 outputs per wave (developer library)>" if key & 128 else
                 "gemm_nt_experimental<%s->%s>" if key & 32 else
                 "gemm_nt_pipe_kernel<%s->%s, 256x128 tile, 2-stage LDS-direct>")
         return kind % ("fp32" if key & 8 else "bf16", "fp32" if (key & 4 or key & 8) else "bf16") + x3
-    return x3.strip() + "gemm_kernel<%s->%s, A %s, B %s>" % ("fp32" if key & 8 else "bf16",
+    return (x3.strip() + " " if x3 else "") + "gemm_kernel<%s->%s, A %s, B %s>" % ("fp32" if key & 8 else "bf16",
                                                 "fp32" if (key & 4 or key & 8) else "bf16",
                                                 "Kstrided" if key & 2 else "Kcontig",
                                                 "Kstrided" if key & 1 else "Kcontig")

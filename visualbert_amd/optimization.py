@@ -113,7 +113,13 @@ class BertAdam(Optimizer):
 
     All parameters must live in one visualbert_amd ParameterArena (every model built by
     visualbert_amd.modeling does).  State (exp_avg = 'next_m', exp_avg_sq = 'next_v', step counters)
-    is held as flat device buffers."""
+    is held as flat device buffers.
+
+    `if p.grad is None: continue` (optimization.py:254-255) follows the zero_grad semantics of the reference's era
+    (torch < 2: gradients are zeroed in place, so a parameter is skipped only until its first backward): a tensor that has
+    ever received a gradient keeps stepping (weight decay, moment decay, counter) in steps that do not reach it.  Under
+    torch >= 2's zero_grad(set_to_none=True) the reference itself would skip it again; `zero_grad()` here is one memset of
+    the gradient arena either way.  load_state_dict keeps the moments / counters of parameters the checkpoint omits."""
 
     def __init__(self, params, lr=None, warmup=-1, t_total=-1, schedule='warmup_linear', b1=0.9, b2=0.999, e=1e-6,
                  weight_decay=0.01, max_grad_norm=1.0, **kwargs):
@@ -310,8 +316,16 @@ class BertAdam(Optimizer):
                 group["schedule"] = _SCHEDULE_CLASSES[sch["class"]](**kw)
         # the fused state caches weight decay, the decay / optimise flags and the device tables: rebuild it from the
         # hyper-parameters just restored (the moments and counters are overwritten from the checkpoint right below)
+        old = self._fused
         self._fused = None
         f = self.fused()
+        if old is not None and old["m"].shape == f["m"].shape:
+            # parameters the checkpoint does not mention keep the moments and counters they had (the reference's
+            # Optimizer.load_state_dict replaces `state` wholesale only for the ids it lists; a partial checkpoint must not
+            # silently zero the rest)
+            f["m"].copy_(old["m"])
+            f["v"].copy_(old["v"])
+            f["steps"].copy_(old["steps"])
         sch0 = self.param_groups[0]["schedule"]
         f["code"] = 1 if type(sch0) is WarmupLinearSchedule else (0 if (type(sch0) is ConstantLR or sch0.t_total < 0) else -1)
         a = f["arena"]

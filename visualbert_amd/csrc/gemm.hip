@@ -241,7 +241,8 @@ VB_DEVICE int xcd_remap(int bid, int nwg) {
 enum { EPI_ADD = 1,          // addend and/or accumulate operands
        EPI_RAGGED = 2,       // N % 8 != 0 or a pointer / leading dimension that is not 16-byte aligned
        EPI_COLSUM = 4,       // fused column sums
-       EPI_ALL = 7 };
+       EPI_ALL = 7,          // everything above, decided at run time (incl. a split result when g.split_out is set)
+       EPI_SPLIT = 8 };      // specialised split-operand epilogues: the result ALWAYS leaves as a bf16 hi | lo image (g.split_out)
 struct EpiLane {             // per-lane constants of an epilogue call
     float bb[8], cs[8];
     float alpha;
@@ -373,8 +374,8 @@ VB_DEVICE void epi_vec8(float (&v)[8], const GemmArgs& g, EpiLane& e, long offc,
         }
     }
     TO* cp = (TO*)g.C + offc;
-    if constexpr (sizeof(TO) == 4 && (OPT & EPI_RAGGED) != 0) {            // the run-time epilogue of the fp32-output kernels only
-        if (g.split_out) {
+    if constexpr (sizeof(TO) == 4 && (OPT & (EPI_RAGGED | EPI_SPLIT)) != 0) {   // run-time epilogue of the fp32-output kernels, or
+        if ((OPT & EPI_SPLIT) != 0 || g.split_out) {                            // a split-operand instantiation that always splits
             bf16* hp = (bf16*)g.C + offc;
             bf16x8 h;
             float lo[8];
@@ -1354,7 +1355,24 @@ int launch_dual(GemmArgs g, hipStream_t stream) {
         if ((g.debug >> 8) > 0) g.stripe = (g.debug >> 8) < g.tiles_n ? (g.debug >> 8) : g.tiles_n;      // developer library only: walk override
         dim3 grid((unsigned)(g.tiles_m * g.tiles_n));
         if constexpr (sizeof(TO) == 4) {
-            if (g.x3) return launch_dual_var<TO, -1, EPI_ALL, 3, true>(g, grid, stream);
+            if (g.x3) {
+                // split-operand mode: the epilogue's row operands are fp32.  The four epilogues an encoder layer uses get their own
+                // instantiations like the bf16 ones below (one activation, no run-time option code: the run-time body is ~4x the
+                // instructions and every tile fetches it); anything else takes the run-time epilogue
+                const int needs = epi_needs(g, 4, 4);
+                if (!(needs & EPI_RAGGED)) {
+                    if (!g.split_out) {
+                        if (g.act == VB_ACT_NONE && needs == 0) return launch_dual_var<TO, VB_ACT_NONE, 0, 3, true>(g, grid, stream);
+                        if (g.act == VB_ACT_NONE && needs == EPI_ADD) return launch_dual_var<TO, VB_ACT_NONE, EPI_ADD, 3, true>(g, grid, stream);
+                    } else {
+                        if (g.act == VB_ACT_GELU_SAVE_GRAD && needs == 0)
+                            return launch_dual_var<TO, VB_ACT_GELU_SAVE_GRAD, EPI_SPLIT, 3, true>(g, grid, stream);
+                        if (g.act == VB_ACT_MUL_AUX && (needs & ~EPI_COLSUM) == 0)
+                            return launch_dual_var<TO, VB_ACT_MUL_AUX, EPI_COLSUM | EPI_SPLIT, 3, true>(g, grid, stream);
+                    }
+                }
+                return launch_dual_var<TO, -1, EPI_ALL, 3, true>(g, grid, stream);
+            }
         }
         const int needs = epi_needs(g, sizeof(T), sizeof(TO));
 #define VB_TRY_EPI(A, O) if (g.act == (A) && (needs & ~(O)) == 0) return launch_dual_act<TO, A, O>(g, grid, stream)

@@ -352,7 +352,7 @@ def test_bert_layer_at_bench_shape(dev, which, mode_name):
     _dump_measured()
 
 
-@pytest.mark.parametrize("which,mode_name", [("bench", "bf16"), ("small", "bf16"), ("bench512", "bf16x3")])
+@pytest.mark.parametrize("which,mode_name", [("bench", "bf16"), ("small", "bf16"), ("bench512", "bf16x3"), ("small", "bf16x3")])
 def test_bert_layer_dropout_run_is_deterministic(dev, which, mode_name):
     """what the bench times: p_hidden = p_attn = 0.1.  The masks are a pure function of (seed, site, element), every kernel
     but the atomically accumulated weight gradients is order-independent: two runs must agree bit for bit."""
@@ -369,6 +369,11 @@ def test_bert_layer_dropout_run_is_deterministic(dev, which, mode_name):
         outs.append([h_out.clone(), sv["ctx"].clone(), sv["keepbits"].clone(), d_in.clone(), sc["t_3h"].clone(), G[1].clone()])
         if rep == 0:
             assert torch.isfinite(h_out.float()).all() and torch.isfinite(d_in.float()).all()
+            if mode.x3:       # with dropout on, the images the producers wrote are those of the DROPPED gradients (dfo, dao) and of dqkv
+                for name, src in (("sp_dfo", sc["t_h1"]), ("sp_dao", sc["t_h4"]), ("sp_dqkv", sc["t_3h"])):
+                    assert torch.equal(sc[name], _split(src)), name
+                for name, src in (("sp_ctx", sv["ctx"]), ("sp_aout", sv["a_out"])):
+                    assert torch.equal(sv[name], _split(src)), name
     for a, b, what in zip(outs[0], outs[1], ("h_out", "ctx", "keep-bits", "d_in", "dqkv")):
         assert torch.equal(a, b), what
     # the q|k|v bias gradient: per-workgroup partial sums, then a second stage whose summation order is not fixed -- equal to

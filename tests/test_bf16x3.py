@@ -67,7 +67,7 @@ def test_split_planes_reconstruct_the_input(dev):
     assert float(bt[:, 37:64].float().abs().max()) == 0.0 and float(bt[:, 64 + 37:].float().abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("variant", [0, 1, 22, 42, 90])
+@pytest.mark.parametrize("variant", [0, 1, 22, 42, 81, 90])
 def test_gemm_bf16x3_epilogues_against_fp64(dev, variant):
     """variant: vb_stream_opts.nt_kernel (0 = chosen from the shape, 1 = generic register-staged kernel, 22 / 42 = the
     two-barrier LDS-direct kernels, 90 = two workgroups per CU)"""
@@ -181,7 +181,7 @@ def test_wgrad_and_dgrad_through_split_operands(dev, tokens):
     assert not isinstance(ops.weight_for(w, torch.float32), ops.SplitOperand)
 
 
-@pytest.mark.parametrize("variant", [1, 42, 90])
+@pytest.mark.parametrize("variant", [1, 42, 81, 90])
 def test_gemm_bf16x3_split_result(dev, variant):
     """out_dtype VB_BF16X3: the fp32 result leaves the epilogue as a split operand (hi | lo planes), here with the FFN-in forward's
     bias + GELU + saved GELU' and with the FFN-out dgrad's x GELU' + column sums -- hi + lo must equal the fp32-output result of

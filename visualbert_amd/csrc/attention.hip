@@ -134,17 +134,18 @@ VB_DEVICE void pair_store_tr(const PairTile<NROWS>& p, unsigned char* lds, int t
 // ---- staging, fp32 sources (fp32 and split modes) ------------------------------------------------------------------------
 // The same for the 4-byte element types -- where it matters more: their tiles fill the LDS, so ONE workgroup per CU has nothing
 // to hide a round trip behind.  Item i = rows (2j, 2j+1) x 8-element chunk dc: four 16-byte loads, all issued before the first store.
-template <int NROWS>
+// NTH: threads of the workgroup that stage the tile together (the 4-byte kernels run with up to 768: see attn_fwd_kernel)
+template <int NROWS, int NTH = NT>
 struct PairTile32 {
-    static constexpr int ITEMS = (NROWS / 2) * 8, PER = (ITEMS + NT - 1) / NT;
+    static constexpr int ITEMS = (NROWS / 2) * 8, PER = (ITEMS + NTH - 1) / NTH;
     f32x4 a0[PER], b0[PER], a1[PER], b1[PER];              // row r: elements 0-3 / 4-7 of the chunk; row r + 1 likewise
 };
 VB_DEVICE f32x4 zsel4(bool ok, const f32x4& x) { return f32x4{ok ? x[0] : 0.f, ok ? x[1] : 0.f, ok ? x[2] : 0.f, ok ? x[3] : 0.f}; }
-template <int NROWS, typename T>
-VB_DEVICE void pair_load32(PairTile32<NROWS>& p, const T* X, long ldx, long row0, int c0, int S, int t) {
+template <int NROWS, typename T, int NTH = NT>
+VB_DEVICE void pair_load32(PairTile32<NROWS, NTH>& p, const T* X, long ldx, long row0, int c0, int S, int t) {
 #pragma unroll
-    for (int k = 0; k < PairTile32<NROWS>::PER; ++k) {     // unconditional loads from clamped rows (see frag_g)
-        const int idx = t + k * NT;
+    for (int k = 0; k < PairTile32<NROWS, NTH>::PER; ++k) {     // unconditional loads from clamped rows (see frag_g)
+        const int idx = t + k * NTH;
         const int dc = idx & 7, r = (idx >> 3) * 2;
         const float* p0 = (const float*)(X + (row0 + (r < S ? r : S - 1)) * ldx + c0 + dc * 8);
         const float* p1 = (const float*)(X + (row0 + (r + 1 < S ? r + 1 : S - 1)) * ldx + c0 + dc * 8);
@@ -152,18 +153,18 @@ VB_DEVICE void pair_load32(PairTile32<NROWS>& p, const T* X, long ldx, long row0
         p.a1[k] = *(const f32x4*)p1; p.b1[k] = *(const f32x4*)(p1 + 4);
     }
 #pragma unroll
-    for (int k = 0; k < PairTile32<NROWS>::PER; ++k) {
-        const int r = ((t + k * NT) >> 3) * 2;
+    for (int k = 0; k < PairTile32<NROWS, NTH>::PER; ++k) {
+        const int r = ((t + k * NTH) >> 3) * 2;
         p.a0[k] = zsel4(r < S, p.a0[k]); p.b0[k] = zsel4(r < S, p.b0[k]);
         p.a1[k] = zsel4(r + 1 < S, p.a1[k]); p.b1[k] = zsel4(r + 1 < S, p.b1[k]);
     }
 }
-template <int NROWS, typename T>
-VB_DEVICE void pair_store_rm32(const PairTile32<NROWS>& p, unsigned char* lds, int t) {
+template <int NROWS, typename T, int NTH = NT>
+VB_DEVICE void pair_store_rm32(const PairTile32<NROWS, NTH>& p, unsigned char* lds, int t) {
 #pragma unroll
-    for (int k = 0; k < PairTile32<NROWS>::PER; ++k) {
-        const int idx = t + k * NT;
-        if (idx >= PairTile32<NROWS>::ITEMS) continue;
+    for (int k = 0; k < PairTile32<NROWS, NTH>::PER; ++k) {
+        const int idx = t + k * NTH;
+        if (idx >= PairTile32<NROWS, NTH>::ITEMS) continue;
         const int dc = idx & 7, r = (idx >> 3) * 2;
         if constexpr (LT<T>::SPLIT) {
             bf16x8 h0, l0, h1, l1;
@@ -177,13 +178,13 @@ VB_DEVICE void pair_store_rm32(const PairTile32<NROWS>& p, unsigned char* lds, i
         }
     }
 }
-template <int NROWS, typename T>
-VB_DEVICE void pair_store_tr32(const PairTile32<NROWS>& p, unsigned char* lds, int t) {
+template <int NROWS, typename T, int NTH = NT>
+VB_DEVICE void pair_store_tr32(const PairTile32<NROWS, NTH>& p, unsigned char* lds, int t) {
     constexpr int pitch = tr_pitch<T>(NROWS);
 #pragma unroll
-    for (int k = 0; k < PairTile32<NROWS>::PER; ++k) {
-        const int idx = t + k * NT;
-        if (idx >= PairTile32<NROWS>::ITEMS) continue;
+    for (int k = 0; k < PairTile32<NROWS, NTH>::PER; ++k) {
+        const int idx = t + k * NTH;
+        if (idx >= PairTile32<NROWS, NTH>::ITEMS) continue;
         const int dc = idx & 7, r = (idx >> 3) * 2;
         if constexpr (LT<T>::SPLIT) {
             typedef bf16 pair_t __attribute__((ext_vector_type(2)));
@@ -289,6 +290,9 @@ struct AttnArgs {
     const void* qkv; const float* mask_add; void* ctx; float* lse; uint64_t* keepbits;   // forward
     const void* dctx; void* dqkv; float* dsum; const void* ctx_fwd;                       // backward
     float* bias_ws;                  // one-pass backward: per-sample column sums of dQ | dK | dV, fp32 [B][3H] (or NULL)
+    // split-operand mode, self-attention only (vb_attn_*_sp): bf16 hi | lo images of the fp32 results written next to them --
+    // ctx_sp [B*S, 2H] (half = H), dqkv_sp [B*S, 6H] (half = 3H; dQ | dK | dV column blocks like dqkv) -- or NULL
+    bf16* ctx_sp; bf16* dqkv_sp;
     // General form (self- AND cross-attention; the forward and the two-pass backward kernels read only these): queries come
     // from q [B*Sq rows, pitch ldq], keys / values from k, v [B*S rows, pitch ldk / ldv] -- for self-attention three column
     // blocks of the packed qkv matrix, for cross-attention (LXRT: language attends to vision and back) different tensors
@@ -317,8 +321,11 @@ VB_DEVICE long keep_index(const AttnArgs& a, int bh, int q, int g, int w, int nw
 // EXACT: every one of the NKF key fragments (and NKS 32-key steps) holds at least one real key -- the launcher's promise for
 // S = 161..176 -- so the per-fragment "is it inside the sequence" branches (46 scalar branches per query block) go, and a
 // chain's first MFMA takes the literal 0 as its C operand instead of four zeroed registers.
-template <typename T, int NKF, bool PF = false, bool EXACT = false>
-VB_KERNEL VB_LAUNCH_BOUNDS2(NT, 3) attn_fwd_kernel(AttnArgs a) {
+// NTH: threads per workgroup = 64 x waves.  bf16 tiles are small enough for three 4-wave workgroups per CU; the 4-byte element
+// types (fp32, split mode) fill the LDS with ONE workgroup's K / V, so that workgroup brings the waves itself: 12 waves (3 per
+// SIMD, the same 168-register budget) walk the query blocks side by side over the same tiles instead of 4 waves in 3 rounds.
+template <typename T, int NKF, bool PF = false, bool EXACT = false, int NTH = NT>
+VB_KERNEL VB_LAUNCH_BOUNDS2(NTH, (NTH == NT ? 3 : 1)) attn_fwd_kernel(AttnArgs a) {
     constexpr int NKV = (NKF + 1) / 2 * 2;
     constexpr int NK = NKF * 16, NKVK = NKV * 16, NKS = NKV / 2, NW = (NKF + 15) / 16;
     VB_DYN_SMEM(smem);
@@ -341,14 +348,14 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(NT, 3) attn_fwd_kernel(AttnArgs a) {
         pair_store_rm<NK>(tk, ldsK, t);
         pair_store_tr<NKVK>(tv, ldsVT, t);                  // rows >= S arrive as zeros: the padded key columns are 0
     } else {
-        PairTile32<NK> tk;
-        PairTile32<NKVK> tv;
-        pair_load32<NK, T>(tk, Kp, a.ldk, rowk, h * D, S, t);
-        pair_load32<NKVK, T>(tv, Vp, a.ldv, rowk, h * D, S, t);
-        pair_store_rm32<NK, T>(tk, ldsK, t);
-        pair_store_tr32<NKVK, T>(tv, ldsVT, t);
+        PairTile32<NK, NTH> tk;
+        PairTile32<NKVK, NTH> tv;
+        pair_load32<NK, T, NTH>(tk, Kp, a.ldk, rowk, h * D, S, t);
+        pair_load32<NKVK, T, NTH>(tv, Vp, a.ldv, rowk, h * D, S, t);
+        pair_store_rm32<NK, T, NTH>(tk, ldsK, t);
+        pair_store_tr32<NKVK, T, NTH>(tv, ldsVT, t);
     }
-    for (int k = t; k < NK; k += NT) ldsMask[k] = k < S ? a.mask_add[(long)b * S + k] : -INFINITY;
+    for (int k = t; k < NK; k += NTH) ldsMask[k] = k < S ? a.mask_add[(long)b * S + k] : -INFINITY;
     __syncthreads();
 
     const int nqf = (Sq + 15) / 16;
@@ -360,7 +367,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(NT, 3) attn_fwd_kernel(AttnArgs a) {
         qn[1] = *(const u32x4*)(qrow + 32 + lg * 8);
     };
     if constexpr (PF) fetch_q(wave);
-    for (int qf = wave; qf < nqf; qf += 4) {
+    for (int qf = wave; qf < nqf; qf += NTH / 64) {
         const int q = qf * 16 + li;
         const bool qok = q < Sq;
         typename VecOf<T>::v8 qb[2];
@@ -369,7 +376,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(NT, 3) attn_fwd_kernel(AttnArgs a) {
             const u32x4 z0 = zsel(qok, qn[0]), z1 = zsel(qok, qn[1]);
             qb[0] = *(const typename VecOf<T>::v8*)&z0;
             qb[1] = *(const typename VecOf<T>::v8*)&z1;
-            fetch_q(qf + 4);                               // past the last block: a clamped (valid, unused) row
+            fetch_q(qf + NTH / 64);                               // past the last block: a clamped (valid, unused) row
         } else {
             const T* qrow = Qp + (rowq + (qok ? q : 0)) * a.ldq + h * D;
             qb[0] = frag_g(qrow, 0, lg, qok);
@@ -456,6 +463,9 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(NT, 3) attn_fwd_kernel(AttnArgs a) {
                     acc = vb_mma(frag_tr(ldsVT, tr_pitch<T>(NKVK), df * 16 + li, ks, lg, T()), pb[ks], acc);
             }
             if (qok) store4(crow + df * 16 + lg * 4, acc);     // lane: query q, d = df*16 + lg*4 + 0..3
+            if constexpr (std::is_same<T, xf32>::value) {
+                if (a.ctx_sp && qok) store_split4(a.ctx_sp + (rowq + q) * (2 * a.ldc) + h * D + df * 16 + lg * 4, a.ldc, acc);
+            }
         }
     }
 }
@@ -463,8 +473,8 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(NT, 3) attn_fwd_kernel(AttnArgs a) {
 // =================================================================================================
 // backward, pass A: dQ and D = rowsum(P o dP)   (per query block, all keys)
 // =================================================================================================
-template <typename T, int NKF>
-VB_KERNEL VB_LAUNCH_BOUNDS(NT) attn_bwd_dq_kernel(AttnArgs a) {
+template <typename T, int NKF, int NTH = NT>
+VB_KERNEL VB_LAUNCH_BOUNDS(NTH) attn_bwd_dq_kernel(AttnArgs a) {
     constexpr int NK = NKF * 16, NKS = NKF / 2, NW = (NKF + 15) / 16;
     VB_DYN_SMEM(smem);
     unsigned char* ldsK = smem;
@@ -487,18 +497,18 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) attn_bwd_dq_kernel(AttnArgs a) {
         pair_store_tr<NK>(tk, ldsKT, t);
         pair_store_rm<NK>(tv, ldsV, t);
     } else {
-        PairTile32<NK> tk, tv;
-        pair_load32<NK, T>(tk, Kp, a.ldk, rowk, h * D, S, t);
-        pair_load32<NK, T>(tv, Vp, a.ldv, rowk, h * D, S, t);
-        pair_store_rm32<NK, T>(tk, ldsK, t);
-        pair_store_tr32<NK, T>(tk, ldsKT, t);
-        pair_store_rm32<NK, T>(tv, ldsV, t);
+        PairTile32<NK, NTH> tk, tv;
+        pair_load32<NK, T, NTH>(tk, Kp, a.ldk, rowk, h * D, S, t);
+        pair_load32<NK, T, NTH>(tv, Vp, a.ldv, rowk, h * D, S, t);
+        pair_store_rm32<NK, T, NTH>(tk, ldsK, t);
+        pair_store_tr32<NK, T, NTH>(tk, ldsKT, t);
+        pair_store_rm32<NK, T, NTH>(tv, ldsV, t);
     }
-    for (int k = t; k < NK; k += NT) ldsMask[k] = k < S ? a.mask_add[(long)b * S + k] : -INFINITY;
+    for (int k = t; k < NK; k += NTH) ldsMask[k] = k < S ? a.mask_add[(long)b * S + k] : -INFINITY;
     __syncthreads();
 
     const int nqf = (Sq + 15) / 16;
-    for (int qf = wave; qf < nqf; qf += 4) {
+    for (int qf = wave; qf < nqf; qf += NTH / 64) {
         const int q = qf * 16 + li;
         const bool qok = q < Sq;
         const T* qrow = Qp + (rowq + (qok ? q : 0)) * a.ldq + h * D;
@@ -560,6 +570,9 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) attn_bwd_dq_kernel(AttnArgs a) {
                     acc = vb_mma(frag_tr(ldsKT, tr_pitch<T>(NK), df * 16 + li, ks, lg, T()), dsb[ks], acc);
             }
             if (qok) store4(dqrow + df * 16 + lg * 4, acc);
+            if constexpr (std::is_same<T, xf32>::value) {
+                if (a.dqkv_sp && qok) store_split4(a.dqkv_sp + (rowq + q) * (2 * a.lddq) + h * D + df * 16 + lg * 4, a.lddq, acc);
+            }
         }
     }
 }
@@ -687,6 +700,9 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) attn_fwd_tiled_kernel(AttnArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[r] = acc[df][r] * inv;
             if (qok) store4(crow + df * 16 + lg * 4, o);
+            if constexpr (std::is_same<T, xf32>::value) {
+                if (a.ctx_sp && qok) store_split4(a.ctx_sp + (rowq + q) * (2 * a.ldc) + h * D + df * 16 + lg * 4, a.ldc, o);
+            }
         }
     }
 }
@@ -805,8 +821,12 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) attn_bwd_dq_tiled_kernel(AttnArgs a) {
         }
         T* dqrow = (T*)a.dq + (rowq + (qok ? q : 0)) * a.lddq + h * D;
 #pragma unroll
-        for (int df = 0; df < 4; ++df)
+        for (int df = 0; df < 4; ++df) {
             if (qok) store4(dqrow + df * 16 + lg * 4, acc[df]);
+            if constexpr (std::is_same<T, xf32>::value) {
+                if (a.dqkv_sp && qok) store_split4(a.dqkv_sp + (rowq + q) * (2 * a.lddq) + h * D + df * 16 + lg * 4, a.lddq, acc[df]);
+            }
+        }
     }
 }
 
@@ -979,6 +999,13 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) attn_bwd_dkv_kernel(AttnArgs a) {
         for (int df = 0; df < 4; ++df) {
             store4(dkrow + df * 16 + lg * 4, dkT[df]);
             store4(dvrow + df * 16 + lg * 4, dvT[df]);
+            if constexpr (std::is_same<T, xf32>::value) {
+                if (a.dqkv_sp) {                            // self-attention: dK | dV are column blocks H.. and 2H.. of the dqkv image
+                    bf16* sp = a.dqkv_sp + (rowk + key) * (2 * a.lddk) + h * D + df * 16 + lg * 4;
+                    store_split4(sp + a.nh * D, a.lddk, dkT[df]);
+                    store_split4(sp + 2 * a.nh * D, a.lddk, dvT[df]);
+                }
+            }
         }
     }
 }
@@ -1345,7 +1372,12 @@ int launch_all(int which, const AttnArgs& a, hipStream_t s) {
             VB_LAUNCH((attn_fwd_tiled_kernel<T, NW>), grid, block, fwd_tiled_smem<T>(), s, a);
             return vb_check_launch();
         }
-        VB_LAUNCH((attn_fwd_kernel<T, NKF>), grid, block, sm, s, a);
+        if constexpr (sizeof(T) == 4 && NKF <= 12 && NKF > 4) {      // 4-byte tiles: one workgroup per CU, so it brings 12 / 8 waves itself
+            constexpr int NTHF = NKF > 8 ? 768 : 512;
+            VB_LAUNCH((attn_fwd_kernel<T, NKF, false, false, NTHF>), grid, dim3(NTHF), sm, s, a);
+        } else {
+            VB_LAUNCH((attn_fwd_kernel<T, NKF>), grid, block, sm, s, a);
+        }
     } else {
         // (S <= 64: only 4 of the one-pass kernel's 12 waves own a key fragment -- the two-pass form plus the separate
         //  bias-gradient pass is faster there: 349 + ~85 us against 483 us per layer at 86 k tokens, S = 56)
@@ -1361,6 +1393,7 @@ int launch_all(int which, const AttnArgs& a, hipStream_t s) {
         const size_t sm1 = dq_smem<T, NKF>(), sm2 = dkv_smem<T, NKF>();
         if (sm2 > kMaxLds) return VB_ERR_UNSUPPORTED;
         if (sm1 > kMaxLds) VB_LAUNCH((attn_bwd_dq_tiled_kernel<T, NW>), grid, block, dq_tiled_smem<T>(), s, a);
+        else if constexpr (sizeof(T) == 4 && NKF <= 12 && NKF > 4) VB_LAUNCH((attn_bwd_dq_kernel<T, NKF, 512>), grid, dim3(512), sm1, s, a);
         else VB_LAUNCH((attn_bwd_dq_kernel<T, NKF>), grid, block, sm1, s, a);
         dim3 grid2((unsigned)(a.B * a.nh), (unsigned)(((a.S + 15) / 16 + 3) / 4));
         VB_LAUNCH((attn_bwd_dkv_kernel<T, NKF>), grid2, block, sm2, s, a);
@@ -1387,7 +1420,8 @@ int dispatch_nkf(int which, const AttnArgs& a, hipStream_t s) {
     if (which == 0 && (a.S + 15) / 16 == 11) {      // forward at S = 161..176 without the prefetch (fp32)
         const size_t sm = fwd_smem<T, 11>();
         // (without the prefetch the branch-free form lets the scheduler hoist every fragment read: 612-1448 bytes of scratch, 4x slower)
-        VB_LAUNCH((attn_fwd_kernel<T, 11>), dim3((unsigned)(a.B * a.nh)), dim3(NT), sm, s, a);
+        if constexpr (sizeof(T) == 4) VB_LAUNCH((attn_fwd_kernel<T, 11, false, false, 768>), dim3((unsigned)(a.B * a.nh)), dim3(768), sm, s, a);
+        else VB_LAUNCH((attn_fwd_kernel<T, 11>), dim3((unsigned)(a.B * a.nh)), dim3(NT), sm, s, a);
         return vb_check_launch();
     }
     if (nkf <= 4) return launch_all<T, 4>(which, a, s);
@@ -1484,11 +1518,19 @@ extern "C" int64_t vb_attn_keepbits_words(int S) {
 extern "C" int vb_attn_fwd(int dtype, const void* qkv, const float* mask_add, void* ctx, float* lse,
                            uint64_t* keepbits, int B, int S, int nh, int head_dim,
                            float p_drop, uint64_t seed, uint32_t stream_id, void* stream) {
+    return vb_attn_fwd_sp(dtype, qkv, mask_add, ctx, lse, keepbits, B, S, nh, head_dim, p_drop, seed, stream_id, nullptr, stream);
+}
+
+int vb_attn_fwd_sp(int dtype, const void* qkv, const float* mask_add, void* ctx, float* lse,
+                   uint64_t* keepbits, int B, int S, int nh, int head_dim,
+                   float p_drop, uint64_t seed, uint32_t stream_id, void* ctx_split, void* stream) {
     AttnArgs a{};
     int rc = fill_args(a, B, S, nh, head_dim, p_drop, seed, stream_id);
     if (rc) return rc;
     if (!qkv || !mask_add || !ctx || (p_drop > 0.f && !keepbits)) return VB_ERR_ARG;
+    if (ctx_split && (dtype != VB_BF16X3 || (((uintptr_t)ctx_split) & 7))) return VB_ERR_ARG;
     a.qkv = qkv; a.mask_add = mask_add; a.ctx = ctx; a.lse = lse; a.keepbits = keepbits;
+    a.ctx_sp = (bf16*)ctx_split;
     set_self(a, dtype, qkv, nullptr);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == VB_BF16) return dispatch_nkf<bf16>(0, a, s);
@@ -1507,12 +1549,22 @@ extern "C" int vb_attn_bwd(int dtype, const void* qkv, const float* mask_add, co
                            const uint64_t* keepbits, float* dsum_ws, void* dqkv, const void* ctx_fwd, float* dqkv_bias,
                            int B, int S, int nh, int head_dim,
                            float p_drop, uint64_t seed, uint32_t stream_id, void* stream) {
+    return vb_attn_bwd_sp(dtype, qkv, mask_add, dctx, lse, keepbits, dsum_ws, dqkv, ctx_fwd, dqkv_bias, B, S, nh, head_dim, p_drop, seed,
+                          stream_id, nullptr, stream);
+}
+
+int vb_attn_bwd_sp(int dtype, const void* qkv, const float* mask_add, const void* dctx, const float* lse,
+                   const uint64_t* keepbits, float* dsum_ws, void* dqkv, const void* ctx_fwd, float* dqkv_bias,
+                   int B, int S, int nh, int head_dim,
+                   float p_drop, uint64_t seed, uint32_t stream_id, void* dqkv_split, void* stream) {
     AttnArgs a{};
     int rc = fill_args(a, B, S, nh, head_dim, p_drop, seed, stream_id);
     if (rc) return rc;
     if (!qkv || !mask_add || !dctx || !lse || !dsum_ws || !dqkv || (p_drop > 0.f && !keepbits)) return VB_ERR_ARG;
+    if (dqkv_split && (dtype != VB_BF16X3 || (((uintptr_t)dqkv_split) & 7))) return VB_ERR_ARG;
     a.qkv = qkv; a.mask_add = mask_add; a.dctx = dctx; a.lse = (float*)lse; a.keepbits = (uint64_t*)keepbits;
     a.dsum = dsum_ws; a.dqkv = dqkv; a.ctx_fwd = ctx_fwd;
+    a.dqkv_sp = (bf16*)dqkv_split;
     set_self(a, dtype, qkv, dqkv);
     a.bias_ws = dqkv_bias ? dsum_ws : nullptr;              // the one-pass kernel does not need D in memory: same scratch
     hipStream_t s = (hipStream_t)stream;

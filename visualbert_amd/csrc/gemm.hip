@@ -919,8 +919,12 @@ VB_DEVICE void gemm_epilogue_private(f32x4 (&acc)[8][4], unsigned char* slab, co
     if constexpr (OPT & EPI_COLSUM) epi_colsum_flush(e, g, nw0, lane);
 }
 
-template <typename T, typename TO, int ACT, int OPT, int SCHED>
+// X3: split-operand mode (see GemmArgs): the copy stream walks 3 K / 64 virtual K tiles whose column offsets come from
+// x3_col_a / x3_col_b; the epilogue's row operands are fp32 (TE).  With a virtual K of >= 2304 the per-tile epilogue is a small
+// share and this kernel's lower LDS traffic per FLOP is what counts (profiles/r04_power_by_kernel.txt: +9 % at K = 3072 in bf16).
+template <typename T, typename TO, int ACT, int OPT, int SCHED, bool X3 = false>
 VB_KERNEL VB_LAUNCH_BOUNDS(512) gemm_nt_8ph_kernel(GemmArgs g) {
+    typedef typename std::conditional<X3, float, T>::type TE;
     constexpr int BK = TT<T>::BK, KSTEPS = TT<T>::KSTEPS, EPC = TT<T>::EPC;
     constexpr int HALF = 128 * 128, BUF = 4 * HALF;
     constexpr int SLOT_A0 = 0, SLOT_A1 = 1, SLOT_B0 = 2, SLOT_B1 = 3;
@@ -975,18 +979,19 @@ VB_KERNEL VB_LAUNCH_BOUNDS(512) gemm_nt_8ph_kernel(GemmArgs g) {
     set_load_tile(0);
     auto issueA = [&](int mh, int par) {
         unsigned char* dst = smem + par * BUF + (mh ? SLOT_A1 : SLOT_A0) * HALF + wave * 2048;
-        const unsigned char* src = A + (long)ld_t * (BK * (int)sizeof(T));
+        const unsigned char* src = A + (X3 ? (long)x3_col_a(g, ld_t, BK) * 2 : (long)ld_t * (BK * (int)sizeof(T)));
         vb_glds16(src + offA[mh][0], dst);
         vb_glds16(src + offA[mh][1], dst + 1024);
     };
     auto issueB = [&](int nh, int par) {
         unsigned char* dst = smem + par * BUF + (nh ? SLOT_B1 : SLOT_B0) * HALF + wave * 2048;
-        const unsigned char* src = B + (long)ld_t * (BK * (int)sizeof(T));
+        const unsigned char* src = B + (X3 ? (long)x3_col_b(g, ld_t, BK) * 2 : (long)ld_t * (BK * (int)sizeof(T)));
         vb_glds16(src + offB[nh][0], dst);
         vb_glds16(src + offB[nh][1], dst + 1024);
     };
+    const int nk = X3 ? 3 * g.kseg : g.K / BK;     // K tiles per output tile (split-operand mode: hi.hi, lo.hi, hi.lo segments)
     auto ld_advance = [&]() {
-        if (++ld_t == g.K / BK) { ld_t = 0; ++ld_j; set_load_tile(ld_j); }
+        if (++ld_t == nk) { ld_t = 0; ++ld_j; set_load_tile(ld_j); }
     };
 
     typename VecOf<T>::v8 fa[4][KSTEPS], fb0[2][KSTEPS], fb1[2][KSTEPS];
@@ -1014,7 +1019,6 @@ VB_KERNEL VB_LAUNCH_BOUNDS(512) gemm_nt_8ph_kernel(GemmArgs g) {
         vb_setprio<0>();
     };
 
-    const int nk = g.K / BK;
     const int GK = my_tiles * nk;                  // K tiles in this workgroup's stream
     if constexpr (SCHED == 1) {
         // ---- FOUR-SLOT schedule: two quadrants (32 MFMAs) per slot, half the barriers.  Per K tile g (buffer g & 1):
@@ -1056,7 +1060,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS(512) gemm_nt_8ph_kernel(GemmArgs g) {
                 // output tile finished: drain it while the next tile's first K tiles are already landing
                 int m0, n0;
                 origin(cj, m0, n0);
-                gemm_epilogue_private<T, TO, ACT, OPT>(acc, slab, g, m0 + wr * 128, n0 + wc * 64, lane);
+                gemm_epilogue_private<TE, TO, ACT, OPT>(acc, slab, g, m0 + wr * 128, n0 + wc * 64, lane);
     #pragma unroll
                 for (int mi = 0; mi < 8; ++mi)
     #pragma unroll
@@ -1112,7 +1116,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS(512) gemm_nt_8ph_kernel(GemmArgs g) {
             // output tile finished: drain it while the next tile's first K tiles are already landing
             int m0, n0;
             origin(cj, m0, n0);
-            gemm_epilogue_private<T, TO, ACT, OPT>(acc, slab, g, m0 + wr * 128, n0 + wc * 64, lane);
+            gemm_epilogue_private<TE, TO, ACT, OPT>(acc, slab, g, m0 + wr * 128, n0 + wc * 64, lane);
 #pragma unroll
             for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
@@ -1123,14 +1127,16 @@ VB_KERNEL VB_LAUNCH_BOUNDS(512) gemm_nt_8ph_kernel(GemmArgs g) {
     if (wr == 0) vb_phase_barrier();               // balance the stagger barrier
 }
 
-template <typename T, typename TO, int ACT, int OPT, int SCHED>
+template <typename T, typename TO, int ACT, int OPT, int SCHED, bool X3 = false>
 int launch_8ph_sched(const GemmArgs& g, dim3 grid, dim3 block, int smem_bytes, hipStream_t stream) {
-    return vb_prof_launch(2.0 * g.M * g.N * g.K, (sizeof(T) == 2 ? 0 : 8) | (sizeof(TO) == 4 ? 4 : 0) | 16, stream, [&]() { VB_LAUNCH((gemm_nt_8ph_kernel<T, TO, ACT, OPT, SCHED>), grid, block, smem_bytes, stream, g); });
+    return vb_prof_launch(2.0 * g.M * g.N * g.K, (sizeof(T) == 2 ? 0 : 8) | (sizeof(TO) == 4 ? 4 : 0) | 16 | (X3 ? 256 : 0), stream, [&]() { VB_LAUNCH((gemm_nt_8ph_kernel<T, TO, ACT, OPT, SCHED, X3>), grid, block, smem_bytes, stream, g); });
 }
 template <typename T, typename TO, int ACT, int OPT>
 int launch_8ph_act(const GemmArgs& g, dim3 grid, dim3 block, int smem_bytes, hipStream_t stream) {
-    if (t_opts.nt_kernel != 80) return launch_8ph_sched<T, TO, ACT, OPT, 1>(g, grid, block, smem_bytes, stream);   // four slots
-    return launch_8ph_sched<T, TO, ACT, OPT, 0>(g, grid, block, smem_bytes, stream);                                // eight slots
+#ifdef VB_DEV_KNOBS
+    if (t_opts.nt_kernel == 80) return launch_8ph_sched<T, TO, ACT, OPT, 0>(g, grid, block, smem_bytes, stream);   // eight slots
+#endif
+    return launch_8ph_sched<T, TO, ACT, OPT, 1>(g, grid, block, smem_bytes, stream);                                // four slots
 }
 template <typename T, typename TO>
 int launch_8ph(GemmArgs g, hipStream_t stream) {
@@ -1148,6 +1154,23 @@ int launch_8ph(GemmArgs g, hipStream_t stream) {
         if (wgs >= ntiles) wgs = ntiles;
         else if (wgs >= 8) wgs &= ~7;
         dim3 grid((unsigned)wgs), block(512);
+        if constexpr (sizeof(TO) == 4) {
+            if (g.x3) {                                     // split operands: the same four specialised epilogues as launch_dual
+                const int needs = epi_needs(g, 4, 4);
+                if (!(needs & EPI_RAGGED)) {
+                    if (!g.split_out) {
+                        if (g.act == VB_ACT_NONE && needs == 0) return launch_8ph_sched<T, TO, VB_ACT_NONE, 0, 1, true>(g, grid, block, SM, stream);
+                        if (g.act == VB_ACT_NONE && needs == EPI_ADD) return launch_8ph_sched<T, TO, VB_ACT_NONE, EPI_ADD, 1, true>(g, grid, block, SM, stream);
+                    } else {
+                        if (g.act == VB_ACT_GELU_SAVE_GRAD && needs == 0)
+                            return launch_8ph_sched<T, TO, VB_ACT_GELU_SAVE_GRAD, EPI_SPLIT, 1, true>(g, grid, block, SM, stream);
+                        if (g.act == VB_ACT_MUL_AUX && (needs & ~EPI_COLSUM) == 0)
+                            return launch_8ph_sched<T, TO, VB_ACT_MUL_AUX, EPI_COLSUM | EPI_SPLIT, 1, true>(g, grid, block, SM, stream);
+                    }
+                }
+                return launch_8ph_sched<T, TO, -1, EPI_ALL, 1, true>(g, grid, block, SM, stream);
+            }
+        }
         const int needs = epi_needs(g, sizeof(T), sizeof(TO));
 #define VB_TRY_EPI(A, O) if (g.act == (A) && (needs & ~(O)) == 0) return launch_8ph_act<T, TO, A, O>(g, grid, block, SM, stream)
         if constexpr (kActSpecialised<T, TO>) {
@@ -2121,7 +2144,9 @@ int dispatch_pipe(const GemmArgs& g, hipStream_t s) {
     if (g.x3) {                                            // split operands: the two-workgroup kernel or the two-barrier ones
         const long t256 = (long)((g.M + 255) / 256) * ((g.N + 255) / 256);
         const long t128 = (long)((g.M + 255) / 256) * ((g.N + 127) / 128);
-        if (variant != 22 && variant != 42 && variant != 90) variant = t256 >= 160 ? 90 : (t128 >= 256 ? 42 : 22);   // (never 100 / 101)
+        // the persistent 256x256 kernel when its tiles fill the chip (virtual K >= 3 x 64 tiles per segment: the epilogue share is
+        // small and its lower LDS traffic per FLOP wins); pinning 90 keeps the two-workgroup kernel (A/B runs)
+        if (variant != 22 && variant != 42 && variant != 90 && variant != 81) variant = t256 >= 160 ? 81 : (t128 >= 256 ? 42 : 22);   // (never 100 / 101)
     }
 #ifdef VB_DEV_KNOBS
     if (variant == 200) {

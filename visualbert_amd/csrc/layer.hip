@@ -145,16 +145,21 @@ extern "C" int vb_bert_layer_fwd(int dtype, const void* h_in, const float* mask_
     // 1. packed Q|K|V projection
     VB_TRY(linear(d, h_in, H, sv.sp_hin, wqkv, wk * H, sv.qkv, 3 * H, bqkv, nullptr, VB_ACT_NONE, nullptr, nullptr, nullptr, stream));
     // 2. fused attention
-    VB_TRY(vb_attn_fwd(d.dtype, sv.qkv, mask_add, sv.ctx, sv.lse, sv.keepbits, B, S, nh, 64, p_attn, seed, sid, stream));
+    //    (split-operand mode: the kernels that PRODUCE a GEMM input write its hi | lo image themselves -- the context here, the
+    //     LayerNorm output below, the three output gradients in the backward -- so the only stand-alone split pass left per layer
+    //     is the one over h_in, which the previous layer / the embeddings produced)
+    VB_TRY(vb_attn_fwd_sp(d.dtype, sv.qkv, mask_add, sv.ctx, sv.lse, sv.keepbits, B, S, nh, 64, p_attn, seed, sid,
+                          d.x3 ? sv.sp_ctx : nullptr, stream));
     // 3. attention output projection
-    VB_TRY(linear(d, sv.ctx, H, sv.sp_ctx, wo, wk * H, sc.t_h0, H, bo, nullptr, VB_ACT_NONE, nullptr, nullptr, nullptr, stream));
+    VB_TRY(linear(d, d.x3 ? (const void*)sv.sp_ctx : (const void*)sv.ctx, H, nullptr, wo, wk * H, sc.t_h0, H, bo, nullptr, VB_ACT_NONE,
+                  nullptr, nullptr, nullptr, stream));
     // 4. dropout + residual + LayerNorm
-    VB_TRY(vb_ln_fwd(edt, sc.t_h0, h_in, sv.z1, sv.a_out, sv.mean1, sv.rstd1, g1, b1, M, H, eps, p_hidden, sid + 1,
-                     0.f, 0, seed, stream));
+    VB_TRY(vb_ln_fwd_sp(edt, sc.t_h0, h_in, sv.z1, sv.a_out, sv.mean1, sv.rstd1, g1, b1, M, H, eps, p_hidden, sid + 1,
+                        0.f, 0, seed, d.x3 ? sv.sp_aout : nullptr, 2 * H, stream));
     // 5. FFN in + erf-GELU (GELU' kept for backward)
     //    (split-operand mode: the activation leaves the GEMM as a split image -- only GEMMs read it: FFN-out and its wgrad)
-    VB_TRY(linear(d, sv.a_out, H, sv.sp_aout, wi, wk * H, d.x3 ? (void*)sv.sp_inter : (void*)sv.inter, I, bi, nullptr,
-                  VB_ACT_GELU_SAVE_GRAD, nullptr, sv.pre, nullptr, stream, d.x3));
+    VB_TRY(linear(d, d.x3 ? (const void*)sv.sp_aout : (const void*)sv.a_out, H, nullptr, wi, wk * H,
+                  d.x3 ? (void*)sv.sp_inter : (void*)sv.inter, I, bi, nullptr, VB_ACT_GELU_SAVE_GRAD, nullptr, sv.pre, nullptr, stream, d.x3));
     // 6. FFN out
     VB_TRY(linear(d, d.x3 ? (const void*)sv.sp_inter : (const void*)sv.inter, I, nullptr, wo2, wk * I, sc.t_h1, H, bo2, nullptr,
                   VB_ACT_NONE, nullptr, nullptr, nullptr, stream));
@@ -210,28 +215,32 @@ extern "C" int vb_bert_layer_bwd(int dtype, const void* h_in, const float* mask_
     unsigned char* dz2 = sc.t_h0;                        // d(a_out) through the residual of the output LN
     unsigned char* dfo = p_hidden > 0.f ? sc.t_h1 : dz2; // d(FFN-out dense output)
     // 1. output LayerNorm backward (+ bias gradient of the FFN-out dense as a by-product)
-    VB_TRY(vb_ln_bwd(edt, d_out, sv.z2, sv.mean2, sv.rstd2, g2, dz2, dfo, G[VB_LW_LN2_G], G[VB_LW_LN2_B],
-                     G[VB_LW_FO_B], M, H, p_hidden, sid + 4, 0.f, 0, seed, sc.ln_ws, stream));
+    //    (split-operand mode: + the hi | lo image of dfo, the next dgrad's and the weight-gradient launch's operand)
+    VB_TRY(vb_ln_bwd_sp(edt, d_out, sv.z2, sv.mean2, sv.rstd2, g2, dz2, dfo, G[VB_LW_LN2_G], G[VB_LW_LN2_B],
+                        G[VB_LW_FO_B], M, H, p_hidden, sid + 4, 0.f, 0, seed, sc.ln_ws, d.x3 ? sc.sp_dfo : nullptr, 2 * H, stream));
     // 2. dgrad FFN-out with the saved GELU' folded into the epilogue: dpre = (dfo Wo2) * gelu'(pre)
     //    (+ bias gradient of FFN-in = column sums of dpre, accumulated by the same epilogue)
     //    (split-operand mode: dpre leaves the GEMM as a split image -- only the next dgrad and the wgrad launch read it)
     unsigned char* dpre = d.x3 ? sc.sp_dpre : sc.t_i;
-    VB_TRY(dgrad(dfo, H, wo2, VB_LWT_FO, I, dpre, nullptr, VB_ACT_MUL_AUX, sv.pre, G[VB_LW_FI_B], sc.sp_dfo, d.x3));
+    VB_TRY(dgrad(d.x3 ? (const void*)sc.sp_dfo : (const void*)dfo, H, wo2, VB_LWT_FO, I, dpre, nullptr, VB_ACT_MUL_AUX, sv.pre,
+                 G[VB_LW_FI_B], nullptr, d.x3));
     // 3. dgrad FFN-in + residual gradient: da = dpre Wi + dz2
     VB_TRY(dgrad(dpre, I, wi, VB_LWT_FI, H, sc.t_h2, dz2, VB_ACT_NONE, nullptr, nullptr, nullptr));
     // 4. attention-output LayerNorm backward
     unsigned char* dz1 = sc.t_h5;
     unsigned char* dao = p_hidden > 0.f ? sc.t_h4 : dz1;
-    VB_TRY(vb_ln_bwd(edt, sc.t_h2, sv.z1, sv.mean1, sv.rstd1, g1, dz1, dao, G[VB_LW_LN1_G], G[VB_LW_LN1_B],
-                     G[VB_LW_AO_B], M, H, p_hidden, sid + 1, 0.f, 0, seed, sc.ln_ws, stream));
+    VB_TRY(vb_ln_bwd_sp(edt, sc.t_h2, sv.z1, sv.mean1, sv.rstd1, g1, dz1, dao, G[VB_LW_LN1_G], G[VB_LW_LN1_B],
+                        G[VB_LW_AO_B], M, H, p_hidden, sid + 1, 0.f, 0, seed, sc.ln_ws, d.x3 ? sc.sp_dao : nullptr, 2 * H, stream));
     // 5. dgrad attention-out: dctx = dao Wo
-    VB_TRY(dgrad(dao, H, wo, VB_LWT_AO, H, sc.t_h3, nullptr, VB_ACT_NONE, nullptr, nullptr, sc.sp_dao));
+    VB_TRY(dgrad(d.x3 ? (const void*)sc.sp_dao : (const void*)dao, H, wo, VB_LWT_AO, H, sc.t_h3, nullptr, VB_ACT_NONE, nullptr, nullptr,
+                 nullptr));
     // 6-8. attention backward (one pass for bf16 and S <= 192, else dQ pass + dK/dV pass) + the q | k | v bias gradient
     //      (per-sample sums out of the one-pass kernel's accumulators; a column-sum pass over dqkv otherwise)
-    VB_TRY(vb_attn_bwd(d.dtype, sv.qkv, mask_add, sc.t_h3, sv.lse, sv.keepbits, sc.dsum, sc.t_3h, sv.ctx, G[VB_LW_QKV_B], B, S, nh,
-                       64, p_attn, seed, sid, stream));
+    VB_TRY(vb_attn_bwd_sp(d.dtype, sv.qkv, mask_add, sc.t_h3, sv.lse, sv.keepbits, sc.dsum, sc.t_3h, sv.ctx, G[VB_LW_QKV_B], B, S, nh,
+                          64, p_attn, seed, sid, d.x3 ? sc.sp_dqkv : nullptr, stream));
     // 9. dgrad QKV + residual gradient: dh = dqkv Wqkv + dz1
-    VB_TRY(dgrad(sc.t_3h, 3 * H, wqkv, VB_LWT_QKV, H, d_in, dz1, VB_ACT_NONE, nullptr, nullptr, sc.sp_dqkv));
+    VB_TRY(dgrad(d.x3 ? (const void*)sc.sp_dqkv : (const void*)sc.t_3h, 3 * H, wqkv, VB_LWT_QKV, H, d_in, dz1, VB_ACT_NONE, nullptr,
+                 nullptr, nullptr));
     // 10. the four weight gradients: dW_fo[H,I] += dfo^T inter, dW_fi[I,H] += dpre^T a_out, dW_ao[H,H] += dao^T ctx,
     //     dW_qkv[3H,H] += dqkv^T h_in
     if (d.x3) {

@@ -40,6 +40,7 @@ VB_DEVICE void apply_dropout8(float (&v)[8], const DropSpec& d, uint64_t group) 
 struct LnFwdArgs {
     const void* x; const void* resid; void* z_out; void* y; float* mean; float* rstd;
     const float* gamma; const float* beta; int M, H; float eps; DropSpec din, dout;
+    bf16* y_split; long ld_split;      // fp32 only: also write y as a bf16 hi | lo image [M, ld_split] (split-operand mode), or NULL
 };
 
 template <typename T, int NC>
@@ -110,7 +111,10 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) ln_fwd_kernel(LnFwdArgs a) {
             for (int j = 0; j < 8; ++j) o[j] = gm[j] * ((v[ci][j] - mean) * rstd) + bt[j];
             const long e = (long)row * H + col;
             if (a.dout.p > 0.f) apply_dropout8(o, a.dout, (uint64_t)(rowc * H + colc) >> 3);
-            if (act && col < H) store8((T*)a.y + e, o);
+            if (act && col < H) {
+                store8((T*)a.y + e, o);
+                if constexpr (sizeof(T) == 4) { if (a.y_split) store_split8(a.y_split + (long)row * a.ld_split + col, a.ld_split / 2, o); }
+            }
         }
         if (act && l32 == 0) {
             if (a.mean) a.mean[row] = mean;
@@ -123,6 +127,7 @@ struct LnBwdArgs {
     const void* dy; const void* z; const float* mean; const float* rstd; const float* gamma;
     void* dz; void* dx; float* dgamma; float* dbeta; float* dbias; int M, H; DropSpec din, dout;
     float* partials;     // [gridDim.x][3][H] when the two-stage column reduction is used, else NULL
+    bf16* dx_split; long ld_split;     // fp32 only: also write dx (= dz when no dropout) as a bf16 hi | lo image, or NULL
 };
 
 // reduce this block's per-lane column partials across its 8 half-waves through LDS ([8][H] floats, plain
@@ -259,6 +264,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(NT, MINW) ln_bwd_kernel(LnBwdArgs a) {
                 if (a.din.p > 0.f) apply_dropout8(dz, a.din, (uint64_t)((long)row * H + (ok ? col : 0)) >> 3);
                 if (a.dx != a.dz && ok) store8((T*)a.dx + e, dz);
             }
+            if constexpr (sizeof(T) == 4) { if (a.dx_split && ok) store_split8(a.dx_split + (long)row * a.ld_split + col, a.ld_split / 2, dz); }
             if (a.dbias) {                                   // bias gradient of the Linear in front: column sums of dx
 #pragma unroll
                 for (int j = 0; j < 8; ++j) accx[ci][j] += ok ? dz[j] : 0.f;
@@ -481,10 +487,19 @@ extern "C" int vb_ln_fwd(int dtype, const void* x, const void* resid, void* z_ou
                          const float* gamma, const float* beta, int M, int H, float eps,
                          float p_in, uint32_t stream_in, float p_out, uint32_t stream_out, uint64_t seed,
                          void* stream) {
+    return vb_ln_fwd_sp(dtype, x, resid, z_out, y, mean, rstd, gamma, beta, M, H, eps, p_in, stream_in, p_out, stream_out, seed,
+                        nullptr, 0, stream);
+}
+
+int vb_ln_fwd_sp(int dtype, const void* x, const void* resid, void* z_out, void* y, float* mean, float* rstd,
+                 const float* gamma, const float* beta, int M, int H, float eps,
+                 float p_in, uint32_t stream_in, float p_out, uint32_t stream_out, uint64_t seed,
+                 void* y_split, int64_t ld_split, void* stream) {
     if (!x || !y || !gamma || !beta || M <= 0 || bad_h(H)) return VB_ERR_ARG;
     if (p_in < 0.f || p_in >= 1.f || p_out < 0.f || p_out >= 1.f) return VB_ERR_ARG;
+    if (y_split && (dtype != VB_F32 || (ld_split % 16) || ld_split < 2 * H || (((uintptr_t)y_split) & 15))) return VB_ERR_ARG;
     LnFwdArgs a{x, resid, z_out, y, mean, rstd, gamma, beta, M, H, eps, make_drop(p_in, seed, stream_in),
-                make_drop(p_out, seed, stream_out)};
+                make_drop(p_out, seed, stream_out), (bf16*)y_split, (long)ld_split};
     dim3 grid(row_grid(M, 4096));
     hipStream_t s = (hipStream_t)stream;
     if (dtype == VB_BF16) VB_DISPATCH_NC(ln_fwd_kernel, bf16, H, grid, 0, s, a);
@@ -501,10 +516,20 @@ extern "C" int vb_ln_bwd(int dtype, const void* dy, const void* z, const float* 
                          const float* gamma, void* dz, void* dx, float* dgamma, float* dbeta, float* dbias,
                          int M, int H, float p_in, uint32_t stream_in, float p_out, uint32_t stream_out,
                          uint64_t seed, float* ws, void* stream) {
+    return vb_ln_bwd_sp(dtype, dy, z, mean, rstd, gamma, dz, dx, dgamma, dbeta, dbias, M, H, p_in, stream_in, p_out, stream_out, seed,
+                        ws, nullptr, 0, stream);
+}
+
+int vb_ln_bwd_sp(int dtype, const void* dy, const void* z, const float* mean, const float* rstd,
+                 const float* gamma, void* dz, void* dx, float* dgamma, float* dbeta, float* dbias,
+                 int M, int H, float p_in, uint32_t stream_in, float p_out, uint32_t stream_out,
+                 uint64_t seed, float* ws, void* dx_split, int64_t ld_split, void* stream) {
     if (!dy || !z || !mean || !rstd || !gamma || !dz || M <= 0 || bad_h(H)) return VB_ERR_ARG;
     if (p_in > 0.f && (!dx || dx == dz)) return VB_ERR_ARG;   // dropped and un-dropped grads differ
+    // the image is of dx (the gradient after the input dropout): without dropout that is dz, and the kernel needs a.dx non-NULL
+    if (dx_split && (dtype != VB_F32 || !dx || (ld_split % 16) || ld_split < 2 * H || (((uintptr_t)dx_split) & 15))) return VB_ERR_ARG;
     LnBwdArgs a{dy, z, mean, rstd, gamma, dz, dx, dgamma, dbeta, dbias, M, H, make_drop(p_in, seed, stream_in),
-                make_drop(p_out, seed, stream_out), ws};
+                make_drop(p_out, seed, stream_out), ws, (bf16*)dx_split, (long)ld_split};
     dim3 grid(row_grid(M, ws ? 1024 : 256));
     hipStream_t s = (hipStream_t)stream;
     const size_t smem = (size_t)H * WAVES_PER_BLOCK * 3 * sizeof(float);

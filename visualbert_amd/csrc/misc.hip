@@ -201,12 +201,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) split_rows_kernel(const float* src, long ld_src, 
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = (c0 + j < cols) ? src[r * ld_src + c0 + j] : 0.0f;
         }
-        float lo[8];
-        bf16x8 h;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { h[j] = (bf16)v[j]; lo[j] = v[j] - (float)h[j]; }
-        *(bf16x8*)(dst + r * ld_dst + c0) = h;
-        store8(dst + r * ld_dst + half + c0, lo);
+        store_split8(dst + r * ld_dst + c0, half, v);
     }
 }
 // transposed: a 64 x 64 tile of src through LDS; dst[c, r] = hi, dst[c, half + r] = lo

@@ -77,6 +77,25 @@ VB_DEVICE void store8(float* p, const float (&v)[8]) {
     *(f32x4*)(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
 }
 
+// split-operand images (VB_BF16X3): x -> hi = bf16(x) (RNE) at p[...] and lo = bf16(x - hi) at p[half + ...] -- bit for bit what
+// vb_split_bf16 writes, so a producer kernel can emit the image of its fp32 result itself (one extra 4-byte-per-element store
+// instead of a separate read-4 / write-4 pass)
+VB_DEVICE void store_split8(bf16* p, long half, const float (&v)[8]) {
+    bf16x8 h;
+    float lo[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { h[j] = (bf16)v[j]; lo[j] = v[j] - (float)h[j]; }
+    *(bf16x8*)p = h;
+    store8(p + half, lo);
+}
+VB_DEVICE void store_split4(bf16* p, long half, const f32x4& v) {
+    bf16x4 h, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { h[j] = (bf16)v[j]; l[j] = (bf16)(v[j] - (float)h[j]); }
+    *(bf16x4*)p = h;
+    *(bf16x4*)(p + half) = l;
+}
+
 // ------------------------------------------------------------------------------------------
 // MFMA: one 16x16 output fragment, K step of 32.
 //   A operand: lane l holds A[i = l&15][k = (l>>4)*8 + j], j = 0..7
@@ -537,6 +556,21 @@ static inline int vb_vendor_nt(const VbVendorGemm&, void*) { return VB_ERR_UNSUP
 #else
 __attribute__((visibility("hidden"))) int vb_vendor_nt(const VbVendorGemm& g, void* stream);   // internal: not part of the C ABI
 #endif
+
+// internal forms of vb_ln_fwd / vb_ln_bwd / vb_attn_fwd / vb_attn_bwd used by layer.hip in the split-operand mode (fp32 tensors
+// only): the same call + the bf16 hi | lo image of the result that the next GEMM reads -- y_split [M, ld] (ld >= 2 H), dx_split
+// likewise, ctx_split [B S, 2 H], dqkv_split [B S, 6 H] -- written by the producing kernel.  NULL image = the exported call.
+__attribute__((visibility("hidden"))) int vb_ln_fwd_sp(int dtype, const void* x, const void* resid, void* z_out, void* y, float* mean,
+    float* rstd, const float* gamma, const float* beta, int M, int H, float eps, float p_in, uint32_t stream_in, float p_out,
+    uint32_t stream_out, uint64_t seed, void* y_split, int64_t ld_split, void* stream);
+__attribute__((visibility("hidden"))) int vb_ln_bwd_sp(int dtype, const void* dy, const void* z, const float* mean, const float* rstd,
+    const float* gamma, void* dz, void* dx, float* dgamma, float* dbeta, float* dbias, int M, int H, float p_in, uint32_t stream_in,
+    float p_out, uint32_t stream_out, uint64_t seed, float* ws, void* dx_split, int64_t ld_split, void* stream);
+__attribute__((visibility("hidden"))) int vb_attn_fwd_sp(int dtype, const void* qkv, const float* mask_add, void* ctx, float* lse,
+    uint64_t* keepbits, int B, int S, int nh, int head_dim, float p_drop, uint64_t seed, uint32_t stream_id, void* ctx_split, void* stream);
+__attribute__((visibility("hidden"))) int vb_attn_bwd_sp(int dtype, const void* qkv, const float* mask_add, const void* dctx,
+    const float* lse, const uint64_t* keepbits, float* dsum_ws, void* dqkv, const void* ctx_fwd, float* dqkv_bias, int B, int S, int nh,
+    int head_dim, float p_drop, uint64_t seed, uint32_t stream_id, void* dqkv_split, void* stream);
 
 static inline int vb_check_launch() {
     hipError_t e = hipGetLastError();

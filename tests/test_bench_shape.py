@@ -52,8 +52,10 @@ class Mode:
         self.act = F32 if self.x3 else BF
         self.code = _lib.VB_BF16X3 if self.x3 else _lib.VB_BF16
         if self.x3:
-            self.gemm, self.attn, self.add, self.ln, self.lnb, self.attnb = (2e-4, 1e-4), (2e-4, 1e-4), (1e-6, 1e-6), (1e-4, 5e-5), (2e-4, 1e-4), (5e-4, 2e-4)
-            self.vec, self.vecb, self.dw = 2e-4, 5e-4, 2e-4
+            # <= 2x what MI355X measured at B = 1024 / 512 (profiles/r04_bench_shape_measured.json: GEMM stages <= 2.0e-5 of max|ref|,
+            # attention 1.3e-5 / 1.6e-5, LayerNorm 2.9e-7 / 1.2e-7, column sums <= 3.1e-6, weight gradients <= 7.4e-6)
+            self.gemm, self.attn, self.add, self.ln, self.lnb, self.attnb = (2e-5, 3e-5), (2e-5, 2e-5), (1e-6, 1e-6), (1e-6, 1e-6), (1e-6, 5e-7), (2e-5, 3e-5)
+            self.vec, self.vecb, self.dw = 2e-6, 6e-6, 1.5e-5
         else:
             self.gemm, self.attn, self.add, self.ln, self.lnb, self.attnb = (0.005, 0.004), (0.01, 0.01), (0.004, 0.001), (0.005, 0.004), (0.01, 0.004), (0.02, 0.01)
             self.vec, self.vecb, self.dw = 2e-3, 1e-2, 1e-3
@@ -411,7 +413,7 @@ def test_logits_past_four_giga_elements(dev, mode_name):
     else:
         _lib.check(L.vb_gemm(_lib.VB_BF16, _lib.VB_F32, 0, 0, _lib.ptr(A), K, _lib.ptr(W), K, _lib.ptr(C), ld, M, V, K, 1.0, None,
                              _lib.ptr(bias), None, 0, 0, None, None, 0, 0, None, _lib.stream_ptr()), "vb_gemm")
-    tol = 1e-4 if x3 else 2e-3
+    tol = 1e-5 if x3 else 2e-3            # measured 2.7e-6 (bf16x3)
     rows = torch.tensor([0, 255, 256, 70343, 70344, 70345, 131071, 131072, 140688, 140689, 140690, 140691, 167679, 167680,
                          167935], device=dev)
     ref = A[rows].double() @ W[:V].double().t() + bias.double()

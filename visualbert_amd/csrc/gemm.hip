@@ -2146,7 +2146,11 @@ int dispatch_pipe(const GemmArgs& g, hipStream_t s) {
         const long t128 = (long)((g.M + 255) / 256) * ((g.N + 127) / 128);
         // the persistent 256x256 kernel when its tiles fill the chip (virtual K >= 3 x 64 tiles per segment: the epilogue share is
         // small and its lower LDS traffic per FLOP wins); pinning 90 keeps the two-workgroup kernel (A/B runs)
-        if (variant != 22 && variant != 42 && variant != 90 && variant != 81) variant = t256 >= 160 ? 81 : (t128 >= 256 ? 42 : 22);   // (never 100 / 101)
+        // Measured inside the step at B = 512 (profiles/r04_x3_gemm_ab.txt): the persistent kernel wins where the epilogue is light
+        // (bias only: 614 -> 576 us; + residual gradient: 917 -> 814 us), the two-workgroup kernel where it is heavy -- GELU + GELU'
+        // with a split result (1195 vs 1253 us), x GELU' + column sums (1240 vs 1271 us) and the 30522-wide fp32 logits (5.96 vs 8.15 ms)
+        const bool light = g.act == VB_ACT_NONE && !g.aux_in && !g.aux_out && !g.colsum && !g.split_out && g.N <= 4096;
+        if (variant != 22 && variant != 42 && variant != 90 && variant != 81) variant = t256 >= 160 ? (light ? 81 : 90) : (t128 >= 256 ? 42 : 22);   // (never 100 / 101)
     }
 #ifdef VB_DEV_KNOBS
     if (variant == 200) {

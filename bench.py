@@ -388,7 +388,7 @@ def main():
     ap.add_argument("--text-len", type=int, default=0)
     ap.add_argument("--regions", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--cpu-batch", type=int, default=8, help="batch of the CPU baseline leg (SURVEY 8d: B = 8, >= 3 timed steps after 1 warm-up)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-GEMM HIP-event timing")
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--no-h2d", action="store_true", help="skip the second timed loop that streams every batch from pinned host memory")

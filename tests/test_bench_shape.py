@@ -283,10 +283,12 @@ def test_bert_layer_at_bench_shape(dev, which, mode_name):
     # ---- forward, stage by stage, every row
     close(sv["qkv"], f(P["h_in"]) @ f(P["wqkv"]).t() + P["bqkv"], mode.gemm, "qkv = h_in Wqkv^T + b")
     ctx_ref, _ = _attn_ref(D, sv["qkv"], P["mask_add"])
-    close(sv["ctx"], ctx_ref, mode.attn, "attention context")
+    # split-operand mode: results that only GEMMs read exist ONLY as their hi | lo images (the context here; dfo, dao, dqkv below)
+    ctx = _unsplit(sv["sp_ctx"], H) if mode.x3 else sv["ctx"]
+    close(ctx, ctx_ref, mode.attn, "attention context")
     del ctx_ref
     ao = sc["t_h0"]
-    close(ao, f(sv["ctx"]) @ f(P["wo"]).t() + P["bo"], mode.gemm, "attention-out dense")
+    close(ao, f(ctx) @ f(P["wo"]).t() + P["bo"], mode.gemm, "attention-out dense")
     z1 = f(ao) + f(P["h_in"])
     close(sv["z1"], z1, mode.add, "z1 = attention-out + residual")                  # one fp32 add, one rounding
     close(sv["a_out"], _ln_ref(z1, P["g1"], P["b1"]), mode.ln, "LayerNorm 1")
@@ -298,8 +300,8 @@ def test_bert_layer_at_bench_shape(dev, which, mode_name):
     cdf = 0.5 * (1.0 + torch.erf(x * 0.70710678118654752440))
     close(sv["pre"], cdf + x * torch.exp(-0.5 * x * x) * 0.39894228040143267794, mode.gemm, "saved GELU'")
     del x, cdf
-    if mode.x3:                                   # the kept images of the three other GEMM inputs are exactly split(input)
-        for name, src in (("sp_hin", P["h_in"]), ("sp_ctx", sv["ctx"]), ("sp_aout", sv["a_out"])):
+    if mode.x3:                                   # the kept images of the GEMM inputs that also exist in fp32 are exactly split(input)
+        for name, src in (("sp_hin", P["h_in"]), ("sp_aout", sv["a_out"])):
             assert torch.equal(sv[name], _split(src)), name
     fo = sc["t_h1"]
     close(fo, f(inter) @ f(P["wo2"]).t() + P["bo2"], mode.gemm, "FFN-out dense")
@@ -336,18 +338,18 @@ def test_bert_layer_at_bench_shape(dev, which, mode_name):
     del dz1_ref, xhat1
     dctx = sc["t_h3"]
     close(dctx, f(dz1) @ f(P["wo"]), mode.gemm, "dgrad attention-out")
-    dqkv = sc["t_3h"]
+    dqkv = _unsplit(sc["sp_dqkv"], 3 * H) if mode.x3 else sc["t_3h"]
     _, dqkv_ref = _attn_ref(D, sv["qkv"], P["mask_add"], dctx)
     close(dqkv, dqkv_ref, mode.attnb, "attention backward (dqkv): one workgroup per (sample, head)")
     vec_close(G[QKV_B], dqkv_ref.sum(0), mode.vecb, "q|k|v bias gradient")
     del dqkv_ref
     close(d_in, f(dqkv) @ f(P["wqkv"]) + f(dz1), mode.gemm, "dgrad QKV + residual gradient (d_in)")
-    if mode.x3:                                   # the output gradients' images the weight-gradient launch read
-        for name, src in (("sp_dfo", dz2), ("sp_dao", dz1), ("sp_dqkv", dqkv)):
+    if mode.x3:                                   # the output gradients' images the weight-gradient launch read (p = 0: dfo = dz2, dao = dz1)
+        for name, src in (("sp_dfo", dz2), ("sp_dao", dz1)):
             assert torch.equal(sc[name], _split(src)), name
     # the four weight gradients of the grouped launch (fp32 atomics over token slices)
     for idx, dy, xx, what in ((FO_W, dz2, inter, "dW FFN-out"), (FI_W, dpre, sv["a_out"], "dW FFN-in"),
-                              (AO_W, dz1, sv["ctx"], "dW attention-out"), (QKV_W, dqkv, P["h_in"], "dW QKV")):
+                              (AO_W, dz1, ctx, "dW attention-out"), (QKV_W, dqkv, P["h_in"], "dW QKV")):
         ref = f(dy).t() @ f(xx)
         vec_close(G[idx], ref, mode.dw, what)
         del ref
@@ -368,14 +370,21 @@ def test_bert_layer_dropout_run_is_deterministic(dev, which, mode_name):
         sv = _saved_views(D, saved, kw, mode)
         d_in, G = _run_bwd(D, P, saved, scratch, weights, dev, 0.1, 0.1, mode=mode)
         sc = _scratch_views(D, scratch, mode)
-        outs.append([h_out.clone(), sv["ctx"].clone(), sv["keepbits"].clone(), d_in.clone(), sc["t_3h"].clone(), G[1].clone()])
+        outs.append([h_out.clone(), (sv["sp_ctx"] if mode.x3 else sv["ctx"]).clone(), sv["keepbits"].clone(), d_in.clone(),
+                     (sc["sp_dqkv"] if mode.x3 else sc["t_3h"]).clone(), G[1].clone()])
         if rep == 0:
             assert torch.isfinite(h_out.float()).all() and torch.isfinite(d_in.float()).all()
-            if mode.x3:       # with dropout on, the images the producers wrote are those of the DROPPED gradients (dfo, dao) and of dqkv
-                for name, src in (("sp_dfo", sc["t_h1"]), ("sp_dao", sc["t_h4"]), ("sp_dqkv", sc["t_3h"])):
-                    assert torch.equal(sc[name], _split(src)), name
-                for name, src in (("sp_ctx", sv["ctx"]), ("sp_aout", sv["a_out"])):
-                    assert torch.equal(sv[name], _split(src)), name
+            if mode.x3:
+                # with dropout on, dfo / dao exist only as images, and they are the images of the DROPPED gradients: each element is
+                # either 0 or dz / (1 - p) (one fp32 multiply), and ~10 % are zero; a_out exists in both forms
+                assert torch.equal(sv["sp_aout"], _split(sv["a_out"]))
+                for name, dz in (("sp_dfo", sc["t_h0"]), ("sp_dao", sc["t_h5"])):
+                    v = _unsplit(sc[name], D.H)
+                    kept = v != 0
+                    frac = 1.0 - float(kept.float().mean())
+                    assert 0.09 < frac < 0.11, (name, frac)
+                    want = dz.float() * (1.0 / (1.0 - 0.1))
+                    assert float((v[kept] - want[kept]).abs().max()) <= 2.0 ** -16 * float(want.abs().max()), name
     for a, b, what in zip(outs[0], outs[1], ("h_out", "ctx", "keep-bits", "d_in", "dqkv")):
         assert torch.equal(a, b), what
     # the q|k|v bias gradient: per-workgroup partial sums, then a second stage whose summation order is not fixed -- equal to

@@ -293,6 +293,7 @@ struct AttnArgs {
     // split-operand mode, self-attention only (vb_attn_*_sp): bf16 hi | lo images of the fp32 results written next to them --
     // ctx_sp [B*S, 2H] (half = H), dqkv_sp [B*S, 6H] (half = 3H; dQ | dK | dV column blocks like dqkv) -- or NULL
     bf16* ctx_sp; bf16* dqkv_sp;
+    int sp_only;                     // with an image: do not write the fp32 result at all (only GEMMs read it, and they read the image)
     // General form (self- AND cross-attention; the forward and the two-pass backward kernels read only these): queries come
     // from q [B*Sq rows, pitch ldq], keys / values from k, v [B*S rows, pitch ldk / ldv] -- for self-attention three column
     // blocks of the packed qkv matrix, for cross-attention (LXRT: language attends to vision and back) different tensors
@@ -462,7 +463,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(NTH, (NTH == NT ? 3 : 1)) attn_fwd_kernel(AttnArgs a
                 if (EXACT || ks * 32 < S)
                     acc = vb_mma(frag_tr(ldsVT, tr_pitch<T>(NKVK), df * 16 + li, ks, lg, T()), pb[ks], acc);
             }
-            if (qok) store4(crow + df * 16 + lg * 4, acc);     // lane: query q, d = df*16 + lg*4 + 0..3
+            if (qok && !a.sp_only) store4(crow + df * 16 + lg * 4, acc);     // lane: query q, d = df*16 + lg*4 + 0..3
             if constexpr (std::is_same<T, xf32>::value) {
                 if (a.ctx_sp && qok) store_split4(a.ctx_sp + (rowq + q) * (2 * a.ldc) + h * D + df * 16 + lg * 4, a.ldc, acc);
             }
@@ -569,7 +570,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NTH) attn_bwd_dq_kernel(AttnArgs a) {
                 if (ks * 32 < S)
                     acc = vb_mma(frag_tr(ldsKT, tr_pitch<T>(NK), df * 16 + li, ks, lg, T()), dsb[ks], acc);
             }
-            if (qok) store4(dqrow + df * 16 + lg * 4, acc);
+            if (qok && !a.sp_only) store4(dqrow + df * 16 + lg * 4, acc);
             if constexpr (std::is_same<T, xf32>::value) {
                 if (a.dqkv_sp && qok) store_split4(a.dqkv_sp + (rowq + q) * (2 * a.lddq) + h * D + df * 16 + lg * 4, a.lddq, acc);
             }
@@ -699,7 +700,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) attn_fwd_tiled_kernel(AttnArgs a) {
             f32x4 o;
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[r] = acc[df][r] * inv;
-            if (qok) store4(crow + df * 16 + lg * 4, o);
+            if (qok && !a.sp_only) store4(crow + df * 16 + lg * 4, o);
             if constexpr (std::is_same<T, xf32>::value) {
                 if (a.ctx_sp && qok) store_split4(a.ctx_sp + (rowq + q) * (2 * a.ldc) + h * D + df * 16 + lg * 4, a.ldc, o);
             }
@@ -822,7 +823,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) attn_bwd_dq_tiled_kernel(AttnArgs a) {
         T* dqrow = (T*)a.dq + (rowq + (qok ? q : 0)) * a.lddq + h * D;
 #pragma unroll
         for (int df = 0; df < 4; ++df) {
-            if (qok) store4(dqrow + df * 16 + lg * 4, acc[df]);
+            if (qok && !a.sp_only) store4(dqrow + df * 16 + lg * 4, acc[df]);
             if constexpr (std::is_same<T, xf32>::value) {
                 if (a.dqkv_sp && qok) store_split4(a.dqkv_sp + (rowq + q) * (2 * a.lddq) + h * D + df * 16 + lg * 4, a.lddq, acc[df]);
             }
@@ -997,8 +998,10 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) attn_bwd_dkv_kernel(AttnArgs a) {
         T* dvrow = (T*)a.dv + (rowk + key) * a.lddv + h * D;
 #pragma unroll
         for (int df = 0; df < 4; ++df) {
-            store4(dkrow + df * 16 + lg * 4, dkT[df]);
-            store4(dvrow + df * 16 + lg * 4, dvT[df]);
+            if (!a.sp_only) {
+                store4(dkrow + df * 16 + lg * 4, dkT[df]);
+                store4(dvrow + df * 16 + lg * 4, dvT[df]);
+            }
             if constexpr (std::is_same<T, xf32>::value) {
                 if (a.dqkv_sp) {                            // self-attention: dK | dV are column blocks H.. and 2H.. of the dqkv image
                     bf16* sp = a.dqkv_sp + (rowk + key) * (2 * a.lddk) + h * D + df * 16 + lg * 4;
@@ -1518,19 +1521,19 @@ extern "C" int64_t vb_attn_keepbits_words(int S) {
 extern "C" int vb_attn_fwd(int dtype, const void* qkv, const float* mask_add, void* ctx, float* lse,
                            uint64_t* keepbits, int B, int S, int nh, int head_dim,
                            float p_drop, uint64_t seed, uint32_t stream_id, void* stream) {
-    return vb_attn_fwd_sp(dtype, qkv, mask_add, ctx, lse, keepbits, B, S, nh, head_dim, p_drop, seed, stream_id, nullptr, stream);
+    return vb_attn_fwd_sp(dtype, qkv, mask_add, ctx, lse, keepbits, B, S, nh, head_dim, p_drop, seed, stream_id, nullptr, 0, stream);
 }
 
 int vb_attn_fwd_sp(int dtype, const void* qkv, const float* mask_add, void* ctx, float* lse,
                    uint64_t* keepbits, int B, int S, int nh, int head_dim,
-                   float p_drop, uint64_t seed, uint32_t stream_id, void* ctx_split, void* stream) {
+                   float p_drop, uint64_t seed, uint32_t stream_id, void* ctx_split, int split_only, void* stream) {
     AttnArgs a{};
     int rc = fill_args(a, B, S, nh, head_dim, p_drop, seed, stream_id);
     if (rc) return rc;
-    if (!qkv || !mask_add || !ctx || (p_drop > 0.f && !keepbits)) return VB_ERR_ARG;
+    if (!qkv || !mask_add || (!ctx && !(ctx_split && split_only)) || (p_drop > 0.f && !keepbits)) return VB_ERR_ARG;
     if (ctx_split && (dtype != VB_BF16X3 || (((uintptr_t)ctx_split) & 7))) return VB_ERR_ARG;
     a.qkv = qkv; a.mask_add = mask_add; a.ctx = ctx; a.lse = lse; a.keepbits = keepbits;
-    a.ctx_sp = (bf16*)ctx_split;
+    a.ctx_sp = (bf16*)ctx_split; a.sp_only = (ctx_split && split_only) ? 1 : 0;
     set_self(a, dtype, qkv, nullptr);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == VB_BF16) return dispatch_nkf<bf16>(0, a, s);
@@ -1550,21 +1553,21 @@ extern "C" int vb_attn_bwd(int dtype, const void* qkv, const float* mask_add, co
                            int B, int S, int nh, int head_dim,
                            float p_drop, uint64_t seed, uint32_t stream_id, void* stream) {
     return vb_attn_bwd_sp(dtype, qkv, mask_add, dctx, lse, keepbits, dsum_ws, dqkv, ctx_fwd, dqkv_bias, B, S, nh, head_dim, p_drop, seed,
-                          stream_id, nullptr, stream);
+                          stream_id, nullptr, 0, stream);
 }
 
 int vb_attn_bwd_sp(int dtype, const void* qkv, const float* mask_add, const void* dctx, const float* lse,
                    const uint64_t* keepbits, float* dsum_ws, void* dqkv, const void* ctx_fwd, float* dqkv_bias,
                    int B, int S, int nh, int head_dim,
-                   float p_drop, uint64_t seed, uint32_t stream_id, void* dqkv_split, void* stream) {
+                   float p_drop, uint64_t seed, uint32_t stream_id, void* dqkv_split, int split_only, void* stream) {
     AttnArgs a{};
     int rc = fill_args(a, B, S, nh, head_dim, p_drop, seed, stream_id);
     if (rc) return rc;
-    if (!qkv || !mask_add || !dctx || !lse || !dsum_ws || !dqkv || (p_drop > 0.f && !keepbits)) return VB_ERR_ARG;
+    if (!qkv || !mask_add || !dctx || !lse || !dsum_ws || (!dqkv && !(dqkv_split && split_only)) || (p_drop > 0.f && !keepbits)) return VB_ERR_ARG;
     if (dqkv_split && (dtype != VB_BF16X3 || (((uintptr_t)dqkv_split) & 7))) return VB_ERR_ARG;
     a.qkv = qkv; a.mask_add = mask_add; a.dctx = dctx; a.lse = (float*)lse; a.keepbits = (uint64_t*)keepbits;
     a.dsum = dsum_ws; a.dqkv = dqkv; a.ctx_fwd = ctx_fwd;
-    a.dqkv_sp = (bf16*)dqkv_split;
+    a.dqkv_sp = (bf16*)dqkv_split; a.sp_only = (dqkv_split && split_only) ? 1 : 0;
     set_self(a, dtype, qkv, dqkv);
     a.bias_ws = dqkv_bias ? dsum_ws : nullptr;              // the one-pass kernel does not need D in memory: same scratch
     hipStream_t s = (hipStream_t)stream;
@@ -1582,5 +1585,11 @@ int vb_attn_bwd_sp(int dtype, const void* qkv, const float* mask_add, const void
         return vb_check_launch();
     }
     // two-pass kernels (fp32 parity mode, long sequences): one column-sum pass over dqkv
+    if (a.sp_only) {
+        // no fp32 dqkv exists: the sums of the image's two planes (bf16 [B S, 2 C]: hi | lo) -- the same bytes as one fp32 pass
+        rc = vb_colsum(VB_BF16, dqkv_split, 2 * C, dqkv_bias, nullptr, B * S, C, stream);
+        if (rc != VB_OK) return rc;
+        return vb_colsum(VB_BF16, (const bf16*)dqkv_split + C, 2 * C, dqkv_bias, nullptr, B * S, C, stream);
+    }
     return vb_colsum(dtype == VB_BF16 ? VB_BF16 : VB_F32, dqkv, C, dqkv_bias, nullptr, B * S, C, stream);
 }

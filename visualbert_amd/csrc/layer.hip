@@ -148,8 +148,10 @@ extern "C" int vb_bert_layer_fwd(int dtype, const void* h_in, const float* mask_
     //    (split-operand mode: the kernels that PRODUCE a GEMM input write its hi | lo image themselves -- the context here, the
     //     LayerNorm output below, the three output gradients in the backward -- so the only stand-alone split pass left per layer
     //     is the one over h_in, which the previous layer / the embeddings produced)
+    //    and where ONLY GEMMs read a result -- the context, and in the backward dfo / dao / dqkv -- its fp32 form is not written
+    //    at all (sv.ctx, sc.t_h1 / t_h4 / t_3h stay untouched in this mode)
     VB_TRY(vb_attn_fwd_sp(d.dtype, sv.qkv, mask_add, sv.ctx, sv.lse, sv.keepbits, B, S, nh, 64, p_attn, seed, sid,
-                          d.x3 ? sv.sp_ctx : nullptr, stream));
+                          d.x3 ? sv.sp_ctx : nullptr, 1, stream));
     // 3. attention output projection
     VB_TRY(linear(d, d.x3 ? (const void*)sv.sp_ctx : (const void*)sv.ctx, H, nullptr, wo, wk * H, sc.t_h0, H, bo, nullptr, VB_ACT_NONE,
                   nullptr, nullptr, nullptr, stream));
@@ -216,7 +218,7 @@ extern "C" int vb_bert_layer_bwd(int dtype, const void* h_in, const float* mask_
     unsigned char* dfo = p_hidden > 0.f ? sc.t_h1 : dz2; // d(FFN-out dense output)
     // 1. output LayerNorm backward (+ bias gradient of the FFN-out dense as a by-product)
     //    (split-operand mode: + the hi | lo image of dfo, the next dgrad's and the weight-gradient launch's operand)
-    VB_TRY(vb_ln_bwd_sp(edt, d_out, sv.z2, sv.mean2, sv.rstd2, g2, dz2, dfo, G[VB_LW_LN2_G], G[VB_LW_LN2_B],
+    VB_TRY(vb_ln_bwd_sp(edt, d_out, sv.z2, sv.mean2, sv.rstd2, g2, dz2, d.x3 ? nullptr : dfo, G[VB_LW_LN2_G], G[VB_LW_LN2_B],
                         G[VB_LW_FO_B], M, H, p_hidden, sid + 4, 0.f, 0, seed, sc.ln_ws, d.x3 ? sc.sp_dfo : nullptr, 2 * H, stream));
     // 2. dgrad FFN-out with the saved GELU' folded into the epilogue: dpre = (dfo Wo2) * gelu'(pre)
     //    (+ bias gradient of FFN-in = column sums of dpre, accumulated by the same epilogue)
@@ -229,7 +231,7 @@ extern "C" int vb_bert_layer_bwd(int dtype, const void* h_in, const float* mask_
     // 4. attention-output LayerNorm backward
     unsigned char* dz1 = sc.t_h5;
     unsigned char* dao = p_hidden > 0.f ? sc.t_h4 : dz1;
-    VB_TRY(vb_ln_bwd_sp(edt, sc.t_h2, sv.z1, sv.mean1, sv.rstd1, g1, dz1, dao, G[VB_LW_LN1_G], G[VB_LW_LN1_B],
+    VB_TRY(vb_ln_bwd_sp(edt, sc.t_h2, sv.z1, sv.mean1, sv.rstd1, g1, dz1, d.x3 ? nullptr : dao, G[VB_LW_LN1_G], G[VB_LW_LN1_B],
                         G[VB_LW_AO_B], M, H, p_hidden, sid + 1, 0.f, 0, seed, sc.ln_ws, d.x3 ? sc.sp_dao : nullptr, 2 * H, stream));
     // 5. dgrad attention-out: dctx = dao Wo
     VB_TRY(dgrad(d.x3 ? (const void*)sc.sp_dao : (const void*)dao, H, wo, VB_LWT_AO, H, sc.t_h3, nullptr, VB_ACT_NONE, nullptr, nullptr,
@@ -237,7 +239,7 @@ extern "C" int vb_bert_layer_bwd(int dtype, const void* h_in, const float* mask_
     // 6-8. attention backward (one pass for bf16 and S <= 192, else dQ pass + dK/dV pass) + the q | k | v bias gradient
     //      (per-sample sums out of the one-pass kernel's accumulators; a column-sum pass over dqkv otherwise)
     VB_TRY(vb_attn_bwd_sp(d.dtype, sv.qkv, mask_add, sc.t_h3, sv.lse, sv.keepbits, sc.dsum, sc.t_3h, sv.ctx, G[VB_LW_QKV_B], B, S, nh,
-                          64, p_attn, seed, sid, d.x3 ? sc.sp_dqkv : nullptr, stream));
+                          64, p_attn, seed, sid, d.x3 ? sc.sp_dqkv : nullptr, 1, stream));
     // 9. dgrad QKV + residual gradient: dh = dqkv Wqkv + dz1
     VB_TRY(dgrad(d.x3 ? (const void*)sc.sp_dqkv : (const void*)sc.t_3h, 3 * H, wqkv, VB_LWT_QKV, H, d_in, dz1, VB_ACT_NONE, nullptr,
                  nullptr, nullptr));

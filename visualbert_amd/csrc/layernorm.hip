@@ -525,9 +525,11 @@ int vb_ln_bwd_sp(int dtype, const void* dy, const void* z, const float* mean, co
                  int M, int H, float p_in, uint32_t stream_in, float p_out, uint32_t stream_out,
                  uint64_t seed, float* ws, void* dx_split, int64_t ld_split, void* stream) {
     if (!dy || !z || !mean || !rstd || !gamma || !dz || M <= 0 || bad_h(H)) return VB_ERR_ARG;
-    if (p_in > 0.f && (!dx || dx == dz)) return VB_ERR_ARG;   // dropped and un-dropped grads differ
-    // the image is of dx (the gradient after the input dropout): without dropout that is dz, and the kernel needs a.dx non-NULL
-    if (dx_split && (dtype != VB_F32 || !dx || (ld_split % 16) || ld_split < 2 * H || (((uintptr_t)dx_split) & 15))) return VB_ERR_ARG;
+    if (dx_split && (dtype != VB_F32 || (ld_split % 16) || ld_split < 2 * H || (((uintptr_t)dx_split) & 15))) return VB_ERR_ARG;
+    // the image is of dx (the gradient after the input dropout).  dx == NULL with an image: dx leaves ONLY as the image -- the
+    // kernel still needs a.dx non-NULL to run the dropout on its registers, and a.dx == a.dz suppresses the fp32 store
+    if (dx_split && !dx) dx = dz;
+    else if (p_in > 0.f && (!dx || dx == dz)) return VB_ERR_ARG;   // dropped and un-dropped grads differ
     LnBwdArgs a{dy, z, mean, rstd, gamma, dz, dx, dgamma, dbeta, dbias, M, H, make_drop(p_in, seed, stream_in),
                 make_drop(p_out, seed, stream_out), ws, (bf16*)dx_split, (long)ld_split};
     dim3 grid(row_grid(M, ws ? 1024 : 256));

@@ -560,6 +560,8 @@ __attribute__((visibility("hidden"))) int vb_vendor_nt(const VbVendorGemm& g, vo
 // internal forms of vb_ln_fwd / vb_ln_bwd / vb_attn_fwd / vb_attn_bwd used by layer.hip in the split-operand mode (fp32 tensors
 // only): the same call + the bf16 hi | lo image of the result that the next GEMM reads -- y_split [M, ld] (ld >= 2 H), dx_split
 // likewise, ctx_split [B S, 2 H], dqkv_split [B S, 6 H] -- written by the producing kernel.  NULL image = the exported call.
+// split_only (attention) / dx == NULL (LayerNorm backward): the fp32 form of that result is NOT written at all -- in the layer only
+// GEMMs consume it, and they read the image; the q | k | v bias gradient is then summed from the image's two planes.
 __attribute__((visibility("hidden"))) int vb_ln_fwd_sp(int dtype, const void* x, const void* resid, void* z_out, void* y, float* mean,
     float* rstd, const float* gamma, const float* beta, int M, int H, float eps, float p_in, uint32_t stream_in, float p_out,
     uint32_t stream_out, uint64_t seed, void* y_split, int64_t ld_split, void* stream);
@@ -567,10 +569,11 @@ __attribute__((visibility("hidden"))) int vb_ln_bwd_sp(int dtype, const void* dy
     const float* gamma, void* dz, void* dx, float* dgamma, float* dbeta, float* dbias, int M, int H, float p_in, uint32_t stream_in,
     float p_out, uint32_t stream_out, uint64_t seed, float* ws, void* dx_split, int64_t ld_split, void* stream);
 __attribute__((visibility("hidden"))) int vb_attn_fwd_sp(int dtype, const void* qkv, const float* mask_add, void* ctx, float* lse,
-    uint64_t* keepbits, int B, int S, int nh, int head_dim, float p_drop, uint64_t seed, uint32_t stream_id, void* ctx_split, void* stream);
+    uint64_t* keepbits, int B, int S, int nh, int head_dim, float p_drop, uint64_t seed, uint32_t stream_id, void* ctx_split,
+    int split_only, void* stream);
 __attribute__((visibility("hidden"))) int vb_attn_bwd_sp(int dtype, const void* qkv, const float* mask_add, const void* dctx,
     const float* lse, const uint64_t* keepbits, float* dsum_ws, void* dqkv, const void* ctx_fwd, float* dqkv_bias, int B, int S, int nh,
-    int head_dim, float p_drop, uint64_t seed, uint32_t stream_id, void* dqkv_split, void* stream);
+    int head_dim, float p_drop, uint64_t seed, uint32_t stream_id, void* dqkv_split, int split_only, void* stream);
 
 static inline int vb_check_launch() {
     hipError_t e = hipGetLastError();

@@ -381,7 +381,7 @@ def main():
     ap.add_argument("--strict-dtype", default="both", choices=[d for d in DTYPES if d != "bf16"] + ["both", "none"],
                     help="after the timed bf16 run, also time a short run of the mode that meets the north-star's 1e-3 "
                          "logit tolerance and report it as `strict_mode` (rank 0, N = 1)")
-    ap.add_argument("--strict-batch", type=int, default=512, help="per-GPU batch of the strict-mode leg (fp32 activations)")
+    ap.add_argument("--strict-batch", type=int, default=1024, help="per-GPU batch of the strict-mode leg (fp32 activations: ~190 GB at 1024)")
     ap.add_argument("--strict-steps", type=int, default=0,
                     help="timed steps of the bf16x3 leg; 0 = max(--steps, 50): SURVEY 8d asks for >= 50 steps and the median")
     ap.add_argument("--strict-warmup", type=int, default=0, help="0 = --warmup")

@@ -1587,9 +1587,7 @@ int vb_attn_bwd_sp(int dtype, const void* qkv, const float* mask_add, const void
     // two-pass kernels (fp32 parity mode, long sequences): one column-sum pass over dqkv
     if (a.sp_only) {
         // no fp32 dqkv exists: the sums of the image's two planes (bf16 [B S, 2 C]: hi | lo) -- the same bytes as one fp32 pass
-        rc = vb_colsum(VB_BF16, dqkv_split, 2 * C, dqkv_bias, nullptr, B * S, C, stream);
-        if (rc != VB_OK) return rc;
-        return vb_colsum(VB_BF16, (const bf16*)dqkv_split + C, 2 * C, dqkv_bias, nullptr, B * S, C, stream);
+        return vb_colsum_image(dqkv_split, 2 * C, dqkv_bias, B * S, C, stream);
     }
     return vb_colsum(dtype == VB_BF16 ? VB_BF16 : VB_F32, dqkv, C, dqkv_bias, nullptr, B * S, C, stream);
 }

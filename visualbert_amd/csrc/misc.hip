@@ -70,8 +70,9 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) scatter_rows_kernel(const T* dout, const int64_t*
 // column sums of a T [M,N] matrix, ACCUMULATED into fp32 out[N] (bias gradients):
 // a lane owns 8 consecutive columns, a wave 512; the 4 waves of a block take interleaved rows.
 template <typename T>
+// fold > 0: the matrix is a split image ([M, 2 fold]: hi | lo planes): column c and column fold + c add to the same out[c]
 VB_KERNEL VB_LAUNCH_BOUNDS(NT) colsum_kernel(const T* x, long ld, float* out, const float* scale_dev, int M, int N,
-                                            int rows_per_block) {
+                                            int rows_per_block, int fold) {
     VB_DYN_SMEM(smem);
     float* red = (float*)smem;                       // [4][512]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -110,7 +111,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) colsum_kernel(const T* x, long ld, float* out, co
     const float sc = scale_dev ? scale_dev[0] : 1.f;
     for (int c = threadIdx.x; c < 512; c += NT) {
         const int cc = blockIdx.x * 512 + c;
-        if (cc < N) atomicAdd(&out[cc], (red[c] + red[512 + c] + red[1024 + c] + red[1536 + c]) * sc);
+        if (cc < N) atomicAdd(&out[fold > 0 && cc >= fold ? cc - fold : cc], (red[c] + red[512 + c] + red[1024 + c] + red[1536 + c]) * sc);
     }
 }
 
@@ -292,18 +293,32 @@ extern "C" int vb_scatter_rows(int dtype, const void* dout, const int64_t* index
     return vb_check_launch();
 }
 
-extern "C" int vb_colsum(int dtype, const void* x, int64_t ld, float* out, const float* scale_dev, int M, int N,
-                         void* stream) {
+static int colsum_launch(int dtype, const void* x, int64_t ld, float* out, const float* scale_dev, int M, int N, int fold, void* stream) {
     if (!x || !out || M <= 0 || N <= 0) return VB_ERR_ARG;
     int rb = 64;                                // rows per block (4 waves x 16 rows)
     while ((long)((M + rb - 1) / rb) * ((N + 511) / 512) > 4096) rb *= 2;
     dim3 grid((unsigned)((N + 511) / 512), (unsigned)((M + rb - 1) / rb));
     hipStream_t s = (hipStream_t)stream;
     const size_t smem = 4 * 512 * sizeof(float);
-    if (dtype == VB_BF16) VB_LAUNCH(colsum_kernel<bf16>, grid, dim3(NT), smem, s, (const bf16*)x, (long)ld, out, scale_dev, M, N, rb);
-    else if (dtype == VB_F32) VB_LAUNCH(colsum_kernel<float>, grid, dim3(NT), smem, s, (const float*)x, (long)ld, out, scale_dev, M, N, rb);
+    if (dtype == VB_BF16) VB_LAUNCH(colsum_kernel<bf16>, grid, dim3(NT), smem, s, (const bf16*)x, (long)ld, out, scale_dev, M, N, rb, fold);
+    else if (dtype == VB_F32) VB_LAUNCH(colsum_kernel<float>, grid, dim3(NT), smem, s, (const float*)x, (long)ld, out, scale_dev, M, N, rb, fold);
     else return VB_ERR_ARG;
     return vb_check_launch();
+}
+
+extern "C" int vb_colsum(int dtype, const void* x, int64_t ld, float* out, const float* scale_dev, int M, int N,
+                         void* stream) {
+    return colsum_launch(dtype, x, ld, out, scale_dev, M, N, 0, stream);
+}
+
+// internal (attention.hip): out[c] += sum over rows of (hi + lo)[r, c] of a split image [M, 2 C] (ld_image elements per row)
+int vb_colsum_image(const void* image, int64_t ld_image, float* out, int M, int C, void* stream) {
+    if ((C % 8) || ld_image < 2 * C) return VB_ERR_ARG;
+    if (ld_image != 2 * C) {                     // padded planes: one pass per plane
+        const int rc = colsum_launch(VB_BF16, image, ld_image, out, nullptr, M, C, 0, stream);
+        return rc != VB_OK ? rc : colsum_launch(VB_BF16, (const bf16*)image + ld_image / 2, ld_image, out, nullptr, M, C, 0, stream);
+    }
+    return colsum_launch(VB_BF16, image, ld_image, out, nullptr, M, 2 * C, C, stream);
 }
 
 extern "C" int vb_act_bwd(int dtype, const void* dy, const void* aux, void* dx, int64_t n, int act, void* stream) {

@@ -575,6 +575,8 @@ __attribute__((visibility("hidden"))) int vb_attn_bwd_sp(int dtype, const void* 
     const float* lse, const uint64_t* keepbits, float* dsum_ws, void* dqkv, const void* ctx_fwd, float* dqkv_bias, int B, int S, int nh,
     int head_dim, float p_drop, uint64_t seed, uint32_t stream_id, void* dqkv_split, int split_only, void* stream);
 
+__attribute__((visibility("hidden"))) int vb_colsum_image(const void* image, int64_t ld_image, float* out, int M, int C, void* stream);
+
 static inline int vb_check_launch() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? VB_OK : VB_ERR_LAUNCH;

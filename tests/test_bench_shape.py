@@ -106,8 +106,9 @@ def _carve(buf, specs):
 def _saved_views(D, saved, keep_words, mode=None):
     B, S, H, I, NH, M = D.B, D.S, D.H, D.I, D.NH, D.M
     A = mode.act if mode is not None else BF
-    specs = [("qkv", A, (M, 3 * H)), ("ctx", A, (M, H)), ("z1", A, (M, H)), ("a_out", A, (M, H)), ("pre", A, (M, I)),
-             ("inter", A, (M, I)), ("z2", A, (M, H)), ("lse", torch.float32, (B, NH, S)), ("mean1", torch.float32, (M,)),
+    x3 = mode is not None and mode.x3          # split-operand mode: ctx and the FFN activation exist only as images (zero-size slots)
+    specs = [("qkv", A, (M, 3 * H)), ("ctx", A, (0 if x3 else M, H)), ("z1", A, (M, H)), ("a_out", A, (M, H)), ("pre", A, (M, I)),
+             ("inter", A, (0 if x3 else M, I)), ("z2", A, (M, H)), ("lse", torch.float32, (B, NH, S)), ("mean1", torch.float32, (M,)),
              ("rstd1", torch.float32, (M,)), ("mean2", torch.float32, (M,)), ("rstd2", torch.float32, (M,)),
              ("keepbits", torch.int64, (keep_words,))]
     if mode is not None and mode.x3:            # the forward's split images, kept for the weight-gradient launch

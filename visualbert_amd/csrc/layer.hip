@@ -32,11 +32,12 @@ Saved carve_saved(unsigned char* base, const Dims& d, bool attn_dropout) {
     size_t o = 0;
     auto take = [&](size_t bytes) { unsigned char* p = base ? base + o : nullptr; o += al(bytes); return p; };
     s.qkv = take((size_t)d.M * 3 * d.H * d.es);
-    s.ctx = take((size_t)d.M * d.H * d.es);
+    s.ctx = take(d.x3 ? 0 : (size_t)d.M * d.H * d.es);      // split-operand mode: the context and the FFN activation exist only as
+                                                              // their images (sp_ctx, sp_inter below): only GEMMs read them
     s.z1 = take((size_t)d.M * d.H * d.es);
     s.a_out = take((size_t)d.M * d.H * d.es);
     s.pre = take((size_t)d.M * d.I * d.es);
-    s.inter = take((size_t)d.M * d.I * d.es);
+    s.inter = take(d.x3 ? 0 : (size_t)d.M * d.I * d.es);
     s.z2 = take((size_t)d.M * d.H * d.es);
     s.lse = (float*)take((size_t)d.B * d.nh * d.S * 4);
     s.mean1 = (float*)take((size_t)d.M * 4);
@@ -238,7 +239,7 @@ extern "C" int vb_bert_layer_bwd(int dtype, const void* h_in, const float* mask_
                  nullptr));
     // 6-8. attention backward (one pass for bf16 and S <= 192, else dQ pass + dK/dV pass) + the q | k | v bias gradient
     //      (per-sample sums out of the one-pass kernel's accumulators; a column-sum pass over dqkv otherwise)
-    VB_TRY(vb_attn_bwd_sp(d.dtype, sv.qkv, mask_add, sc.t_h3, sv.lse, sv.keepbits, sc.dsum, sc.t_3h, sv.ctx, G[VB_LW_QKV_B], B, S, nh,
+    VB_TRY(vb_attn_bwd_sp(d.dtype, sv.qkv, mask_add, sc.t_h3, sv.lse, sv.keepbits, sc.dsum, sc.t_3h, d.x3 ? nullptr : sv.ctx, G[VB_LW_QKV_B], B, S, nh,
                           64, p_attn, seed, sid, d.x3 ? sc.sp_dqkv : nullptr, 1, stream));
     // 9. dgrad QKV + residual gradient: dh = dqkv Wqkv + dz1
     VB_TRY(dgrad(d.x3 ? (const void*)sc.sp_dqkv : (const void*)sc.t_3h, 3 * H, wqkv, VB_LWT_QKV, H, d_in, dz1, VB_ACT_NONE, nullptr,

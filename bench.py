@@ -45,6 +45,9 @@ PEAK_HBM_GBPS = 8000.0
 
 # --dtype -> compute dtype handed to the model (visualbert_amd.modeling.set_compute_dtype)
 DTYPES = {"bf16": "bfloat16", "fp32": "float32", "bf16x3": "bf16x3"}
+# the short re-run of this command line that the PMC passes profile (measure_traffic)
+PMC_CHILD_FLAGS = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-profile", "--no-h2d", "--no-parity", "--strict-dtype", "none",
+                   "--no-vendor-leg", "--pmc-traffic", "off"]
 
 # BASELINE.json configs -> (head, text tokens, regions, feature width, label for config.workload)
 WORKLOADS = {
@@ -114,16 +117,16 @@ def respawn_as_ranks(n):
 
 
 def pmc_traffic(batch, key, workload):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/gpu_pmc_traffic.sh ->
-    profiles/pmc_traffic.json): rocprofv3 cannot wrap this process from the inside, so the counters are collected by
-    that script on the same command line and read back here; (None, why) when the file does not match this run."""
+    """HBM bytes per launch of the dominant kernel from the COMMITTED PMC passes (tools/gpu_pmc_traffic.sh ->
+    profiles/pmc_traffic.json): the fallback when the in-run passes (measure_traffic) are switched off or fail;
+    (None, why) when the file does not match this run."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
             d = json.load(f)
     except (OSError, ValueError):
         return None, "no profiles/pmc_traffic.json"
-    if workload != "pretrain" or d.get("per_gpu_batch") != batch or (key & 15):
+    if workload != "pretrain" or d.get("per_gpu_batch") != batch or (key & 15) or (key & 256):
         return None, "committed PMC pass is for another configuration"
     fam = "gemm_nt_dual_kernel<bf16->bf16>" if key & 64 else ("gemm_nt_8ph_kernel<bf16->bf16>" if key & 16 else None)
     ent = d.get("kernels", {}).get(fam)
@@ -132,6 +135,71 @@ def pmc_traffic(batch, key, workload):
     return ent["traffic_bytes_per_launch"], ("committed PMC pass profiles/pmc_traffic.json (tools/gpu_pmc_traffic.sh: separate "
                                              "FETCH_SIZE / WRITE_SIZE runs of this command, 2 x FETCH_SIZE + WRITE_SIZE); "
                                              "not measured inside this run")
+
+
+def kernel_name_filter(key):
+    """(substring, x3?) that picks the dominant GEMM family's instantiations out of rocprofv3's (mangled) kernel names"""
+    if key & 3:
+        return None
+    to = "f" if key & 4 else "DF16b"
+    if key & 64:
+        return "gemm_nt_dual_kernelI" + to, bool(key & 256)
+    if key & 16:
+        return "gemm_nt_8ph_kernelIDF16b" + to, bool(key & 256)
+    return None
+
+
+def measure_traffic(key, child_args, timeout=240):
+    """HBM traffic per launch of the dominant kernel, MEASURED FOR THIS RUN: rocprofv3 cannot wrap a process from the inside, so
+    bench.py re-runs its own command line twice (2 steps each) as `rocprofv3 --kernel-trace --pmc <counter>` children -- separate
+    FETCH_SIZE and WRITE_SIZE passes, kernel trace only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes -- and sums the
+    counters over the launches of that kernel family: 2 x FETCH_SIZE (gfx950 tallies the 128-byte requests of wide coalesced
+    reads at 64 B) + WRITE_SIZE, both reported in KB.  -> (bytes per launch, source string) or (None, why)."""
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    flt = kernel_name_filter(key)
+    exe = shutil.which("rocprofv3")
+    if flt is None or exe is None:
+        return None, "no rocprofv3 on this machine" if exe is None else "dominant kernel is not an NT GEMM family"
+    sub, x3 = flt
+    per_launch, launches = {}, 0
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="vb_pmc_", dir="/tmp")
+        cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__)] + child_args
+        try:
+            subprocess.run(cmd, env=env, cwd="/tmp", timeout=timeout, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                           start_new_session=True)
+            dbs = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith("_results.db")]
+            if not dbs:
+                return None, "rocprofv3 --pmc %s pass left no results database" % counter
+            cur = sqlite3.connect(dbs[0]).cursor()
+            cols = [r[1] for r in cur.execute("pragma table_info(counters_collection)").fetchall()]
+            kcol = "kernel_name" if "kernel_name" in cols else "name"
+            vcol = "value" if "value" in cols else "counter_value"
+            dcol = "dispatch_id" if "dispatch_id" in cols else kcol
+            total, calls = 0.0, 0
+            for name, v, n in cur.execute("select %s, sum(%s), count(distinct %s) from counters_collection group by %s"
+                                          % (kcol, vcol, dcol, kcol)).fetchall():
+                if sub in name and (("Lb1E" in name) == x3):
+                    total += float(v)
+                    calls += int(n)
+            if not calls:
+                return None, "no launches of %s in the %s pass" % (sub, counter)
+            per_launch[counter], launches = total * 1024.0 / calls, calls
+        except (subprocess.TimeoutExpired, sqlite3.Error, OSError) as e:
+            return None, "rocprofv3 --pmc %s pass failed: %r" % (counter, e)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    traffic = 2.0 * per_launch["FETCH_SIZE"] + per_launch["WRITE_SIZE"]
+    return int(round(traffic)), ("measured by this run: two `rocprofv3 --kernel-trace --pmc` children of this command line "
+                                 "(FETCH_SIZE, WRITE_SIZE; %d launches of the kernel family; 2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes); "
+                                 "fetch %.0f MB + write %.0f MB per launch"
+                                 % (launches, 2.0 * per_launch["FETCH_SIZE"] / 1e6, per_launch["WRITE_SIZE"] / 1e6))
 
 
 def measured_mfma_ceiling(dev):
@@ -233,14 +301,30 @@ def timed_steps(mw, batch, steps, warmup, barrier, profile=True):
     return elapsed, median_ms, summ
 
 
-def roofline_of(summ, steps, peak, batch, workload):
+def traffic_for(key, batch, workload, child_args):
+    """roofline.traffic: measured for this run when child_args is given (measure_traffic), else / on failure the committed pass"""
+    traffic, src = (None, "switched off (--pmc-traffic off, or N > 1)")
+    if child_args is not None:
+        traffic, src = measure_traffic(key, child_args)
+    if traffic is None:
+        why = src
+        traffic, src = pmc_traffic(batch, key, workload)
+        src = "%s [in-run PMC passes: %s]" % (src, why)
+    return traffic, src
+
+
+def dominant_key(summ):
+    return max(summ.items(), key=lambda kv: kv[1]["ms"])[0]
+
+
+def roofline_of(summ, steps, peak, batch, workload, traffic_child_args=None):
     """dominant kernel = the GEMM instantiation with the largest total HIP-event time inside the timed region; achieved =
     its algorithmic FLOPs (2 M N K per launch: the split-operand mode's three MFMA passes are NOT counted three times) over its
     summed launch durations."""
     from visualbert_amd import ops
     key, d = max(summ.items(), key=lambda kv: kv[1]["ms"])
     ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
-    traffic, traffic_src = pmc_traffic(batch, key, workload)
+    traffic, traffic_src = traffic_for(key, batch, workload, traffic_child_args)
     return dict(bound="mfma", achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
                 traffic=traffic, traffic_source=traffic_src,
                 kernel=ops.gemm_key_name(key),
@@ -257,7 +341,7 @@ def roofline_of(summ, steps, peak, batch, workload):
                            for k, v in summ.items()})
 
 
-def strict_mode(dev, head, T, R, Dv, V, batch, steps, warmup, dtype_name, flops_per_sample_, workload, full=True):
+def strict_mode(dev, head, T, R, Dv, V, batch, steps, warmup, dtype_name, flops_per_sample_, workload, full=True, pmc=False):
     """the mode that MEETS the north-star's logit tolerance (<= 1e-3 against the fp32 reference), measured on the same step
     (dropout on, dense decoder, BertAdam) with the same loop as the headline (timed_steps) and -- full=True -- its own roofline
     object, plus its max|dlogit| against the oracle on the B = 2 side batch.  The headline `value` stays the bf16 number
@@ -286,10 +370,13 @@ def strict_mode(dev, head, T, R, Dv, V, batch, steps, warmup, dtype_name, flops_
                tflops=round(batch / dt * flops_per_sample_ / 1e12, 1),
                step_mfu=round(batch / dt * flops_per_sample_ / (peak * 1e12), 4))
     if full and summ:
-        out["roofline"] = roofline_of(summ, steps, peak, batch, workload)
+        del mw, model, b                            # the PMC children need the memory
+        torch.cuda.empty_cache()
+        child = ["--workload", workload, "--dtype", dtype_name, "--batch", str(batch)] + PMC_CHILD_FLAGS if pmc else None
+        out["roofline"] = roofline_of(summ, steps, peak, batch, workload, child)
         out["roofline"]["note"] = ("algorithmic FLOPs: the three bf16 MFMA passes of a split-operand product count once; the matrix "
                                    "pipe executes 3 x `achieved`")
-    del mw, model, b
+    mw = model = b = None
     torch.cuda.empty_cache()
     return out
 
@@ -402,6 +489,9 @@ def main():
                     help="skip the extra timed leg with the plain GEMMs on hipBLASLt (N = 1 only; never part of `value`)")
     ap.add_argument("--nt-kernel", type=int, default=0,
                     help="vb_stream_opts.nt_kernel for the whole run (0 = chosen per shape; 81 / 90 for A/B runs)")
+    ap.add_argument("--pmc-traffic", default="auto", choices=["auto", "off"],
+                    help="auto (N = 1): measure roofline.traffic for THIS run with two rocprofv3 --pmc children of the same command "
+                         "line (adds ~1 min per timed mode); off: report the committed PMC pass (profiles/pmc_traffic.json) or null")
     ap.add_argument("--selftest-launch", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -578,13 +668,22 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         cpu = strict = None
-        if world == 1 and args.strict_dtype != "none" and args.dtype == "bf16":
+        pmc_on = world == 1 and args.pmc_traffic == "auto"
+        if pmc_on and roofline is not None:
+            # the PMC children re-run this command line: give them the memory first
             del mw, model, batch
+            batch = mw = model = None
+            torch.cuda.empty_cache()
+            child = ["--workload", args.workload, "--dtype", args.dtype, "--batch", str(B)] + \
+                    (["--nt-kernel", str(args.nt_kernel)] if args.nt_kernel else []) + PMC_CHILD_FLAGS
+            roofline["traffic"], roofline["traffic_source"] = traffic_for(dominant_key(summ), B, args.workload, child)
+        if world == 1 and args.strict_dtype != "none" and args.dtype == "bf16":
+            batch = mw = model = None
             torch.cuda.empty_cache()
             kinds = ["bf16x3", "fp32"] if args.strict_dtype == "both" else [args.strict_dtype]
             n_strict = args.strict_steps or max(args.steps, 50)
             strict = strict_mode(dev, head, T, R, Dv, V, args.strict_batch, n_strict, args.strict_warmup or args.warmup,
-                                 kinds[0], fps, args.workload)
+                                 kinds[0], fps, args.workload, pmc=pmc_on)
             for extra in kinds[1:]:                         # the exact fp32 kernels: a short run (they are 3x slower still)
                 strict[extra + "_kernels"] = strict_mode(dev, head, T, R, Dv, V, min(args.strict_batch, 256), 6, 2, extra, fps,
                                                          args.workload, full=False)

@@ -138,15 +138,30 @@ def pmc_traffic(batch, key, workload):
 
 
 def kernel_name_filter(key):
-    """(substring, x3?) that picks the dominant GEMM family's instantiations out of rocprofv3's (mangled) kernel names"""
+    """predicate over rocprofv3's kernel names that picks the dominant GEMM family's instantiations.  rocprofv3 demangles some
+    instantiations and leaves others mangled (its demangler trips over the __bf16 template argument), so both spellings are
+    matched: family name, split-operand flag (last template argument), output type."""
     if key & 3:
         return None
-    to = "f" if key & 4 else "DF16b"
-    if key & 64:
-        return "gemm_nt_dual_kernelI" + to, bool(key & 256)
-    if key & 16:
-        return "gemm_nt_8ph_kernelIDF16b" + to, bool(key & 256)
-    return None
+    fam = "gemm_nt_dual_kernel" if key & 64 else ("gemm_nt_8ph_kernel" if key & 16 else None)
+    if fam is None:
+        return None
+    x3, to_f32 = bool(key & 256), bool(key & 4)
+
+    def match(name):
+        if fam not in name:
+            return False
+        if (("Lb1E" in name) or (", true>" in name)) != x3:
+            return False
+        if x3:
+            return True                                       # every split-operand instantiation writes fp32 (or a split image)
+        if fam + "I" in name:                                 # mangled: dual <TO, ...>, 8ph <T, TO, ...>
+            tag = fam + ("I" if key & 64 else "IDF16b") + ("f" if to_f32 else "DF16b")
+            return tag in name
+        if key & 64:                                          # demangled: the first template argument is the output type
+            return (fam + "<float" in name) == to_f32
+        return ("_Accum, float" in name) == to_f32
+    return match
 
 
 def measure_traffic(key, child_args, timeout=240):
@@ -159,11 +174,10 @@ def measure_traffic(key, child_args, timeout=240):
     import sqlite3
     import subprocess
     import tempfile
-    flt = kernel_name_filter(key)
+    match = kernel_name_filter(key)
     exe = shutil.which("rocprofv3")
-    if flt is None or exe is None:
+    if match is None or exe is None:
         return None, "no rocprofv3 on this machine" if exe is None else "dominant kernel is not an NT GEMM family"
-    sub, x3 = flt
     per_launch, launches = {}, 0
     env = dict(os.environ, TMPDIR="/tmp")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
@@ -185,11 +199,11 @@ def measure_traffic(key, child_args, timeout=240):
             total, calls = 0.0, 0
             for name, v, n in cur.execute("select %s, sum(%s), count(distinct %s) from counters_collection group by %s"
                                           % (kcol, vcol, dcol, kcol)).fetchall():
-                if sub in name and (("Lb1E" in name) == x3):
+                if match(name):
                     total += float(v)
                     calls += int(n)
             if not calls:
-                return None, "no launches of %s in the %s pass" % (sub, counter)
+                return None, "no launches of the dominant kernel family in the %s pass" % counter
             per_launch[counter], launches = total * 1024.0 / calls, calls
         except (subprocess.TimeoutExpired, sqlite3.Error, OSError) as e:
             return None, "rocprofv3 --pmc %s pass failed: %r" % (counter, e)

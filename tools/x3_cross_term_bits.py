@@ -1,0 +1,86 @@
+#!/usr/bin/env python
+"""VERDICT r03 "Next" 1(d): do the two CROSS terms of the split-operand product (lo.hi and hi.lo, 2^-9 below hi.hi) survive being
+rounded to fewer bits -- i.e. could they ride a cheaper matrix pipe (fp8 MFMA runs at twice the bf16 rate on gfx950)?
+
+CPU experiment on the oracle (test infrastructure), BERT-base VisualBERT pre-training forward, BASELINE configs[1] shapes: every
+nn.Linear of the model is replaced by   y = hi_x.hi_w + q_lo(lo_x).q_hi(hi_w) + q_hi(hi_x).q_lo(lo_w)   with hi = bf16(v), lo = v - hi
+and q_n = round-to-nearest-even to n significant bits (8 = bf16 = what the kernels do; 4 = fp8 e4m3; 3 = fp8 e5m2; exponent range
+is NOT limited here, i.e. perfect per-block scaling is assumed -- an optimistic bound for an fp8 pipe).  The attention core stays
+exact.  max|dlogit| against the fp32 forward is what the north-star bounds at 1e-3.
+
+    python tools/x3_cross_term_bits.py [--batch 2] > profiles/r04_x3_cross_term_bits.txt
+"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+from oracle import visualbert_oracle as vo  # noqa: E402
+
+
+def bf16(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def rnd(x, bits):
+    if bits >= 24:
+        return x
+    m, e = torch.frexp(x)
+    return torch.ldexp(torch.round(m * (1 << bits)) / (1 << bits), e)
+
+
+def make_linear(bits_hi, bits_lo, cross=True):
+    def linear(x, w, b, mode, part="enc"):
+        xh, wh = bf16(x), bf16(w)
+        y = F.linear(xh, wh)
+        if cross:
+            xl, wl = x - xh, w - wh
+            y = y + F.linear(rnd(xl, bits_lo), rnd(wh, bits_hi)) + F.linear(rnd(xh, bits_hi), rnd(wl, bits_lo))
+        return y if b is None else y + b
+    return linear
+
+
+ARMS = [("hi.hi only (plain bf16 operands in every Linear)", None),
+        ("cross terms on bf16 operands: hi 8 bits, lo 8 bits  (= the bf16x3 kernels)", (8, 8)),
+        ("cross terms: hi 6 bits, lo 6 bits", (6, 6)),
+        ("cross terms: hi 5 bits, lo 5 bits", (5, 5)),
+        ("cross terms on fp8 e4m3-like operands: hi 4 bits, lo 4 bits", (4, 4)),
+        ("cross terms: hi 4 bits, lo 8 bits (only the LARGE operand of each cross term narrowed)", (4, 8)),
+        ("cross terms on fp8 e5m2-like operands: hi 3 bits, lo 3 bits", (3, 3))]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=2)
+    ap.add_argument("--seeds", type=int, nargs="+", default=[11, 12])
+    args = ap.parse_args()
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    cfg = vo.OracleConfig(**vo.CONFIGS["base"])
+    print("# split-operand product with NARROWED cross terms: BERT-base VisualBERT pre-training forward, B=%d x (128 tok + 36 regions), "
+          "ragged; every nn.Linear emulated, attention core exact; reference = the fp32 forward; north-star tolerance 1e-3" % args.batch)
+    orig = vo.linear
+    for seed in args.seeds:
+        sd = vo.synth_state_dict(cfg, "pretraining", seed)
+        batch = vo.synth_batch(cfg, args.batch, 128, 36, seed, "pretraining", ragged=True)
+        with torch.no_grad():
+            ref = vo.objective_forward(sd, cfg, "pretraining", mode="fp32", **batch)["logits"]
+        print("\nseed %d: fp32 logits absmax %.3f" % (seed, float(ref.abs().max())))
+        for name, bits in ARMS:
+            vo.linear = make_linear(0, 0, cross=False) if bits is None else make_linear(*bits)
+            try:
+                with torch.no_grad():
+                    lg = vo.objective_forward(sd, cfg, "pretraining", mode="fp32", **batch)["logits"]
+            finally:
+                vo.linear = orig
+            d = (lg - ref).abs()
+            print("  %-92s max|dlogit| %.3e  mean %.3e  %s" % (name, float(d.max()), float(d.mean()),
+                                                              "meets 1e-3" if float(d.max()) <= 1e-3 else "MISSES 1e-3"))
+            sys.stdout.flush()
+
+
+if __name__ == "__main__":
+    main()

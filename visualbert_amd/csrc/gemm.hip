@@ -2301,6 +2301,10 @@ extern "C" int vb_wgrad_grouped(int dtype, int n, const void* const* dy, const i
         // split operands [tokens][hi | lo]: dW += dy_hi^T x_hi + dy_lo^T x_hi + dy_hi^T x_lo -- three passes of the bf16 path
         // over the planes (the accumulation into the fp32 dW is what the kernel does anyway)
         const void* dyp[VB_TN_MAX]; const void* xp[VB_TN_MAX];
+        struct ProfScope {                                   // launch records: algorithmic FLOPs (the three passes sum to 2 M N K), tagged
+            ProfScope() { t_vb_prof_scale = 1.0 / 3.0; t_vb_prof_key_or = 256; }
+            ~ProfScope() { t_vb_prof_scale = 1.0; t_vb_prof_key_or = 0; }
+        } prof_scope;
         for (int pass = 0; pass < 3; ++pass) {
             for (int i = 0; i < n; ++i) {
                 if ((ld_dy[i] % 16) || (ld_x[i] % 16) || n_out[i] > ld_dy[i] / 2 || n_in[i] > ld_x[i] / 2) return VB_ERR_UNSUPPORTED;

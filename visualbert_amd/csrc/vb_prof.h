@@ -5,6 +5,10 @@
 #pragma once
 #include "vb_rt.h"
 #include <stdint.h>
+// a caller that runs ONE algorithmic product as several launches (the split-operand weight gradient: three plane pairs) scales
+// the recorded FLOPs so that their sum is the algorithmic figure, and tags the records (key bit 256 = split operands)
+static thread_local double t_vb_prof_scale = 1.0;
+static thread_local int t_vb_prof_key_or = 0;
 #ifndef VB_EMU
 #include <mutex>
 #include <utility>
@@ -28,7 +32,7 @@ static inline int vb_prof_launch(double flops, int key, hipStream_t stream, F&& 
     if (t_vb_prof) {
         VbProfRec r;
         if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return VB_ERR_LAUNCH;
-        r.flops = flops; r.key = key;
+        r.flops = flops * t_vb_prof_scale; r.key = key | t_vb_prof_key_or;
         (void)hipEventRecord(r.e0, stream);
         launch();
         (void)hipEventRecord(r.e1, stream);

@@ -69,3 +69,26 @@ def test_driver_command_two_ranks_end_to_end(dev):
     assert d["parity"] and d["parity"]["max_dlogit_vs_fp32_ref"] < 0.1
     assert d["value"] > 0 and d["final_loss"] == d["final_loss"]
     assert 5.0 < d["final_loss"] < 15.0                             # ~ln(30522) + ln 2 after three steps from random weights
+
+
+def test_pmc_kernel_name_matcher():
+    """bench.py's in-run PMC traffic leg picks the dominant GEMM family out of rocprofv3's kernel names, which arrive mangled for
+    some instantiations and (mis)demangled for others (the demangler trips over __bf16): both spellings, output type and the
+    split-operand flag must be told apart (names as rocprofv3 printed them on MI355X, profiles/r04_final_kernel_stats_*.txt)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    mangled_dual_bf16 = "_ZN12_GLOBAL__N_119gemm_nt_dual_kernelIDF16bLi0ELi1ELi3ELb0EEEvNS_8GemmArgsE"
+    demangled_dual_bf16 = "gemm_nt_dual_kernel<bool _Accum, int, ELi4E, 3, false>(GemmArgs)"
+    dual_f32 = "gemm_nt_dual_kernel<float, 0, 2, 3, false>(GemmArgs)"
+    dual_x3 = "gemm_nt_dual_kernel<float, 4, 8, 3, true>(GemmArgs)"
+    ph8_bf16 = "_ZN12_GLOBAL__N_118gemm_nt_8ph_kernelIDF16bDF16bLi0ELi0ELi1ELb0EEEvNS_8GemmArgsE"
+    ph8_x3 = "gemm_nt_8ph_kernel<bool _Accum, 0, 0, 1, true>(GemmArgs)"
+    ph8_x3_mangled = "_ZN12_GLOBAL__N_118gemm_nt_8ph_kernelIDF16bfLi0ELi0ELi1ELb1EEEvNS_8GemmArgsE"
+    names = [mangled_dual_bf16, demangled_dual_bf16, dual_f32, dual_x3, ph8_bf16, ph8_x3, ph8_x3_mangled, "gemm_tn_8ph_kernel(TnArgs)"]
+    pick = lambda key: [n for n in names if bench.kernel_name_filter(key)(n)]
+    assert pick(64) == [mangled_dual_bf16, demangled_dual_bf16]            # the bf16 headline's dominant family
+    assert pick(64 | 4) == [dual_f32]                                      # its fp32-logit instantiation
+    assert pick(64 | 4 | 256) == [dual_x3]
+    assert pick(16) == [ph8_bf16]
+    assert pick(16 | 4 | 256) == [ph8_x3, ph8_x3_mangled]                  # the strict leg's dominant family
+    assert bench.kernel_name_filter(1) is None and bench.kernel_name_filter(19) is None    # not an NT GEMM family

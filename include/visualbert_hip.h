@@ -324,7 +324,10 @@ int vb_act_bwd(int dtype, const void* dy, const void* aux, void* dx, int64_t n, 
  *   weights[VB_LW_COUNT]: matrices in T ([3H,H] packed q|k|v, [H,H], [I,H], [H,I]); biases and LayerNorm
  *                         parameters fp32.   grads[VB_LW_COUNT]: fp32 accumulation targets, same order.
  *   saved  : vb_bert_layer_saved_bytes() bytes written by forward, read by backward (qkv, ctx, lse,
- *            keep-bits, pre-LN sums + statistics, attention output, FFN pre-activation and activation)
+ *            keep-bits, pre-LN sums + statistics, attention output, FFN pre-activation and activation).
+ *            The layout is the library's business (opaque to the caller).  VB_BF16X3: tensors that only GEMMs
+ *            read -- the context and the FFN activation here; dfo, dao, dqkv, d(pre-activation) in the scratch
+ *            during backward -- exist ONLY as their bf16 hi | lo images, written by the kernels that produce them
  *   scratch: vb_bert_layer_scratch_bytes() bytes of temporaries, reusable by every layer on one stream
  *   h_in/h_out/d_out/d_in: T [B*S, H];  mask_add: fp32 [B,S].  Dropout sites use stream ids sid..sid+4.
  * ---------------------------------------------------------------------------------------------- */

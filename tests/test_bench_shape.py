@@ -7,8 +7,8 @@ the chain of per-stage checks covers the whole layer, over EVERY row -- not a sa
 
   test_bert_layer_at_bench_shape      vb_bert_layer_fwd / vb_bert_layer_bwd, B = 1024, S = 164, ragged masks, p = 0 -- in bf16 AND in
                                       the split-operand bf16x3 mode (fp32 activations, [M, 2K] hi | lo operand images, three K
-                                      segments, split epilogues, split-operand attention) at B = 1024 and at the strict-mode
-                                      bench leg's B = 512, with fp32-class tolerances ("missing" 4)
+                                      segments, split epilogues, split-operand attention) at B = 1024 (the strict-mode bench leg's
+                                      batch) and at B = 512, with fp32-class tolerances ("missing" 4)
   test_bert_layer_dropout_run_is_deterministic   the same call with p = 0.1 twice: bit-identical activations and input
                                       gradients (a race in an asynchronous copy pipeline shows up as a flipped bit)
   test_logits_past_four_giga_elements decoder GEMM + vb_ce_fwd_bwd_rows on both sides of the 2^31- and 2^32-element marks
@@ -37,7 +37,7 @@ class Dims:
 
 
 BENCH = Dims(1024, 164, 768, 3072, 12)       # bench.py's default per-GPU batch (configs[1])
-BENCH512 = Dims(512, 164, 768, 3072, 12)     # bench.py's strict-mode (bf16x3) leg
+BENCH512 = Dims(512, 164, 768, 3072, 12)     # half the bench batch (other tile counts per launch, other workgroup walks)
 SMALL = Dims(3, 164, 128, 256, 2)            # the same checks at a size the kernel-logic simulator finishes (VB_EMU=1)
 F32 = torch.float32
 

@@ -868,6 +868,18 @@ VB_DEVICE void gemm_epilogue_fragrow(f32x4 (&a)[4], unsigned char* slab, const G
     }
     vb_wave_sync();
 }
+// developer library: pause after every fragment row of the epilogue (debug bits 20-21: 256 / 1024 / 3072 cycles) -- spreads a wave's 16
+// stores in time so that the co-resident workgroup's copies can interleave with them (profiles/r04_gemm_store_ablation_b1024.txt)
+VB_DEVICE void epi_pause(const GemmArgs& g) {
+#ifdef VB_DEV_KNOBS
+    const int p = (g.debug >> 20) & 3;
+    if (p == 1) __builtin_amdgcn_s_sleep(4);
+    else if (p == 2) __builtin_amdgcn_s_sleep(16);
+    else if (p == 3) __builtin_amdgcn_s_sleep(48);
+#else
+    (void)g;
+#endif
+}
 template <typename T, typename TO, int ACT, int OPT>
 VB_DEVICE void gemm_epilogue_private(f32x4 (&acc)[8][4], unsigned char* slab, const GemmArgs& g, int mw0, int nw0, int lane) {
     EpiLane e;
@@ -907,15 +919,23 @@ VB_DEVICE void gemm_epilogue_private(f32x4 (&acc)[8][4], unsigned char* slab, co
     // constant indices spelled out: the accumulators must never be addressed by a loop variable
     preload(0);
     gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[0], slab, g, mw0 + 0, lane, e, pre[0], pre_kind, offc, offa);
+    epi_pause(g);
     gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[1], slab, g, mw0 + 16, lane, e, pre[1], pre_kind, offc + stepc, offa + stepa);
+    epi_pause(g);
     gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[2], slab, g, mw0 + 32, lane, e, pre[2], pre_kind, offc + 2 * stepc, offa + 2 * stepa);
+    epi_pause(g);
     gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[3], slab, g, mw0 + 48, lane, e, pre[3], pre_kind, offc + 3 * stepc, offa + 3 * stepa);
+    epi_pause(g);
     preload(4);
     offc += 4 * stepc; offa += 4 * stepa;
     gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[4], slab, g, mw0 + 64, lane, e, pre[0], pre_kind, offc, offa);
+    epi_pause(g);
     gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[5], slab, g, mw0 + 80, lane, e, pre[1], pre_kind, offc + stepc, offa + stepa);
+    epi_pause(g);
     gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[6], slab, g, mw0 + 96, lane, e, pre[2], pre_kind, offc + 2 * stepc, offa + 2 * stepa);
+    epi_pause(g);
     gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[7], slab, g, mw0 + 112, lane, e, pre[3], pre_kind, offc + 3 * stepc, offa + 3 * stepa);
+    epi_pause(g);
     if constexpr (OPT & EPI_COLSUM) epi_colsum_flush(e, g, nw0, lane);
 }
 
@@ -1375,7 +1395,7 @@ int launch_dual(GemmArgs g, hipStream_t stream) {
         // other shape of the step is within noise or slower with stripes (the decoder +5 %: A re-read per stripe costs more
         // than B re-read per row panel, which the memory-side cache serves)
         g.stripe = (g.tiles_n > 12 && g.tiles_n <= 20) ? (g.tiles_n + 2) / 3 : g.tiles_n;
-        if ((g.debug >> 8) > 0) g.stripe = (g.debug >> 8) < g.tiles_n ? (g.debug >> 8) : g.tiles_n;      // developer library only: walk override
+        if (((g.debug >> 8) & 0xFFF) > 0) g.stripe = ((g.debug >> 8) & 0xFFF) < g.tiles_n ? ((g.debug >> 8) & 0xFFF) : g.tiles_n;      // developer library only: walk override
         dim3 grid((unsigned)(g.tiles_m * g.tiles_n));
         if constexpr (sizeof(TO) == 4) {
             if (g.x3) {

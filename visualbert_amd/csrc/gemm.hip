@@ -355,8 +355,7 @@ VB_DEVICE void epi_vec8(float (&v)[8], const GemmArgs& g, EpiLane& e, long offc,
 #pragma unroll
         for (int j = 0; j < 8; j += 2) {
             f32x2 y2, d2;
-            if constexpr (sizeof(T) == 2) gelu_and_grad2_bf16(f32x2{v[j], v[j + 1]}, y2, d2);     // results leave as bf16: polynomial form
-            else gelu_and_grad2(f32x2{v[j], v[j + 1]}, y2, d2);
+            gelu_and_grad2(f32x2{v[j], v[j + 1]}, y2, d2);
             v[j] = y2[0]; v[j + 1] = y2[1]; d[j] = d2[0]; d[j + 1] = d2[1];
         }
         store8((T*)g.aux_out + offa, d);                                  // gelu'(pre), what backward multiplies by

@@ -536,30 +536,6 @@ VB_DEVICE void gelu_and_grad2(f32x2 x, f32x2& y, f32x2& dy) {
     y = x * cdf;
     dy = cdf + xpdf;
 }
-// bf16-output form of the same pair (the FFN-in epilogue of the bf16 mode): Phi(x) - 1/2 = x P(x^2) and gelu'(x) - 1/2 = x R(x^2) as degree-8
-// polynomials in u = x^2 on |x| <= 4.5 (Chebyshev-node fits; x clamped: Phi(-4.5) = 3.4e-6), no v_rcp / v_exp: 22 issue slots per pair
-// where the A&S form costs ~37 slot-equivalents (its four quarter-rate transcendentals count four slots each) -- the store ablation prices the
-// FFN-in epilogue's arithmetic at ~270 us of 1111 us (profiles/r04_gemm_store_ablation_b1024.txt).  Max |error| over all x: gelu 1.5e-4 (<= 0.12 of
-// a bf16 half-ulp wherever |gelu| >= 0.05), gelu' 3.9e-4; the fp32 / split-operand modes keep the A&S form (1.5e-7).
-VB_DEVICE void gelu_and_grad2_bf16(f32x2 x, f32x2& y, f32x2& dy) {
-#ifdef VB_EMU
-    const f32x2 xc = f32x2{fminf(fmaxf(x[0], -4.5f), 4.5f), fminf(fmaxf(x[1], -4.5f), 4.5f)};
-#else
-    const f32x2 xc = f32x2{__builtin_amdgcn_fmed3f(x[0], -4.5f, 4.5f), __builtin_amdgcn_fmed3f(x[1], -4.5f, 4.5f)};
-#endif
-    const f32x2 u = xc * xc;
-    f32x2 p = vb_fma2(u, vb_splat2(4.457127842e-11f), vb_splat2(-4.572156416e-09f));
-    f32x2 r = vb_fma2(u, vb_splat2(5.008391691e-10f), vb_splat2(-4.993786243e-08f));
-    p = vb_fma2(p, u, vb_splat2(2.051920504e-07f));  r = vb_fma2(r, u, vb_splat2(2.147887449e-06f));
-    p = vb_fma2(p, u, vb_splat2(-5.355152022e-06f)); r = vb_fma2(r, u, vb_splat2(-5.250652273e-05f));
-    p = vb_fma2(p, u, vb_splat2(9.162140668e-05f));  r = vb_fma2(r, u, vb_splat2(8.108394741e-04f));
-    p = vb_fma2(p, u, vb_splat2(-1.103958688e-03f)); r = vb_fma2(r, u, vb_splat2(-8.319852280e-03f));
-    p = vb_fma2(p, u, vb_splat2(9.820541485e-03f));  r = vb_fma2(r, u, vb_splat2(5.770461258e-02f));
-    p = vb_fma2(p, u, vb_splat2(-6.637849057e-02f)); r = vb_fma2(r, u, vb_splat2(-2.644094065e-01f));
-    p = vb_fma2(p, u, vb_splat2(3.989283995e-01f));  r = vb_fma2(r, u, vb_splat2(7.976922665e-01f));
-    y = x * vb_fma2(xc, p, vb_splat2(0.5f));
-    dy = vb_fma2(xc, r, vb_splat2(0.5f));
-}
 VB_DEVICE float gelu_f(float x) { float c, d; gelu_parts(x, c, d); return x * c; }
 // d/dx [x * Phi(x)] = Phi(x) + x * phi(x)
 VB_DEVICE float gelu_grad_f(float x) { float c, d; gelu_parts(x, c, d); return c + x * d; }

@@ -43,11 +43,7 @@ enum { VB_F32 = 0, VB_BF16 = 1,
        VB_BF16X3 = 2 };
 enum { VB_KCONTIG = 0, VB_KSTRIDED = 1 };
 enum { VB_ACT_NONE = 0, VB_ACT_GELU = 1, VB_ACT_TANH = 2, VB_ACT_GELU_GRAD = 3,
-       VB_ACT_GELU_SAVE_GRAD = 4, VB_ACT_MUL_AUX = 5,
-       /* the bf16 encoder layer's pair: like 4 / 5 with the saved derivative held in ONE byte per element -- aux is uint8
-        * [M, ld_aux] with q = round((gelu'(x) + 0.25) * 180), i.e. gelu' in [-0.25, 1.1667] on a grid of 1/180 (|error| <= 2.8e-3;
-        * gelu' itself lies in [-0.13, 1.13]); VB_BF16 GEMMs only.  Halves the second result the FFN-in forward has to store. */
-       VB_ACT_GELU_SAVE_GRAD8 = 6, VB_ACT_MUL_AUX8 = 7 };
+       VB_ACT_GELU_SAVE_GRAD = 4, VB_ACT_MUL_AUX = 5 };
 
 /* library / build identification: returns a static string such as "visualbert_hip gfx950 r1" */
 const char* vb_version(void);

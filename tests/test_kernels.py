@@ -603,51 +603,6 @@ def test_gemm_specialised_epilogues(dev, variant):                          # th
         assert (Cf - ref[:, :Nr]).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
 
 
-@pytest.mark.parametrize("variant", [1, 42, 81, 90])
-def test_gemm_one_byte_gelu_derivative(dev, variant):
-    """VB_ACT_GELU_SAVE_GRAD8 / VB_ACT_MUL_AUX8 (the bf16 encoder layer's FFN pair): the forward GEMM saves gelu'(x) as
-    q = round((g' + 0.25) * 180) in ONE byte per element, the dgrad GEMM multiplies by the decoded value.  The codes must be the
-    nearest grid points of the exact derivative (off by one only where bf16-level differences of x straddle a rounding boundary),
-    the product must equal the one computed from the decoded codes, and non-bf16 GEMMs must refuse the pair."""
-    L = _lib.lib()
-    M, N, K = 530, 512, 192
-    g = torch.Generator().manual_seed(60 + variant)
-    dt = torch.bfloat16
-    A = (torch.randn(M, K, generator=g) * 0.5).to(dt).to(dev)
-    B = (torch.randn(N, K, generator=g) * 0.2).to(dt).to(dev)
-    bias = torch.randn(N, generator=g).to(dev)
-    ref = A.float() @ B.float().t() + bias
-    gprime = lambda x: 0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
-    with _lib.stream_opts(nt_kernel=variant):
-        aux = torch.zeros(M, N, dtype=torch.uint8, device=dev)
-        C = gemm(dev, dt, A, B, M, N, K, 0, 0, bias=bias, act=_lib.VB_ACT_GELU_SAVE_GRAD8, aux_out=aux)
-        assert (C.float() - torch.nn.functional.gelu(ref)).abs().max().item() <= 1.2e-2 * max(1.0, ref.abs().max().item())
-        want = torch.clamp(torch.floor((gprime(ref) + 0.25) * 180.0 + 0.5), 0, 255)
-        off = (aux.float() - want).abs()
-        assert off.max().item() <= 1.0 and (off > 0).float().mean().item() < 0.02           # fp32 summation order moves x by ~1e-6
-        dec = aux.float() / 180.0 - 0.25
-        assert (dec - gprime(ref)).abs().max().item() <= 0.5 / 180.0 + 1.0 / 180.0 * float((off > 0).any()) + 1e-4
-        dy = (torch.randn(M, K, generator=g) * 0.5).to(dt).to(dev)
-        cs = torch.ones(N, device=dev)
-        D = gemm(dev, dt, dy, B, M, N, K, 0, 0, act=_lib.VB_ACT_MUL_AUX8, aux_in=aux, colsum=cs)
-        ref2 = (dy.float() @ B.float().t()) * dec
-        assert (D.float() - ref2).abs().max().item() <= 1.2e-2 * max(1.0, ref2.abs().max().item())
-        assert (cs - (1.0 + ref2.sum(0))).abs().max().item() <= 2e-2 * max(1.0, ref2.sum(0).abs().max().item())
-        # ragged N: the rolled per-element path
-        Nr = N - 3
-        aux_r = torch.zeros(M, N, dtype=torch.uint8, device=dev)[:, :Nr]
-        Cr = gemm(dev, dt, A, B[:Nr], M, Nr, K, 0, 0, bias=bias[:Nr].contiguous(), act=_lib.VB_ACT_GELU_SAVE_GRAD8, aux_out=aux_r)
-        assert (Cr.float() - torch.nn.functional.gelu(ref[:, :Nr])).abs().max().item() <= 1.2e-2 * max(1.0, ref.abs().max().item())
-        assert (aux_r.float() - want[:, :Nr]).abs().max().item() <= 1.0
-    # fp32 GEMMs keep the exact derivative: the one-byte pair is refused
-    Af, Bf = A.float(), B.float()
-    auxf = torch.zeros(M, N, dtype=torch.uint8, device=dev)
-    Cf = torch.empty(M, N, device=dev)
-    rc = L.vb_gemm(_lib.VB_F32, _lib.VB_F32, 0, 0, _lib.ptr(Af), K, _lib.ptr(Bf), K, _lib.ptr(Cf), N, M, N, K, 1.0, None, _lib.ptr(bias),
-                   None, 0, _lib.VB_ACT_GELU_SAVE_GRAD8, None, _lib.ptr(auxf), N, 0, None, _lib.stream_ptr())
-    assert rc == -3
-
-
 @pytest.mark.parametrize("wgs", [0, 2])
 def test_gemm_direct_b_kernel(dev, wgs):
     """nt_kernel 101: the four-wave 256x256 kernel whose B operand goes straight from global memory into MFMA-layout registers

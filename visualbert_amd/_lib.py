@@ -15,7 +15,6 @@ DEFAULT_LIB = os.path.join(_HERE, "libvisualbert_hip.so")
 VB_F32, VB_BF16, VB_BF16X3 = 0, 1, 2
 VB_KCONTIG, VB_KSTRIDED = 0, 1
 VB_ACT_NONE, VB_ACT_GELU, VB_ACT_TANH, VB_ACT_GELU_GRAD, VB_ACT_GELU_SAVE_GRAD, VB_ACT_MUL_AUX = 0, 1, 2, 3, 4, 5
-VB_ACT_GELU_SAVE_GRAD8, VB_ACT_MUL_AUX8 = 6, 7        # saved gelu' as uint8 codes (include/visualbert_hip.h)
 
 _i, _i64, _f, _p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 _u32, _u64 = ctypes.c_uint32, ctypes.c_uint64

@@ -243,22 +243,6 @@ enum { EPI_ADD = 1,          // addend and/or accumulate operands
        EPI_COLSUM = 4,       // fused column sums
        EPI_ALL = 7,          // everything above, decided at run time (incl. a split result when g.split_out is set)
        EPI_SPLIT = 8 };      // specialised split-operand epilogues: the result ALWAYS leaves as a bf16 hi | lo image (g.split_out)
-// saved gelu' in one byte (VB_ACT_GELU_SAVE_GRAD8 / VB_ACT_MUL_AUX8): q = round((g' + 0.25) * 180), g' = q / 180 - 0.25
-VB_DEVICE unsigned gq_enc(float d) {
-    float q = d * 180.0f + 45.5f;                            // + 0.25 * 180 + 0.5: truncation below rounds to nearest
-    q = q < 0.f ? 0.f : (q > 255.f ? 255.f : q);
-    return (unsigned)q;
-}
-VB_DEVICE float gq_dec(unsigned q) { return (float)q * (1.0f / 180.0f) - 0.25f; }
-VB_DEVICE void gq_store8(unsigned char* p, const float (&d)[8]) {
-    const unsigned lo = gq_enc(d[0]) | (gq_enc(d[1]) << 8) | (gq_enc(d[2]) << 16) | (gq_enc(d[3]) << 24);
-    const unsigned hi = gq_enc(d[4]) | (gq_enc(d[5]) << 8) | (gq_enc(d[6]) << 16) | (gq_enc(d[7]) << 24);
-    *(u32x2*)p = u32x2{lo, hi};
-}
-VB_DEVICE void gq_decode8(float (&x)[8], unsigned lo, unsigned hi) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { x[j] = gq_dec((lo >> (8 * j)) & 255u); x[4 + j] = gq_dec((hi >> (8 * j)) & 255u); }
-}
 struct EpiLane {             // per-lane constants of an epilogue call
     float bb[8], cs[8];
     float alpha;
@@ -276,8 +260,7 @@ VB_DEVICE void epi_lane_init(EpiLane& e, const GemmArgs& g, int nw0, int lane) {
     if constexpr (OPT & EPI_RAGGED) {
         e.vec = full && (((g.ldc * (g.split_out ? 2 : sizeof(TO))) | (uintptr_t)g.C) & 15) == 0 &&
                 (!g.addend || (((g.ld_addend * sizeof(T)) | (uintptr_t)g.addend) & 15) == 0) &&
-                (!(g.aux_in || g.aux_out) || (g.act >= VB_ACT_GELU_SAVE_GRAD8 ? ((g.ld_aux | (uintptr_t)g.aux_in | (uintptr_t)g.aux_out) & 7) == 0
-                                              : (((g.ld_aux * sizeof(T)) | (uintptr_t)g.aux_in | (uintptr_t)g.aux_out) & 15) == 0));
+                (!(g.aux_in || g.aux_out) || (((g.ld_aux * sizeof(T)) | (uintptr_t)g.aux_in | (uintptr_t)g.aux_out) & 15) == 0);
         if (g.bias && full) {
             if ((((uintptr_t)(g.bias + e.ncol)) & 15) == 0) load8(e.bb, g.bias + e.ncol);
             else {
@@ -298,8 +281,7 @@ static int epi_needs(const GemmArgs& g, size_t t_size, size_t to_size) {
     bool aligned = (g.N % 8) == 0 && (((g.ldc * to_size) | (uintptr_t)g.C) & 15) == 0 &&
                    (!g.bias || ((uintptr_t)g.bias & 15) == 0) &&
                    (!g.addend || (((g.ld_addend * t_size) | (uintptr_t)g.addend) & 15) == 0) &&
-                   (!(g.aux_in || g.aux_out) || (g.act >= VB_ACT_GELU_SAVE_GRAD8 ? ((g.ld_aux | (uintptr_t)g.aux_in | (uintptr_t)g.aux_out) & 7) == 0
-                                                 : (((g.ld_aux * t_size) | (uintptr_t)g.aux_in | (uintptr_t)g.aux_out) & 15) == 0));
+                   (!(g.aux_in || g.aux_out) || (((g.ld_aux * t_size) | (uintptr_t)g.aux_in | (uintptr_t)g.aux_out) & 15) == 0);
     if (!aligned) n |= EPI_RAGGED;
     return n;
 }
@@ -321,13 +303,6 @@ VB_DEVICE void epi_scalar(float x, const GemmArgs& g, float alpha, long m, int n
         x = y;
     } else if (g.act == VB_ACT_MUL_AUX) {
         x *= to_f32(((const T*)g.aux_in)[m * g.ld_aux + n]);
-    } else if (g.act == VB_ACT_GELU_SAVE_GRAD8) {
-        float y, dy;
-        gelu_and_grad_f(x, y, dy);
-        ((unsigned char*)g.aux_out)[m * g.ld_aux + n] = (unsigned char)gq_enc(dy);
-        x = y;
-    } else if (g.act == VB_ACT_MUL_AUX8) {
-        x *= gq_dec(((const unsigned char*)g.aux_in)[m * g.ld_aux + n]);
     }
     if (g.addend) x += to_f32(((const T*)g.addend)[m * g.ld_addend + n]);
     TO* cp = (TO*)g.C + m * g.ldc + n;
@@ -341,10 +316,6 @@ template <typename T, typename TO, int ACT, int OPT>
 VB_DEVICE void epi_load8(float (&xa)[8], float (&xd)[8], float (&xc)[8], const GemmArgs& g, long m, int ncol) {
     const int act = ACT >= 0 ? ACT : g.act;
     if (act == VB_ACT_GELU_GRAD || act == VB_ACT_MUL_AUX) load8(xa, (const T*)g.aux_in + m * g.ld_aux + ncol);
-    if (act == VB_ACT_MUL_AUX8) {
-        const u32x2 q = *(const u32x2*)((const unsigned char*)g.aux_in + m * g.ld_aux + ncol);
-        gq_decode8(xa, q[0], q[1]);
-    }
     if constexpr (OPT & EPI_ADD) {
         if (g.addend) load8(xd, (const T*)g.addend + m * g.ld_addend + ncol);
         if (g.accumulate) load8(xc, (const TO*)g.C + m * g.ldc + ncol);
@@ -359,7 +330,7 @@ template <typename T, typename TO, int ACT, int OPT>
 VB_DEVICE void epi_vec8(float (&v)[8], const GemmArgs& g, EpiLane& e, long offc, long offa,
                         const float (&xa)[8], const float (&xd)[8], const float (&xc)[8]) {
     const int act = ACT >= 0 ? ACT : g.act;
-    if constexpr (ACT == VB_ACT_GELU_SAVE_GRAD || ACT == VB_ACT_GELU_SAVE_GRAD8) {
+    if constexpr (ACT == VB_ACT_GELU_SAVE_GRAD) {
 #pragma unroll
         for (int j = 0; j < 8; j += 2) {                  // packed fp32 FMA: two columns per issue slot
             const f32x2 r = vb_fma2(f32x2{v[j], v[j + 1]}, vb_splat2(e.alpha), f32x2{e.bb[j], e.bb[j + 1]});
@@ -388,16 +359,7 @@ VB_DEVICE void epi_vec8(float (&v)[8], const GemmArgs& g, EpiLane& e, long offc,
             v[j] = y2[0]; v[j + 1] = y2[1]; d[j] = d2[0]; d[j + 1] = d2[1];
         }
         store8((T*)g.aux_out + offa, d);                                  // gelu'(pre), what backward multiplies by
-    } else if (act == VB_ACT_GELU_SAVE_GRAD8) {
-        float d[8];
-#pragma unroll
-        for (int j = 0; j < 8; j += 2) {
-            f32x2 y2, d2;
-            gelu_and_grad2(f32x2{v[j], v[j + 1]}, y2, d2);
-            v[j] = y2[0]; v[j + 1] = y2[1]; d[j] = d2[0]; d[j + 1] = d2[1];
-        }
-        gq_store8((unsigned char*)g.aux_out + offa, d);                   // gelu'(pre) as one byte per element
-    } else if (act == VB_ACT_MUL_AUX || act == VB_ACT_MUL_AUX8) {
+    } else if (act == VB_ACT_MUL_AUX) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] *= xa[j];
     }
@@ -819,8 +781,6 @@ int launch_pipe(GemmArgs g, hipStream_t stream) {
         VB_TRY_EPI(VB_ACT_NONE, 0);                        // forward projections, dgrad attention-out
         VB_TRY_EPI(VB_ACT_GELU_SAVE_GRAD, 0);              // FFN-in forward
         VB_TRY_EPI(VB_ACT_MUL_AUX, EPI_COLSUM);            // FFN-out dgrad (+ FFN-in bias gradient)
-        VB_TRY_EPI(VB_ACT_GELU_SAVE_GRAD8, 0);             // the same pair with the derivative saved in one byte (the bf16 encoder layer)
-        VB_TRY_EPI(VB_ACT_MUL_AUX8, EPI_COLSUM);
         VB_TRY_EPI(VB_ACT_NONE, EPI_ADD);                  // dgrads that add the residual gradient
     } else if constexpr (sizeof(T) == 2) {
         VB_TRY_EPI(VB_ACT_NONE, EPI_RAGGED);               // MLM decoder logits (N = vocabulary size)
@@ -869,10 +829,6 @@ VB_DEVICE void gemm_epilogue_fragrow(f32x4 (&a)[4], unsigned char* slab, const G
     for (int it = 0; it < 2; ++it) {
         const int m = mrow0 + it * 8 + (lane >> 3);
         if constexpr (sizeof(T) == 2) {
-            if (pre_kind == 3) {                        // saved gelu' codes (one byte each) already in registers
-                gq_decode8(xa[it], pre[it][0], pre[it][1]);
-                continue;
-            }
             if (pre_kind) {                             // row operand already in registers (gemm_epilogue_private)
                 const bf16x8 x = *(const bf16x8*)&pre[it];
 #pragma unroll
@@ -893,7 +849,7 @@ VB_DEVICE void gemm_epilogue_fragrow(f32x4 (&a)[4], unsigned char* slab, const G
             f32x4 hi = *(const f32x4*)(src + 16);
 #pragma unroll
             for (int j = 0; j < 4; ++j) { v[j] = lo[j]; v[4 + j] = hi[j]; }
-            if constexpr (ACT == VB_ACT_GELU_SAVE_GRAD || ACT == VB_ACT_GELU_SAVE_GRAD8)
+            if constexpr (ACT == VB_ACT_GELU_SAVE_GRAD)
                 epi_vec8<T, TO, ACT, OPT>(v, g, e, offc + it * 8 * g.ldc, offa + it * 8 * g.ld_aux, xa[it], xd[it], xc[it]);
             else
                 epi_vec8<T, TO, ACT, OPT>(v, g, e, (long)m * g.ldc + e.ncol, (long)m * g.ld_aux + e.ncol, xa[it], xd[it], xc[it]);
@@ -931,15 +887,14 @@ VB_DEVICE void gemm_epilogue_private(f32x4 (&acc)[8][4], unsigned char* slab, co
     // The per-row operand of the specialised epilogues (saved GELU' / residual gradient) is fetched for the WHOLE 128x64
     // block in two batches of 8 independent 16-byte loads per lane (the fragment registers are dead by now) instead of
     // two per fragment row, each waiting out an HBM round trip before its multiply (8 round trips per tile).
-    constexpr bool PRE_AUX8 = sizeof(T) == 2 && !(OPT & EPI_RAGGED) && ACT == VB_ACT_MUL_AUX8;
-    constexpr bool PRE_AUX = PRE_AUX8 || (sizeof(T) == 2 && !(OPT & EPI_RAGGED) && (ACT == VB_ACT_MUL_AUX || ACT == VB_ACT_GELU_GRAD));
+    constexpr bool PRE_AUX = sizeof(T) == 2 && !(OPT & EPI_RAGGED) && (ACT == VB_ACT_MUL_AUX || ACT == VB_ACT_GELU_GRAD);
     constexpr bool PRE_ADD = sizeof(T) == 2 && !(OPT & EPI_RAGGED) && ACT >= 0 && !PRE_AUX && (OPT & EPI_ADD);
     u32x4 pre[4][2];                                // two batches of 4 fragment rows (8 loads in flight, 32 VGPRs)
     int pre_kind = 0;
     const unsigned char* pbase = nullptr;
     long pld = 0;
     if constexpr (PRE_AUX || PRE_ADD) {
-        if (PRE_AUX) { pbase = (const unsigned char*)g.aux_in; pld = g.ld_aux; pre_kind = PRE_AUX8 ? 3 : 1; }
+        if (PRE_AUX) { pbase = (const unsigned char*)g.aux_in; pld = g.ld_aux; pre_kind = 1; }
         else if (g.addend && !g.accumulate) { pbase = (const unsigned char*)g.addend; pld = g.ld_addend; pre_kind = 2; }
     }
     // row addressing without per-row 64-bit multiplies: one product per matrix here, 64-bit adds from then on
@@ -956,12 +911,7 @@ VB_DEVICE void gemm_epilogue_private(f32x4 (&acc)[8][4], unsigned char* slab, co
                         int m = mw0 + (mi0 + mi) * 16 + it * 8 + (lane >> 3);
                         m = m < g.M ? m : g.M - 1;                  // clamped rows are loaded but never stored
                         const int n = e.ncol < g.N ? e.ncol : 0;
-                        if constexpr (PRE_AUX8) {                   // one byte per element: 8 bytes per lane
-                            const u32x2 q = *(const u32x2*)(pbase + ((long)m * pld + n));
-                            pre[mi][it] = u32x4{q[0], q[1], 0u, 0u};
-                        } else {
-                            pre[mi][it] = *(const u32x4*)(pbase + ((long)m * pld + n) * 2);
-                        }
+                        pre[mi][it] = *(const u32x4*)(pbase + ((long)m * pld + n) * 2);
                     }
             }
         }
@@ -1247,8 +1197,6 @@ int launch_8ph(GemmArgs g, hipStream_t stream) {
             VB_TRY_EPI(VB_ACT_NONE, 0);
             VB_TRY_EPI(VB_ACT_GELU_SAVE_GRAD, 0);
             VB_TRY_EPI(VB_ACT_MUL_AUX, EPI_COLSUM);
-            VB_TRY_EPI(VB_ACT_GELU_SAVE_GRAD8, 0);
-            VB_TRY_EPI(VB_ACT_MUL_AUX8, EPI_COLSUM);
             VB_TRY_EPI(VB_ACT_NONE, EPI_ADD);
         } else {
             VB_TRY_EPI(VB_ACT_NONE, EPI_RAGGED);
@@ -1475,8 +1423,6 @@ int launch_dual(GemmArgs g, hipStream_t stream) {
             VB_TRY_EPI(VB_ACT_NONE, 0);
             VB_TRY_EPI(VB_ACT_GELU_SAVE_GRAD, 0);
             VB_TRY_EPI(VB_ACT_MUL_AUX, EPI_COLSUM);
-            VB_TRY_EPI(VB_ACT_GELU_SAVE_GRAD8, 0);
-            VB_TRY_EPI(VB_ACT_MUL_AUX8, EPI_COLSUM);
             VB_TRY_EPI(VB_ACT_NONE, EPI_ADD);
         } else {
             VB_TRY_EPI(VB_ACT_NONE, EPI_RAGGED);
@@ -1880,8 +1826,6 @@ int launch_big(GemmArgs g, hipStream_t stream, bool b_direct = false) {
             VB_TRY_EPI(VB_ACT_NONE, 0);
             VB_TRY_EPI(VB_ACT_GELU_SAVE_GRAD, 0);
             VB_TRY_EPI(VB_ACT_MUL_AUX, EPI_COLSUM);
-            VB_TRY_EPI(VB_ACT_GELU_SAVE_GRAD8, 0);
-            VB_TRY_EPI(VB_ACT_MUL_AUX8, EPI_COLSUM);
             VB_TRY_EPI(VB_ACT_NONE, EPI_ADD);
         } else {
             VB_TRY_EPI(VB_ACT_NONE, EPI_RAGGED);
@@ -2317,10 +2261,9 @@ extern "C" int vb_gemm(int dtype, int out_dtype, int a_layout, int b_layout,
     // vector loads are 16 bytes: leading dimensions and base pointers must keep them aligned
     if ((lda % 8) || (ldb % 8) || (((uintptr_t)A | (uintptr_t)B) & 15)) return VB_ERR_ARG;
     (void)epc;
-    if ((act == VB_ACT_GELU_GRAD || act == VB_ACT_MUL_AUX || act == VB_ACT_MUL_AUX8) && !aux_in) return VB_ERR_ARG;
-    if ((act == VB_ACT_GELU_SAVE_GRAD || act == VB_ACT_GELU_SAVE_GRAD8) && !aux_out) return VB_ERR_ARG;
-    if (act < VB_ACT_NONE || act > VB_ACT_MUL_AUX8) return VB_ERR_ARG;
-    if (act >= VB_ACT_GELU_SAVE_GRAD8 && dtype != VB_BF16) return VB_ERR_UNSUPPORTED;      // one-byte derivative: the bf16 mode's pair
+    if ((act == VB_ACT_GELU_GRAD || act == VB_ACT_MUL_AUX) && !aux_in) return VB_ERR_ARG;
+    if (act == VB_ACT_GELU_SAVE_GRAD && !aux_out) return VB_ERR_ARG;
+    if (act < VB_ACT_NONE || act > VB_ACT_MUL_AUX) return VB_ERR_ARG;
     GemmArgs g;
     g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
     g.bias = bias; g.addend = addend; g.ld_addend = ld_addend; g.aux_in = aux_in; g.aux_out = aux_out;

@@ -36,9 +36,7 @@ Saved carve_saved(unsigned char* base, const Dims& d, bool attn_dropout) {
                                                               // their images (sp_ctx, sp_inter below): only GEMMs read them
     s.z1 = take((size_t)d.M * d.H * d.es);
     s.a_out = take((size_t)d.M * d.H * d.es);
-    s.pre = take((size_t)d.M * d.I * (d.dtype == VB_BF16 ? 1 : d.es));   // saved gelu'(pre-activation); bf16 mode: one byte per element
-                                                                          // (VB_ACT_GELU_SAVE_GRAD8: the FFN-in forward's second result is what that GEMM
-                                                                          //  pays for -- profiles/r04_gemm_store_ablation_b1024.txt)
+    s.pre = take((size_t)d.M * d.I * d.es);
     s.inter = take(d.x3 ? 0 : (size_t)d.M * d.I * d.es);
     s.z2 = take((size_t)d.M * d.H * d.es);
     s.lse = (float*)take((size_t)d.B * d.nh * d.S * 4);
@@ -164,8 +162,7 @@ extern "C" int vb_bert_layer_fwd(int dtype, const void* h_in, const float* mask_
     // 5. FFN in + erf-GELU (GELU' kept for backward)
     //    (split-operand mode: the activation leaves the GEMM as a split image -- only GEMMs read it: FFN-out and its wgrad)
     VB_TRY(linear(d, d.x3 ? (const void*)sv.sp_aout : (const void*)sv.a_out, H, nullptr, wi, wk * H,
-                  d.x3 ? (void*)sv.sp_inter : (void*)sv.inter, I, bi, nullptr,
-                  d.dtype == VB_BF16 ? VB_ACT_GELU_SAVE_GRAD8 : VB_ACT_GELU_SAVE_GRAD, nullptr, sv.pre, nullptr, stream, d.x3));
+                  d.x3 ? (void*)sv.sp_inter : (void*)sv.inter, I, bi, nullptr, VB_ACT_GELU_SAVE_GRAD, nullptr, sv.pre, nullptr, stream, d.x3));
     // 6. FFN out
     VB_TRY(linear(d, d.x3 ? (const void*)sv.sp_inter : (const void*)sv.inter, I, nullptr, wo2, wk * I, sc.t_h1, H, bo2, nullptr,
                   VB_ACT_NONE, nullptr, nullptr, nullptr, stream));
@@ -228,8 +225,7 @@ extern "C" int vb_bert_layer_bwd(int dtype, const void* h_in, const float* mask_
     //    (+ bias gradient of FFN-in = column sums of dpre, accumulated by the same epilogue)
     //    (split-operand mode: dpre leaves the GEMM as a split image -- only the next dgrad and the wgrad launch read it)
     unsigned char* dpre = d.x3 ? sc.sp_dpre : sc.t_i;
-    VB_TRY(dgrad(d.x3 ? (const void*)sc.sp_dfo : (const void*)dfo, H, wo2, VB_LWT_FO, I, dpre, nullptr,
-                 d.dtype == VB_BF16 ? VB_ACT_MUL_AUX8 : VB_ACT_MUL_AUX, sv.pre,
+    VB_TRY(dgrad(d.x3 ? (const void*)sc.sp_dfo : (const void*)dfo, H, wo2, VB_LWT_FO, I, dpre, nullptr, VB_ACT_MUL_AUX, sv.pre,
                  G[VB_LW_FI_B], nullptr, d.x3));
     // 3. dgrad FFN-in + residual gradient: da = dpre Wi + dz2
     VB_TRY(dgrad(dpre, I, wi, VB_LWT_FI, H, sc.t_h2, dz2, VB_ACT_NONE, nullptr, nullptr, nullptr));

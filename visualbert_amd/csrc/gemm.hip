@@ -341,7 +341,7 @@ VB_DEVICE void epi_vec8(float (&v)[8], const GemmArgs& g, EpiLane& e, long offc,
         for (int j = 0; j < 8; ++j) v[j] = v[j] * e.alpha + e.bb[j];
     }
     if (act == VB_ACT_GELU) {
-        if (g.aux_out) store8((T*)g.aux_out + offa, v);                   // pre-activation, kept for backward
+        if (g.aux_out) store8_nt((T*)g.aux_out + offa, v);                // pre-activation, kept for backward
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
     } else if (act == VB_ACT_TANH) {
@@ -358,7 +358,7 @@ VB_DEVICE void epi_vec8(float (&v)[8], const GemmArgs& g, EpiLane& e, long offc,
             gelu_and_grad2(f32x2{v[j], v[j + 1]}, y2, d2);
             v[j] = y2[0]; v[j + 1] = y2[1]; d[j] = d2[0]; d[j + 1] = d2[1];
         }
-        store8((T*)g.aux_out + offa, d);                                  // gelu'(pre), what backward multiplies by
+        store8_nt((T*)g.aux_out + offa, d);                               // gelu'(pre), what backward multiplies by
     } else if (act == VB_ACT_MUL_AUX) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] *= xa[j];
@@ -381,8 +381,12 @@ VB_DEVICE void epi_vec8(float (&v)[8], const GemmArgs& g, EpiLane& e, long offc,
             float lo[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) { h[j] = (bf16)v[j]; lo[j] = v[j] - (float)h[j]; }
+#ifdef VB_EMU
             *(bf16x8*)hp = h;
-            store8(hp + g.ldc / 2, lo);
+#else
+            __builtin_nontemporal_store(*(const u32x4*)&h, (u32x4*)hp);
+#endif
+            store8_nt(hp + g.ldc / 2, lo);
             if constexpr (OPT & EPI_COLSUM) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) e.cs[j] += v[j];
@@ -390,8 +394,28 @@ VB_DEVICE void epi_vec8(float (&v)[8], const GemmArgs& g, EpiLane& e, long offc,
             return;
         }
     }
+#ifdef VB_DEV_KNOBS
+    // store ablations (developer library; results WRONG or merely differently cached): bit 22 = every tile's rows wrap into the first 256
+    // rows of C (the stores hit the same L2-resident lines: no HBM write traffic); bits 23-24 = cache-policy bits on the store
+    // instruction (1: sc1, 2: sc0 sc1 = system scope, 3: nt)
+    if constexpr (sizeof(TO) == 2) {
+        if (g.debug & (0xF << 22)) {
+            if (g.debug & (1 << 22)) cp = (TO*)g.C + (offc % (256 * g.ldc));
+            bf16x8 xv;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xv[j] = (bf16)v[j];
+            const u32x4 w = *(const u32x4*)&xv;
+            const int pol = (g.debug >> 23) & 3;
+            if (pol == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(cp), "v"(w) : "memory");
+            else if (pol == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(cp), "v"(w) : "memory");
+            else if (pol == 3) asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(cp), "v"(w) : "memory");
+            else *(u32x4*)cp = w;
+            return;
+        }
+    }
+#endif
     if (g.debug & 128) { if (v[0] == 123.456f) store8(cp, v); }           // ablation: no global stores
-    else store8(cp, v);
+    else store8_nt(cp, v);                                                // streaming store: see store8_nt
     if constexpr (OPT & EPI_COLSUM) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) e.cs[j] += v[j];

@@ -381,11 +381,7 @@ VB_DEVICE void epi_vec8(float (&v)[8], const GemmArgs& g, EpiLane& e, long offc,
             float lo[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) { h[j] = (bf16)v[j]; lo[j] = v[j] - (float)h[j]; }
-#ifdef VB_EMU
-            *(bf16x8*)hp = h;
-#else
-            __builtin_nontemporal_store(*(const u32x4*)&h, (u32x4*)hp);
-#endif
+            vb_store16_nt(hp, *(const u32x4*)&h);
             store8_nt(hp + g.ldc / 2, lo);
             if constexpr (OPT & EPI_COLSUM) {
 #pragma unroll
@@ -414,8 +410,11 @@ VB_DEVICE void epi_vec8(float (&v)[8], const GemmArgs& g, EpiLane& e, long offc,
         }
     }
 #endif
-    if (g.debug & 128) { if (v[0] == 123.456f) store8(cp, v); }           // ablation: no global stores
-    else store8_nt(cp, v);                                                // streaming store: see store8_nt
+#ifdef VB_DEV_KNOBS
+    if (g.debug & 128) { if (v[0] == 123.456f) store8(cp, v); }           // ablation (developer library): no global stores
+    else
+#endif
+    store8_nt(cp, v);                                                     // streaming store: see store8_nt (vb_rt.h)
     if constexpr (OPT & EPI_COLSUM) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) e.cs[j] += v[j];

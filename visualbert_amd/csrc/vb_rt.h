@@ -81,23 +81,26 @@ VB_DEVICE void store8(float* p, const float (&v)[8]) {
 // GEMM epilogues.  A written-back C tile otherwise sits in L2 as dirty lines and evicts the operand panels the K loops of the same
 // XCD are streaming; with nt the lines are marked for early eviction.  Measured at M = 167,936 (profiles/r04_gemm_store_variants_b1024.txt):
 // QKV forward 654 -> 556 us, attention-out 225 -> 185 us -- most of the way to the same kernels with the stores predicated off (543 / 180).
+// (inline asm, not __builtin_nontemporal_store: when such a store sits in one arm of an if / else whose other arm also stores to the same
+//  address -- the epilogue's ablation switch -- the optimiser merges the two and drops the nontemporal flag: the plain-epilogue kernels
+//  came out with 0 of 16 stores marked.)
+VB_DEVICE void vb_store16_nt(void* p, const u32x4& w) {
+#ifdef VB_EMU
+    *(u32x4*)p = w;
+#else
+    asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(p), "v"(w) : "memory");
+#endif
+}
 VB_DEVICE void store8_nt(bf16* p, const float (&v)[8]) {
     bf16x8 x;
 #pragma unroll
     for (int j = 0; j < 8; ++j) x[j] = (bf16)v[j];
-#ifdef VB_EMU
-    *(bf16x8*)p = x;
-#else
-    __builtin_nontemporal_store(*(const u32x4*)&x, (u32x4*)p);
-#endif
+    vb_store16_nt(p, *(const u32x4*)&x);
 }
 VB_DEVICE void store8_nt(float* p, const float (&v)[8]) {
-#ifdef VB_EMU
-    store8(p, v);
-#else
-    __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, (f32x4*)p);
-    __builtin_nontemporal_store(f32x4{v[4], v[5], v[6], v[7]}, (f32x4*)(p + 4));
-#endif
+    const f32x4 a = f32x4{v[0], v[1], v[2], v[3]}, b = f32x4{v[4], v[5], v[6], v[7]};
+    vb_store16_nt(p, *(const u32x4*)&a);
+    vb_store16_nt(p + 4, *(const u32x4*)&b);
 }
 // split-operand images (VB_BF16X3): x -> hi = bf16(x) (RNE) at p[...] and lo = bf16(x - hi) at p[half + ...] -- bit for bit what
 // vb_split_bf16 writes, so a producer kernel can emit the image of its fp32 result itself (one extra 4-byte-per-element store

@@ -402,9 +402,9 @@ VB_DEVICE void epi_vec8(float (&v)[8], const GemmArgs& g, EpiLane& e, long offc,
             for (int j = 0; j < 8; ++j) xv[j] = (bf16)v[j];
             const u32x4 w = *(const u32x4*)&xv;
             const int pol = (g.debug >> 23) & 3;
-            if (pol == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(cp), "v"(w) : "memory");
-            else if (pol == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(cp), "v"(w) : "memory");
-            else if (pol == 3) asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(cp), "v"(w) : "memory");
+            if (pol == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(cp), "v"(w) : "memory");
+            else if (pol == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(cp), "v"(w) : "memory");
+            else if (pol == 3) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" :: "v"(cp), "v"(w) : "memory");
             else *(u32x4*)cp = w;
             return;
         }

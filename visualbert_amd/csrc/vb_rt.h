@@ -88,7 +88,10 @@ VB_DEVICE void vb_store16_nt(void* p, const u32x4& w) {
 #ifdef VB_EMU
     *(u32x4*)p = w;
 #else
-    asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(p), "v"(w) : "memory");
+    // s_nop 1: gfx940-family store-data hazard -- a VALU write to the data registers of a > 8-byte store within 2 wait states of its
+    // issue corrupts the store (the compiler pads its own stores; it cannot see inside an asm statement: without the nop every GEMM test
+    // failed with garbage results)
+    asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" :: "v"(p), "v"(w) : "memory");
 #endif
 }
 VB_DEVICE void store8_nt(bf16* p, const float (&v)[8]) {

@@ -86,6 +86,10 @@ struct GemmArgs {
     // split_out (VB_BF16X3 output): C is a bf16 [M, ldc] SPLIT operand -- the fp32 result leaves as hi = bf16(v) in column n and
     // lo = bf16(v - hi) in column ldc / 2 + n (what vb_split_bf16 would make of it), ready to be the next GEMM's operand
     int split_out;
+    // streaming (nt) stores for the results (vb_rt.h: store8_nt).  Decided per call by vb_gemm: short reductions (K <= 1024) -- many
+    // output tiles per second, whose dirty lines would push the operand panels out of the XCD's L2 -- gain 5-13 % alone at M = 167,936; long
+    // ones (K >= 2048) lose up to 12 % with them (profiles/r04_gemm_nt_stores.txt), and so does nothing in the split-operand mode
+    int nt_store;
 };
 // K tile `v` of the (virtual) K loop -> element offset of its first column inside a row of A / of B
 VB_DEVICE int x3_col_a(const GemmArgs& g, int v, int bk) {
@@ -341,7 +345,7 @@ VB_DEVICE void epi_vec8(float (&v)[8], const GemmArgs& g, EpiLane& e, long offc,
         for (int j = 0; j < 8; ++j) v[j] = v[j] * e.alpha + e.bb[j];
     }
     if (act == VB_ACT_GELU) {
-        if (g.aux_out) store8_nt((T*)g.aux_out + offa, v);                // pre-activation, kept for backward
+        if (g.aux_out) { if (g.nt_store) store8_nt((T*)g.aux_out + offa, v); else store8((T*)g.aux_out + offa, v); }   // pre-activation, kept for backward
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
     } else if (act == VB_ACT_TANH) {
@@ -358,7 +362,8 @@ VB_DEVICE void epi_vec8(float (&v)[8], const GemmArgs& g, EpiLane& e, long offc,
             gelu_and_grad2(f32x2{v[j], v[j + 1]}, y2, d2);
             v[j] = y2[0]; v[j + 1] = y2[1]; d[j] = d2[0]; d[j + 1] = d2[1];
         }
-        store8_nt((T*)g.aux_out + offa, d);                               // gelu'(pre), what backward multiplies by
+        if (g.nt_store) store8_nt((T*)g.aux_out + offa, d);               // gelu'(pre), what backward multiplies by
+        else store8((T*)g.aux_out + offa, d);
     } else if (act == VB_ACT_MUL_AUX) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] *= xa[j];
@@ -381,8 +386,8 @@ VB_DEVICE void epi_vec8(float (&v)[8], const GemmArgs& g, EpiLane& e, long offc,
             float lo[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) { h[j] = (bf16)v[j]; lo[j] = v[j] - (float)h[j]; }
-            vb_store16_nt(hp, *(const u32x4*)&h);
-            store8_nt(hp + g.ldc / 2, lo);
+            *(bf16x8*)hp = h;
+            store8(hp + g.ldc / 2, lo);
             if constexpr (OPT & EPI_COLSUM) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) e.cs[j] += v[j];
@@ -414,7 +419,7 @@ VB_DEVICE void epi_vec8(float (&v)[8], const GemmArgs& g, EpiLane& e, long offc,
     if (g.debug & 128) { if (v[0] == 123.456f) store8(cp, v); }           // ablation (developer library): no global stores
     else
 #endif
-    store8_nt(cp, v);                                                     // streaming store: see store8_nt (vb_rt.h)
+    { if (g.nt_store) store8_nt(cp, v); else store8(cp, v); }             // streaming or plain store: GemmArgs::nt_store
     if constexpr (OPT & EPI_COLSUM) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) e.cs[j] += v[j];
@@ -2294,6 +2299,7 @@ extern "C" int vb_gemm(int dtype, int out_dtype, int a_layout, int b_layout,
     g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
     g.debug = g_debug; g.trace = g_trace;
     g.split_out = split_out ? 1 : 0;
+    g.nt_store = (!x3 && dtype == VB_BF16 && K <= 1024) ? 1 : 0;
     g.x3 = x3 ? 1 : 0; g.a_lo = x3 ? (int)(lda / 2) : 0; g.b_lo = x3 ? (int)(ldb / 2) : 0; g.kseg = x3 ? K / 64 : 0;
     g.stripe = 0;
     const int bk = dtype == VB_F32 ? 32 : 64;

@@ -1318,6 +1318,15 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(256, 2) gemm_nt_dual_kernel(GemmArgs g) {
     };
     // is_b: the copy belongs to operand B (the K tile -> column map of the split-operand mode differs per operand)
     auto issue_a = [&](const unsigned (&off)[4], int kt, int slot) {
+#ifdef VB_DEV_KNOBS
+        if (g.debug & (1 << 25)) {                             // developer experiment: the A (activation) copies marked streaming
+            unsigned char* dst = smem + slot * HALF + wave * 4096;
+            const unsigned koff = X3 ? (unsigned)x3_col_a(g, kt, BK) * 2u : (unsigned)kt * (BK * 2);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) vb_glds16_buf_nt(A, off[i], koff, dst + i * 1024);
+            return;
+        }
+#endif
         issue_at(A, off, X3 ? (unsigned)x3_col_a(g, kt, BK) * 2u : (unsigned)kt * (BK * 2), slot);
     };
     auto issue_b = [&](int kt, int slot) {

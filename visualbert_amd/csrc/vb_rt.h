@@ -196,6 +196,7 @@ VB_DEVICE vb_buf vb_make_buf(const void* p) { return vb_buf{(const unsigned char
 VB_DEVICE void vb_glds16_buf(vb_buf b, unsigned voff, unsigned soff, unsigned char* lds_wave_base) {
     memcpy(lds_wave_base + ::hipemu::cur()->lane * 16, b.base + voff + soff, 16);
 }
+VB_DEVICE void vb_glds16_buf_nt(vb_buf b, unsigned voff, unsigned soff, unsigned char* lds_wave_base) { vb_glds16_buf(b, voff, soff, lds_wave_base); }
 #else
 typedef __amdgpu_buffer_rsrc_t vb_buf;
 VB_DEVICE vb_buf vb_make_buf(const void* p) {
@@ -203,6 +204,10 @@ VB_DEVICE vb_buf vb_make_buf(const void* p) {
 }
 VB_DEVICE void vb_glds16_buf(vb_buf b, unsigned voff, unsigned soff, unsigned char* lds_wave_base) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(b, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, (int)soff, 0, 0);
+}
+// the same copy marked streaming (aux bit 1 = nt): developer experiment -- activations read once per column-tile pass need not displace the weights
+VB_DEVICE void vb_glds16_buf_nt(vb_buf b, unsigned voff, unsigned soff, unsigned char* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(b, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, (int)soff, 0, 2);
 }
 #endif
 

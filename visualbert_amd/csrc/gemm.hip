@@ -1890,8 +1890,7 @@ int launch_big(GemmArgs g, hipStream_t stream, bool b_direct = false) {
 // an XCD gets consecutive items = the tiles of one problem and token slice, which share operand panels in its L2).
 // Partial tiles are added with fp32 atomics (the output is an accumulator anyway).
 // =================================================================================================
-constexpr int VB_TN_MAX = 24;          // problems per launch (the ABI takes up to 8; the split-operand mode makes 3 of each: plane pairs)
-constexpr int VB_TN_ABI_MAX = 8;
+constexpr int VB_TN_MAX = 8;
 struct TnProblem {
     const void* A; const void* B; float* C;      // dY [tokens][out], X [tokens][in], dW [out][in]
     long lda, ldb, ldc;
@@ -2350,43 +2349,31 @@ extern "C" int vb_gemm(int dtype, int out_dtype, int a_layout, int b_layout,
     return dispatch<float>(1, a_layout, b_layout, g, s);
 }
 
-static int wgrad_grouped_impl(int dtype, int n, const void* const* dy, const int64_t* ld_dy, const void* const* x,
-                              const int64_t* ld_x, void* const* dw, const int64_t* ld_dw, const int* n_out,
-                              const int* n_in, int tokens, float alpha, const float* alpha_dev, void* stream);
-
 extern "C" int vb_wgrad_grouped(int dtype, int n, const void* const* dy, const int64_t* ld_dy, const void* const* x,
                                 const int64_t* ld_x, void* const* dw, const int64_t* ld_dw, const int* n_out,
                                 const int* n_in, int tokens, float alpha, const float* alpha_dev, void* stream) {
-    if (n <= 0 || n > VB_TN_ABI_MAX || !dy || !ld_dy || !x || !ld_x || !dw || !ld_dw || !n_out || !n_in || tokens <= 0)
+    if (n <= 0 || n > VB_TN_MAX || !dy || !ld_dy || !x || !ld_x || !dw || !ld_dw || !n_out || !n_in || tokens <= 0)
         return VB_ERR_ARG;
     if (dtype != VB_F32 && dtype != VB_BF16 && dtype != VB_BF16X3) return VB_ERR_ARG;
     if (dtype == VB_BF16X3) {
-        // split operands [tokens][hi | lo]: dW += dy_hi^T x_hi + dy_lo^T x_hi + dy_hi^T x_lo -- the three plane pairs of every problem
-        // as 3 n problems of ONE launch of the bf16 path (they accumulate into the same fp32 dW, which the kernel does with atomics
-        // anyway): one set of tails and one cost-model decision over 3 x the tiles instead of three launches
-        const void* dyp[VB_TN_MAX]; const void* xp[VB_TN_MAX]; void* dwp[VB_TN_MAX];
-        int64_t ldy[VB_TN_MAX], ldx[VB_TN_MAX], ldw[VB_TN_MAX];
-        int no[VB_TN_MAX], ni[VB_TN_MAX];
-        struct ProfScope {                                   // launch records: algorithmic FLOPs (the three plane pairs sum to 2 M N K), tagged
+        // split operands [tokens][hi | lo]: dW += dy_hi^T x_hi + dy_lo^T x_hi + dy_hi^T x_lo -- three passes of the bf16 path
+        // over the planes (the accumulation into the fp32 dW is what the kernel does anyway)
+        const void* dyp[VB_TN_MAX]; const void* xp[VB_TN_MAX];
+        struct ProfScope {                                   // launch records: algorithmic FLOPs (the three passes sum to 2 M N K), tagged
             ProfScope() { t_vb_prof_scale = 1.0 / 3.0; t_vb_prof_key_or = 256; }
             ~ProfScope() { t_vb_prof_scale = 1.0; t_vb_prof_key_or = 0; }
         } prof_scope;
-        for (int pass = 0; pass < 3; ++pass)
+        for (int pass = 0; pass < 3; ++pass) {
             for (int i = 0; i < n; ++i) {
                 if ((ld_dy[i] % 16) || (ld_x[i] % 16) || n_out[i] > ld_dy[i] / 2 || n_in[i] > ld_x[i] / 2) return VB_ERR_UNSUPPORTED;
-                const int q = pass * n + i;
-                dyp[q] = (const bf16*)dy[i] + (pass == 1 ? ld_dy[i] / 2 : 0);
-                xp[q] = (const bf16*)x[i] + (pass == 2 ? ld_x[i] / 2 : 0);
-                dwp[q] = dw[i]; ldy[q] = ld_dy[i]; ldx[q] = ld_x[i]; ldw[q] = ld_dw[i]; no[q] = n_out[i]; ni[q] = n_in[i];
+                dyp[i] = (const bf16*)dy[i] + (pass == 1 ? ld_dy[i] / 2 : 0);
+                xp[i] = (const bf16*)x[i] + (pass == 2 ? ld_x[i] / 2 : 0);
             }
-        return wgrad_grouped_impl(VB_BF16, 3 * n, dyp, ldy, xp, ldx, dwp, ldw, no, ni, tokens, alpha, alpha_dev, stream);
+            const int rc = vb_wgrad_grouped(VB_BF16, n, dyp, ld_dy, xp, ld_x, dw, ld_dw, n_out, n_in, tokens, alpha, alpha_dev, stream);
+            if (rc != VB_OK) return rc;
+        }
+        return VB_OK;
     }
-    return wgrad_grouped_impl(dtype, n, dy, ld_dy, x, ld_x, dw, ld_dw, n_out, n_in, tokens, alpha, alpha_dev, stream);
-}
-
-static int wgrad_grouped_impl(int dtype, int n, const void* const* dy, const int64_t* ld_dy, const void* const* x,
-                              const int64_t* ld_x, void* const* dw, const int64_t* ld_dw, const int* n_out,
-                              const int* n_in, int tokens, float alpha, const float* alpha_dev, void* stream) {
     t_opts = vb_opts_for(stream);
     vb_prof_select(stream);
     // the grouped kernel takes whole 64-token K tiles; the last tokens % 64 rows (ragged B x S) go through the generic kernel below

@@ -110,7 +110,7 @@ def _saved_views(D, saved, keep_words, mode=None):
     specs = [("qkv", A, (M, 3 * H)), ("ctx", A, (0 if x3 else M, H)), ("z1", A, (M, H)), ("a_out", A, (M, H)), ("pre", A, (M, I)),
              ("inter", A, (0 if x3 else M, I)), ("z2", A, (M, H)), ("lse", torch.float32, (B, NH, S)), ("mean1", torch.float32, (M,)),
              ("rstd1", torch.float32, (M,)), ("mean2", torch.float32, (M,)), ("rstd2", torch.float32, (M,)),
-             ("keepbits", torch.int64, (keep_words,))]
+             ("keepbits", torch.int64, (keep_words,)), ("ln_rb1", torch.int32, (64 + 2 * H,)), ("ln_rb2", torch.int32, (64 + 2 * H,))]
     if mode is not None and mode.x3:            # the forward's split images, kept for the weight-gradient launch
         specs += [("sp_hin", BF, (M, 2 * H)), ("sp_ctx", BF, (M, 2 * H)), ("sp_aout", BF, (M, 2 * H)), ("sp_inter", BF, (M, 2 * I))]
     v, total = _carve(saved, specs)
@@ -203,7 +203,7 @@ def _run_layer(D, P, dev, p_hidden, p_attn, seed=0x1234567, sid=40, mode=None):
     return saved, scratch, h_out, weights
 
 
-def _run_bwd(D, P, saved, scratch, weights, dev, p_hidden, p_attn, seed=0x1234567, sid=40, mode=None):
+def _run_bwd(D, P, saved, scratch, weights, dev, p_hidden, p_attn, seed=0x1234567, sid=40, mode=None, h_out=None):
     B, S, H, I, NH, M = D.B, D.S, D.H, D.I, D.NH, D.M
     L = _lib.lib()
     code = mode.code if mode is not None else _lib.VB_BF16
@@ -212,7 +212,7 @@ def _run_bwd(D, P, saved, scratch, weights, dev, p_hidden, p_attn, seed=0x123456
     d_in = torch.empty(M, H, dtype=P["h_in"].dtype, device=dev)
     wts = [P["wqkv_t"], P["wo_t"], P["wi_t"], P["wo2_t"]]
     ld_t = (ctypes.c_int64 * 4)(*[w.stride(0) for w in wts])
-    _lib.check(L.vb_bert_layer_bwd(code, _lib.ptr(P["h_in"]), _lib.ptr(P["mask_add"]), _lib.ptr(P["d_out"]), _lib.ptr(d_in),
+    _lib.check(L.vb_bert_layer_bwd(code, _lib.ptr(P["h_in"]), _lib.ptr(h_out), _lib.ptr(P["mask_add"]), _lib.ptr(P["d_out"]), _lib.ptr(d_in),
                                    _lib.ptr(saved), _lib.ptr(scratch), _ptr_array(weights), _ptr_array(grads), _ptr_array(wts),
                                    ld_t, B, S, H, I, NH, p_hidden, p_attn, seed, sid, _lib.stream_ptr()), "vb_bert_layer_bwd")
     return d_in, grads
@@ -224,8 +224,9 @@ def _ln_ref(z, gamma, beta):
     return gamma * (z - mean) / torch.sqrt(var + 1e-12) + beta
 
 
-def _ln_bwd_ref(dy, z, mean, rstd, gamma):
-    xhat = (z - mean[:, None]) * rstd[:, None]
+def _ln_bwd_ref(dy, z, mean, rstd, gamma, y=None, beta=None):
+    """y given: the LayerNorm forward wrote no z (bf16, |beta| <= 2 |gamma|) and the backward takes x-hat from its output"""
+    xhat = (y - beta) / gamma if y is not None else (z - mean[:, None]) * rstd[:, None]
     dxh = dy * gamma
     return rstd[:, None] * (dxh - dxh.mean(-1, keepdim=True) - xhat * (dxh * xhat).mean(-1, keepdim=True)), xhat
 
@@ -256,7 +257,7 @@ def _sized(dev, which):
         pytest.skip("bench-sized layer: GPU only")
     if which == "small" and dev.type == "cuda" and os.environ.get("VB_SMALL_ON_GPU") != "1":
         pytest.skip("the small size validates this test's own references on the kernel-logic simulator (VB_EMU=1)")
-    return {"bench": BENCH, "bench512": BENCH512, "small": SMALL}[which]
+    return {"bench": BENCH, "bench512": BENCH512, "small": SMALL, "guard": SMALL}[which]
 
 
 def _dump_measured():
@@ -269,14 +270,18 @@ def _dump_measured():
         pass
 
 
-@pytest.mark.parametrize("which,mode_name", [("bench", "bf16"), ("small", "bf16"), ("bench", "bf16x3"), ("bench512", "bf16x3"),
-                                             ("small", "bf16x3")])
+@pytest.mark.parametrize("which,mode_name", [("bench", "bf16"), ("small", "bf16"), ("guard", "bf16"), ("bench", "bf16x3"),
+                                             ("bench512", "bf16x3"), ("small", "bf16x3")])
 def test_bert_layer_at_bench_shape(dev, which, mode_name):
+    """"guard": the small size (GPU and simulator) with ONE channel of the first LayerNorm at |beta| = 3 |gamma| -- that launch must
+    keep its pre-LN sum and the backward must read it, while the second LayerNorm of the same layer still rebuilds x-hat from y"""
     D = _sized(dev, which)
     mode = Mode(mode_name)
     tag = "%s/%s: " % (which, mode_name)
     H, I = D.H, D.I
     P = _layer_problem(D, dev, mode=mode)
+    if which == "guard":
+        P["b1"][5] = 3.0 * P["g1"][5].abs()
     saved, scratch, h_out, weights = _run_layer(D, P, dev, 0.0, 0.0, mode=mode)
     sv, sc = _saved_views(D, saved, 0, mode), _scratch_views(D, scratch, mode)
     f = lambda t: t.float()
@@ -291,8 +296,19 @@ def test_bert_layer_at_bench_shape(dev, which, mode_name):
     ao = sc["t_h0"]
     close(ao, f(ctx) @ f(P["wo"]).t() + P["bo"], mode.gemm, "attention-out dense")
     z1 = f(ao) + f(P["h_in"])
-    close(sv["z1"], z1, mode.add, "z1 = attention-out + residual")                  # one fp32 add, one rounding
+    # bf16: the forward skips the pre-LN sums when |beta| <= 2 |gamma| on every channel (true for this problem's parameters: the
+    # backward rebuilds x-hat from the LayerNorm outputs); fp32 / bf16x3 always keep them
+    rebuilt1 = rebuilt2 = not mode.x3
+    if which == "guard":
+        rebuilt1 = False
+    assert mode.x3 or [int(sv["ln_rb1"][0]), int(sv["ln_rb2"][0])] == [int(rebuilt1), int(rebuilt2)]
+    if not rebuilt1:
+        close(sv["z1"], z1, mode.add, "z1 = attention-out + residual")              # one fp32 add, one rounding
     close(sv["a_out"], _ln_ref(z1, P["g1"], P["b1"]), mode.ln, "LayerNorm 1")
+    if rebuilt1:                                   # how far the rebuilt x-hat is from the exact one (the numerics the mode signs up for)
+        xe = (z1 - z1.mean(-1, keepdim=True)) * sv["rstd1"][:, None]
+        MEASURED[tag + "x-hat 1 rebuilt from y vs exact"] = dict(err_over_max=float(((f(sv["a_out"]) - P["b1"]) / P["g1"] - xe).abs().max() / xe.abs().max()))
+        del xe
     del z1
     x = f(sv["a_out"]) @ f(P["wi"]).t() + P["bi"]
     # split-operand mode: the activation leaves the FFN-in GEMM as a split image (only GEMMs read it)
@@ -307,13 +323,14 @@ def test_bert_layer_at_bench_shape(dev, which, mode_name):
     fo = sc["t_h1"]
     close(fo, f(inter) @ f(P["wo2"]).t() + P["bo2"], mode.gemm, "FFN-out dense")
     z2 = f(fo) + f(sv["a_out"])
-    close(sv["z2"], z2, mode.add, "z2 = FFN-out + residual")
+    if not rebuilt2:
+        close(sv["z2"], z2, mode.add, "z2 = FFN-out + residual")
     close(h_out, _ln_ref(z2, P["g2"], P["b2"]), mode.ln, "LayerNorm 2 (h_out)")
     del z2
     # ---- backward (reuses the scratch: the forward temporaries above are dead from here)
-    d_in, G = _run_bwd(D, P, saved, scratch, weights, dev, 0.0, 0.0, mode=mode)
+    d_in, G = _run_bwd(D, P, saved, scratch, weights, dev, 0.0, 0.0, mode=mode, h_out=h_out)
     QKV_W, QKV_B, AO_W, AO_B, LN1_G, LN1_B, FI_W, FI_B, FO_W, FO_B, LN2_G, LN2_B = range(12)
-    dz2_ref, xhat2 = _ln_bwd_ref(f(P["d_out"]), f(sv["z2"]), sv["mean2"], sv["rstd2"], P["g2"])
+    dz2_ref, xhat2 = _ln_bwd_ref(f(P["d_out"]), f(sv["z2"]), sv["mean2"], sv["rstd2"], P["g2"], *((f(h_out), P["b2"]) if rebuilt2 else ()))
     dz2 = sc["t_h0"]
     close(dz2, dz2_ref, mode.lnb, "LayerNorm 2 backward")
 
@@ -331,7 +348,7 @@ def test_bert_layer_at_bench_shape(dev, which, mode_name):
     vec_close(G[FI_B], f(dpre).sum(0), mode.vecb, "FFN-in bias gradient (column sums)")
     da = sc["t_h2"]
     close(da, f(dpre) @ f(P["wi"]) + f(dz2), mode.gemm, "dgrad FFN-in + residual gradient")
-    dz1_ref, xhat1 = _ln_bwd_ref(f(da), f(sv["z1"]), sv["mean1"], sv["rstd1"], P["g1"])
+    dz1_ref, xhat1 = _ln_bwd_ref(f(da), f(sv["z1"]), sv["mean1"], sv["rstd1"], P["g1"], *((f(sv["a_out"]), P["b1"]) if rebuilt1 else ()))
     dz1 = sc["t_h5"]
     close(dz1, dz1_ref, mode.lnb, "LayerNorm 1 backward")
     vec_close(G[LN1_G], (f(da) * xhat1).sum(0), mode.vec, "d gamma 1")
@@ -369,7 +386,7 @@ def test_bert_layer_dropout_run_is_deterministic(dev, which, mode_name):
         saved, scratch, h_out, weights = _run_layer(D, P, dev, 0.1, 0.1, mode=mode)
         kw = _lib.lib().vb_attn_keepbits_words(D.S) * D.B * D.NH
         sv = _saved_views(D, saved, kw, mode)
-        d_in, G = _run_bwd(D, P, saved, scratch, weights, dev, 0.1, 0.1, mode=mode)
+        d_in, G = _run_bwd(D, P, saved, scratch, weights, dev, 0.1, 0.1, mode=mode, h_out=h_out)
         sc = _scratch_views(D, scratch, mode)
         outs.append([h_out.clone(), (sv["sp_ctx"] if mode.x3 else sv["ctx"]).clone(), sv["keepbits"].clone(), d_in.clone(),
                      (sc["sp_dqkv"] if mode.x3 else sc["t_3h"]).clone(), G[1].clone()])

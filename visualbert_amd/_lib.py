@@ -70,7 +70,7 @@ SIGNATURES = {
     "vb_bert_layer_saved_bytes": (_i64, [_i, _i, _i, _i, _i, _i, _f]),
     "vb_bert_layer_scratch_bytes": (_i64, [_i, _i, _i, _i, _i, _i]),
     "vb_bert_layer_fwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _f, _u64, _u32, _p]),
-    "vb_bert_layer_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _u64, _u32, _p]),
+    "vb_bert_layer_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _u64, _u32, _p]),
     "vb_comm_unique_id": (_i, [_p]),
     "vb_comm_init": (_i, [_p, _i, _i, _p]),
     "vb_comm_nranks": (_i, [_p]),

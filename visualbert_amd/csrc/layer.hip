@@ -21,6 +21,7 @@ struct Saved {
     unsigned char *qkv, *ctx, *z1, *a_out, *pre, *inter, *z2;
     float *lse, *mean1, *rstd1, *mean2, *rstd2;
     uint64_t* keepbits;
+    int *ln_rb1, *ln_rb2;   // records of the two LayerNorm forwards (bf16): [0] = 1: no z was written, the backward rebuilds x-hat from y
     // bf16x3 only: the split (hi | lo) images of the four GEMM inputs the forward made anyway -- they are the x operands of the
     // backward's weight-gradient launch, so keeping them saves four split passes per layer (19 % of the mode's split traffic)
     unsigned char *sp_hin, *sp_ctx, *sp_aout, *sp_inter;
@@ -45,6 +46,7 @@ Saved carve_saved(unsigned char* base, const Dims& d, bool attn_dropout) {
     s.mean2 = (float*)take((size_t)d.M * 4);
     s.rstd2 = (float*)take((size_t)d.M * 4);
     s.keepbits = (uint64_t*)take(attn_dropout ? (size_t)d.B * d.nh * vb_attn_keepbits_words(d.S) * 8 : 0);
+    s.ln_rb1 = (int*)take((size_t)vb_ln_rebuild_bytes(d.H)); s.ln_rb2 = (int*)take((size_t)vb_ln_rebuild_bytes(d.H));
     const size_t sh = d.x3 ? (size_t)d.M * 2 * d.H * 2 : 0, si = d.x3 ? (size_t)d.M * 2 * d.I * 2 : 0;
     s.sp_hin = take(sh); s.sp_ctx = take(sh); s.sp_aout = take(sh); s.sp_inter = take(si);
     s.total = o;
@@ -157,8 +159,12 @@ extern "C" int vb_bert_layer_fwd(int dtype, const void* h_in, const float* mask_
     VB_TRY(linear(d, d.x3 ? (const void*)sv.sp_ctx : (const void*)sv.ctx, H, nullptr, wo, wk * H, sc.t_h0, H, bo, nullptr, VB_ACT_NONE,
                   nullptr, nullptr, nullptr, stream));
     // 4. dropout + residual + LayerNorm
+    //    (bf16: the pre-LN sum z is NOT written when the backward can rebuild x-hat from the output it reads anyway -- three tensors
+    //     per launch instead of four; decided in the kernel from gamma / beta and recorded in sv.ln_rb1 / ln_rb2.  fp32 / bf16x3 keep z)
+    int* rb1 = dtype == VB_BF16 ? sv.ln_rb1 : nullptr;
+    int* rb2 = dtype == VB_BF16 ? sv.ln_rb2 : nullptr;
     VB_TRY(vb_ln_fwd_sp(edt, sc.t_h0, h_in, sv.z1, sv.a_out, sv.mean1, sv.rstd1, g1, b1, M, H, eps, p_hidden, sid + 1,
-                        0.f, 0, seed, d.x3 ? sv.sp_aout : nullptr, 2 * H, stream));
+                        0.f, 0, seed, d.x3 ? sv.sp_aout : nullptr, 2 * H, rb1, stream));
     // 5. FFN in + erf-GELU (GELU' kept for backward)
     //    (split-operand mode: the activation leaves the GEMM as a split image -- only GEMMs read it: FFN-out and its wgrad)
     VB_TRY(linear(d, d.x3 ? (const void*)sv.sp_aout : (const void*)sv.a_out, H, nullptr, wi, wk * H,
@@ -167,13 +173,13 @@ extern "C" int vb_bert_layer_fwd(int dtype, const void* h_in, const float* mask_
     VB_TRY(linear(d, d.x3 ? (const void*)sv.sp_inter : (const void*)sv.inter, I, nullptr, wo2, wk * I, sc.t_h1, H, bo2, nullptr,
                   VB_ACT_NONE, nullptr, nullptr, nullptr, stream));
     // 7. dropout + residual + LayerNorm
-    VB_TRY(vb_ln_fwd(edt, sc.t_h1, sv.a_out, sv.z2, h_out, sv.mean2, sv.rstd2, g2, b2, M, H, eps, p_hidden, sid + 4,
-                     0.f, 0, seed, stream));
+    VB_TRY(vb_ln_fwd_sp(edt, sc.t_h1, sv.a_out, sv.z2, h_out, sv.mean2, sv.rstd2, g2, b2, M, H, eps, p_hidden, sid + 4,
+                        0.f, 0, seed, nullptr, 0, rb2, stream));
     return VB_OK;
 }
 
 // grads[]: fp32 accumulation targets in VB_LW_* order (all required)
-extern "C" int vb_bert_layer_bwd(int dtype, const void* h_in, const float* mask_add, const void* d_out, void* d_in,
+extern "C" int vb_bert_layer_bwd(int dtype, const void* h_in, const void* h_out, const float* mask_add, const void* d_out, void* d_in,
                                  const void* saved, void* scratch, const void* const* weights, void* const* grads,
                                  const void* const* weights_t, const int64_t* ld_t,
                                  int B, int S, int H, int I, int nh, float p_hidden, float p_attn,
@@ -182,6 +188,7 @@ extern "C" int vb_bert_layer_bwd(int dtype, const void* h_in, const float* mask_
     if (!fill_dims(d, dtype, B, S, H, I, nh) || !h_in || !mask_add || !d_out || !d_in || !saved || !scratch ||
         !weights || !grads)
         return VB_ERR_ARG;
+    if (dtype == VB_BF16 && !h_out) return VB_ERR_ARG;       // the output LayerNorm's backward may rebuild x-hat from it
     Saved sv = carve_saved((unsigned char*)saved, d, p_attn > 0.f);
     Scratch sc = carve_scratch((unsigned char*)scratch, d);
     const int M = (int)d.M;
@@ -191,6 +198,8 @@ extern "C" int vb_bert_layer_bwd(int dtype, const void* h_in, const float* mask_
     const void* wi = weights[VB_LW_FI_W];
     const void* wo2 = weights[VB_LW_FO_W];
     const float* g2 = (const float*)weights[VB_LW_LN2_G];
+    const int* rb1 = dtype == VB_BF16 ? sv.ln_rb1 : nullptr;
+    const int* rb2 = dtype == VB_BF16 ? sv.ln_rb2 : nullptr;
     float* G[VB_LW_COUNT];
     for (int i = 0; i < VB_LW_COUNT; ++i) { G[i] = (float*)grads[i]; if (!G[i]) return VB_ERR_ARG; }
     // dgrad dx[M,in] = dy[M,out] W[out,in]: with W^T [in, ld>=out] both operands are K-contiguous (LDS-direct
@@ -220,7 +229,7 @@ extern "C" int vb_bert_layer_bwd(int dtype, const void* h_in, const float* mask_
     // 1. output LayerNorm backward (+ bias gradient of the FFN-out dense as a by-product)
     //    (split-operand mode: + the hi | lo image of dfo, the next dgrad's and the weight-gradient launch's operand)
     VB_TRY(vb_ln_bwd_sp(edt, d_out, sv.z2, sv.mean2, sv.rstd2, g2, dz2, d.x3 ? nullptr : dfo, G[VB_LW_LN2_G], G[VB_LW_LN2_B],
-                        G[VB_LW_FO_B], M, H, p_hidden, sid + 4, 0.f, 0, seed, sc.ln_ws, d.x3 ? sc.sp_dfo : nullptr, 2 * H, stream));
+                        G[VB_LW_FO_B], M, H, p_hidden, sid + 4, 0.f, 0, seed, sc.ln_ws, d.x3 ? sc.sp_dfo : nullptr, 2 * H, h_out, rb2, stream));
     // 2. dgrad FFN-out with the saved GELU' folded into the epilogue: dpre = (dfo Wo2) * gelu'(pre)
     //    (+ bias gradient of FFN-in = column sums of dpre, accumulated by the same epilogue)
     //    (split-operand mode: dpre leaves the GEMM as a split image -- only the next dgrad and the wgrad launch read it)
@@ -233,7 +242,7 @@ extern "C" int vb_bert_layer_bwd(int dtype, const void* h_in, const float* mask_
     unsigned char* dz1 = sc.t_h5;
     unsigned char* dao = p_hidden > 0.f ? sc.t_h4 : dz1;
     VB_TRY(vb_ln_bwd_sp(edt, sc.t_h2, sv.z1, sv.mean1, sv.rstd1, g1, dz1, d.x3 ? nullptr : dao, G[VB_LW_LN1_G], G[VB_LW_LN1_B],
-                        G[VB_LW_AO_B], M, H, p_hidden, sid + 1, 0.f, 0, seed, sc.ln_ws, d.x3 ? sc.sp_dao : nullptr, 2 * H, stream));
+                        G[VB_LW_AO_B], M, H, p_hidden, sid + 1, 0.f, 0, seed, sc.ln_ws, d.x3 ? sc.sp_dao : nullptr, 2 * H, sv.a_out, rb1, stream));
     // 5. dgrad attention-out: dctx = dao Wo
     VB_TRY(dgrad(d.x3 ? (const void*)sc.sp_dao : (const void*)dao, H, wo, VB_LWT_AO, H, sc.t_h3, nullptr, VB_ACT_NONE, nullptr, nullptr,
                  nullptr));

@@ -41,13 +41,57 @@ struct LnFwdArgs {
     const void* x; const void* resid; void* z_out; void* y; float* mean; float* rstd;
     const float* gamma; const float* beta; int M, H; float eps; DropSpec din, dout;
     bf16* y_split; long ld_split;      // fp32 only: also write y as a bf16 hi | lo image [M, ld_split] (split-operand mode), or NULL
+    int* rebuild;                      // non-NULL (vb_ln_rebuild_bytes(H) bytes): z_out is written only if the backward cannot rebuild
+                                       // x-hat from y (see ln_rebuildable); the verdict and the per-channel tables go here
 };
+
+// May the backward take x-hat = (y - beta) / gamma from the output it already has instead of from a saved pre-LN sum z?
+// Rounding y to T costs x-hat 2^-9 (|x-hat| + |beta| / |gamma|) per element where the z route costs 2^-9 |x-hat + mean * rstd|: the
+// same order while |beta| <= 2 |gamma| on every channel (true at initialisation: gamma = 1, beta = 0), unbounded when a trained
+// LayerNorm has a channel with |gamma| << |beta|.  So the kernels decide per launch, from the parameters themselves: each lane
+// tests the channels it owns, the half-wave (which owns all H channels between its lanes) agrees, every workgroup reaches the same
+// verdict, workgroup 0 records it for the backward (which must not re-derive it: an optimizer step may lie in between).
+constexpr int LN_RB_TABLE = 64;       // floats from the verdict to the tables (256 bytes)
+template <int NC>
+VB_DEVICE bool ln_rebuildable(const float* gamma, const float* beta, int H, int l32) {
+    float bad = 0.f;
+#pragma unroll
+    for (int ci = 0; ci < NC; ++ci) {
+        const int col = (l32 + 32 * ci) * 8;
+        const int colc = col < H ? col : 0;
+        float gm[8], bt[8];
+        load8(gm, gamma + colc); load8(bt, beta + colc);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bad += (fabsf(gm[j]) > 1e-30f && fabsf(bt[j]) <= 2.f * fabsf(gm[j])) ? 0.f : 1.f;
+    }
+    return half_sum(bad) == 0.f;
+}
 
 template <typename T, int NC>
 VB_KERNEL VB_LAUNCH_BOUNDS(NT) ln_fwd_kernel(LnFwdArgs a) {
     const int l32 = threadIdx.x & 31, hw = threadIdx.x >> 5;
     const int H = a.H;
     const float invH = 1.0f / (float)H;
+    bool write_z = a.z_out != nullptr;
+    if (a.rebuild) {
+        const bool rb = ln_rebuildable<NC>(a.gamma, a.beta, H, l32);
+        if (rb) write_z = false;
+        if (blockIdx.x == 0 && hw == 0) {          // the record for the backward: the verdict + 1 / gamma and -beta / gamma per channel
+            if (l32 == 0) *a.rebuild = rb ? 1 : 0;
+            float* tab = (float*)a.rebuild + LN_RB_TABLE;
+#pragma unroll
+            for (int ci = 0; ci < NC; ++ci) {
+                const int col = (l32 + 32 * ci) * 8;
+                if (rb && col < H) {
+                    float gm[8], bt[8], rg[8], c[8];
+                    load8(gm, a.gamma + col); load8(bt, a.beta + col);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { rg[j] = 1.0f / gm[j]; c[j] = -bt[j] * rg[j]; }
+                    store8(tab + col, rg); store8(tab + H + col, c);
+                }
+            }
+        }
+    }
     // the trip count is uniform per workgroup (wave shuffles below need all 64 lanes); a half-wave
     // whose row is past the end just keeps its lanes predicated off
     for (int base = blockIdx.x * HW_PER_BLOCK; base < a.M; base += gridDim.x * HW_PER_BLOCK) {
@@ -86,7 +130,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) ln_fwd_kernel(LnFwdArgs a) {
         for (int ci = 0; ci < NC; ++ci) {
             const int col = (l32 + 32 * ci) * 8;
             const bool ok = act && col < H;
-            if (a.z_out && ok) store8((T*)a.z_out + (long)row * H + col, v[ci]);
+            if (write_z && ok) store8((T*)a.z_out + (long)row * H + col, v[ci]);
 #pragma unroll
             for (int j = 0; j < 8; ++j) { v[ci][j] = ok ? v[ci][j] : 0.f; s += v[ci][j]; }
         }
@@ -128,6 +172,7 @@ struct LnBwdArgs {
     void* dz; void* dx; float* dgamma; float* dbeta; float* dbias; int M, H; DropSpec din, dout;
     float* partials;     // [gridDim.x][3][H] when the two-stage column reduction is used, else NULL
     bf16* dx_split; long ld_split;     // fp32 only: also write dx (= dz when no dropout) as a bf16 hi | lo image, or NULL
+    const void* y; const int* rebuild;   // *rebuild != 0: x-hat = (y - beta) / gamma, tables behind the verdict (the forward wrote no z)
 };
 
 // reduce this block's per-lane column partials across its 8 half-waves through LDS ([8][H] floats, plain
@@ -216,6 +261,8 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(NT, MINW) ln_bwd_kernel(LnBwdArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) { accg[ci][j] = 0.f; accb[ci][j] = 0.f; accx[ci][j] = 0.f; }
 
+    const bool rebuild = a.rebuild && *a.rebuild != 0;
+    const T* xsrc = (const T*)(rebuild ? a.y : a.z);
     for (int row = blockIdx.x * WAVES_PER_BLOCK + wave; row < a.M; row += gridDim.x * WAVES_PER_BLOCK) {
         const float mean = a.mean[row], rstd = a.rstd[row];
         float dy[NC2][8], xh[NC2][8];
@@ -227,7 +274,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(NT, MINW) ln_bwd_kernel(LnBwdArgs a) {
 #pragma unroll
         for (int ci = 0; ci < NC2; ++ci) {
             const int col = (lane + 64 * ci) * 8;
-            load8(xh[ci], (const T*)a.z + (long)row * H + (col < H ? col : 0));
+            load8(xh[ci], xsrc + (long)row * H + (col < H ? col : 0));
         }
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -238,10 +285,18 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(NT, MINW) ln_bwd_kernel(LnBwdArgs a) {
             float gm[8];
             load8(gm, a.gamma + colc);
             if (a.dout.p > 0.f) apply_dropout8(dy[ci], a.dout, (uint64_t)((long)row * H + colc) >> 3);
+            if (rebuild) {                                    // uniform: x-hat = y / gamma - beta / gamma from the LayerNorm's own output
+                float rg[8], c[8];
+                load8(rg, (const float*)a.rebuild + LN_RB_TABLE + colc); load8(c, (const float*)a.rebuild + LN_RB_TABLE + H + colc);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xh[ci][j] = fmaf(xh[ci][j], rg[j], c[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xh[ci][j] = (xh[ci][j] - mean) * rstd;
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float d = ok ? dy[ci][j] : 0.f;         // columns past H contribute exact zeros
-                xh[ci][j] = (xh[ci][j] - mean) * rstd;
                 accg[ci][j] += d * xh[ci][j];                 // dgamma
                 accb[ci][j] += d;                             // dbeta
                 dy[ci][j] = d * gm[j];                        // g = dy * gamma
@@ -488,18 +543,19 @@ extern "C" int vb_ln_fwd(int dtype, const void* x, const void* resid, void* z_ou
                          float p_in, uint32_t stream_in, float p_out, uint32_t stream_out, uint64_t seed,
                          void* stream) {
     return vb_ln_fwd_sp(dtype, x, resid, z_out, y, mean, rstd, gamma, beta, M, H, eps, p_in, stream_in, p_out, stream_out, seed,
-                        nullptr, 0, stream);
+                        nullptr, 0, nullptr, stream);
 }
 
 int vb_ln_fwd_sp(int dtype, const void* x, const void* resid, void* z_out, void* y, float* mean, float* rstd,
                  const float* gamma, const float* beta, int M, int H, float eps,
                  float p_in, uint32_t stream_in, float p_out, uint32_t stream_out, uint64_t seed,
-                 void* y_split, int64_t ld_split, void* stream) {
+                 void* y_split, int64_t ld_split, int* rebuild, void* stream) {
     if (!x || !y || !gamma || !beta || M <= 0 || bad_h(H)) return VB_ERR_ARG;
+    if (rebuild && (p_out > 0.f || !z_out)) return VB_ERR_ARG;      // a dropped output cannot give x-hat back; z_out is the fallback
     if (p_in < 0.f || p_in >= 1.f || p_out < 0.f || p_out >= 1.f) return VB_ERR_ARG;
     if (y_split && (dtype != VB_F32 || (ld_split % 16) || ld_split < 2 * H || (((uintptr_t)y_split) & 15))) return VB_ERR_ARG;
     LnFwdArgs a{x, resid, z_out, y, mean, rstd, gamma, beta, M, H, eps, make_drop(p_in, seed, stream_in),
-                make_drop(p_out, seed, stream_out), (bf16*)y_split, (long)ld_split};
+                make_drop(p_out, seed, stream_out), (bf16*)y_split, (long)ld_split, rebuild};
     dim3 grid(row_grid(M, 4096));
     hipStream_t s = (hipStream_t)stream;
     if (dtype == VB_BF16) VB_DISPATCH_NC(ln_fwd_kernel, bf16, H, grid, 0, s, a);
@@ -507,6 +563,8 @@ int vb_ln_fwd_sp(int dtype, const void* x, const void* resid, void* z_out, void*
     else return VB_ERR_ARG;
     return vb_check_launch();
 }
+
+int64_t vb_ln_rebuild_bytes(int H) { return (int64_t)(LN_RB_TABLE + 2 * H) * (int64_t)sizeof(float); }
 
 extern "C" int64_t vb_ln_bwd_ws_bytes(int M, int H) {
     return (int64_t)row_grid(M, 1024) * 3 * H * (int64_t)sizeof(float);
@@ -517,21 +575,22 @@ extern "C" int vb_ln_bwd(int dtype, const void* dy, const void* z, const float* 
                          int M, int H, float p_in, uint32_t stream_in, float p_out, uint32_t stream_out,
                          uint64_t seed, float* ws, void* stream) {
     return vb_ln_bwd_sp(dtype, dy, z, mean, rstd, gamma, dz, dx, dgamma, dbeta, dbias, M, H, p_in, stream_in, p_out, stream_out, seed,
-                        ws, nullptr, 0, stream);
+                        ws, nullptr, 0, nullptr, nullptr, stream);
 }
 
 int vb_ln_bwd_sp(int dtype, const void* dy, const void* z, const float* mean, const float* rstd,
                  const float* gamma, void* dz, void* dx, float* dgamma, float* dbeta, float* dbias,
                  int M, int H, float p_in, uint32_t stream_in, float p_out, uint32_t stream_out,
-                 uint64_t seed, float* ws, void* dx_split, int64_t ld_split, void* stream) {
+                 uint64_t seed, float* ws, void* dx_split, int64_t ld_split, const void* y, const int* rebuild, void* stream) {
     if (!dy || !z || !mean || !rstd || !gamma || !dz || M <= 0 || bad_h(H)) return VB_ERR_ARG;
+    if (rebuild && (!y || p_out > 0.f)) return VB_ERR_ARG;
     if (dx_split && (dtype != VB_F32 || (ld_split % 16) || ld_split < 2 * H || (((uintptr_t)dx_split) & 15))) return VB_ERR_ARG;
     // the image is of dx (the gradient after the input dropout).  dx == NULL with an image: dx leaves ONLY as the image -- the
     // kernel still needs a.dx non-NULL to run the dropout on its registers, and a.dx == a.dz suppresses the fp32 store
     if (dx_split && !dx) dx = dz;
     else if (p_in > 0.f && (!dx || dx == dz)) return VB_ERR_ARG;   // dropped and un-dropped grads differ
     LnBwdArgs a{dy, z, mean, rstd, gamma, dz, dx, dgamma, dbeta, dbias, M, H, make_drop(p_in, seed, stream_in),
-                make_drop(p_out, seed, stream_out), ws, (bf16*)dx_split, (long)ld_split};
+                make_drop(p_out, seed, stream_out), ws, (bf16*)dx_split, (long)ld_split, y, rebuild};
     dim3 grid(row_grid(M, ws ? 1024 : 256));
     hipStream_t s = (hipStream_t)stream;
     const size_t smem = (size_t)H * WAVES_PER_BLOCK * 3 * sizeof(float);

@@ -955,12 +955,12 @@ class BertLayerFn(torch.autograd.Function):
                                   seed, sid, stream_ptr()), "vb_bert_layer_fwd")
         ctx.layer = layer
         ctx.cfg = (B, S, H, I, nh, p_hidden, p_attn, seed, sid)
-        ctx.save_for_backward(h2, mask_add, saved)
+        ctx.save_for_backward(h2, mask_add, saved, out)     # out: the bf16 output LayerNorm's backward may rebuild x-hat from it
         return out.view(B, S, H)
 
     @staticmethod
     def backward(ctx, dy):
-        h2, mask_add, saved = ctx.saved_tensors
+        h2, mask_add, saved, out = ctx.saved_tensors
         B, S, H, I, nh, p_hidden, p_attn, seed, sid = ctx.cfg
         layer = ctx.layer
         at, im, om = layer.attention, layer.intermediate, layer.output
@@ -995,7 +995,7 @@ class BertLayerFn(torch.autograd.Function):
                 w_ = w_.buf
             wt_arr[i] = w_.data_ptr() if w_ is not None else None
             ld_arr[i] = w_.stride(0) if w_ is not None else 0
-        check(L.vb_bert_layer_bwd(code, ptr(h2), ptr(mask_add), ptr(dy2), ptr(d_in), ptr(saved), ptr(scratch),
+        check(L.vb_bert_layer_bwd(code, ptr(h2), ptr(out), ptr(mask_add), ptr(dy2), ptr(d_in), ptr(saved), ptr(scratch),
                                   _ptr_array(weights), _ptr_array(grads), wt_arr, ld_arr, B, S, H, I, nh,
                                   float(p_hidden), float(p_attn), seed, sid, stream_ptr()), "vb_bert_layer_bwd")
         if direct_qkv:

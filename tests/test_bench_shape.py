@@ -39,6 +39,7 @@ class Dims:
 BENCH = Dims(1024, 164, 768, 3072, 12)       # bench.py's default per-GPU batch (configs[1])
 BENCH512 = Dims(512, 164, 768, 3072, 12)     # half the bench batch (other tile counts per launch, other workgroup walks)
 SMALL = Dims(3, 164, 128, 256, 2)            # the same checks at a size the kernel-logic simulator finishes (VB_EMU=1)
+MID = Dims(1, 24, 768, 256, 12)              # BERT-base width on the simulator: the H = 768 LayerNorm backward (12 columns per lane)
 F32 = torch.float32
 
 
@@ -110,7 +111,7 @@ def _saved_views(D, saved, keep_words, mode=None):
     specs = [("qkv", A, (M, 3 * H)), ("ctx", A, (0 if x3 else M, H)), ("z1", A, (M, H)), ("a_out", A, (M, H)), ("pre", A, (M, I)),
              ("inter", A, (0 if x3 else M, I)), ("z2", A, (M, H)), ("lse", torch.float32, (B, NH, S)), ("mean1", torch.float32, (M,)),
              ("rstd1", torch.float32, (M,)), ("mean2", torch.float32, (M,)), ("rstd2", torch.float32, (M,)),
-             ("keepbits", torch.int64, (keep_words,)), ("ln_rb1", torch.int32, (64 + 2 * H,)), ("ln_rb2", torch.int32, (64 + 2 * H,))]
+             ("keepbits", torch.int64, (keep_words,)), ("ln_flags", torch.int32, (2,))]
     if mode is not None and mode.x3:            # the forward's split images, kept for the weight-gradient launch
         specs += [("sp_hin", BF, (M, 2 * H)), ("sp_ctx", BF, (M, 2 * H)), ("sp_aout", BF, (M, 2 * H)), ("sp_inter", BF, (M, 2 * I))]
     v, total = _carve(saved, specs)
@@ -255,9 +256,9 @@ def _attn_ref(D, qkv, mask_add, dctx=None, chunk=64):
 def _sized(dev, which):
     if which.startswith("bench") and dev.type != "cuda":
         pytest.skip("bench-sized layer: GPU only")
-    if which == "small" and dev.type == "cuda" and os.environ.get("VB_SMALL_ON_GPU") != "1":
+    if which in ("small", "mid") and dev.type == "cuda" and os.environ.get("VB_SMALL_ON_GPU") != "1":
         pytest.skip("the small size validates this test's own references on the kernel-logic simulator (VB_EMU=1)")
-    return {"bench": BENCH, "bench512": BENCH512, "small": SMALL, "guard": SMALL}[which]
+    return {"bench": BENCH, "bench512": BENCH512, "small": SMALL, "guard": SMALL, "mid": MID}[which]
 
 
 def _dump_measured():
@@ -270,8 +271,8 @@ def _dump_measured():
         pass
 
 
-@pytest.mark.parametrize("which,mode_name", [("bench", "bf16"), ("small", "bf16"), ("guard", "bf16"), ("bench", "bf16x3"),
-                                             ("bench512", "bf16x3"), ("small", "bf16x3")])
+@pytest.mark.parametrize("which,mode_name", [("bench", "bf16"), ("small", "bf16"), ("guard", "bf16"), ("mid", "bf16"), ("bench", "bf16x3"),
+                                             ("bench512", "bf16x3"), ("small", "bf16x3"), ("mid", "bf16x3")])
 def test_bert_layer_at_bench_shape(dev, which, mode_name):
     """"guard": the small size (GPU and simulator) with ONE channel of the first LayerNorm at |beta| = 3 |gamma| -- that launch must
     keep its pre-LN sum and the backward must read it, while the second LayerNorm of the same layer still rebuilds x-hat from y"""
@@ -301,7 +302,7 @@ def test_bert_layer_at_bench_shape(dev, which, mode_name):
     rebuilt1 = rebuilt2 = not mode.x3
     if which == "guard":
         rebuilt1 = False
-    assert mode.x3 or [int(sv["ln_rb1"][0]), int(sv["ln_rb2"][0])] == [int(rebuilt1), int(rebuilt2)]
+    assert mode.x3 or sv["ln_flags"].tolist() == [int(rebuilt1), int(rebuilt2)], sv["ln_flags"].tolist()
     if not rebuilt1:
         close(sv["z1"], z1, mode.add, "z1 = attention-out + residual")              # one fp32 add, one rounding
     close(sv["a_out"], _ln_ref(z1, P["g1"], P["b1"]), mode.ln, "LayerNorm 1")

@@ -239,7 +239,7 @@ def ref_ln(z, gamma, beta):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("MH", [(37, 128), (21, 768), (9, 1024), (2100, 768)])   # last: sliced second-stage reduction
+@pytest.mark.parametrize("MH", [(37, 128), (21, 768), (13, 640), (9, 1024), (2100, 768)])   # 640: a partly filled 4-column chunk; last: sliced second-stage reduction
 def test_layernorm_residual_fwd_bwd(dev, dt, MH):
     M, H = MH
     g = torch.Generator().manual_seed(3)

@@ -21,7 +21,7 @@ struct Saved {
     unsigned char *qkv, *ctx, *z1, *a_out, *pre, *inter, *z2;
     float *lse, *mean1, *rstd1, *mean2, *rstd2;
     uint64_t* keepbits;
-    int *ln_rb1, *ln_rb2;   // records of the two LayerNorm forwards (bf16): [0] = 1: no z was written, the backward rebuilds x-hat from y
+    int* ln_flags;      // [2] device ints written by the two LayerNorm forwards (bf16): 1 = no z was written, the backward rebuilds x-hat from y
     // bf16x3 only: the split (hi | lo) images of the four GEMM inputs the forward made anyway -- they are the x operands of the
     // backward's weight-gradient launch, so keeping them saves four split passes per layer (19 % of the mode's split traffic)
     unsigned char *sp_hin, *sp_ctx, *sp_aout, *sp_inter;
@@ -46,7 +46,7 @@ Saved carve_saved(unsigned char* base, const Dims& d, bool attn_dropout) {
     s.mean2 = (float*)take((size_t)d.M * 4);
     s.rstd2 = (float*)take((size_t)d.M * 4);
     s.keepbits = (uint64_t*)take(attn_dropout ? (size_t)d.B * d.nh * vb_attn_keepbits_words(d.S) * 8 : 0);
-    s.ln_rb1 = (int*)take((size_t)vb_ln_rebuild_bytes(d.H)); s.ln_rb2 = (int*)take((size_t)vb_ln_rebuild_bytes(d.H));
+    s.ln_flags = (int*)take(8);
     const size_t sh = d.x3 ? (size_t)d.M * 2 * d.H * 2 : 0, si = d.x3 ? (size_t)d.M * 2 * d.I * 2 : 0;
     s.sp_hin = take(sh); s.sp_ctx = take(sh); s.sp_aout = take(sh); s.sp_inter = take(si);
     s.total = o;
@@ -160,9 +160,10 @@ extern "C" int vb_bert_layer_fwd(int dtype, const void* h_in, const float* mask_
                   nullptr, nullptr, nullptr, stream));
     // 4. dropout + residual + LayerNorm
     //    (bf16: the pre-LN sum z is NOT written when the backward can rebuild x-hat from the output it reads anyway -- three tensors
-    //     per launch instead of four; decided in the kernel from gamma / beta and recorded in sv.ln_rb1 / ln_rb2.  fp32 / bf16x3 keep z)
-    int* rb1 = dtype == VB_BF16 ? sv.ln_rb1 : nullptr;
-    int* rb2 = dtype == VB_BF16 ? sv.ln_rb2 : nullptr;
+    //     per launch instead of four; decided in the kernel from gamma / beta and recorded in sv.ln_flags.  fp32 / bf16x3 keep z)
+    static const bool no_rb = getenv("VB_LN_NOREBUILD") != nullptr;     // EXPERIMENT (one GPU session)
+    int* rb1 = dtype == VB_BF16 && !no_rb ? sv.ln_flags : nullptr;
+    int* rb2 = dtype == VB_BF16 && !no_rb ? sv.ln_flags + 1 : nullptr;
     VB_TRY(vb_ln_fwd_sp(edt, sc.t_h0, h_in, sv.z1, sv.a_out, sv.mean1, sv.rstd1, g1, b1, M, H, eps, p_hidden, sid + 1,
                         0.f, 0, seed, d.x3 ? sv.sp_aout : nullptr, 2 * H, rb1, stream));
     // 5. FFN in + erf-GELU (GELU' kept for backward)
@@ -194,12 +195,13 @@ extern "C" int vb_bert_layer_bwd(int dtype, const void* h_in, const void* h_out,
     const int M = (int)d.M;
     const void* wqkv = weights[VB_LW_QKV_W];
     const void* wo = weights[VB_LW_AO_W];
-    const float* g1 = (const float*)weights[VB_LW_LN1_G];
+    const float* g1 = (const float*)weights[VB_LW_LN1_G]; const float* b1 = (const float*)weights[VB_LW_LN1_B];
     const void* wi = weights[VB_LW_FI_W];
     const void* wo2 = weights[VB_LW_FO_W];
-    const float* g2 = (const float*)weights[VB_LW_LN2_G];
-    const int* rb1 = dtype == VB_BF16 ? sv.ln_rb1 : nullptr;
-    const int* rb2 = dtype == VB_BF16 ? sv.ln_rb2 : nullptr;
+    const float* g2 = (const float*)weights[VB_LW_LN2_G]; const float* b2 = (const float*)weights[VB_LW_LN2_B];
+    static const bool no_rb = getenv("VB_LN_NOREBUILD") != nullptr;     // EXPERIMENT (one GPU session)
+    const int* rb1 = dtype == VB_BF16 && !no_rb ? sv.ln_flags : nullptr;
+    const int* rb2 = dtype == VB_BF16 && !no_rb ? sv.ln_flags + 1 : nullptr;
     float* G[VB_LW_COUNT];
     for (int i = 0; i < VB_LW_COUNT; ++i) { G[i] = (float*)grads[i]; if (!G[i]) return VB_ERR_ARG; }
     // dgrad dx[M,in] = dy[M,out] W[out,in]: with W^T [in, ld>=out] both operands are K-contiguous (LDS-direct
@@ -229,7 +231,7 @@ extern "C" int vb_bert_layer_bwd(int dtype, const void* h_in, const void* h_out,
     // 1. output LayerNorm backward (+ bias gradient of the FFN-out dense as a by-product)
     //    (split-operand mode: + the hi | lo image of dfo, the next dgrad's and the weight-gradient launch's operand)
     VB_TRY(vb_ln_bwd_sp(edt, d_out, sv.z2, sv.mean2, sv.rstd2, g2, dz2, d.x3 ? nullptr : dfo, G[VB_LW_LN2_G], G[VB_LW_LN2_B],
-                        G[VB_LW_FO_B], M, H, p_hidden, sid + 4, 0.f, 0, seed, sc.ln_ws, d.x3 ? sc.sp_dfo : nullptr, 2 * H, h_out, rb2, stream));
+                        G[VB_LW_FO_B], M, H, p_hidden, sid + 4, 0.f, 0, seed, sc.ln_ws, d.x3 ? sc.sp_dfo : nullptr, 2 * H, h_out, b2, rb2, stream));
     // 2. dgrad FFN-out with the saved GELU' folded into the epilogue: dpre = (dfo Wo2) * gelu'(pre)
     //    (+ bias gradient of FFN-in = column sums of dpre, accumulated by the same epilogue)
     //    (split-operand mode: dpre leaves the GEMM as a split image -- only the next dgrad and the wgrad launch read it)
@@ -242,7 +244,7 @@ extern "C" int vb_bert_layer_bwd(int dtype, const void* h_in, const void* h_out,
     unsigned char* dz1 = sc.t_h5;
     unsigned char* dao = p_hidden > 0.f ? sc.t_h4 : dz1;
     VB_TRY(vb_ln_bwd_sp(edt, sc.t_h2, sv.z1, sv.mean1, sv.rstd1, g1, dz1, d.x3 ? nullptr : dao, G[VB_LW_LN1_G], G[VB_LW_LN1_B],
-                        G[VB_LW_AO_B], M, H, p_hidden, sid + 1, 0.f, 0, seed, sc.ln_ws, d.x3 ? sc.sp_dao : nullptr, 2 * H, sv.a_out, rb1, stream));
+                        G[VB_LW_AO_B], M, H, p_hidden, sid + 1, 0.f, 0, seed, sc.ln_ws, d.x3 ? sc.sp_dao : nullptr, 2 * H, sv.a_out, b1, rb1, stream));
     // 5. dgrad attention-out: dctx = dao Wo
     VB_TRY(dgrad(d.x3 ? (const void*)sc.sp_dao : (const void*)dao, H, wo, VB_LWT_AO, H, sc.t_h3, nullptr, VB_ACT_NONE, nullptr, nullptr,
                  nullptr));

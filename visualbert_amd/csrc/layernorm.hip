@@ -41,8 +41,8 @@ struct LnFwdArgs {
     const void* x; const void* resid; void* z_out; void* y; float* mean; float* rstd;
     const float* gamma; const float* beta; int M, H; float eps; DropSpec din, dout;
     bf16* y_split; long ld_split;      // fp32 only: also write y as a bf16 hi | lo image [M, ld_split] (split-operand mode), or NULL
-    int* rebuild;                      // non-NULL (vb_ln_rebuild_bytes(H) bytes): z_out is written only if the backward cannot rebuild
-                                       // x-hat from y (see ln_rebuildable); the verdict and the per-channel tables go here
+    int* rebuild;                      // non-NULL: z_out is written only if the backward cannot rebuild x-hat from y (see
+                                       // ln_rebuildable); the verdict (one device int) goes here
 };
 
 // May the backward take x-hat = (y - beta) / gamma from the output it already has instead of from a saved pre-LN sum z?
@@ -51,7 +51,6 @@ struct LnFwdArgs {
 // LayerNorm has a channel with |gamma| << |beta|.  So the kernels decide per launch, from the parameters themselves: each lane
 // tests the channels it owns, the half-wave (which owns all H channels between its lanes) agrees, every workgroup reaches the same
 // verdict, workgroup 0 records it for the backward (which must not re-derive it: an optimizer step may lie in between).
-constexpr int LN_RB_TABLE = 64;       // floats from the verdict to the tables (256 bytes)
 template <int NC>
 VB_DEVICE bool ln_rebuildable(const float* gamma, const float* beta, int H, int l32) {
     float bad = 0.f;
@@ -76,21 +75,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) ln_fwd_kernel(LnFwdArgs a) {
     if (a.rebuild) {
         const bool rb = ln_rebuildable<NC>(a.gamma, a.beta, H, l32);
         if (rb) write_z = false;
-        if (blockIdx.x == 0 && hw == 0) {          // the record for the backward: the verdict + 1 / gamma and -beta / gamma per channel
-            if (l32 == 0) *a.rebuild = rb ? 1 : 0;
-            float* tab = (float*)a.rebuild + LN_RB_TABLE;
-#pragma unroll
-            for (int ci = 0; ci < NC; ++ci) {
-                const int col = (l32 + 32 * ci) * 8;
-                if (rb && col < H) {
-                    float gm[8], bt[8], rg[8], c[8];
-                    load8(gm, a.gamma + col); load8(bt, a.beta + col);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) { rg[j] = 1.0f / gm[j]; c[j] = -bt[j] * rg[j]; }
-                    store8(tab + col, rg); store8(tab + H + col, c);
-                }
-            }
-        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) *a.rebuild = rb ? 1 : 0;
     }
     // the trip count is uniform per workgroup (wave shuffles below need all 64 lanes); a half-wave
     // whose row is past the end just keeps its lanes predicated off
@@ -172,7 +157,7 @@ struct LnBwdArgs {
     void* dz; void* dx; float* dgamma; float* dbeta; float* dbias; int M, H; DropSpec din, dout;
     float* partials;     // [gridDim.x][3][H] when the two-stage column reduction is used, else NULL
     bf16* dx_split; long ld_split;     // fp32 only: also write dx (= dz when no dropout) as a bf16 hi | lo image, or NULL
-    const void* y; const int* rebuild;   // *rebuild != 0: x-hat = (y - beta) / gamma, tables behind the verdict (the forward wrote no z)
+    const void* y; const float* beta; const int* rebuild;   // *rebuild != 0: x-hat = (y - beta) / gamma (the forward wrote no z)
 };
 
 // reduce this block's per-lane column partials across its 8 half-waves through LDS ([8][H] floats, plain
@@ -248,7 +233,7 @@ VB_DEVICE float wave_sum64(float v) {
     v += __shfl_xor(v, 32);
     return v;
 }
-template <typename T, int NC2, int MINW>
+template <typename T, int NC2, int MINW, int RB = 0>
 VB_KERNEL VB_LAUNCH_BOUNDS2(NT, MINW) ln_bwd_kernel(LnBwdArgs a) {
     VB_DYN_SMEM(smem);
     float* lds = (float*)smem;
@@ -261,7 +246,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(NT, MINW) ln_bwd_kernel(LnBwdArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) { accg[ci][j] = 0.f; accb[ci][j] = 0.f; accx[ci][j] = 0.f; }
 
-    const bool rebuild = a.rebuild && *a.rebuild != 0;
+    const bool rebuild = RB && *a.rebuild != 0;
     const T* xsrc = (const T*)(rebuild ? a.y : a.z);
     for (int row = blockIdx.x * WAVES_PER_BLOCK + wave; row < a.M; row += gridDim.x * WAVES_PER_BLOCK) {
         const float mean = a.mean[row], rstd = a.rstd[row];
@@ -285,11 +270,14 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(NT, MINW) ln_bwd_kernel(LnBwdArgs a) {
             float gm[8];
             load8(gm, a.gamma + colc);
             if (a.dout.p > 0.f) apply_dropout8(dy[ci], a.dout, (uint64_t)((long)row * H + colc) >> 3);
-            if (rebuild) {                                    // uniform: x-hat = y / gamma - beta / gamma from the LayerNorm's own output
-                float rg[8], c[8];
-                load8(rg, (const float*)a.rebuild + LN_RB_TABLE + colc); load8(c, (const float*)a.rebuild + LN_RB_TABLE + H + colc);
+            if constexpr (RB == 1) {
+                float bt[8];
+                load8(bt, a.beta + colc);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) xh[ci][j] = fmaf(xh[ci][j], rg[j], c[j]);
+                for (int j = 0; j < 8; ++j) {
+                    const float sub = rebuild ? bt[j] : mean, q = rebuild ? fast_rcp(gm[j]) : rstd;
+                    xh[ci][j] = (xh[ci][j] - sub) * q;
+                }
             } else {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) xh[ci][j] = (xh[ci][j] - mean) * rstd;
@@ -339,6 +327,143 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(NT, MINW) ln_bwd_kernel(LnBwdArgs a) {
     __syncthreads();
     // reduce the waves' accumulators, then this block's row of the partials workspace (two-stage, no global
     // atomics) or fp32 atomics straight into HBM
+    float* part = a.partials ? a.partials + (long)blockIdx.x * 3 * H : nullptr;
+    for (int i = threadIdx.x; i < 3 * H; i += NT) {
+        const int which = i / H, c = i - which * H;
+        float* out = which == 0 ? a.dgamma : (which == 1 ? a.dbeta : a.dbias);
+        if (!out) continue;
+        float sum = 0.f;
+#pragma unroll
+        for (int h = 0; h < WAVES_PER_BLOCK; ++h) sum += lds[(long)h * 3 * H + i];
+        if (part) part[i] = sum;
+        else atomicAdd(&out[c], sum);
+    }
+}
+
+// 512 < H <= 768 (BERT-base): one wave per row with TWELVE columns per lane -- the 8-column chunk `lane` and the 4-column chunk at
+// 512 + 4 lane -- so that H = 768 keeps all 64 lanes busy in both chunks.  The generic kernel above gives a lane two 8-column chunks, the
+// second one only on lanes 0..31: registers for 16 columns (48 accumulators + 32 row values -> the 128-register budget of four waves
+// per SIMD is met with spills) and a quarter of the vector work masked off.  Here: 36 accumulators + 24 row values.
+// RB: the launch may find x-hat in the LayerNorm's own output (*a.rebuild, the forward's verdict): x-hat = (v - sub) q with
+// (v, sub, q) = (y, beta_c, 1 / gamma_c) or (z, mean_r, rstd_r).  ONE instruction stream -- beta is loaded unconditionally next to gamma,
+// the source pointer and the operands are selected by a launch-uniform condition: a branch around the extra loads put two more
+// exposed memory round trips into every row of this latency-bound kernel (188 -> 276 us per launch, profiles/r04_ln_rebuild.txt).
+template <int W, typename T> VB_DEVICE void loadw(float (&v)[W], const T* p) {
+    if constexpr (W == 8) load8(v, p);
+    else if constexpr (sizeof(T) == 2) { const bf16x4 x = *(const bf16x4*)p; v[0] = (float)x[0]; v[1] = (float)x[1]; v[2] = (float)x[2]; v[3] = (float)x[3]; }
+    else { const f32x4 x = *(const f32x4*)p; v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3]; }
+}
+template <int W, typename T> VB_DEVICE void storew(T* p, const float (&v)[W]) {
+    if constexpr (W == 8) store8(p, v);
+    else if constexpr (sizeof(T) == 2) { bf16x4 x; x[0] = (bf16)v[0]; x[1] = (bf16)v[1]; x[2] = (bf16)v[2]; x[3] = (bf16)v[3]; *(bf16x4*)p = x; }
+    else *(f32x4*)p = f32x4{v[0], v[1], v[2], v[3]};
+}
+// keep mask / (1 - p) of the W elements that start at element index e (a multiple of W): half a generator group when W = 4
+template <int W> VB_DEVICE void dropw(float (&v)[W], const DropSpec& d, uint64_t e) {
+    Rand8 r = vb_dropout_bits8(d.seed, e >> 3, d.stream);
+    if constexpr (W == 4) {                        // the group's upper half: words 2, 3 (selected, not indexed: r must stay in registers)
+        const bool hi = (e & 4) != 0;
+        r.w[0] = hi ? r.w[2] : r.w[0]; r.w[1] = hi ? r.w[3] : r.w[1];
+    }
+#pragma unroll
+    for (int j = 0; j < W; ++j) v[j] = rand8_keep(r, j, d.thresh) ? v[j] * d.scale : 0.0f;
+}
+template <typename T, bool RB>
+VB_KERNEL VB_LAUNCH_BOUNDS2(NT, 4) ln_bwd12_kernel(LnBwdArgs a) {
+    VB_DYN_SMEM(smem);
+    float* lds = (float*)smem;
+    const int lane = threadIdx.x & 63, wave = vb_uniform((int)threadIdx.x >> 6);
+    const int H = a.H;
+    const float invH = 1.0f / (float)H;
+    float accg[12], accb[12], accx[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) { accg[j] = 0.f; accb[j] = 0.f; accx[j] = 0.f; }
+    const bool rebuild = RB && *a.rebuild != 0;
+    const T* xsrc = (const T*)(rebuild ? a.y : a.z);
+    const int colA = lane * 8, colB = 512 + lane * 4;
+    const bool okB = colB < H;                                     // a 4-column chunk is inside or outside as a whole (H % 8 == 0)
+    const int colBc = okB ? colB : 0;
+    typedef std::integral_constant<int, 8> W8;
+    typedef std::integral_constant<int, 4> W4;
+
+    for (int row = blockIdx.x * WAVES_PER_BLOCK + wave; row < a.M; row += gridDim.x * WAVES_PER_BLOCK) {
+        const float mean = a.mean[row], rstd = a.rstd[row];
+        const long rb = (long)row * H;
+        float dyA[8], dyB[4], xhA[8], xhB[4];
+        loadw<8>(dyA, (const T*)a.dy + rb + colA); loadw<4>(dyB, (const T*)a.dy + rb + colBc);
+        loadw<8>(xhA, xsrc + rb + colA); loadw<4>(xhB, xsrc + rb + colBc);
+        float s1 = 0.f, s2 = 0.f;
+        // gamma / beta through a base the compiler cannot fold into a loop-invariant 64-bit lane address: kept that way they cost
+        // four VGPR pairs, which were spilled and reloaded (behind s_waitcnt vmcnt(0)) in every row; scalar base + 32-bit lane offset
+        // is the form the row tensors' loads have anyway
+        int zs = 0;
+        vb_pin_s(zs);
+        const float* gbase = a.gamma + zs;
+        const float* bbase = a.beta + zs;
+        // phase 1 of a chunk: x-hat, column partials, g = dy gamma (in place of dy), row sums
+        // (all of a row's loads go out together, ahead of the first use)
+        float gmA[8], gmB[4], btA[8], btB[4];
+        loadw<8>(gmA, gbase + colA); loadw<4>(gmB, gbase + colBc);
+        if constexpr (RB) { loadw<8>(btA, bbase + colA); loadw<4>(btB, bbase + colBc); }
+        auto phase1 = [&](auto wtag, float (&dy)[decltype(wtag)::value], float (&xh)[decltype(wtag)::value], const float (&gm)[decltype(wtag)::value],
+                          const float (&bt)[decltype(wtag)::value], int col, bool ok, float* ag, float* ab) {
+            constexpr int W = decltype(wtag)::value;
+            if (a.dout.p > 0.f) dropw<W>(dy, a.dout, (uint64_t)(rb + col));
+            if constexpr (RB) {
+#pragma unroll
+                for (int j = 0; j < W; ++j) xh[j] = (xh[j] - (rebuild ? bt[j] : mean)) * (rebuild ? fast_rcp(gm[j]) : rstd);
+            } else {
+#pragma unroll
+                for (int j = 0; j < W; ++j) xh[j] = (xh[j] - mean) * rstd;
+            }
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+                const float d = ok ? dy[j] : 0.f;             // columns past H contribute exact zeros
+                ag[j] += d * xh[j];                           // dgamma
+                ab[j] += d;                                   // dbeta
+                dy[j] = d * gm[j];                            // g = dy * gamma
+                s1 += dy[j];
+                s2 += dy[j] * xh[j];
+            }
+        };
+        phase1(W8(), dyA, xhA, gmA, btA, colA, true, accg, accb);
+        phase1(W4(), dyB, xhB, gmB, btB, colBc, okB, accg + 8, accb + 8);
+        s1 = wave_sum64(s1) * invH;
+        s2 = wave_sum64(s2) * invH;
+        auto phase2 = [&](auto wtag, float (&g)[decltype(wtag)::value], float (&xh)[decltype(wtag)::value], int col, bool ok, float* ax) {
+            constexpr int W = decltype(wtag)::value;
+            const long e = rb + col;
+            float dz[W];
+#pragma unroll
+            for (int j = 0; j < W; ++j) dz[j] = rstd * (g[j] - s1 - xh[j] * s2);
+            if (ok) storew<W>((T*)a.dz + e, dz);
+            if (a.dx) {
+                if (a.din.p > 0.f) dropw<W>(dz, a.din, (uint64_t)e);
+                if (a.dx != a.dz && ok) storew<W>((T*)a.dx + e, dz);
+            }
+            if constexpr (sizeof(T) == 4) {
+                if (a.dx_split && ok) {
+                    if constexpr (W == 8) store_split8(a.dx_split + (long)row * a.ld_split + col, a.ld_split / 2, dz);
+                    else store_split4(a.dx_split + (long)row * a.ld_split + col, a.ld_split / 2, f32x4{dz[0], dz[1], dz[2], dz[3]});
+                }
+            }
+            if (a.dbias) {                                   // bias gradient of the Linear in front: column sums of dx
+#pragma unroll
+                for (int j = 0; j < W; ++j) ax[j] += ok ? dz[j] : 0.f;
+            }
+        };
+        phase2(W8(), dyA, xhA, colA, true, accx);
+        phase2(W4(), dyB, xhB, colBc, okB, accx + 8);
+    }
+    // the waves' accumulators -> LDS [wave][3][H]
+    float* my = lds + (long)wave * 3 * H;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { my[colA + j] = accg[j]; my[H + colA + j] = accb[j]; my[2 * H + colA + j] = accx[j]; }
+    if (okB) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { my[colB + j] = accg[8 + j]; my[H + colB + j] = accb[8 + j]; my[2 * H + colB + j] = accx[8 + j]; }
+    }
+    __syncthreads();
     float* part = a.partials ? a.partials + (long)blockIdx.x * 3 * H : nullptr;
     for (int i = threadIdx.x; i < 3 * H; i += NT) {
         const int which = i / H, c = i - which * H;
@@ -564,8 +689,6 @@ int vb_ln_fwd_sp(int dtype, const void* x, const void* resid, void* z_out, void*
     return vb_check_launch();
 }
 
-int64_t vb_ln_rebuild_bytes(int H) { return (int64_t)(LN_RB_TABLE + 2 * H) * (int64_t)sizeof(float); }
-
 extern "C" int64_t vb_ln_bwd_ws_bytes(int M, int H) {
     return (int64_t)row_grid(M, 1024) * 3 * H * (int64_t)sizeof(float);
 }
@@ -575,31 +698,41 @@ extern "C" int vb_ln_bwd(int dtype, const void* dy, const void* z, const float* 
                          int M, int H, float p_in, uint32_t stream_in, float p_out, uint32_t stream_out,
                          uint64_t seed, float* ws, void* stream) {
     return vb_ln_bwd_sp(dtype, dy, z, mean, rstd, gamma, dz, dx, dgamma, dbeta, dbias, M, H, p_in, stream_in, p_out, stream_out, seed,
-                        ws, nullptr, 0, nullptr, nullptr, stream);
+                        ws, nullptr, 0, nullptr, nullptr, nullptr, stream);
 }
 
 int vb_ln_bwd_sp(int dtype, const void* dy, const void* z, const float* mean, const float* rstd,
                  const float* gamma, void* dz, void* dx, float* dgamma, float* dbeta, float* dbias,
                  int M, int H, float p_in, uint32_t stream_in, float p_out, uint32_t stream_out,
-                 uint64_t seed, float* ws, void* dx_split, int64_t ld_split, const void* y, const int* rebuild, void* stream) {
+                 uint64_t seed, float* ws, void* dx_split, int64_t ld_split, const void* y, const float* beta, const int* rebuild,
+                 void* stream) {
     if (!dy || !z || !mean || !rstd || !gamma || !dz || M <= 0 || bad_h(H)) return VB_ERR_ARG;
-    if (rebuild && (!y || p_out > 0.f)) return VB_ERR_ARG;
+    if (rebuild && (!y || !beta || p_out > 0.f || dtype != VB_BF16)) return VB_ERR_ARG;
     if (dx_split && (dtype != VB_F32 || (ld_split % 16) || ld_split < 2 * H || (((uintptr_t)dx_split) & 15))) return VB_ERR_ARG;
     // the image is of dx (the gradient after the input dropout).  dx == NULL with an image: dx leaves ONLY as the image -- the
     // kernel still needs a.dx non-NULL to run the dropout on its registers, and a.dx == a.dz suppresses the fp32 store
     if (dx_split && !dx) dx = dz;
     else if (p_in > 0.f && (!dx || dx == dz)) return VB_ERR_ARG;   // dropped and un-dropped grads differ
     LnBwdArgs a{dy, z, mean, rstd, gamma, dz, dx, dgamma, dbeta, dbias, M, H, make_drop(p_in, seed, stream_in),
-                make_drop(p_out, seed, stream_out), ws, (bf16*)dx_split, (long)ld_split, y, rebuild};
+                make_drop(p_out, seed, stream_out), ws, (bf16*)dx_split, (long)ld_split, y, beta, rebuild};
     dim3 grid(row_grid(M, ws ? 1024 : 256));
     hipStream_t s = (hipStream_t)stream;
     const size_t smem = (size_t)H * WAVES_PER_BLOCK * 3 * sizeof(float);
     // <.., 4>: four waves per SIMD (128 VGPRs, a 12-byte spill) beat three without the spill: 109 vs 130 us at M = 83,968
-    if (dtype == VB_BF16) {
-        if (H <= 512) VB_LAUNCH((ln_bwd_kernel<bf16, 1, 4>), grid, dim3(NT), smem, s, a);
+    static const int exp_ = getenv("VB_LN_EXP") ? atoi(getenv("VB_LN_EXP")) : 0;          // EXPERIMENT (one GPU session): 0 | 1 | 3
+    const bool twelve = H > 512 && H <= 768 && exp_ == 0;
+    if (dtype == VB_BF16 && rebuild) {
+        if (twelve) VB_LAUNCH((ln_bwd12_kernel<bf16, true>), grid, dim3(NT), smem, s, a);
+        else if (H <= 512) VB_LAUNCH((ln_bwd_kernel<bf16, 1, 4, 1>), grid, dim3(NT), smem, s, a);
+        else if (exp_ == 3) VB_LAUNCH((ln_bwd_kernel<bf16, 2, 3, 1>), grid, dim3(NT), smem, s, a);
+        else VB_LAUNCH((ln_bwd_kernel<bf16, 2, 4, 1>), grid, dim3(NT), smem, s, a);
+    } else if (dtype == VB_BF16) {
+        if (twelve) VB_LAUNCH((ln_bwd12_kernel<bf16, false>), grid, dim3(NT), smem, s, a);
+        else if (H <= 512) VB_LAUNCH((ln_bwd_kernel<bf16, 1, 4>), grid, dim3(NT), smem, s, a);
         else VB_LAUNCH((ln_bwd_kernel<bf16, 2, 4>), grid, dim3(NT), smem, s, a);
     } else if (dtype == VB_F32) {
-        if (H <= 512) VB_LAUNCH((ln_bwd_kernel<float, 1, 4>), grid, dim3(NT), smem, s, a);
+        if (twelve) VB_LAUNCH((ln_bwd12_kernel<float, false>), grid, dim3(NT), smem, s, a);
+        else if (H <= 512) VB_LAUNCH((ln_bwd_kernel<float, 1, 4>), grid, dim3(NT), smem, s, a);
         else VB_LAUNCH((ln_bwd_kernel<float, 2, 4>), grid, dim3(NT), smem, s, a);
     } else return VB_ERR_ARG;
     if (ws && (dgamma || dbeta || dbias)) {

@@ -429,8 +429,10 @@ VB_DEVICE float row16_sum(float v) {
 // meant to run under) instead of right behind the load.
 #ifdef VB_EMU
 template <typename V> VB_DEVICE void vb_pin(V&) {}
+VB_DEVICE void vb_pin_s(int&) {}
 #else
 template <typename V> VB_DEVICE void vb_pin(V& v) { asm volatile("" : "+v"(v)); }
+VB_DEVICE void vb_pin_s(int& v) { asm volatile("" : "+s"(v)); }        // the same for a wave-uniform (scalar register) value
 #endif
 
 // sum over aligned groups of 8 lanes (quad swaps + half-row mirror on the VALU, no LDS-crossbar shuffles)
@@ -596,15 +598,14 @@ __attribute__((visibility("hidden"))) int vb_vendor_nt(const VbVendorGemm& g, vo
 // split_only (attention) / dx == NULL (LayerNorm backward): the fp32 form of that result is NOT written at all -- in the layer only
 // GEMMs consume it, and they read the image; the q | k | v bias gradient is then summed from the image's two planes.
 // rebuild (LayerNorm, device int): the forward skips z_out when the backward can take x-hat from y (layernorm.hip: ln_rebuildable) and
-// records its decision (+ 1 / gamma, -beta / gamma per channel) there, vb_ln_rebuild_bytes(H) bytes; the backward is handed y and the same record.
+// records its decision there; the backward (bf16 only) is handed y, beta and the same int.
 __attribute__((visibility("hidden"))) int vb_ln_fwd_sp(int dtype, const void* x, const void* resid, void* z_out, void* y, float* mean,
     float* rstd, const float* gamma, const float* beta, int M, int H, float eps, float p_in, uint32_t stream_in, float p_out,
     uint32_t stream_out, uint64_t seed, void* y_split, int64_t ld_split, int* rebuild, void* stream);
 __attribute__((visibility("hidden"))) int vb_ln_bwd_sp(int dtype, const void* dy, const void* z, const float* mean, const float* rstd,
     const float* gamma, void* dz, void* dx, float* dgamma, float* dbeta, float* dbias, int M, int H, float p_in, uint32_t stream_in,
-    float p_out, uint32_t stream_out, uint64_t seed, float* ws, void* dx_split, int64_t ld_split, const void* y, const int* rebuild,
-    void* stream);
-__attribute__((visibility("hidden"))) int64_t vb_ln_rebuild_bytes(int H);
+    float p_out, uint32_t stream_out, uint64_t seed, float* ws, void* dx_split, int64_t ld_split, const void* y, const float* beta,
+    const int* rebuild, void* stream);
 __attribute__((visibility("hidden"))) int vb_attn_fwd_sp(int dtype, const void* qkv, const float* mask_add, void* ctx, float* lse,
     uint64_t* keepbits, int B, int S, int nh, int head_dim, float p_drop, uint64_t seed, uint32_t stream_id, void* ctx_split,
     int split_only, void* stream);

@@ -331,7 +331,7 @@ int vb_act_bwd(int dtype, const void* dy, const void* aux, void* dx, int64_t n, 
  *   scratch: vb_bert_layer_scratch_bytes() bytes of temporaries, reusable by every layer on one stream
  *   h_in/h_out/d_out/d_in: T [B*S, H];  mask_add: fp32 [B,S].  Dropout sites use stream ids sid..sid+4.
  *   The backward is handed the forward's h_out again (required for VB_BF16, ignored otherwise): in bf16 a LayerNorm forward does
- *   not write its pre-LN sum when the backward can rebuild x-hat = (y - beta) / gamma from the output it reads anyway (three
+ *   (H <= 768) not write its pre-LN sum when the backward can rebuild x-hat = (y - beta) / gamma from the output it reads anyway (three
  *   tensors per launch instead of four).  The kernels decide that themselves from the parameters (|beta| <= 2 |gamma| on every
  *   channel -- the rounding of y then costs x-hat no more than the rounding of a saved sum would) and record it in `saved`.
  * ---------------------------------------------------------------------------------------------- */

@@ -161,9 +161,9 @@ extern "C" int vb_bert_layer_fwd(int dtype, const void* h_in, const float* mask_
     // 4. dropout + residual + LayerNorm
     //    (bf16: the pre-LN sum z is NOT written when the backward can rebuild x-hat from the output it reads anyway -- three tensors
     //     per launch instead of four; decided in the kernel from gamma / beta and recorded in sv.ln_flags.  fp32 / bf16x3 keep z)
-    static const bool no_rb = getenv("VB_LN_NOREBUILD") != nullptr;     // EXPERIMENT (one GPU session)
-    int* rb1 = dtype == VB_BF16 && !no_rb ? sv.ln_flags : nullptr;
-    int* rb2 = dtype == VB_BF16 && !no_rb ? sv.ln_flags + 1 : nullptr;
+    const bool rb = dtype == VB_BF16 && H <= 768;       // (wider rows: the backward's rebuild-capable form does not pay, layernorm.hip)
+    int* rb1 = rb ? sv.ln_flags : nullptr;
+    int* rb2 = rb ? sv.ln_flags + 1 : nullptr;
     VB_TRY(vb_ln_fwd_sp(edt, sc.t_h0, h_in, sv.z1, sv.a_out, sv.mean1, sv.rstd1, g1, b1, M, H, eps, p_hidden, sid + 1,
                         0.f, 0, seed, d.x3 ? sv.sp_aout : nullptr, 2 * H, rb1, stream));
     // 5. FFN in + erf-GELU (GELU' kept for backward)
@@ -199,9 +199,9 @@ extern "C" int vb_bert_layer_bwd(int dtype, const void* h_in, const void* h_out,
     const void* wi = weights[VB_LW_FI_W];
     const void* wo2 = weights[VB_LW_FO_W];
     const float* g2 = (const float*)weights[VB_LW_LN2_G]; const float* b2 = (const float*)weights[VB_LW_LN2_B];
-    static const bool no_rb = getenv("VB_LN_NOREBUILD") != nullptr;     // EXPERIMENT (one GPU session)
-    const int* rb1 = dtype == VB_BF16 && !no_rb ? sv.ln_flags : nullptr;
-    const int* rb2 = dtype == VB_BF16 && !no_rb ? sv.ln_flags + 1 : nullptr;
+    const bool rb = dtype == VB_BF16 && H <= 768;
+    const int* rb1 = rb ? sv.ln_flags : nullptr;
+    const int* rb2 = rb ? sv.ln_flags + 1 : nullptr;
     float* G[VB_LW_COUNT];
     for (int i = 0; i < VB_LW_COUNT; ++i) { G[i] = (float*)grads[i]; if (!G[i]) return VB_ERR_ARG; }
     // dgrad dx[M,in] = dy[M,out] W[out,in]: with W^T [in, ld>=out] both operands are K-contiguous (LDS-direct

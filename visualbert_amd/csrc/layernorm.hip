@@ -676,7 +676,7 @@ int vb_ln_fwd_sp(int dtype, const void* x, const void* resid, void* z_out, void*
                  float p_in, uint32_t stream_in, float p_out, uint32_t stream_out, uint64_t seed,
                  void* y_split, int64_t ld_split, int* rebuild, void* stream) {
     if (!x || !y || !gamma || !beta || M <= 0 || bad_h(H)) return VB_ERR_ARG;
-    if (rebuild && (p_out > 0.f || !z_out)) return VB_ERR_ARG;      // a dropped output cannot give x-hat back; z_out is the fallback
+    if (rebuild && (p_out > 0.f || !z_out || H > 768)) return VB_ERR_ARG;   // a dropped output cannot give x-hat back; z_out is the fallback
     if (p_in < 0.f || p_in >= 1.f || p_out < 0.f || p_out >= 1.f) return VB_ERR_ARG;
     if (y_split && (dtype != VB_F32 || (ld_split % 16) || ld_split < 2 * H || (((uintptr_t)y_split) & 15))) return VB_ERR_ARG;
     LnFwdArgs a{x, resid, z_out, y, mean, rstd, gamma, beta, M, H, eps, make_drop(p_in, seed, stream_in),
@@ -707,7 +707,7 @@ int vb_ln_bwd_sp(int dtype, const void* dy, const void* z, const float* mean, co
                  uint64_t seed, float* ws, void* dx_split, int64_t ld_split, const void* y, const float* beta, const int* rebuild,
                  void* stream) {
     if (!dy || !z || !mean || !rstd || !gamma || !dz || M <= 0 || bad_h(H)) return VB_ERR_ARG;
-    if (rebuild && (!y || !beta || p_out > 0.f || dtype != VB_BF16)) return VB_ERR_ARG;
+    if (rebuild && (!y || !beta || p_out > 0.f || dtype != VB_BF16 || H > 768)) return VB_ERR_ARG;
     if (dx_split && (dtype != VB_F32 || (ld_split % 16) || ld_split < 2 * H || (((uintptr_t)dx_split) & 15))) return VB_ERR_ARG;
     // the image is of dx (the gradient after the input dropout).  dx == NULL with an image: dx leaves ONLY as the image -- the
     // kernel still needs a.dx non-NULL to run the dropout on its registers, and a.dx == a.dz suppresses the fp32 store
@@ -718,14 +718,15 @@ int vb_ln_bwd_sp(int dtype, const void* dy, const void* z, const float* mean, co
     dim3 grid(row_grid(M, ws ? 1024 : 256));
     hipStream_t s = (hipStream_t)stream;
     const size_t smem = (size_t)H * WAVES_PER_BLOCK * 3 * sizeof(float);
-    // <.., 4>: four waves per SIMD (128 VGPRs, a 12-byte spill) beat three without the spill: 109 vs 130 us at M = 83,968
-    static const int exp_ = getenv("VB_LN_EXP") ? atoi(getenv("VB_LN_EXP")) : 0;          // EXPERIMENT (one GPU session): 0 | 1 | 3
-    const bool twelve = H > 512 && H <= 768 && exp_ == 0;
+    // generic kernel <.., 4>: four waves per SIMD (128 VGPRs, a 12-byte spill) beat three without the spill: 109 vs 130 us at M = 83,968
+    // 512 < H <= 768: twelve columns per lane (113 VGPRs, no spills, every lane busy): 188.7 -> 182.4 us per launch at M = 167,936 in the
+    // step, 191.8 us in the rebuild-capable form (profiles/r04_ln_rebuild.txt).  The generic kernel's rebuild-capable form exists for
+    // H <= 512 only (one chunk per lane, 87 VGPRs); with two full chunks it spills (340 us) -- layer.hip does not ask for it there.
+    const bool twelve = H > 512 && H <= 768;
     if (dtype == VB_BF16 && rebuild) {
         if (twelve) VB_LAUNCH((ln_bwd12_kernel<bf16, true>), grid, dim3(NT), smem, s, a);
         else if (H <= 512) VB_LAUNCH((ln_bwd_kernel<bf16, 1, 4, 1>), grid, dim3(NT), smem, s, a);
-        else if (exp_ == 3) VB_LAUNCH((ln_bwd_kernel<bf16, 2, 3, 1>), grid, dim3(NT), smem, s, a);
-        else VB_LAUNCH((ln_bwd_kernel<bf16, 2, 4, 1>), grid, dim3(NT), smem, s, a);
+        else return VB_ERR_UNSUPPORTED;
     } else if (dtype == VB_BF16) {
         if (twelve) VB_LAUNCH((ln_bwd12_kernel<bf16, false>), grid, dim3(NT), smem, s, a);
         else if (H <= 512) VB_LAUNCH((ln_bwd_kernel<bf16, 1, 4>), grid, dim3(NT), smem, s, a);

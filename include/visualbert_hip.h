@@ -330,10 +330,11 @@ int vb_act_bwd(int dtype, const void* dy, const void* aux, void* dx, int64_t n, 
  *            during backward -- exist ONLY as their bf16 hi | lo images, written by the kernels that produce them
  *   scratch: vb_bert_layer_scratch_bytes() bytes of temporaries, reusable by every layer on one stream
  *   h_in/h_out/d_out/d_in: T [B*S, H];  mask_add: fp32 [B,S].  Dropout sites use stream ids sid..sid+4.
- *   The backward is handed the forward's h_out again (required for VB_BF16, ignored otherwise): in bf16 a LayerNorm forward does
- *   (H <= 768) not write its pre-LN sum when the backward can rebuild x-hat = (y - beta) / gamma from the output it reads anyway (three
- *   tensors per launch instead of four).  The kernels decide that themselves from the parameters (|beta| <= 2 |gamma| on every
- *   channel -- the rounding of y then costs x-hat no more than the rounding of a saved sum would) and record it in `saved`.
+ *   The backward is handed the forward's h_out again (required when H <= 768): a LayerNorm forward does not write its pre-LN sum
+ *   when the backward can rebuild x-hat = (y - beta) / gamma from the output it reads anyway (three tensors per launch instead of
+ *   four).  The kernels decide that themselves from the parameters (|beta| <= 2 |gamma| on every channel -- the rounding of y then
+ *   costs x-hat no more than the rounding of a saved sum would) and record it in `saved`; gamma / beta must not change between a
+ *   layer's forward and its backward (as for every weight the backward reads).
  * ---------------------------------------------------------------------------------------------- */
 enum { VB_LW_QKV_W = 0, VB_LW_QKV_B, VB_LW_AO_W, VB_LW_AO_B, VB_LW_LN1_G, VB_LW_LN1_B,
        VB_LW_FI_W, VB_LW_FI_B, VB_LW_FO_W, VB_LW_FO_B, VB_LW_LN2_G, VB_LW_LN2_B, VB_LW_COUNT };

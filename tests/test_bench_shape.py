@@ -297,12 +297,12 @@ def test_bert_layer_at_bench_shape(dev, which, mode_name):
     ao = sc["t_h0"]
     close(ao, f(ctx) @ f(P["wo"]).t() + P["bo"], mode.gemm, "attention-out dense")
     z1 = f(ao) + f(P["h_in"])
-    # bf16: the forward skips the pre-LN sums when |beta| <= 2 |gamma| on every channel (true for this problem's parameters: the
-    # backward rebuilds x-hat from the LayerNorm outputs); fp32 / bf16x3 always keep them
-    rebuilt1 = rebuilt2 = not mode.x3
+    # the forward skips the pre-LN sums when |beta| <= 2 |gamma| on every channel (true for this problem's parameters: the backward
+    # rebuilds x-hat from the LayerNorm outputs)
+    rebuilt1 = rebuilt2 = True
     if which == "guard":
         rebuilt1 = False
-    assert mode.x3 or sv["ln_flags"].tolist() == [int(rebuilt1), int(rebuilt2)], sv["ln_flags"].tolist()
+    assert sv["ln_flags"].tolist() == [int(rebuilt1), int(rebuilt2)], sv["ln_flags"].tolist()
     if not rebuilt1:
         close(sv["z1"], z1, mode.add, "z1 = attention-out + residual")              # one fp32 add, one rounding
     close(sv["a_out"], _ln_ref(z1, P["g1"], P["b1"]), mode.ln, "LayerNorm 1")

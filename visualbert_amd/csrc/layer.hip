@@ -21,7 +21,7 @@ struct Saved {
     unsigned char *qkv, *ctx, *z1, *a_out, *pre, *inter, *z2;
     float *lse, *mean1, *rstd1, *mean2, *rstd2;
     uint64_t* keepbits;
-    int* ln_flags;      // [2] device ints written by the two LayerNorm forwards (bf16): 1 = no z was written, the backward rebuilds x-hat from y
+    int* ln_flags;      // [2] device ints written by the two LayerNorm forwards: 1 = no z was written, the backward rebuilds x-hat from y
     // bf16x3 only: the split (hi | lo) images of the four GEMM inputs the forward made anyway -- they are the x operands of the
     // backward's weight-gradient launch, so keeping them saves four split passes per layer (19 % of the mode's split traffic)
     unsigned char *sp_hin, *sp_ctx, *sp_aout, *sp_inter;
@@ -159,9 +159,9 @@ extern "C" int vb_bert_layer_fwd(int dtype, const void* h_in, const float* mask_
     VB_TRY(linear(d, d.x3 ? (const void*)sv.sp_ctx : (const void*)sv.ctx, H, nullptr, wo, wk * H, sc.t_h0, H, bo, nullptr, VB_ACT_NONE,
                   nullptr, nullptr, nullptr, stream));
     // 4. dropout + residual + LayerNorm
-    //    (bf16: the pre-LN sum z is NOT written when the backward can rebuild x-hat from the output it reads anyway -- three tensors
-    //     per launch instead of four; decided in the kernel from gamma / beta and recorded in sv.ln_flags.  fp32 / bf16x3 keep z)
-    const bool rb = dtype == VB_BF16 && H <= 768;       // (wider rows: the backward's rebuild-capable form does not pay, layernorm.hip)
+    //    (the pre-LN sum z is NOT written when the backward can rebuild x-hat from the output it reads anyway -- three tensors per
+    //     launch instead of four; decided in the kernel from gamma / beta and recorded in sv.ln_flags)
+    const bool rb = H <= 768;                           // (wider rows: the backward's rebuild-capable form does not pay, layernorm.hip)
     int* rb1 = rb ? sv.ln_flags : nullptr;
     int* rb2 = rb ? sv.ln_flags + 1 : nullptr;
     VB_TRY(vb_ln_fwd_sp(edt, sc.t_h0, h_in, sv.z1, sv.a_out, sv.mean1, sv.rstd1, g1, b1, M, H, eps, p_hidden, sid + 1,
@@ -189,7 +189,7 @@ extern "C" int vb_bert_layer_bwd(int dtype, const void* h_in, const void* h_out,
     if (!fill_dims(d, dtype, B, S, H, I, nh) || !h_in || !mask_add || !d_out || !d_in || !saved || !scratch ||
         !weights || !grads)
         return VB_ERR_ARG;
-    if (dtype == VB_BF16 && !h_out) return VB_ERR_ARG;       // the output LayerNorm's backward may rebuild x-hat from it
+    if (H <= 768 && !h_out) return VB_ERR_ARG;               // the output LayerNorm's backward may rebuild x-hat from it
     Saved sv = carve_saved((unsigned char*)saved, d, p_attn > 0.f);
     Scratch sc = carve_scratch((unsigned char*)scratch, d);
     const int M = (int)d.M;
@@ -199,7 +199,7 @@ extern "C" int vb_bert_layer_bwd(int dtype, const void* h_in, const void* h_out,
     const void* wi = weights[VB_LW_FI_W];
     const void* wo2 = weights[VB_LW_FO_W];
     const float* g2 = (const float*)weights[VB_LW_LN2_G]; const float* b2 = (const float*)weights[VB_LW_LN2_B];
-    const bool rb = dtype == VB_BF16 && H <= 768;
+    const bool rb = H <= 768;
     const int* rb1 = rb ? sv.ln_flags : nullptr;
     const int* rb2 = rb ? sv.ln_flags + 1 : nullptr;
     float* G[VB_LW_COUNT];

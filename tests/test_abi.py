@@ -37,6 +37,22 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert b"gfx950" in lib.vb_version()
 
 
+def test_layer_backward_insists_on_the_forward_output():
+    """argument checks only (they run on the host, before any launch): with H <= 768 the LayerNorm forward may have skipped its pre-LN
+    sum, so the backward cannot run without h_out; the saved-workspace size answers without a device too"""
+    from visualbert_amd import _lib
+    L = _lib.lib()
+    B, S, H, I, NH = 2, 16, 768, 3072, 12
+    assert L.vb_bert_layer_saved_bytes(_lib.VB_BF16, B, S, H, I, NH, 0.1) > 0
+    assert L.vb_bert_layer_saved_bytes(_lib.VB_BF16, B, S, H + 4, I, NH, 0.1) == -1          # H is not heads x 64
+    buf = (ctypes.c_char * 4096)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    arr12, arr4 = (ctypes.c_void_p * 12)(*([p.value] * 12)), (ctypes.c_void_p * 4)(*([p.value] * 4))
+    ld = (ctypes.c_int64 * 4)(H, H, H, I)
+    rc = L.vb_bert_layer_bwd(_lib.VB_BF16, p, None, p, p, p, p, p, arr12, arr12, arr4, ld, B, S, H, I, NH, 0.1, 0.1, 1, 1, None)
+    assert rc == -1, rc                                                                      # VB_ERR_ARG: no h_out
+
+
 def test_developer_knobs_are_not_in_the_product_library():
     """ablation bits, timelines and measurement kernels (include/visualbert_hip_dev.h) exist only in the developer build."""
     from visualbert_amd import _lib

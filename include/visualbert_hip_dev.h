@@ -33,6 +33,14 @@ int vb_mfma_peak(int kind, int iters, int blocks, float* out, void* stream);
  * 1-KiB pieces from a span-byte window with `depth` (1,2,4,8,16) pieces in flight */
 int vb_glds_stream(int depth, const void* src, int64_t span, int iters, int blocks, float* sink, void* stream);
 
+/* groundwork for the block-scaled fp8 cross terms of the split-operand product; not used by the product.
+ * vb_mma_f8_probe: ONE v_mfma_scale_f32_16x16x128_f8f6f4 through csrc/vb_rt.h's vb_mma_f8 with the documented lane layout:
+ *   A, B: [16][128] OCP e4m3 bytes (K contiguous); scale_a, scale_b: [16][4] E8M0 bytes per (row, 32-element K block);
+ *   D[16][16] fp32 = sum_k A[i][k] 2^(scale_a[i][k/32] - 127) B[j][k] 2^(scale_b[j][k/32] - 127)
+ * vb_cvt_fp8_probe: y[n] e4m3 bytes = round-to-nearest-even of x[n] (|x| <= 448, n % 4 == 0) through vb_cvt4_fp8 */
+int vb_mma_f8_probe(const void* A, const void* B, const void* scale_a, const void* scale_b, float* D, void* stream);
+int vb_cvt_fp8_probe(const float* x, void* y, int n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -151,6 +151,58 @@ inline void mma_16x16x32(const float a[8], const float b[8], float c[4]) {
     }
 }
 
+// ---- v_mfma_scale_f32_16x16x128_f8f6f4, both operands OCP e4m3 (layout probed on gfx950: tools/probes/fp8_mfma_probe.hip) ----
+//   operand lane l holds row (A) / column (B) l & 15 and 32 bytes j = 0..31 with K index k = 64 (j >> 4) + 16 (l >> 4) + (j & 15)
+//   scale register: byte 0 of lane 16 b + r = E8M0 scale (2^(s - 127)) of K block b = k >> 5 of row / column r
+//   C/D as every 16x16 f32 MFMA: lane l reg i -> row 4 (l >> 4) + i, column l & 15
+inline float e4m3_to_float(unsigned char v) {
+    const int s = v >> 7, e = (v >> 3) & 15, m = v & 7;
+    float x;
+    if (e == 15 && m == 7) x = __builtin_nanf("");
+    else if (e == 0) x = ldexpf((float)m, -9);
+    else x = ldexpf(1.0f + (float)m / 8.0f, e - 7);
+    return s ? -x : x;
+}
+struct MmaF8Slot { unsigned char a[32]; unsigned char b[32]; int sa, sb; };
+inline void mma_scale_16x16x128_f8(const unsigned char a[32], const unsigned char b[32], int sa, int sb, float c[4]) {
+    MmaF8Slot s;
+    memcpy(s.a, a, 32); memcpy(s.b, b, 32); s.sa = sa; s.sb = sb;
+    auto buf = wave_exchange(&s, sizeof(s));
+    const int lane = cur()->lane, col = lane & 15, g = lane >> 4;
+    for (int i = 0; i < 4; ++i) {
+        const int row = g * 4 + i;
+        double acc = 0.0;
+        for (int q = 0; q < 4; ++q) {                       // the lane group that holds k = 64 (j >> 4) + 16 q + (j & 15)
+            const MmaF8Slot* la = (const MmaF8Slot*)buf[row + 16 * q];
+            const MmaF8Slot* lb = (const MmaF8Slot*)buf[col + 16 * q];
+            for (int j = 0; j < 32; ++j) {
+                const int k = 64 * (j >> 4) + 16 * q + (j & 15), blk = k >> 5;
+                const int ea = ((const MmaF8Slot*)buf[16 * blk + row])->sa & 255, eb = ((const MmaF8Slot*)buf[16 * blk + col])->sb & 255;
+                acc += (double)ldexpf(e4m3_to_float(la->a[j]), ea - 127) * (double)ldexpf(e4m3_to_float(lb->b[j]), eb - 127);
+            }
+        }
+        c[i] = (float)((double)c[i] + acc);
+    }
+}
+// round to nearest even onto the e4m3 grid (|x| <= 448; what v_cvt_pk_fp8_f32 does for in-range inputs)
+inline unsigned char float_to_e4m3(float x) {
+    const unsigned char sgn = x < 0.f || (x == 0.f && __builtin_signbit(x)) ? 0x80 : 0;
+    float a = fabsf(x);
+    if (!(a == a)) return sgn | 0x7f;
+    if (a > 448.f) a = 448.f;
+    if (a == 0.f) return sgn;
+    int e;
+    frexpf(a, &e);                                          // a = f 2^e, f in [0.5, 1)
+    int ee = e - 1;                                         // a = (1 + m/8) 2^ee
+    if (ee < -6) ee = -6;                                   // subnormal spacing 2^-9
+    const float q = ldexpf(a, 3 - ee);                      // in units of 2^(ee - 3)
+    float r = nearbyintf(q);                                // RNE (default rounding mode)
+    int mant = (int)r, ex = ee + 7;
+    if (ee == -6 && mant < 8) return sgn | (unsigned char)mant;          // subnormal (exponent field 0)
+    if (mant == 16) { mant = 8; ex += 1; }
+    return sgn | (unsigned char)((ex << 3) | (mant - 8));
+}
+
 inline float atomic_add_f32(float* p, float v) {
     unsigned* up = (unsigned*)p;
     unsigned old = __atomic_load_n(up, __ATOMIC_RELAXED);

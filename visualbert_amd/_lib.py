@@ -83,6 +83,8 @@ DEV_SIGNATURES = {
     "vb_gemm_set_trace": (_i, [_p]),
     "vb_mfma_peak": (_i, [_i, _i, _i, _p, _p]),
     "vb_glds_stream": (_i, [_i, _p, _i64, _i, _i, _p, _p]),
+    "vb_mma_f8_probe": (_i, [_p, _p, _p, _p, _p, _p]),
+    "vb_cvt_fp8_probe": (_i, [_p, _p, _i, _p]),
 }
 VB_COMM_ID_BYTES = 128
 

@@ -383,3 +383,40 @@ extern "C" int vb_stream_get_opts(void* stream, vb_stream_opts* out) {
     *out = vb_opts_for(stream);
     return VB_OK;
 }
+
+// ---- developer library and simulator only: one wave through vb_mma_f8 / vb_cvt4_fp8 (the documented lane layout is what the test pins) ----
+#if defined(VB_DEV_KNOBS) || defined(VB_EMU)
+namespace {
+// A [16][128], B [16][128] e4m3 bytes (row-major, K contiguous); sa, sb [16][4] E8M0 bytes per (row, 32-element K block); D [16][16] fp32
+VB_KERNEL VB_LAUNCH_BOUNDS(64) mma_f8_probe_kernel(const unsigned char* A, const unsigned char* B, const unsigned char* sa,
+                                                  const unsigned char* sb, float* D) {
+    const int l = threadIdx.x, r = l & 15, q = l >> 4;
+    i32x8 av, bv;
+    unsigned char* ab = (unsigned char*)&av;
+    unsigned char* bb = (unsigned char*)&bv;
+    for (int j = 0; j < 32; ++j) {
+        const int k = 64 * (j >> 4) + 16 * q + (j & 15);
+        ab[j] = A[r * 128 + k]; bb[j] = B[r * 128 + k];
+    }
+    const int s_a = sa[r * 4 + q], s_b = sb[r * 4 + q];      // lane 16 q + r: block q of row r
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc = vb_mma_f8(av, bv, acc, s_a, s_b);
+    for (int i = 0; i < 4; ++i) D[(4 * q + i) * 16 + r] = acc[i];
+}
+VB_KERNEL VB_LAUNCH_BOUNDS(64) cvt_fp8_probe_kernel(const float* x, uint32_t* y, int n4) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i < n4) y[i] = vb_cvt4_fp8(x[4 * i], x[4 * i + 1], x[4 * i + 2], x[4 * i + 3]);
+}
+}  // namespace
+extern "C" int vb_mma_f8_probe(const void* A, const void* B, const void* scale_a, const void* scale_b, float* D, void* stream) {
+    if (!A || !B || !scale_a || !scale_b || !D) return VB_ERR_ARG;
+    VB_LAUNCH(mma_f8_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const unsigned char*)A, (const unsigned char*)B,
+              (const unsigned char*)scale_a, (const unsigned char*)scale_b, D);
+    return vb_check_launch();
+}
+extern "C" int vb_cvt_fp8_probe(const float* x, void* y, int n, void* stream) {
+    if (!x || !y || n <= 0 || (n & 3)) return VB_ERR_ARG;
+    VB_LAUNCH(cvt_fp8_probe_kernel, dim3((unsigned)((n / 4 + 63) / 64)), dim3(64), 0, (hipStream_t)stream, x, (uint32_t*)y, n / 4);
+    return vb_check_launch();
+}
+#endif

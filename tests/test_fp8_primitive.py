@@ -74,8 +74,13 @@ def test_scaled_fp8_mfma_matches_the_documented_layout(dev, seed):
     if dev.type == "cuda":
         torch.cuda.synchronize()
     got = D.cpu().numpy().astype(np.float64)
-    scale = np.abs(a) @ np.abs(b).T                          # fp32 accumulation of 128 products: a few ulps of the absolute sum
-    assert np.all(np.abs(got - ref) <= 1e-5 * scale + 1e-30), float(np.max(np.abs(got - ref) / (scale + 1e-30)))
+    # The instruction does not accumulate its 128 products as an exact fp32 chain: with operands spread over e4m3's whole range
+    # (2^-9 .. 448, times scales of 2^-7 .. 2^7) MI355X is within 1.1e-4 of the sum of |a||b| (products are aligned to the largest
+    # one and truncated); the one-hot case (seed 2) is exact and is what pins the K order and the scale placement.  For the cross
+    # terms this primitive is for (2^-9 of the main term) that is 2e-7 of the result.
+    scale = np.abs(a) @ np.abs(b).T
+    err = float(np.max(np.abs(got - ref) / (scale + 1e-30)))
+    assert err <= (0.0 if seed == 2 else 3e-4), err
 
 
 def test_fp8_conversion_rounds_to_nearest_even(dev):

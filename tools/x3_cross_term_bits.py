@@ -44,13 +44,40 @@ def make_linear(bits_hi, bits_lo, cross=True):
     return linear
 
 
+def e4m3_scaled(x, block):
+    """what an fp8 plane would really hold: x -> OCP e4m3 (4 significant bits, normal exponents 2^-6 .. 2^8, subnormal spacing 2^-9,
+    max 448) under a power-of-two scale per row (block = 0) or per `block` consecutive K elements of a row, chosen so that the
+    group's largest magnitude lands in [224, 448]; returns the dequantised values"""
+    K = x.size(-1)
+    g = x.reshape(-1, K) if block == 0 else x.reshape(-1, block)
+    amax = g.abs().amax(-1, keepdim=True)
+    sc = torch.exp2(torch.floor(torch.log2(448.0 / amax.clamp_min(2.0 ** -100)))).clamp(max=2.0 ** 100)   # power of two: the E8M0 scale's reciprocal
+    y = g * sc
+    m, e = torch.frexp(y)                                            # y = m 2^e, |m| in [0.5, 1)
+    e_eff = torch.clamp(e, min=-5)                                   # below 2^-6 the spacing stays 2^-9 (subnormals)
+    q = torch.ldexp(torch.round(torch.ldexp(m, e - e_eff) * 16) / 16, e_eff)
+    q = torch.clamp(q, -448.0, 448.0)
+    return (q / sc).reshape(x.shape)
+
+
+def make_linear_fp8(block):
+    def linear(x, w, b, mode, part="enc"):
+        xh, wh = bf16(x), bf16(w)
+        xl, wl = x - xh, w - wh
+        y = F.linear(xh, wh) + F.linear(e4m3_scaled(xl, block), e4m3_scaled(wh, block)) + F.linear(e4m3_scaled(xh, block), e4m3_scaled(wl, block))
+        return y if b is None else y + b
+    return linear
+
+
 ARMS = [("hi.hi only (plain bf16 operands in every Linear)", None),
         ("cross terms on bf16 operands: hi 8 bits, lo 8 bits  (= the bf16x3 kernels)", (8, 8)),
         ("cross terms: hi 6 bits, lo 6 bits", (6, 6)),
         ("cross terms: hi 5 bits, lo 5 bits", (5, 5)),
         ("cross terms on fp8 e4m3-like operands: hi 4 bits, lo 4 bits", (4, 4)),
         ("cross terms: hi 4 bits, lo 8 bits (only the LARGE operand of each cross term narrowed)", (4, 8)),
-        ("cross terms on fp8 e5m2-like operands: hi 3 bits, lo 3 bits", (3, 3))]
+        ("cross terms on fp8 e5m2-like operands: hi 3 bits, lo 3 bits", (3, 3)),
+        ("cross terms in REAL e4m3 (range-limited), one power-of-two scale per 32 K elements of a row", "fp8:32"),
+        ("cross terms in REAL e4m3 (range-limited), ONE power-of-two scale per ROW (no scale traffic in the K loop)", "fp8:0")]
 
 
 def main():
@@ -70,7 +97,8 @@ def main():
             ref = vo.objective_forward(sd, cfg, "pretraining", mode="fp32", **batch)["logits"]
         print("\nseed %d: fp32 logits absmax %.3f" % (seed, float(ref.abs().max())))
         for name, bits in ARMS:
-            vo.linear = make_linear(0, 0, cross=False) if bits is None else make_linear(*bits)
+            vo.linear = (make_linear(0, 0, cross=False) if bits is None else make_linear_fp8(int(bits.split(':')[1])) if isinstance(bits, str)
+                         else make_linear(*bits))
             try:
                 with torch.no_grad():
                     lg = vo.objective_forward(sd, cfg, "pretraining", mode="fp32", **batch)["logits"]

@@ -40,6 +40,14 @@ int vb_glds_stream(int depth, const void* src, int64_t span, int iters, int bloc
  * vb_cvt_fp8_probe: y[n] e4m3 bytes = round-to-nearest-even of x[n] (|x| <= 448, n % 4 == 0) through vb_cvt4_fp8 */
 int vb_mma_f8_probe(const void* A, const void* B, const void* scale_a, const void* scale_b, float* D, void* stream);
 int vb_cvt_fp8_probe(const float* x, void* y, int n, void* stream);
+/* PROTOTYPE of the split-operand GEMM with its two cross terms on the fp8 pipe (csrc/gemm.hip, end of file).
+ * vb_split_f8: fp32 x[rows, cols] -> image[rows, ld_img bf16 elements = 4 K bytes, K = ld_img / 2 >= cols, K % 128 == 0 for the GEMM]:
+ *   [ hi = bf16(x): K bf16 | hi8: K e4m3 bytes | lo8 = (x - hi): K e4m3 bytes ], each fp8 plane times ONE power of two per row;
+ *   scale_hi / scale_lo [rows]: the E8M0 bytes (value = byte-decoded x 2^(scale - 127))
+ * vb_gemm_x3f8: C[M, N] fp32 = A B^T (+ bias) from two such images; M, N multiples of 256, K of 128 */
+int vb_split_f8(const float* x, int64_t ldx, void* image, int64_t ld_img, int rows, int cols, void* scale_hi, void* scale_lo, void* stream);
+int vb_gemm_x3f8(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int M, int N, int K, const float* bias,
+                 const void* sa_hi, const void* sa_lo, const void* sb_hi, const void* sb_lo, void* stream);
 
 #ifdef __cplusplus
 }

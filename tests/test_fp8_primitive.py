@@ -108,3 +108,85 @@ def test_fp8_conversion_rounds_to_nearest_even(dev):
     assert np.array_equal(np.abs(got), np.abs(want)), np.flatnonzero(np.abs(got) != np.abs(want))[:10]
     nz = want != 0
     assert np.array_equal(np.sign(got[nz]), np.sign(want[nz]))
+
+
+def _bind(L):
+    for name in ("vb_split_f8", "vb_gemm_x3f8"):
+        fn = getattr(L, name)
+        fn.restype, fn.argtypes = _lib.DEV_SIGNATURES[name]
+
+
+def _split_f8(L, dev, x, K):
+    rows, cols = x.shape
+    img = torch.zeros(rows, 4 * K, dtype=torch.uint8, device=dev)
+    s_hi = torch.zeros(rows, dtype=torch.uint8, device=dev)
+    s_lo = torch.zeros(rows, dtype=torch.uint8, device=dev)
+    _lib.check(L.vb_split_f8(_lib.ptr(x), x.stride(0), _lib.ptr(img), 2 * K, rows, cols, _lib.ptr(s_hi), _lib.ptr(s_lo), _lib.stream_ptr()), "vb_split_f8")
+    return img, s_hi, s_lo
+
+
+def _decode(img, s_hi, s_lo, K):
+    """fp64 values of the three planes of an image: hi (bf16), hi8 and lo8 (e4m3 x 2^(scale - 127))"""
+    table = e4m3_values()
+    raw = img.cpu().numpy()
+    hi = torch.from_numpy(raw[:, :2 * K].copy()).view(torch.bfloat16).float().numpy().astype(np.float64)
+    h8 = table[raw[:, 2 * K:3 * K]] * 2.0 ** (s_hi.cpu().numpy().astype(np.float64)[:, None] - 127)
+    l8 = table[raw[:, 3 * K:4 * K]] * 2.0 ** (s_lo.cpu().numpy().astype(np.float64)[:, None] - 127)
+    return hi, h8, l8
+
+
+def test_split_f8_planes(dev):
+    g = torch.Generator().manual_seed(3)
+    rows, cols, K = 37, 200, 256
+    x = (torch.randn(rows, cols, generator=g) * torch.exp(torch.randn(rows, 1, generator=g))).to(dev)
+    x[5] = 0.0                                                # an all-zero row
+    with _Probe(dev) as L:
+        _bind(L)
+        img, s_hi, s_lo = _split_f8(L, dev, x, K)
+    hi, h8, l8 = _decode(img, s_hi, s_lo, K)
+    xr = x.cpu().double().numpy()
+    want_hi = x.cpu().to(torch.bfloat16).double().numpy()
+    assert np.array_equal(hi[:, :cols], want_hi) and not hi[:, cols:].any()
+    lo = xr - want_hi
+    # every fp8 plane: within half a step of the e4m3 grid of its row's scale (4 significant bits while the element is within 2^-14 of
+    # the row's largest; the row's largest itself lands in [224, 448])
+    for plane, ref in ((h8, want_hi), (l8, lo)):
+        amax = np.abs(ref).max(1, keepdims=True)
+        assert np.all(np.abs(plane[:, :cols] - ref) <= np.maximum(np.abs(ref) * 2.0 ** -4, amax * 2.0 ** -17) * 1.0001 + 1e-300)
+        assert not plane[:, cols:].any()
+    sc = 2.0 ** (127 - s_hi.cpu().numpy().astype(np.float64))
+    nz = np.abs(want_hi).max(1) > 0
+    top = np.abs(want_hi).max(1)[nz] * sc[nz]
+    assert np.all((top > 223.9) & (top <= 448.0)), (top.min(), top.max())
+
+
+@pytest.mark.parametrize("shape", [(256, 256, 256), (512, 256, 128), (256, 512, 384)])
+def test_gemm_x3f8_prototype(dev, shape):
+    """C = hi.hi (bf16 pipe) + lo8.hi8 + hi8.lo8 (fp8 pipe) of the two images, checked (a) against exactly that sum formed in fp64 from
+    the images' own bytes -- the kernel's index logic -- and (b) against the fp64 product of the fp32 operands -- what the mode is for"""
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).to(dev)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    C = torch.full((M, N), float("nan"), device=dev)
+    with _Probe(dev) as L:
+        _bind(L)
+        ia, ah, al = _split_f8(L, dev, x, K)
+        ib, bh, bl = _split_f8(L, dev, w, K)
+        _lib.check(L.vb_gemm_x3f8(_lib.ptr(ia), 2 * K, _lib.ptr(ib), 2 * K, _lib.ptr(C), N, M, N, K, _lib.ptr(bias), _lib.ptr(ah), _lib.ptr(al),
+                                  _lib.ptr(bh), _lib.ptr(bl), _lib.stream_ptr()), "vb_gemm_x3f8")
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    got = C.cpu().double().numpy()
+    xh, x8, xl8 = _decode(ia, ah, al, K)
+    wh, w8, wl8 = _decode(ib, bh, bl, K)
+    b = bias.cpu().double().numpy()
+    want = xh @ wh.T + xl8 @ w8.T + x8 @ wl8.T + b
+    mag = np.abs(xh) @ np.abs(wh).T + 1.0
+    err_logic = float(np.max(np.abs(got - want) / mag))
+    exact = x.cpu().double().numpy() @ w.cpu().double().numpy().T + b
+    err_exact = float(np.max(np.abs(got - exact) / mag))
+    print("x3f8 %s: vs its own planes %.2e, vs the fp64 product %.2e (of sum |x||w|)" % (shape, err_logic, err_exact))
+    assert err_logic <= 2e-6, err_logic                       # fp32 accumulation + the fp8 instruction's truncation of 2^-9-sized terms
+    assert err_exact <= 3e-4, err_exact                       # the cross terms carry 4 significant bits: ~2^-13 of the product

@@ -85,6 +85,8 @@ DEV_SIGNATURES = {
     "vb_glds_stream": (_i, [_i, _p, _i64, _i, _i, _p, _p]),
     "vb_mma_f8_probe": (_i, [_p, _p, _p, _p, _p, _p]),
     "vb_cvt_fp8_probe": (_i, [_p, _p, _i, _p]),
+    "vb_split_f8": (_i, [_p, _i64, _p, _i64, _i, _i, _p, _p, _p]),
+    "vb_gemm_x3f8": (_i, [_p, _i64, _p, _i64, _p, _i64, _i, _i, _i, _p, _p, _p, _p, _p, _p]),
 }
 VB_COMM_ID_BYTES = 128
 

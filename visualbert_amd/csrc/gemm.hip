@@ -2510,3 +2510,226 @@ extern "C" int vb_glds_stream(int depth, const void* src, int64_t span, int iter
 
 extern "C" int vb_gemm_set_trace(void* device_u64x1024) { g_trace = (unsigned long long*)device_u64x1024; return VB_OK; }
 #endif  // VB_DEV_KNOBS
+
+// =================================================================================================
+// PROTOTYPE (developer library and simulator only): the split-operand product with its two cross terms on the
+// block-scaled fp8 pipe.  Operand image row (ld bf16 elements = 4 K bytes, as in VB_BF16X3): [ hi: K bf16 | hi8: K e4m3 | lo8: K e4m3 ]
+// with ONE power-of-two scale per row and fp8 plane (vb_split_f8; per-row scales are as good as per-32-element ones here:
+// profiles/r04_x3_cross_term_bits.txt -- and leave the K loop free of scale traffic).  The persistent 256x256 kernel walks
+//   K / 64 tiles  hi . hi     on v_mfma_f32_16x16x32_bf16            (128-byte rows of 64 bf16)
+//   K / 128 tiles lo8 . hi8   on v_mfma_scale_f32_16x16x128_f8f6f4   (128-byte rows of 128 e4m3)
+//   K / 128 tiles hi8 . lo8
+// into the same fp32 accumulators: K / 32 tile slots instead of 3 K / 64, and the LDS stage, the copy stream and the fragment reads
+// are byte for byte those of the bf16 kernel -- an fp8 operand of the K = 128 instruction IS the pair of 16-byte chunks (lg, 4 + lg)
+// of a row that the two bf16 K steps read (vb_rt.h: vb_mma_f8).  Plain epilogue (+ bias), fp32 result, M, N multiples of 256.
+// =================================================================================================
+#if defined(VB_DEV_KNOBS) || defined(VB_EMU)
+struct F8Scales { const unsigned char *a_hi, *a_lo, *b_hi, *b_lo; };     // E8M0 byte per row and plane
+
+VB_KERNEL VB_LAUNCH_BOUNDS(512) gemm_nt_8ph_f8_kernel(GemmArgs g, F8Scales sc) {
+    typedef bf16 T;
+    constexpr int HALF = 128 * 128, BUF = 4 * HALF;
+    constexpr int SLOT_A0 = 0, SLOT_A1 = 1, SLOT_B0 = 2, SLOT_B1 = 3;
+    VB_DYN_SMEM(smem);
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = vb_uniform(t >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int li = lane & 15, lg = lane >> 4;
+    const int ntiles = g.tiles_m * g.tiles_n;
+    const int G = (int)gridDim.x;
+    const int my_tiles = (ntiles - (int)blockIdx.x + G - 1) / G;
+    const unsigned char* A = (const unsigned char*)g.A;
+    const unsigned char* B = (const unsigned char*)g.B;
+    unsigned char* slab = smem + 2 * BUF + wave * EPI8_BYTES_PER_WAVE;
+    const int kb = g.K / 64, kf = g.K / 128, nk = kb + 2 * kf;      // tile slots per output tile: bf16 | lo8.hi8 | hi8.lo8
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int l3 = lane >> 3;
+    const int rowA = (wave >> 2) * 128 + (wave & 3) * 16 + l3;
+    const int rowB = (wave >> 1) * 64 + (wave & 1) * 16 + l3;
+    const int csrc0 = ((lane & 7) ^ swz(wave * 16 + l3)) * 16;
+    const int csrc1 = csrc0 ^ 64;
+    unsigned offA[2][2], offB[2][2];
+    int ld_j = 0, ld_t = 0;
+    auto origin = [&](int j, int& m0, int& n0) {
+        const int tile = xcd_remap((int)blockIdx.x + G * j, ntiles);
+        m0 = (tile / g.tiles_n) * 256; n0 = (tile % g.tiles_n) * 256;
+    };
+    auto set_load_tile = [&](int j) {
+        int m0, n0;
+        origin(j, m0, n0);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int a0 = m0 + rowA + h * 64, a1 = a0 + 8, b0 = n0 + rowB + h * 32, b1 = b0 + 8;
+            a0 = a0 < g.M ? a0 : g.M - 1; a1 = a1 < g.M ? a1 : g.M - 1;
+            b0 = b0 < g.N ? b0 : g.N - 1; b1 = b1 < g.N ? b1 : g.N - 1;
+            offA[h][0] = (unsigned)(a0 * (int)g.lda) * 2u + csrc0;
+            offA[h][1] = (unsigned)(a1 * (int)g.lda) * 2u + csrc1;
+            offB[h][0] = (unsigned)(b0 * (int)g.ldb) * 2u + csrc0;
+            offB[h][1] = (unsigned)(b1 * (int)g.ldb) * 2u + csrc1;
+        }
+    };
+    set_load_tile(0);
+    // byte offset of tile slot v inside an operand row: the hi plane, then the fp8 planes (hi8 at 2 K, lo8 at 3 K bytes)
+    auto off_a = [&](int v) { return v < kb ? v * 128 : (v < kb + kf ? 3 * g.K + (v - kb) * 128 : 2 * g.K + (v - kb - kf) * 128); };
+    auto off_b = [&](int v) { return v < kb ? v * 128 : (v < kb + kf ? 2 * g.K + (v - kb) * 128 : 3 * g.K + (v - kb - kf) * 128); };
+    auto issueA = [&](int mh, int par) {
+        unsigned char* dst = smem + par * BUF + (mh ? SLOT_A1 : SLOT_A0) * HALF + wave * 2048;
+        const unsigned char* src = A + off_a(ld_t);
+        vb_glds16(src + offA[mh][0], dst);
+        vb_glds16(src + offA[mh][1], dst + 1024);
+    };
+    auto issueB = [&](int nh, int par) {
+        unsigned char* dst = smem + par * BUF + (nh ? SLOT_B1 : SLOT_B0) * HALF + wave * 2048;
+        const unsigned char* src = B + off_b(ld_t);
+        vb_glds16(src + offB[nh][0], dst);
+        vb_glds16(src + offB[nh][1], dst + 1024);
+    };
+    auto ld_advance = [&]() {
+        if (++ld_t == nk) { ld_t = 0; ++ld_j; set_load_tile(ld_j); }
+    };
+
+    bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+    auto readA = [&](const unsigned char* half) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fa[f][ks] = load_frag(half, wr * 64 + f * 16 + li, ks, lg, T());
+    };
+    auto readB = [&](bf16x8 (&fb)[2][2], const unsigned char* half) {
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fb[f][ks] = load_frag(half, wc * 32 + f * 16 + li, ks, lg, T());
+    };
+    // per-row scales of the CURRENT output tile, four fragments per register (the instruction selects the byte):
+    //   sAh / sAl [mh]: byte f = scale of rows m0 + wr 128 + mh 64 + f 16 + li of the hi8 / lo8 plane of A
+    //   sBh / sBl     : byte nh 2 + q = scale of rows n0 + wc 64 + nh 32 + q 16 + li of B
+    int sAh[2], sAl[2], sBh, sBl;
+    auto load_scales = [&](int cj) {
+        int m0, n0;
+        origin(cj, m0, n0);
+        unsigned ah[2] = {0u, 0u}, al[2] = {0u, 0u}, bh = 0u, bl = 0u;
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                int r = m0 + wr * 128 + mh * 64 + f * 16 + li;
+                r = r < g.M ? r : g.M - 1;
+                ah[mh] |= (unsigned)sc.a_hi[r] << (8 * f); al[mh] |= (unsigned)sc.a_lo[r] << (8 * f);
+            }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int r = n0 + wc * 64 + (i >> 1) * 32 + (i & 1) * 16 + li;
+            r = r < g.N ? r : g.N - 1;
+            bh |= (unsigned)sc.b_hi[r] << (8 * i); bl |= (unsigned)sc.b_lo[r] << (8 * i);
+        }
+        sAh[0] = (int)ah[0]; sAh[1] = (int)ah[1]; sAl[0] = (int)al[0]; sAl[1] = (int)al[1]; sBh = (int)bh; sBl = (int)bl;
+    };
+    auto cat = [](bf16x8 x, bf16x8 y) {
+        i32x8 o;
+        const u32x4 a = *(const u32x4*)&x, b = *(const u32x4*)&y;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { o[j] = (int)a[j]; o[4 + j] = (int)b[j]; }
+        return o;
+    };
+    // one quadrant (64 x 32 outputs of this wave) from the fragments in registers; seg: 0 = bf16 hi.hi, 1 = lo8.hi8, 2 = hi8.lo8
+    auto quad = [&](auto mhtag, auto nhtag, bf16x8 (&fb)[2][2], int seg) {
+        constexpr int mh = decltype(mhtag)::value, nh = decltype(nhtag)::value;
+        vb_setprio<1>();
+        if (seg == 0) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int f = 0; f < 4; ++f)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        acc[mh * 4 + f][nh * 2 + q] = vb_mma(fa[f][ks], fb[q][ks], acc[mh * 4 + f][nh * 2 + q]);
+        } else {
+            const int sa = seg == 1 ? sAl[mh] : sAh[mh], sb = seg == 1 ? sBh : sBl;
+            vb_static_for<0, 4>([&](auto ftag) {
+                constexpr int f = decltype(ftag)::value;
+                vb_static_for<0, 2>([&](auto qtag) {
+                    constexpr int q = decltype(qtag)::value;
+                    acc[mh * 4 + f][nh * 2 + q] = vb_mma_f8_op<f, nh * 2 + q>(cat(fa[f][0], fa[f][1]), cat(fb[q][0], fb[q][1]),
+                                                                               acc[mh * 4 + f][nh * 2 + q], sa, sb);
+                });
+            });
+        }
+        vb_setprio<0>();
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+
+    const int GK = my_tiles * nk;
+    issueA(0, 0); issueB(0, 0); issueB(1, 0); issueA(1, 0);
+    if (GK > 1) { ld_advance(); issueA(0, 1); issueB(0, 1); issueB(1, 1); vb_wait_vmcnt<6>(); }
+    else vb_wait_vmcnt<0>();
+    load_scales(0);
+    vb_phase_barrier();
+    if (wr == 1) vb_phase_barrier();               // waves 4-7 run one barrier behind waves 0-3
+    int ct = 0, cj = 0;
+    for (int gk = 0; gk < GK; ++gk) {
+        const int par = gk & 1;
+        const unsigned char* buf = smem + par * BUF;
+        const bool n1 = gk + 1 < GK, n2 = gk + 2 < GK;
+        const int seg = ct < kb ? 0 : (ct < kb + kf ? 1 : 2);
+        // ---- E
+        readB(fb0, buf + SLOT_B0 * HALF);
+        readA(buf + SLOT_A0 * HALF);
+        readB(fb1, buf + SLOT_B1 * HALF);
+        if (n1) { issueA(1, par ^ 1); vb_wait_vmcnt<8>(); } else vb_wait_vmcnt<0>();
+        vb_raw_barrier();
+        vb_sched_fence();
+        quad(I0(), I0(), fb0, seg);
+        quad(I0(), I1(), fb1, seg);
+        vb_phase_barrier();
+        // ---- O
+        readA(buf + SLOT_A1 * HALF);
+        if (n2) { ld_advance(); issueA(0, par); issueB(0, par); issueB(1, par); vb_wait_vmcnt<8>(); }
+        else if (n1) vb_wait_vmcnt<2>();
+        else vb_wait_vmcnt<0>();
+        vb_raw_barrier();
+        vb_sched_fence();
+        quad(I1(), I1(), fb1, seg);
+        quad(I1(), I0(), fb0, seg);
+        vb_phase_barrier();
+        if (++ct == nk) {
+            int m0, n0;
+            origin(cj, m0, n0);
+            gemm_epilogue_private<float, float, VB_ACT_NONE, 0>(acc, slab, g, m0 + wr * 128, n0 + wc * 64, lane);
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+            ct = 0; ++cj;
+            if (cj < my_tiles) load_scales(cj);
+        }
+    }
+    if (wr == 0) vb_phase_barrier();               // balance the stagger barrier
+}
+
+extern "C" int vb_gemm_x3f8(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int M, int N, int K,
+                            const float* bias, const void* sa_hi, const void* sa_lo, const void* sb_hi, const void* sb_lo, void* stream) {
+    if (!A || !B || !C || !sa_hi || !sa_lo || !sb_hi || !sb_lo || M <= 0 || N <= 0 || K <= 0) return VB_ERR_ARG;
+    if ((M % 256) || (N % 256) || (K % 128) || lda < 2 * (int64_t)K || ldb < 2 * (int64_t)K || (lda % 8) || (ldb % 8) || ldc < N || (ldc % 4))
+        return VB_ERR_UNSUPPORTED;
+    if ((long)M * lda >= (1L << 30) || (long)N * ldb >= (1L << 30)) return VB_ERR_UNSUPPORTED;
+    GemmArgs g{};
+    g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.bias = bias; g.alpha = 1.f;
+    g.act = VB_ACT_NONE; g.tiles_m = M / 256; g.tiles_n = N / 256; g.x3 = 1; g.kseg = K / 64;
+    const int ntiles = g.tiles_m * g.tiles_n;
+    int wgs = vb_num_cus();
+    if (wgs >= ntiles) wgs = ntiles;
+    else if (wgs >= 8) wgs &= ~7;
+    constexpr int SM = 2 * 4 * 128 * 128 + 8 * EPI8_BYTES_PER_WAVE;
+    F8Scales sc{(const unsigned char*)sa_hi, (const unsigned char*)sa_lo, (const unsigned char*)sb_hi, (const unsigned char*)sb_lo};
+    hipStream_t s = (hipStream_t)stream;
+    return vb_prof_launch(2.0 * M * N * K, 4 | 16 | 256 | 512, s, [&]() { VB_LAUNCH(gemm_nt_8ph_f8_kernel, dim3((unsigned)wgs), dim3(512), SM, s, g, sc); });
+}
+#endif

@@ -408,6 +408,56 @@ VB_KERNEL VB_LAUNCH_BOUNDS(64) cvt_fp8_probe_kernel(const float* x, uint32_t* y,
     if (i < n4) y[i] = vb_cvt4_fp8(x[4 * i], x[4 * i + 1], x[4 * i + 2], x[4 * i + 3]);
 }
 }  // namespace
+namespace {
+// vb_split_f8: one wave per row.  image row = [ hi: cols bf16 (zero padded to K) | hi8: K e4m3 | lo8: K e4m3 ], K = ld_img / 2;
+// hi = bf16(x), lo = x - hi; each fp8 plane holds its values times 2^e with e = floor(log2(448 / max|row|)) (one per row and plane),
+// scale byte = 127 - e (E8M0: the value is byte-encoded x 2^(scale - 127))
+VB_DEVICE int f8_row_exp(float amax) {
+    if (!(amax > 0.f)) return 0;
+    int ex;
+    const float m = frexpf(amax, &ex);                      // amax = m 2^ex, m in [0.5, 1)
+    int e = (m <= 0.875f ? 9 : 8) - ex;                     // 448 / amax = (448 / m) 2^-ex, 448 / m in (448, 896]
+    return e > 126 ? 126 : (e < -127 ? -127 : e);
+}
+VB_KERNEL VB_LAUNCH_BOUNDS(256) split_f8_kernel(const float* x, long ldx, unsigned char* img, long ld_img, int rows, int cols,
+                                               unsigned char* s_hi, unsigned char* s_lo) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int K = (int)(ld_img / 2);
+    for (int r = blockIdx.x * 4 + wave; r < rows; r += gridDim.x * 4) {
+        const float* xr = x + (long)r * ldx;
+        float mh = 0.f, ml = 0.f;
+        for (int c = lane; c < cols; c += 64) {
+            const float v = xr[c];
+            const float h = (float)(bf16)v;
+            mh = fmaxf(mh, fabsf(h)); ml = fmaxf(ml, fabsf(v - h));
+        }
+        for (int o = 32; o > 0; o >>= 1) { mh = fmaxf(mh, __shfl_xor(mh, o)); ml = fmaxf(ml, __shfl_xor(ml, o)); }
+        const int eh = f8_row_exp(mh), el = f8_row_exp(ml);
+        if (lane == 0) { s_hi[r] = (unsigned char)(127 - eh); s_lo[r] = (unsigned char)(127 - el); }
+        unsigned char* row = img + (long)r * ld_img * 2;
+        for (int c = lane * 4; c < K; c += 256) {
+            float v[4], h[4], l[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j] = c + j < cols ? xr[c + j] : 0.f;
+                h[j] = (float)(bf16)v[j]; l[j] = v[j] - h[j];
+                ((bf16*)row)[c + j] = (bf16)v[j];
+            }
+            *(uint32_t*)(row + 2 * K + c) = vb_cvt4_fp8(ldexpf(h[0], eh), ldexpf(h[1], eh), ldexpf(h[2], eh), ldexpf(h[3], eh));
+            *(uint32_t*)(row + 3 * K + c) = vb_cvt4_fp8(ldexpf(l[0], el), ldexpf(l[1], el), ldexpf(l[2], el), ldexpf(l[3], el));
+        }
+    }
+}
+}  // namespace
+extern "C" int vb_split_f8(const float* x, int64_t ldx, void* image, int64_t ld_img, int rows, int cols, void* scale_hi, void* scale_lo,
+                           void* stream) {
+    if (!x || !image || !scale_hi || !scale_lo || rows <= 0 || cols <= 0 || (ld_img % 8) || cols > ld_img / 2 || ldx < cols) return VB_ERR_ARG;
+    long blocks = (rows + 3) / 4;
+    if (blocks > 8192) blocks = 8192;
+    VB_LAUNCH(split_f8_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (long)ldx, (unsigned char*)image, (long)ld_img,
+              rows, cols, (unsigned char*)scale_hi, (unsigned char*)scale_lo);
+    return vb_check_launch();
+}
 extern "C" int vb_mma_f8_probe(const void* A, const void* B, const void* scale_a, const void* scale_b, float* D, void* stream) {
     if (!A || !B || !scale_a || !scale_b || !D) return VB_ERR_ARG;
     VB_LAUNCH(mma_f8_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const unsigned char*)A, (const unsigned char*)B,

@@ -180,6 +180,10 @@ VB_DEVICE f32x4 vb_mma_f8(i32x8 a, i32x8 b, f32x4 c, int scale_a, int scale_b) {
     f32x4 o; for (int r = 0; r < 4; ++r) o[r] = fc[r];
     return o;
 }
+// OA / OB: which BYTE of the scale registers holds this fragment's scale (an immediate of the instruction): four fragments share a register
+template <int OA, int OB> VB_DEVICE f32x4 vb_mma_f8_op(i32x8 a, i32x8 b, f32x4 c, int scale_a, int scale_b) {
+    return vb_mma_f8(a, b, c, (int)((unsigned)scale_a >> (8 * OA)), (int)((unsigned)scale_b >> (8 * OB)));
+}
 VB_DEVICE uint32_t vb_cvt4_fp8(float x0, float x1, float x2, float x3) {
     return (uint32_t)::hipemu::float_to_e4m3(x0) | ((uint32_t)::hipemu::float_to_e4m3(x1) << 8) |
            ((uint32_t)::hipemu::float_to_e4m3(x2) << 16) | ((uint32_t)::hipemu::float_to_e4m3(x3) << 24);
@@ -187,6 +191,9 @@ VB_DEVICE uint32_t vb_cvt4_fp8(float x0, float x1, float x2, float x3) {
 #else
 VB_DEVICE f32x4 vb_mma_f8(i32x8 a, i32x8 b, f32x4 c, int scale_a, int scale_b) {
     return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, scale_a, 0, scale_b);
+}
+template <int OA, int OB> VB_DEVICE f32x4 vb_mma_f8_op(i32x8 a, i32x8 b, f32x4 c, int scale_a, int scale_b) {
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, OA, scale_a, OB, scale_b);
 }
 VB_DEVICE uint32_t vb_cvt4_fp8(float x0, float x1, float x2, float x3) {
     int w = 0;

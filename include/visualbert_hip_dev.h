@@ -43,7 +43,8 @@ int vb_cvt_fp8_probe(const float* x, void* y, int n, void* stream);
 /* PROTOTYPE of the split-operand GEMM with its two cross terms on the fp8 pipe (csrc/gemm.hip, end of file).
  * vb_split_f8: fp32 x[rows, cols] -> image[rows, ld_img bf16 elements = 4 K bytes, K = ld_img / 2 >= cols, K % 128 == 0 for the GEMM]:
  *   [ hi = bf16(x): K bf16 | hi8: K e4m3 bytes | lo8 = (x - hi): K e4m3 bytes ], each fp8 plane times ONE power of two per row;
- *   scale_hi / scale_lo [rows]: the E8M0 bytes (value = byte-decoded x 2^(scale - 127))
+ *   scale_hi / scale_lo [round_up(rows, 64)]: the E8M0 bytes (value = byte-decoded x 2^(scale - 127)), row r at byte
+ *   (r & ~63) | ((r & 15) << 2) | ((r >> 4) & 3) -- the four fragments of a 64-row block a GEMM lane needs are one dword
  * vb_gemm_x3f8: C[M, N] fp32 = A B^T (+ bias) from two such images; M, N multiples of 256, K of 128 */
 int vb_split_f8(const float* x, int64_t ldx, void* image, int64_t ld_img, int rows, int cols, void* scale_hi, void* scale_lo, void* stream);
 int vb_gemm_x3f8(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int M, int N, int K, const float* bias,

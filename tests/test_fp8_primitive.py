@@ -119,8 +119,8 @@ def _bind(L):
 def _split_f8(L, dev, x, K):
     rows, cols = x.shape
     img = torch.zeros(rows, 4 * K, dtype=torch.uint8, device=dev)
-    s_hi = torch.zeros(rows, dtype=torch.uint8, device=dev)
-    s_lo = torch.zeros(rows, dtype=torch.uint8, device=dev)
+    s_hi = torch.zeros((rows + 63) // 64 * 64, dtype=torch.uint8, device=dev)
+    s_lo = torch.zeros((rows + 63) // 64 * 64, dtype=torch.uint8, device=dev)
     _lib.check(L.vb_split_f8(_lib.ptr(x), x.stride(0), _lib.ptr(img), 2 * K, rows, cols, _lib.ptr(s_hi), _lib.ptr(s_lo), _lib.stream_ptr()), "vb_split_f8")
     return img, s_hi, s_lo
 
@@ -129,6 +129,9 @@ def _decode(img, s_hi, s_lo, K):
     """fp64 values of the three planes of an image: hi (bf16), hi8 and lo8 (e4m3 x 2^(scale - 127))"""
     table = e4m3_values()
     raw = img.cpu().numpy()
+    r = np.arange(raw.shape[0])
+    perm = (r & ~63) | ((r & 15) << 2) | ((r >> 4) & 3)      # where vb_split_f8 puts row r's scale
+    s_hi, s_lo = s_hi.cpu()[perm], s_lo.cpu()[perm]
     hi = torch.from_numpy(raw[:, :2 * K].copy()).view(torch.bfloat16).float().numpy().astype(np.float64)
     h8 = table[raw[:, 2 * K:3 * K]] * 2.0 ** (s_hi.cpu().numpy().astype(np.float64)[:, None] - 127)
     l8 = table[raw[:, 3 * K:4 * K]] * 2.0 ** (s_lo.cpu().numpy().astype(np.float64)[:, None] - 127)
@@ -154,7 +157,8 @@ def test_split_f8_planes(dev):
         amax = np.abs(ref).max(1, keepdims=True)
         assert np.all(np.abs(plane[:, :cols] - ref) <= np.maximum(np.abs(ref) * 2.0 ** -4, amax * 2.0 ** -17) * 1.0001 + 1e-300)
         assert not plane[:, cols:].any()
-    sc = 2.0 ** (127 - s_hi.cpu().numpy().astype(np.float64))
+    r = np.arange(rows)
+    sc = 2.0 ** (127 - s_hi.cpu().numpy()[(r & ~63) | ((r & 15) << 2) | ((r >> 4) & 3)].astype(np.float64))
     nz = np.abs(want_hi).max(1) > 0
     top = np.abs(want_hi).max(1)[nz] * sc[nz]
     assert np.all((top > 223.9) & (top <= 448.0)), (top.min(), top.max())

@@ -41,8 +41,8 @@ def main():
         # the prototype's images
         xi = torch.zeros(M, 4 * K, dtype=torch.uint8, device=dev)
         wi = torch.zeros(N, 4 * K, dtype=torch.uint8, device=dev)
-        sx = [torch.zeros(M, dtype=torch.uint8, device=dev) for _ in range(2)]
-        sw = [torch.zeros(N, dtype=torch.uint8, device=dev) for _ in range(2)]
+        sx = [torch.zeros((M + 63) // 64 * 64, dtype=torch.uint8, device=dev) for _ in range(2)]
+        sw = [torch.zeros((N + 63) // 64 * 64, dtype=torch.uint8, device=dev) for _ in range(2)]
         _lib.check(L.vb_split_f8(_lib.ptr(x), K, _lib.ptr(xi), 2 * K, M, K, _lib.ptr(sx[0]), _lib.ptr(sx[1]), _lib.stream_ptr()), "split_f8")
         _lib.check(L.vb_split_f8(_lib.ptr(w), K, _lib.ptr(wi), 2 * K, N, K, _lib.ptr(sw[0]), _lib.ptr(sw[1]), _lib.stream_ptr()), "split_f8")
         C3 = torch.empty(M, N, device=dev)

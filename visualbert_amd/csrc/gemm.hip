@@ -2594,70 +2594,65 @@ VB_KERNEL VB_LAUNCH_BOUNDS(512) gemm_nt_8ph_f8_kernel(GemmArgs g, F8Scales sc) {
         if (++ld_t == nk) { ld_t = 0; ++ld_j; set_load_tile(ld_j); }
     };
 
-    bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+    // a fragment = the two 16-byte chunks (lg, 4 + lg) of a 128-byte row, kept as ONE 8-register tuple: its halves are the operands of
+    // the two bf16 K steps, the whole tuple is the operand of the K = 128 fp8 instruction (no register copies between the two forms)
+    typedef int i32x4v __attribute__((ext_vector_type(4)));
+    i32x8 fa[4], fb0[2], fb1[2];
+    auto frag8 = [&](const unsigned char* half, int row) {
+        const bf16x8 lo = load_frag(half, row, 0, lg, T()), hi = load_frag(half, row, 1, lg, T());
+        const i32x4v a = *(const i32x4v*)&lo, b = *(const i32x4v*)&hi;
+        return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
     auto readA = [&](const unsigned char* half) {
 #pragma unroll
-        for (int f = 0; f < 4; ++f)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) fa[f][ks] = load_frag(half, wr * 64 + f * 16 + li, ks, lg, T());
+        for (int f = 0; f < 4; ++f) fa[f] = frag8(half, wr * 64 + f * 16 + li);
     };
-    auto readB = [&](bf16x8 (&fb)[2][2], const unsigned char* half) {
+    auto readB = [&](i32x8 (&fb)[2], const unsigned char* half) {
 #pragma unroll
-        for (int f = 0; f < 2; ++f)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) fb[f][ks] = load_frag(half, wc * 32 + f * 16 + li, ks, lg, T());
+        for (int f = 0; f < 2; ++f) fb[f] = frag8(half, wc * 32 + f * 16 + li);
+    };
+    auto part = [](const i32x8& v, auto kstag) {            // K step ks of a fragment, as the bf16 MFMA takes it
+        constexpr int ks = decltype(kstag)::value;
+        const i32x4v h = ks == 0 ? __builtin_shufflevector(v, v, 0, 1, 2, 3) : __builtin_shufflevector(v, v, 4, 5, 6, 7);
+        return *(const bf16x8*)&h;
     };
     // per-row scales of the CURRENT output tile, four fragments per register (the instruction selects the byte):
     //   sAh / sAl [mh]: byte f = scale of rows m0 + wr 128 + mh 64 + f 16 + li of the hi8 / lo8 plane of A
     //   sBh / sBl     : byte nh 2 + q = scale of rows n0 + wc 64 + nh 32 + q 16 + li of B
     int sAh[2], sAl[2], sBh, sBl;
+    // (vb_split_f8 stores the scale of row r at byte (r & ~63) | ((r & 15) << 2) | ((r >> 4) & 3): the four scales a lane needs for
+    //  the fragments f = 0..3 of a 64-row block are one aligned dword -- six loads per output tile instead of 48 byte loads, whose
+    //  48 result registers at the tile boundary cost spills that were reloaded inside the K loop)
     auto load_scales = [&](int cj) {
         int m0, n0;
         origin(cj, m0, n0);
-        unsigned ah[2] = {0u, 0u}, al[2] = {0u, 0u}, bh = 0u, bl = 0u;
 #pragma unroll
-        for (int mh = 0; mh < 2; ++mh)
-#pragma unroll
-            for (int f = 0; f < 4; ++f) {
-                int r = m0 + wr * 128 + mh * 64 + f * 16 + li;
-                r = r < g.M ? r : g.M - 1;
-                ah[mh] |= (unsigned)sc.a_hi[r] << (8 * f); al[mh] |= (unsigned)sc.a_lo[r] << (8 * f);
-            }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int r = n0 + wc * 64 + (i >> 1) * 32 + (i & 1) * 16 + li;
-            r = r < g.N ? r : g.N - 1;
-            bh |= (unsigned)sc.b_hi[r] << (8 * i); bl |= (unsigned)sc.b_lo[r] << (8 * i);
+        for (int mh = 0; mh < 2; ++mh) {
+            const int r0 = m0 + wr * 128 + mh * 64 + li * 4;
+            sAh[mh] = *(const int*)(sc.a_hi + r0); sAl[mh] = *(const int*)(sc.a_lo + r0);
         }
-        sAh[0] = (int)ah[0]; sAh[1] = (int)ah[1]; sAl[0] = (int)al[0]; sAl[1] = (int)al[1]; sBh = (int)bh; sBl = (int)bl;
+        const int c0 = n0 + wc * 64 + li * 4;
+        sBh = *(const int*)(sc.b_hi + c0); sBl = *(const int*)(sc.b_lo + c0);
     };
-    auto cat = [](bf16x8 x, bf16x8 y) {
-        i32x8 o;
-        const u32x4 a = *(const u32x4*)&x, b = *(const u32x4*)&y;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { o[j] = (int)a[j]; o[4 + j] = (int)b[j]; }
-        return o;
-    };
-    // one quadrant (64 x 32 outputs of this wave) from the fragments in registers; seg: 0 = bf16 hi.hi, 1 = lo8.hi8, 2 = hi8.lo8
-    auto quad = [&](auto mhtag, auto nhtag, bf16x8 (&fb)[2][2], int seg) {
-        constexpr int mh = decltype(mhtag)::value, nh = decltype(nhtag)::value;
+    // one quadrant (64 x 32 outputs of this wave) from the fragments in registers; SEG: 0 = bf16 hi.hi, 1 = lo8.hi8, 2 = hi8.lo8
+    auto quad = [&](auto mhtag, auto nhtag, i32x8 (&fb)[2], auto segtag) {
+        constexpr int mh = decltype(mhtag)::value, nh = decltype(nhtag)::value, SEG = decltype(segtag)::value;
         vb_setprio<1>();
-        if (seg == 0) {
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
+        if constexpr (SEG == 0) {
+            vb_static_for<0, 2>([&](auto kstag) {
 #pragma unroll
                 for (int f = 0; f < 4; ++f)
 #pragma unroll
                     for (int q = 0; q < 2; ++q)
-                        acc[mh * 4 + f][nh * 2 + q] = vb_mma(fa[f][ks], fb[q][ks], acc[mh * 4 + f][nh * 2 + q]);
+                        acc[mh * 4 + f][nh * 2 + q] = vb_mma(part(fa[f], kstag), part(fb[q], kstag), acc[mh * 4 + f][nh * 2 + q]);
+            });
         } else {
-            const int sa = seg == 1 ? sAl[mh] : sAh[mh], sb = seg == 1 ? sBh : sBl;
+            const int sa = SEG == 1 ? sAl[mh] : sAh[mh], sb = SEG == 1 ? sBh : sBl;
             vb_static_for<0, 4>([&](auto ftag) {
                 constexpr int f = decltype(ftag)::value;
                 vb_static_for<0, 2>([&](auto qtag) {
                     constexpr int q = decltype(qtag)::value;
-                    acc[mh * 4 + f][nh * 2 + q] = vb_mma_f8_op<f, nh * 2 + q>(cat(fa[f][0], fa[f][1]), cat(fb[q][0], fb[q][1]),
-                                                                               acc[mh * 4 + f][nh * 2 + q], sa, sb);
+                    acc[mh * 4 + f][nh * 2 + q] = vb_mma_f8_op<f, nh * 2 + q>(fa[f], fb[q], acc[mh * 4 + f][nh * 2 + q], sa, sb);
                 });
             });
         }
@@ -2673,12 +2668,29 @@ VB_KERNEL VB_LAUNCH_BOUNDS(512) gemm_nt_8ph_f8_kernel(GemmArgs g, F8Scales sc) {
     load_scales(0);
     vb_phase_barrier();
     if (wr == 1) vb_phase_barrier();               // waves 4-7 run one barrier behind waves 0-3
-    int ct = 0, cj = 0;
-    for (int gk = 0; gk < GK; ++gk) {
+    typedef std::integral_constant<int, 2> I2;
+    // The fp8 MFMAs are plain register operations to the compiler: nothing ties them to the barriers (asm statements that mention no
+    // accumulator), and it SANK the first phase's 16 below the phase barrier, the next fragment reads and the next barrier, next to the
+    // second phase's 16 -- both wave groups then compute at the same time and read at the same time, and an fp8 slot cost twice a bf16
+    // slot (second measurement: 0.92 - 1.01 of the bf16 form's time instead of 2/3).  Redefining a phase's accumulators in front of
+    // its closing barrier pins the phase's MFMAs where they are written.
+    auto pin_rows = [&](auto mhtag, auto segtag) {
+        if constexpr (decltype(segtag)::value != 0) {
+            constexpr int mh = decltype(mhtag)::value;
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) vb_pin(acc[mh * 4 + f][n]);
+        }
+    };
+    int gk = 0;
+    // one tile slot held in buffer gk & 1; SEG is a compile-time property of the loop it runs in (three loops per output tile): with the
+    // segment as a run-time branch around the two kinds of MFMA blocks the kernel needed 244 bytes of scratch, reloaded behind
+    // s_waitcnt vmcnt(0) inside the K loop -- which drains the copy stream: 4.5x SLOWER than the bf16 form (first measurement)
+    auto slot = [&](auto segtag) {
         const int par = gk & 1;
         const unsigned char* buf = smem + par * BUF;
         const bool n1 = gk + 1 < GK, n2 = gk + 2 < GK;
-        const int seg = ct < kb ? 0 : (ct < kb + kf ? 1 : 2);
         // ---- E
         readB(fb0, buf + SLOT_B0 * HALF);
         readA(buf + SLOT_A0 * HALF);
@@ -2686,8 +2698,9 @@ VB_KERNEL VB_LAUNCH_BOUNDS(512) gemm_nt_8ph_f8_kernel(GemmArgs g, F8Scales sc) {
         if (n1) { issueA(1, par ^ 1); vb_wait_vmcnt<8>(); } else vb_wait_vmcnt<0>();
         vb_raw_barrier();
         vb_sched_fence();
-        quad(I0(), I0(), fb0, seg);
-        quad(I0(), I1(), fb1, seg);
+        quad(I0(), I0(), fb0, segtag);
+        quad(I0(), I1(), fb1, segtag);
+        pin_rows(I0(), segtag);
         vb_phase_barrier();
         // ---- O
         readA(buf + SLOT_A1 * HALF);
@@ -2696,20 +2709,24 @@ VB_KERNEL VB_LAUNCH_BOUNDS(512) gemm_nt_8ph_f8_kernel(GemmArgs g, F8Scales sc) {
         else vb_wait_vmcnt<0>();
         vb_raw_barrier();
         vb_sched_fence();
-        quad(I1(), I1(), fb1, seg);
-        quad(I1(), I0(), fb0, seg);
+        quad(I1(), I1(), fb1, segtag);
+        quad(I1(), I0(), fb0, segtag);
+        pin_rows(I1(), segtag);
         vb_phase_barrier();
-        if (++ct == nk) {
-            int m0, n0;
-            origin(cj, m0, n0);
-            gemm_epilogue_private<float, float, VB_ACT_NONE, 0>(acc, slab, g, m0 + wr * 128, n0 + wc * 64, lane);
+        ++gk;
+    };
+    for (int cj = 0; cj < my_tiles; ++cj) {
+        for (int c = 0; c < kb; ++c) slot(I0());
+        for (int c = 0; c < kf; ++c) slot(I1());
+        for (int c = 0; c < kf; ++c) slot(I2());
+        int m0, n0;
+        origin(cj, m0, n0);
+        gemm_epilogue_private<float, float, VB_ACT_NONE, 0>(acc, slab, g, m0 + wr * 128, n0 + wc * 64, lane);
 #pragma unroll
-            for (int mi = 0; mi < 8; ++mi)
+        for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-            ct = 0; ++cj;
-            if (cj < my_tiles) load_scales(cj);
-        }
+            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (cj + 1 < my_tiles) load_scales(cj + 1);
     }
     if (wr == 0) vb_phase_barrier();               // balance the stagger barrier
 }

@@ -411,7 +411,8 @@ VB_KERNEL VB_LAUNCH_BOUNDS(64) cvt_fp8_probe_kernel(const float* x, uint32_t* y,
 namespace {
 // vb_split_f8: one wave per row.  image row = [ hi: cols bf16 (zero padded to K) | hi8: K e4m3 | lo8: K e4m3 ], K = ld_img / 2;
 // hi = bf16(x), lo = x - hi; each fp8 plane holds its values times 2^e with e = floor(log2(448 / max|row|)) (one per row and plane),
-// scale byte = 127 - e (E8M0: the value is byte-encoded x 2^(scale - 127))
+// scale byte = 127 - e (E8M0: the value is byte-encoded x 2^(scale - 127)), stored at (r & ~63) | ((r & 15) << 2) | ((r >> 4) & 3) of
+// scale_hi / scale_lo (round_up(rows, 64) bytes each)
 VB_DEVICE int f8_row_exp(float amax) {
     if (!(amax > 0.f)) return 0;
     int ex;
@@ -433,7 +434,8 @@ VB_KERNEL VB_LAUNCH_BOUNDS(256) split_f8_kernel(const float* x, long ldx, unsign
         }
         for (int o = 32; o > 0; o >>= 1) { mh = fmaxf(mh, __shfl_xor(mh, o)); ml = fmaxf(ml, __shfl_xor(ml, o)); }
         const int eh = f8_row_exp(mh), el = f8_row_exp(ml);
-        if (lane == 0) { s_hi[r] = (unsigned char)(127 - eh); s_lo[r] = (unsigned char)(127 - el); }
+        const int pr = (r & ~63) | ((r & 15) << 2) | ((r >> 4) & 3);      // the GEMM reads four fragments' scales as one dword
+        if (lane == 0) { s_hi[pr] = (unsigned char)(127 - eh); s_lo[pr] = (unsigned char)(127 - el); }
         unsigned char* row = img + (long)r * ld_img * 2;
         for (int c = lane * 4; c < K; c += 256) {
             float v[4], h[4], l[4];

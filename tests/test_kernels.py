@@ -272,10 +272,11 @@ def test_layernorm_residual_fwd_bwd(dev, dt, MH):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-def test_layernorm_dropout_consistency(dev, dt):
+@pytest.mark.parametrize("H", [768, 640, 256])        # 768 / 640: the 8 + 4-columns-per-lane backward (640: a partly filled 4-column chunk)
+def test_layernorm_dropout_consistency(dev, dt, H):
     """dropout masks are regenerated, not stored: forward and backward must agree on them, the keep
     rate must be 1-p, and different stream ids must give different masks."""
-    M, H, p = 64, 768, 0.1
+    M, p = 64, 0.1
     g = torch.Generator().manual_seed(4)
     x = (1.0 + torch.rand(M, H, generator=g)).to(dt).to(dev)        # strictly positive: zeros == dropped
     zero = torch.zeros(M, H, dtype=dt, device=dev)

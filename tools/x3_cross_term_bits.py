@@ -44,14 +44,16 @@ def make_linear(bits_hi, bits_lo, cross=True):
     return linear
 
 
-def e4m3_scaled(x, block):
+def e4m3_scaled(x, block, slack=0):
     """what an fp8 plane would really hold: x -> OCP e4m3 (4 significant bits, normal exponents 2^-6 .. 2^8, subnormal spacing 2^-9,
     max 448) under a power-of-two scale per row (block = 0) or per `block` consecutive K elements of a row, chosen so that the
     group's largest magnitude lands in [224, 448]; returns the dequantised values"""
     K = x.size(-1)
-    g = x.reshape(-1, K) if block == 0 else x.reshape(-1, block)
+    g = x.reshape(1, -1) if block < 0 else (x.reshape(-1, K) if block == 0 else x.reshape(-1, block))     # block < 0: ONE scale per tensor
     amax = g.abs().amax(-1, keepdim=True)
-    sc = torch.exp2(torch.floor(torch.log2(448.0 / amax.clamp_min(2.0 ** -100)))).clamp(max=2.0 ** 100)   # power of two: the E8M0 scale's reciprocal
+    # (slack: the scale is chosen from an a-priori BOUND of the row's magnitude that is 2^slack too large -- what a producer that does not
+    #  own whole rows would have to do, e.g. |y_row| <= |x_row|_2 max_j |W_j|_2 for a GEMM epilogue: the plane uses 2^-slack of its range)
+    sc = torch.exp2(torch.floor(torch.log2(448.0 / amax.clamp_min(2.0 ** -100))) - slack).clamp(max=2.0 ** 100)   # power of two: the E8M0 scale's reciprocal
     y = g * sc
     m, e = torch.frexp(y)                                            # y = m 2^e, |m| in [0.5, 1)
     e_eff = torch.clamp(e, min=-5)                                   # below 2^-6 the spacing stays 2^-9 (subnormals)
@@ -60,11 +62,13 @@ def e4m3_scaled(x, block):
     return (q / sc).reshape(x.shape)
 
 
-def make_linear_fp8(block):
+def make_linear_fp8(block, slack=0):
     def linear(x, w, b, mode, part="enc"):
         xh, wh = bf16(x), bf16(w)
         xl, wl = x - xh, w - wh
-        y = F.linear(xh, wh) + F.linear(e4m3_scaled(xl, block), e4m3_scaled(wh, block)) + F.linear(e4m3_scaled(xh, block), e4m3_scaled(wl, block))
+        # (the slack applies to the ACTIVATION planes only: weights are split by a pass that owns whole rows)
+        wb = max(block, 0)
+        y = F.linear(xh, wh) + F.linear(e4m3_scaled(xl, block, slack), e4m3_scaled(wh, wb)) + F.linear(e4m3_scaled(xh, block, slack), e4m3_scaled(wl, wb))
         return y if b is None else y + b
     return linear
 
@@ -77,7 +81,14 @@ ARMS = [("hi.hi only (plain bf16 operands in every Linear)", None),
         ("cross terms: hi 4 bits, lo 8 bits (only the LARGE operand of each cross term narrowed)", (4, 8)),
         ("cross terms on fp8 e5m2-like operands: hi 3 bits, lo 3 bits", (3, 3)),
         ("cross terms in REAL e4m3 (range-limited), one power-of-two scale per 32 K elements of a row", "fp8:32"),
-        ("cross terms in REAL e4m3 (range-limited), ONE power-of-two scale per ROW (no scale traffic in the K loop)", "fp8:0")]
+        ("cross terms in REAL e4m3 (range-limited), ONE power-of-two scale per ROW (no scale traffic in the K loop)", "fp8:0"),
+        ("  ... per-row scale from a bound 2^3 too large (activation planes)", "fp8:0:3"),
+        ("  ... per-row scale from a bound 2^5 too large", "fp8:0:5"),
+        ("  ... per-row scale from a bound 2^7 too large", "fp8:0:7"),
+        ("  ... per-row scale from a bound 2^9 too large", "fp8:0:9"),
+        ("cross terms in REAL e4m3, ONE scale per TENSOR for the activation planes (per row for the weights), exact tensor maximum", "fp8:-1:0"),
+        ("  ... one scale per tensor from a bound 2^4 too large (e.g. last step's maximum with headroom)", "fp8:-1:4"),
+        ("  ... one scale per tensor from a bound 2^8 too large", "fp8:-1:8")]
 
 
 def main():
@@ -97,7 +108,7 @@ def main():
             ref = vo.objective_forward(sd, cfg, "pretraining", mode="fp32", **batch)["logits"]
         print("\nseed %d: fp32 logits absmax %.3f" % (seed, float(ref.abs().max())))
         for name, bits in ARMS:
-            vo.linear = (make_linear(0, 0, cross=False) if bits is None else make_linear_fp8(int(bits.split(':')[1])) if isinstance(bits, str)
+            vo.linear = (make_linear(0, 0, cross=False) if bits is None else make_linear_fp8(*[int(v) for v in bits.split(':')[1:]]) if isinstance(bits, str)
                          else make_linear(*bits))
             try:
                 with torch.no_grad():

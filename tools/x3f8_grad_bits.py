@@ -23,19 +23,22 @@ from oracle import visualbert_oracle as vo  # noqa: E402
 from x3_cross_term_bits import bf16, e4m3_scaled  # noqa: E402
 
 
-def planes(v, fmt):
-    """(hi, q(hi), q(lo)) of a [rows, K] matrix whose K is the reduction axis"""
+def planes(v, fmt, weight):
+    """(hi, q(hi), q(lo)) of a [rows, K] matrix whose K is the reduction axis.  fmt "e4m3t": ONE scale per tensor (from a bound 2^4 too
+    large) for activations and gradients, per-row scales for weights (their split pass owns whole rows)"""
     hi = bf16(v)
     lo = v - hi
     if fmt == "bf16":
         return hi, hi, bf16(lo)
+    if fmt == "e4m3t" and not weight:
+        return hi, e4m3_scaled(hi, -1, 4), e4m3_scaled(lo, -1, 4)
     return hi, e4m3_scaled(hi, 0), e4m3_scaled(lo, 0)
 
 
-def prod(a, b, fmt):
+def prod(a, b, fmt, b_is_weight):
     """a [M, K] . b [N, K]^T with split operands"""
-    ah, aq, al = planes(a, fmt)
-    bh, bq, bl = planes(b, fmt)
+    ah, aq, al = planes(a, fmt, False)
+    bh, bq, bl = planes(b, fmt, b_is_weight)
     return ah @ bh.t() + al @ bq.t() + aq @ bl.t()
 
 
@@ -44,7 +47,7 @@ def make_linear(fmt, backward_too):
         @staticmethod
         def forward(ctx, x, w):
             ctx.save_for_backward(x, w)
-            return prod(x.reshape(-1, x.size(-1)), w, fmt).reshape(*x.shape[:-1], w.size(0))
+            return prod(x.reshape(-1, x.size(-1)), w, fmt, True).reshape(*x.shape[:-1], w.size(0))
 
         @staticmethod
         def backward(ctx, dy):
@@ -53,8 +56,8 @@ def make_linear(fmt, backward_too):
             f = fmt if backward_too else "exact"
             if f == "exact":
                 return (dy2 @ w).reshape(x.shape), dy2.t() @ x2
-            dx = prod(dy2, w.t().contiguous(), f)            # reduce over out-features: rows of dy, rows of W^T
-            dw = prod(dy2.t().contiguous(), x2.t().contiguous(), f)   # reduce over tokens: rows of dy^T, rows of x^T
+            dx = prod(dy2, w.t().contiguous(), f, True)            # reduce over out-features: rows of dy, rows of W^T
+            dw = prod(dy2.t().contiguous(), x2.t().contiguous(), f, False)   # reduce over tokens: rows of dy^T, rows of x^T
             return dx.reshape(x.shape), dw
 
     def linear(x, w, b, mode, part="enc"):
@@ -85,7 +88,8 @@ def main():
     orig = vo.linear
     for name, fmt, bwd in (("cross terms bf16 (the shipping bf16x3 arithmetic), forward + backward", "bf16", True),
                            ("cross terms e4m3 / per-row scale, forward only (backward exact)", "e4m3", False),
-                           ("cross terms e4m3 / per-row scale, forward + backward", "e4m3", True)):
+                           ("cross terms e4m3 / per-row scale, forward + backward", "e4m3", True),
+                           ("cross terms e4m3 / ONE scale per activation or gradient tensor (2^4 headroom), forward + backward", "e4m3t", True)):
         vo.linear = make_linear(fmt, bwd)
         try:
             lg, g = step()

@@ -51,6 +51,10 @@ CASES = [
     ("base_pretraining_b16", "base", "pretraining", 16, 128, 36, 31, dict(compact=True)),   # S = 164, M = 2624 tokens
     ("base_vqa_b16", "base", "vqa", 16, 20, 36, 32, dict(compact=True)),                    # S = 56
     ("base_nlvr_b8", "base", "nlvr", 8, 40, 72, 33, dict(compact=True)),                    # S = 112 (2 x 36 regions)
+    # trained-like stress weights (oracle.stress_state_dict): wide attention scores, LayerNorm gamma outliers, channels with
+    # |beta| > 2 |gamma| in the odd layers, outlier embedding rows, bias sigma 0.2 -- what a checkpoint loaded through
+    # modeling.py:486-596 looks like and an init-distribution model does not
+    ("base_pretraining_stress_b8", "base", "pretraining", 8, 128, 36, 34, dict(compact=True, stress=True)),
 ]
 
 LR, WARMUP, T_TOTAL = 5e-5, 0.1, 100
@@ -119,7 +123,7 @@ def make_case(stem, cfg_name, head, B, T, R, seed, options=None):
     options = options or {}
     cfg_kwargs = vo.CONFIGS[cfg_name]
     cfg = vo.OracleConfig(bypass_transformer=bool(options.get("bypass")), **cfg_kwargs)
-    sd = vo.synth_state_dict(cfg, head, seed)
+    sd = vo.stress_state_dict(cfg, head, seed) if options.get("stress") else vo.synth_state_dict(cfg, head, seed)
     batch = vo.synth_batch(cfg, B, T, R, seed, head, alignment=int(options.get("alignment", 0)))
     if options.get("text_only"):
         batch = OrderedDict((k, v) for k, v in batch.items() if not k.startswith("image_"))

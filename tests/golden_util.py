@@ -27,6 +27,11 @@ BASE_CASES = {
     "base_vqa_b16": ("base", "vqa"),
     "base_nlvr_b8": ("base", "nlvr"),
 }
+# trained-like stress weights (oracle.stress_state_dict): its own table -- the bf16 bounds of BASE_CASES were
+# measured at init-distribution weights
+STRESS_CASES = {
+    "base_pretraining_stress_b8": ("base", "pretraining", dict(stress=True)),
+}
 SUB_MAX = 1024
 
 
@@ -41,13 +46,13 @@ N_STEPS = 3
 
 
 def load_case(stem):
-    table = CASES if stem in CASES else BASE_CASES
+    table = CASES if stem in CASES else (BASE_CASES if stem in BASE_CASES else STRESS_CASES)
     cfg_name, head = table[stem][:2]
     options = table[stem][2] if len(table[stem]) > 2 else {}
     g = np.load(os.path.join(GOLDEN_DIR, stem + ".npz"), allow_pickle=False)
     B, T, R, seed = [int(x) for x in g["meta"]]
     cfg = vo.OracleConfig(bypass_transformer=bool(options.get("bypass")), **vo.CONFIGS[cfg_name])
-    sd = vo.synth_state_dict(cfg, head, seed)
+    sd = vo.stress_state_dict(cfg, head, seed) if options.get("stress") else vo.synth_state_dict(cfg, head, seed)
     batch = vo.synth_batch(cfg, B, T, R, seed, head, alignment=int(options.get("alignment", 0)))
     if options.get("text_only"):
         batch = type(batch)((k, v) for k, v in batch.items() if not k.startswith("image_"))

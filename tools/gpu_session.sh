@@ -1,0 +1,76 @@
+#!/bin/bash
+# ONE parameterised GPU session script (replaces the per-session tools/gpu_r0N_run*.sh of rounds 1-4):
+#
+#     gpurun --timeout 900 -- 'bash tools/gpu_session.sh TAG step [step ...]'
+#
+# Every step writes gpurun_out/${TAG}_<step>.* ; the summaries worth keeping are copied to profiles/ by hand afterwards.
+#   gate        fp8-cross-term logits gate on the three pre-registered inputs (tools/x3f8_logits.py)
+#   stress      tests/test_parity_at_scale.py -k stress (trained-like golden of the real reference, three modes)
+#   pytest      the whole GPU suite
+#   smoke       __graft_entry__.smoke()
+#   bench       default bench.py line (the driver's command) -> ${TAG}_bench.json
+#   stats       rocprofv3 --kernel-trace --stats of a short quiet bench run, bf16 and bf16x3
+#   pmc         per-kernel PMC passes of the bf16 step (MFMA busy, LDS conflicts, waits; tools/gpu_pmc_step)
+#   gemmab:<arms>   tools/gemm_ab.py 1024 <arms...>   (developer library; arms separated by ',')
+#   attn        tools/attn_bench.py at the bench shape (B = 1024, S = 164) + in-step stats
+#   nlvr2real   bench.py --workload nlvr2-real + kernel stats
+#   sweep       batch sweep B = 8 / 64 / 256 / 1024, bf16 and bf16x3 (tools/batch_sweep.py)
+#   py:<file>   python <file> (any extra tool; ':' separated arguments)
+TAG=${1:-r05}
+shift
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+QUIET="--no-cpu-baseline --no-profile --no-h2d --no-parity --strict-dtype none --no-vendor-leg --pmc-traffic off"
+for step in "$@"; do
+  echo "=== $step ($(date +%T))"
+  case "$step" in
+    gate)
+      timeout 600 python tools/x3f8_logits.py --cases base_pretraining_b16 base_pretraining_stress_b8 trained > gpurun_out/${TAG}_x3f8_gate.txt 2> gpurun_out/${TAG}_x3f8_gate.err
+      echo "rc=$?" >> gpurun_out/${TAG}_x3f8_gate.err; cat gpurun_out/${TAG}_x3f8_gate.txt; tail -n 3 gpurun_out/${TAG}_x3f8_gate.err ;;
+    stress)
+      timeout 900 python -m pytest tests/test_parity_at_scale.py -m gpu -q -k stress --tb=short -p no:cacheprovider -s > gpurun_out/${TAG}_stress.log 2>&1
+      echo "rc=$?" >> gpurun_out/${TAG}_stress.log; grep -E "^stress @|passed|failed|rc=|Error|assert" gpurun_out/${TAG}_stress.log | cut -c1-900 ;;
+    pytest)
+      timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/${TAG}_pytest.log 2>&1
+      echo "rc=$?" >> gpurun_out/${TAG}_pytest.log; tail -n 8 gpurun_out/${TAG}_pytest.log ;;
+    smoke)
+      timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${TAG}_smoke.log 2>&1; echo "rc=$?" >> gpurun_out/${TAG}_smoke.log
+      tail -n 3 gpurun_out/${TAG}_smoke.log ;;
+    bench)
+      START=$(date +%s)
+      timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
+      echo "rc=$? wall=$(( $(date +%s) - START ))s" >> gpurun_out/${TAG}_bench.err; tail -n 2 gpurun_out/${TAG}_bench.err
+      python tools/bench_digest.py gpurun_out/${TAG}_bench.json ;;
+    benchq)     # the headline loop only (no strict / vendor / cpu legs): quick A/B of `value`
+      timeout 600 python bench.py --steps 20 --warmup 5 $QUIET > gpurun_out/${TAG}_benchq.json 2> gpurun_out/${TAG}_benchq.err
+      python tools/bench_digest.py gpurun_out/${TAG}_benchq.json ;;
+    stats)
+      timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/pf -o f -- python bench.py --steps 8 --warmup 2 $QUIET > gpurun_out/pf.log 2>&1
+      python tools/rocpd_summary.py gpurun_out/pf/f_results.db > gpurun_out/${TAG}_kernel_stats_b1024.txt 2>&1; rm -rf gpurun_out/pf
+      head -n 30 gpurun_out/${TAG}_kernel_stats_b1024.txt | cut -c1-200 ;;
+    statsx3)
+      timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/pf -o f -- python bench.py --dtype bf16x3 --batch 1024 --steps 8 --warmup 2 $QUIET > gpurun_out/pf2.log 2>&1
+      python tools/rocpd_summary.py gpurun_out/pf/f_results.db > gpurun_out/${TAG}_kernel_stats_bf16x3_b1024.txt 2>&1; rm -rf gpurun_out/pf
+      head -n 24 gpurun_out/${TAG}_kernel_stats_bf16x3_b1024.txt | cut -c1-200 ;;
+    pmc)
+      bash tools/gpu_r04_pmc_step.sh ${TAG} ;;
+    gemmab:*)
+      arms=$(echo "${step#gemmab:}" | tr ',' ' ')
+      VB_DEV=1 VB_NOCHECK=1 timeout 400 python tools/gemm_ab.py 1024 $arms > gpurun_out/${TAG}_gemm_ab.txt 2>&1; cut -c1-260 gpurun_out/${TAG}_gemm_ab.txt ;;
+    attn)
+      timeout 300 python tools/attn_bench.py 1024 164 > gpurun_out/${TAG}_attn_bench.txt 2>&1; tail -n 12 gpurun_out/${TAG}_attn_bench.txt ;;
+    nlvr2real)
+      timeout 600 python bench.py --workload nlvr2-real --steps 10 --warmup 3 --no-cpu-baseline --strict-dtype none --no-vendor-leg --pmc-traffic off > gpurun_out/${TAG}_bench_nlvr2_real.json 2> gpurun_out/${TAG}_bench_nlvr2_real.err
+      python tools/bench_digest.py gpurun_out/${TAG}_bench_nlvr2_real.json
+      timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/pf -o f -- python bench.py --workload nlvr2-real --steps 4 --warmup 2 $QUIET > gpurun_out/pf3.log 2>&1
+      python tools/rocpd_summary.py gpurun_out/pf/f_results.db > gpurun_out/${TAG}_kernel_stats_nlvr2_real.txt 2>&1; rm -rf gpurun_out/pf
+      head -n 16 gpurun_out/${TAG}_kernel_stats_nlvr2_real.txt | cut -c1-200 ;;
+    sweep)
+      timeout 900 python tools/batch_sweep.py > gpurun_out/${TAG}_batch_sweep.txt 2> gpurun_out/${TAG}_batch_sweep.err; cat gpurun_out/${TAG}_batch_sweep.txt ;;
+    py:*)
+      cmd=$(echo "${step#py:}" | tr ':' ' ')
+      name=$(echo "${step#py:}" | tr -c 'A-Za-z0-9_\n' '_' | cut -c1-60)
+      timeout 600 python $cmd > gpurun_out/${TAG}_${name}.txt 2>&1; echo "rc=$?"; tail -n 40 gpurun_out/${TAG}_${name}.txt | cut -c1-260 ;;
+    *) echo "unknown step $step" ;;
+  esac
+done

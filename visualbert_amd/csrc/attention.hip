@@ -285,6 +285,29 @@ VB_DEVICE void store4(bf16* p, const f32x4& v) { *(bf16x4*)p = bf16x4{(bf16)v[0]
 VB_DEVICE void store4(float* p, const f32x4& v) { *(f32x4*)p = v; }
 VB_DEVICE void pack_b(x3frag& o, const f32x4& a, const f32x4& b) { split8(a, b, o.hi, o.lo); }
 VB_DEVICE void store4(xf32* p, const f32x4& v) { *(f32x4*)p = v; }
+// Two adjacent 16-column blocks (df = 2 j, 2 j + 1) of one row of a [.., 64]-wide head: lane (li, lg) holds columns 4 lg .. 4 lg + 3 of
+// each block (ve, vo); row32 = this lane's row + 32 j.  bf16 with a 16-byte-aligned row (`wide`, wave-uniform): ONE 16-byte store per
+// lane after a v_permlane16_swap pair instead of two 8-byte stores (store instructions are issue-bound, ~64 cycles each whatever
+// their width: guide T21).  The swaps run on ALL lanes (they exchange data between the four lane groups of the same row); only the
+// store is predicated.  Other element types: the two plain stores.
+VB_DEVICE void store4x2(bf16* row32, int lg, const f32x4& ve, const f32x4& vo, bool ok, bool wide) {
+    if (wide) {
+        const bf16x4 e = bf16x4{(bf16)ve[0], (bf16)ve[1], (bf16)ve[2], (bf16)ve[3]}, o = bf16x4{(bf16)vo[0], (bf16)vo[1], (bf16)vo[2], (bf16)vo[3]};
+        u32x2 eu = __builtin_bit_cast(u32x2, e), ou = __builtin_bit_cast(u32x2, o);
+        uint32_t e0 = eu[0], e1 = eu[1], o0 = ou[0], o1 = ou[1];
+        vb_permlane16_swap(e0, o0);
+        vb_permlane16_swap(e1, o1);
+        if (ok) *(u32x4*)(row32 + vb_wide_col(lg)) = u32x4{e0, e1, o0, o1};
+    } else if (ok) {
+        store4(row32 + lg * 4, ve);
+        store4(row32 + 16 + lg * 4, vo);
+    }
+}
+template <typename T> VB_DEVICE void store4x2(T* row32, int lg, const f32x4& ve, const f32x4& vo, bool ok, bool) {
+    if (ok) { store4(row32 + lg * 4, ve); store4(row32 + 16 + lg * 4, vo); }
+}
+// is a bf16 row pointer family (base, pitch in elements) 16-byte aligned at every head's column 0?  (heads are 64 elements = 128 B wide)
+VB_DEVICE bool wide_ok(const void* base, long ld_elems) { return ((((uintptr_t)base) | (uintptr_t)(ld_elems * 2)) & 15) == 0; }
 
 struct AttnArgs {
     const void* qkv; const float* mask_add; void* ctx; float* lse; uint64_t* keepbits;   // forward

@@ -378,6 +378,26 @@ VB_DEVICE float vb_pair_sum32(float x) {
 }
 #endif
 
+// v_permlane16_swap_b32 a, b (gfx950): the ODD 16-lane rows of a are exchanged with the EVEN rows of b (a.row1 <-> b.row0,
+// a.row3 <-> b.row2); the other rows stay.  Used to turn two 8-byte-per-lane results of an MFMA-layout epilogue (lane (li, lg) holds
+// columns 4 lg .. 4 lg + 3 of two adjacent 16-column blocks) into ONE 16-byte-per-lane store: a store instruction costs the CU's
+// vector-memory path ~64 cycles whatever its width (guide T21), so halving the instruction count halves the store tail.
+// Inline asm for the same reason as vb_pair_sum32 (the builtin's second result is mis-folded by hipcc 7.2); s_nop pads cover the
+// VALU-write -> permlane-read and permlane-write -> VALU-read hazards the compiler cannot see inside an asm statement.
+#ifdef VB_EMU
+VB_DEVICE void vb_permlane16_swap(uint32_t& a, uint32_t& b) {
+    const bool odd = ((::hipemu::cur()->lane >> 4) & 1) != 0;
+    const uint32_t pa = (uint32_t)__shfl_xor((int)a, 16), pb = (uint32_t)__shfl_xor((int)b, 16);
+    if (odd) a = pb; else b = pa;
+}
+#else
+VB_DEVICE void vb_permlane16_swap(uint32_t& a, uint32_t& b) {
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+#endif
+// element offset of the 8 contiguous columns lane group lg owns after vb_permlane16_swap of blocks (2j, 2j + 1), inside the 32 columns
+VB_DEVICE int vb_wide_col(int lg) { return (lg & 1) * 16 + (lg >> 1) * 8; }
+
 // value known to be identical in every lane of the wave: keep it in a scalar register (addresses built from it
 // become scalar arithmetic instead of per-lane VALU + v_readfirstlane at every use)
 #ifdef VB_EMU

@@ -57,6 +57,10 @@ WORKLOADS = {
                 what="VQA2.0 fine-tuning step (3129-answer head, KL-div on soft scores) incl. dropout, BertAdam"),
     "nlvr2": dict(head="nlvr", T=40, R=72, Dv=2048, batch=1536, cfg="configs[4]",
                   what="NLVR2 paired-image fine-tuning step (2 x 36 regions, 2-way head) incl. dropout, BertAdam"),
+    # NLVR2 as the reference really runs it (configs/nlvr2/fine-tune.json:5,7; dataloaders/nlvr_dataset.py:98-106): 2 x 144 regions of
+    # 1024-d detectron features + 128 text tokens, S = 416 -- the long-sequence attention stress SURVEY 8d names (232 GF trained / sample)
+    "nlvr2-real": dict(head="nlvr", T=128, R=288, Dv=1024, batch=384, cfg="configs[4] at the reference's own shape (nlvr2/fine-tune.json)",
+                       what="NLVR2 paired-image fine-tuning step (2 x 144 regions x 1024-d, 2-way head) incl. dropout, BertAdam"),
 }
 
 
@@ -186,8 +190,19 @@ def measure_traffic(key, child_args, timeout=240):
         d = tempfile.mkdtemp(prefix="vb_pmc_", dir="/tmp")
         cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__)] + child_args
         try:
-            subprocess.run(cmd, env=env, cwd="/tmp", timeout=timeout, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
-                           start_new_session=True)
+            # own session = own process group: on a timeout the WHOLE group goes (rocprofv3 and the python grandchild that holds
+            # GPU memory), not just the direct child
+            proc = subprocess.Popen(cmd, env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                proc.wait(timeout=timeout)
+            except subprocess.TimeoutExpired:
+                import signal
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                proc.wait()
+                raise
             dbs = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith("_results.db")]
             if not dbs:
                 return None, "rocprofv3 --pmc %s pass left no results database" % counter
@@ -211,9 +226,13 @@ def measure_traffic(key, child_args, timeout=240):
             shutil.rmtree(d, ignore_errors=True)
     traffic = 2.0 * per_launch["FETCH_SIZE"] + per_launch["WRITE_SIZE"]
     return int(round(traffic)), ("measured by this run: two `rocprofv3 --kernel-trace --pmc` children of this command line "
-                                 "(FETCH_SIZE, WRITE_SIZE; %d launches of the kernel family; 2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes); "
-                                 "fetch %.0f MB + write %.0f MB per launch"
-                                 % (launches, 2.0 * per_launch["FETCH_SIZE"] / 1e6, per_launch["WRITE_SIZE"] / 1e6))
+                                 "(FETCH_SIZE, WRITE_SIZE; %d launches of the kernel family; 2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes: the "
+                                 "doubling is MI355X_MICROARCH.md's gfx950 correction for wide coalesced reads, calibrated there on a "
+                                 "streaming copy -- the RAW counters are FETCH_SIZE %.0f MB, WRITE_SIZE %.0f MB per launch, so the true "
+                                 "figure lies between %.0f and %.0f MB); fetch %.0f MB + write %.0f MB per launch"
+                                 % (launches, per_launch["FETCH_SIZE"] / 1e6, per_launch["WRITE_SIZE"] / 1e6,
+                                    (per_launch["FETCH_SIZE"] + per_launch["WRITE_SIZE"]) / 1e6, traffic / 1e6,
+                                    2.0 * per_launch["FETCH_SIZE"] / 1e6, per_launch["WRITE_SIZE"] / 1e6))
 
 
 def measured_mfma_ceiling(dev):
@@ -264,13 +283,17 @@ def cpu_baseline(batch_size, T, R, head, steps=3):
                        "%d threads, %.2f s/step" % (steps, head, batch_size, T, R, torch.get_num_threads(), dt))
 
 
-def parity_side_batch(model, dev, head, T, R):
-    """bf16 kernels against the fp32 oracle (the reference's arithmetic) on a B = 2 ragged side batch, eval mode."""
+SIDE_BATCH = 16
+
+
+def parity_side_batch(model, dev, head, T, R, Dv=0):
+    """bf16 kernels against the fp32 oracle (the reference's arithmetic) on a B = 16 ragged side batch, eval mode (B = 2 until
+    round 4; the weights are whatever the timed steps left: |logit|max ~ 12-15, trained-like statistics)."""
     import torch
     from oracle import visualbert_oracle as vo
-    cfg = vo.OracleConfig(**vo.CONFIGS["base"])
+    cfg = vo.OracleConfig(**dict(vo.CONFIGS["base"], **({"visual_embedding_dim": Dv} if Dv else {})))
     sd = {k: v.detach().float().cpu() for k, v in model.bert.state_dict().items() if k in vo.param_shapes(cfg, head)}
-    batch = vo.synth_batch(cfg, 2, T, R, 77, head, ragged=True)
+    batch = vo.synth_batch(cfg, SIDE_BATCH, T, R, 77, head, ragged=True)
     with torch.no_grad():
         ref = vo.objective_forward(sd, cfg, head, mode="fp32", **batch)
     was = model.training
@@ -281,7 +304,7 @@ def parity_side_batch(model, dev, head, T, R):
     lg = out["logits"].float().cpu().reshape(ref["logits"].shape)
     d = (lg - ref["logits"]).abs().flatten()
     k = max(1, int(d.numel() * 1e-3))
-    return dict(reference="fp32 oracle (oracle/visualbert_oracle.py, pinned to the real reference by tests/golden), B=2 ragged, eval",
+    return dict(reference="fp32 oracle (oracle/visualbert_oracle.py, pinned to the real reference by tests/golden), B=%d ragged, eval" % SIDE_BATCH,
                 max_dlogit_vs_fp32_ref=float(d.max()), mean=float(d.mean()), p999=float(d.topk(k).values[-1]),
                 top1_agree=float((lg.argmax(-1) == ref["logits"].argmax(-1)).float().mean()),
                 dloss=abs(float(out["loss"]) - float(ref["loss"])), logits_absmax=float(ref["logits"].abs().max()),
@@ -374,7 +397,7 @@ def strict_mode(dev, head, T, R, Dv, V, batch, steps, warmup, dtype_name, flops_
     b = synthetic_batch(head, batch, T, R, Dv, V, seed=0, device=dev)
     elapsed, median_ms, summ = timed_steps(mw, b, steps, warmup, torch.cuda.synchronize, profile=full)
     dt = elapsed / steps
-    par = parity_side_batch(model, dev, head, T, R)
+    par = parity_side_batch(model, dev, head, T, R, Dv)
     peak = PEAK_BF16_TFLOPS if dtype_name != "fp32" else PEAK_F32_TFLOPS
     out = dict(dtype=dtype_name, value=round(batch / dt, 2), unit="samples/s", per_gpu_batch=batch, steps=steps, warmup=warmup,
                ms_per_step=round(dt * 1e3, 3), ms_per_step_median=round(median_ms, 3),
@@ -427,7 +450,21 @@ def hbm_bound_kernels(model, M, H, dev, optimizer=None, V=0):
     t_b = timed(lambda: L.vb_ln_bwd(_lib.VB_BF16, _lib.ptr(x), _lib.ptr(z), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(gamma),
                                     _lib.ptr(dz), _lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db), _lib.ptr(dbias), M, H, 0.1, 11,
                                     0.0, 12, 5, _lib.ptr(ws), _lib.stream_ptr()))
-    rows_list = [("ln_fwd (dropout + residual + LayerNorm)", t_f, 4 * M * H * 2), ("ln_bwd", t_b, 4 * M * H * 2)]
+    rows_list = [("ln_fwd 4-tensor form (dropout + residual + LayerNorm, z written: heads / embeddings / H > 768)", t_f, 4 * M * H * 2),
+                 ("ln_bwd 4-tensor form", t_b, 4 * M * H * 2)]
+    # what the encoder layers SHIP (vb_bert_layer_fwd / _bwd -> vb_ln_fwd_rb / vb_ln_bwd_rb): the forward skips the pre-LN sum, the
+    # backward rebuilds x-hat from y -- three [M, H] streams per launch (x, resid in, y out | dy, y in, dz out; dx = dz here: no input
+    # dropout on this site's gradient path is a separate stream only when p_in > 0, as in the layer: dy, y in; dz, dx out)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    t_f3 = timed(lambda: L.vb_ln_fwd_rb(_lib.VB_BF16, _lib.ptr(x), _lib.ptr(r), _lib.ptr(z), _lib.ptr(y), _lib.ptr(mean),
+                                        _lib.ptr(rstd), _lib.ptr(gamma), _lib.ptr(beta), M, H, 1e-12, 0.1, 11, 5, _lib.ptr(flag),
+                                        _lib.stream_ptr()))
+    assert int(flag.item()) == 1, "gamma = 1, beta = 0 must be rebuildable"
+    t_b3 = timed(lambda: L.vb_ln_bwd_rb(_lib.VB_BF16, _lib.ptr(x), _lib.ptr(z), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(gamma),
+                                        _lib.ptr(dz), _lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db), _lib.ptr(dbias), M, H, 0.1, 11, 5,
+                                        _lib.ptr(ws), _lib.ptr(y), _lib.ptr(beta), _lib.ptr(flag), _lib.stream_ptr()))
+    rows_list += [("ln_fwd as shipped in the layers (3 tensors: x-hat rebuilt from y in the backward)", t_f3, 3 * M * H * 2),
+                  ("ln_bwd as shipped in the layers (dy, y in; dz, dx out)", t_b3, 4 * M * H * 2)]
     if optimizer is not None:                            # the fused multi-tensor BertAdam step on the live arena (after the timed region)
         n_par = sum(p.numel() for p in model.parameters())
         t_a = timed(lambda: optimizer.step(), n=5)
@@ -503,6 +540,8 @@ def main():
                     help="skip the extra timed leg with the plain GEMMs on hipBLASLt (N = 1 only; never part of `value`)")
     ap.add_argument("--nt-kernel", type=int, default=0,
                     help="vb_stream_opts.nt_kernel for the whole run (0 = chosen per shape; 81 / 90 for A/B runs)")
+    ap.add_argument("--attn-two-pass", type=int, default=0,
+                    help="vb_stream_opts.attn_two_pass for the whole run (A/B: 1 = two-pass attention backward, 2 = one-pass without its L2 prefetch)")
     ap.add_argument("--pmc-traffic", default="auto", choices=["auto", "off"],
                     help="auto (N = 1): measure roofline.traffic for THIS run with two rocprofv3 --pmc children of the same command "
                          "line (adds ~1 min per timed mode); off: report the committed PMC pass (profiles/pmc_traffic.json) or null")
@@ -582,9 +621,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if args.nt_kernel:
+    if args.nt_kernel or args.attn_two_pass:
         from visualbert_amd import _lib
-        _lib.set_opts(nt_kernel=args.nt_kernel)
+        _lib.set_opts(nt_kernel=args.nt_kernel, attn_two_pass=args.attn_two_pass)
     elapsed, median_ms, summ = timed_steps(mw, batch, args.steps, args.warmup, barrier, profile=not args.no_profile)
     et = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if use_dist:
@@ -657,8 +696,18 @@ def main():
     peak = PEAK_BF16_TFLOPS if args.dtype in ("bf16", "bf16x3") else PEAK_F32_TFLOPS     # bf16x3 runs on the bf16 matrix pipe
 
     roofline = par = None
+    executed = None
     if rank == 0:
         if summ:
+            # what the hardware EXECUTED per step: every GEMM launch's 2 M N K from the per-launch profile (the MLM decoder's dgrad /
+            # wgrad run over the labelled rows only -- exact, the skipped gradient rows are identically zero -- so this is below the
+            # 3 x forward rule `step_mfu` prices) + the attention core (forward 4 S^2 d per head, backward 2.5 x that)
+            gemm_flops = sum(x["flops"] for x in summ.values()) / args.steps
+            attn_flops = L * 3.5 * 4.0 * S * S * 64 * (H // 64) * B
+            executed = dict(tflop_per_step=round((gemm_flops + attn_flops) / 1e12, 2), gemm_tflop_per_step=round(gemm_flops / 1e12, 2),
+                            attention_tflop_per_step=round(attn_flops / 1e12, 2),
+                            step_mfu_executed=round((gemm_flops + attn_flops) / (elapsed / args.steps) / (peak * 1e12), 4),
+                            note="step_mfu prices SURVEY 8d's 3 x forward FLOPs per sample; this is the arithmetic the step really ran")
             roofline = roofline_of(summ, args.steps, peak, B, args.workload)
             if dtype == torch.bfloat16:
                 ceil_tf = measured_mfma_ceiling(dev)
@@ -671,7 +720,7 @@ def main():
                 roofline["hbm_bound"] = hbm_bound_kernels(model, B * S, H, dev, optimizer=mw.optimizer,
                                                             V=30522 if head == "pretraining" else 0)
         if not args.no_parity:
-            par = parity_side_batch(model, dev, head, T, R)
+            par = parity_side_batch(model, dev, head, T, R, Dv)
     # The collective part of the job ends HERE: the communicator and the process group are torn down before rank 0 starts its
     # long host-side legs (strict-mode models, the CPU baseline), so no rank sits in an RCCL barrier under a watchdog meanwhile.
     if use_dist:
@@ -705,7 +754,8 @@ def main():
             cpu = cpu_baseline(args.cpu_batch, T, R, head)
         metric = {"pretrain": "pretrain samples/sec (BERT-base, 36 regions+128 tok)",
                   "vqa": "VQA2.0 fine-tune samples/sec (BERT-base, 36 regions+20 tok)",
-                  "nlvr2": "NLVR2 fine-tune samples/sec (BERT-base, 2x36 regions+40 tok)"}[args.workload]
+                  "nlvr2": "NLVR2 fine-tune samples/sec (BERT-base, 2x36 regions+40 tok)",
+                  "nlvr2-real": "NLVR2 fine-tune samples/sec (BERT-base, 2x144 regions x 1024-d + 128 tok, the reference's shape)"}[args.workload]
         out = {
             "metric": metric,
             "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -719,6 +769,8 @@ def main():
             "value_with_h2d": round(h2d, 2) if h2d is not None else None,
             "train_gflop_per_sample": round(fps / 1e9, 2),
             "step_mfu": round(value * fps / (world * peak * 1e12), 4),
+            "step_mfu_executed": executed["step_mfu_executed"] if executed else None,
+            "executed": executed,
             "final_loss": round(loss, 4),
             "rccl_ranks_seen": ranks_seen,
             "allreduce": allreduce,

@@ -59,7 +59,8 @@ const char* vb_version(void);
  *              tiles; 81 = persistent 256x256 tile; 90 = 256x128 tiles, two workgroups per compute unit; 1 = the generic
  *              register-staged kernel.  Anything else is VB_ERR_ARG: experiment arms and the vendor-library yardstick exist in
  *              the developer library only (include/visualbert_hip_dev.h).  This library owns no device memory.
- *   attn_two_pass: 1 = two-pass attention backward even where the one-pass kernel applies.
+ *   attn_two_pass: 1 = two-pass attention backward even where the one-pass kernel applies; 2 = the one-pass kernel without its
+ *                  L2 prefetch for a later workgroup (A/B arm: same instructions otherwise, same results).
  *   reserved: must be 0 (VB_ERR_ARG otherwise).
  * vb_stream_set_opts(stream, NULL) forgets the stream's entry (call it before destroying a stream).
  * ---------------------------------------------------------------------------------------------- */
@@ -124,6 +125,19 @@ int vb_ln_bwd(int dtype, const void* dy, const void* z, const float* mean, const
 /* ws (optional, vb_ln_bwd_ws_bytes(M,H) bytes): per-block partial column sums -> two-stage reduction with no
  * global atomics; NULL falls back to fp32 atomics on dgamma/dbeta/dbias. */
 int64_t vb_ln_bwd_ws_bytes(int M, int H);
+/* The THREE-tensor form vb_bert_layer_fwd / _bwd run (H <= 768, no output dropout): the forward tests gamma / beta in the kernel --
+ * |beta| <= 2 |gamma| on every channel -- and, if so, does NOT write z_out (three [M,H] streams per launch instead of four) and
+ * sets *rebuild = 1; the backward, handed the forward's output y, beta and the same device int, then takes
+ * x-hat = (y - beta) / gamma instead of (z - mean) rstd.  *rebuild = 0: z_out was written and the backward reads it (both must
+ * always be passed).  gamma / beta must be unchanged between the two calls.  Same arithmetic contract as vb_ln_fwd / vb_ln_bwd
+ * otherwise (modeling.py:171-175, :272-273, :317-318). */
+int vb_ln_fwd_rb(int dtype, const void* x, const void* resid, void* z_out, void* y, float* mean, float* rstd,
+                 const float* gamma, const float* beta, int M, int H, float eps,
+                 float p_in, uint32_t stream_in, uint64_t seed, int* rebuild, void* stream);
+int vb_ln_bwd_rb(int dtype, const void* dy, const void* z, const float* mean, const float* rstd,
+                 const float* gamma, void* dz, void* dx, float* dgamma, float* dbeta, float* dbias,
+                 int M, int H, float p_in, uint32_t stream_in, uint64_t seed, float* ws,
+                 const void* y, const float* beta, const int* rebuild, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * BertEmbeddingsWithVisualEmbedding gather-add.

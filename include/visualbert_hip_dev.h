@@ -22,6 +22,8 @@ extern "C" {
 
 /* ablation switch for kernel analysis (results are WRONG when non-zero): 1 skip tile loads, 2 skip fragment
  * reads, 4 skip MFMAs in the pipelined kernel, 128 predicate the epilogue's global stores off */
+/* bit 26 (1 << 26): the bf16 epilogues' streaming (`nt`) stores replaced by plain stores -- results are IDENTICAL (this bit does not
+ * make them wrong): the bit-compare arm of tests/test_kernels.py::test_streaming_stores_equal_plain_stores */
 int vb_gemm_set_debug(int bits);
 /* debug bit 64 (256x128 pipelined kernel, bf16): waves 0 and 4 of workgroup 0 write per-K-tile shader-clock stamps
  * {landed, barrier, copies issued, frags0, mfma0, frags1, mfma1} to this device buffer (uint64[2][64][8]) */

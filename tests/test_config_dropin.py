@@ -118,3 +118,33 @@ def test_reference_configs_drop_in(path):
         return
     mw = _check_wrapper(args)
     assert mw.model.training_head_type == args.model.training_head_type
+
+
+def test_restore_checkpoint_pretrained_reports_and_refuses_a_checkpoint_that_matches_nothing(tmp_path, caplog):
+    """model_wrapper.py:201-221 prints Skipped / Successfully loaded / Part load failed per key; here the same pass strips a
+    DataParallel "module." prefix, logs the counts and RAISES when no tensor matched (a mistyped checkpoint must not silently
+    train from random weights -- ADVICE r04)."""
+    import logging
+    small = BertConfig(100, hidden_size=128, num_hidden_layers=1, num_attention_heads=2, intermediate_size=128)
+    src = VisualBERTFixedImageEmbedding(config=small, training_head_type="nlvr", visual_embedding_dim=32)
+    dst = VisualBERTFixedImageEmbedding(config=small, training_head_type="nlvr", visual_embedding_dim=32)
+    mw = ModelWrapper.__new__(ModelWrapper)                       # the loader needs the model only
+    mw.model = dst
+    mw._after_weights_changed = lambda: None
+    good = {"module." + k: v.clone() for k, v in src.state_dict().items()}
+    some = next(k for k in good if k.endswith("query.weight"))
+    good["module.not.a.parameter"] = torch.zeros(3)
+    good[some] = torch.zeros(5, 5)                                # one shape mismatch
+    torch.save(good, str(tmp_path / "good.th"))
+    with caplog.at_level(logging.INFO, logger="visualbert_amd.model"):
+        loaded, unknown, mismatch = mw.restore_checkpoint_pretrained(str(tmp_path / "good.th"))
+    assert unknown == ["not.a.parameter"] and mismatch == [some[len("module."):]]
+    assert len(loaded) == len(src.state_dict()) - 1
+    assert any("Skipped: not.a.parameter" in r.message for r in caplog.records)
+    assert any("Part load failed" in r.message for r in caplog.records)
+    for k, v in src.state_dict().items():
+        if k != some[len("module."):]:
+            assert torch.equal(dst.state_dict()[k], v), k
+    torch.save({"totally.different": torch.zeros(2)}, str(tmp_path / "bad.th"))
+    with pytest.raises(RuntimeError, match="no tensor of the checkpoint matches"):
+        mw.restore_checkpoint_pretrained(str(tmp_path / "bad.th"))

@@ -604,6 +604,53 @@ def test_gemm_specialised_epilogues(dev, variant):                          # th
         assert (Cf - ref[:, :Nr]).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("variant", [81, 90])
+def test_streaming_stores_equal_plain_stores(dev, variant):
+    """The bf16 epilogues of the K <= 1024 GEMMs leave through hand-written `global_store_dwordx4 ... nt` (csrc/vb_rt.h: vb_store16_nt --
+    inline asm with its own s_nop for the store-data hazard, invisible to the compiler's hazard pass).  Every epilogue
+    variant of the step, on ragged M / N, for both kernels that use them: BIT-identical to the same launch with plain stores
+    (developer library, debug bit 26) -- C and the auxiliary result."""
+    if dev.type != "cuda":
+        pytest.skip("needs libvisualbert_hip_dev.so (debug bit 26)")
+    g = torch.Generator().manual_seed(260 + variant)
+    dt = torch.bfloat16
+    with _lib.dev_library() as L:
+        L.vb_gemm_set_debug.restype, L.vb_gemm_set_debug.argtypes = _lib.DEV_SIGNATURES["vb_gemm_set_debug"]
+        for (M, N, K) in ((530, 512, 192), (777, 328, 768), (256, 1024, 1024), (1000, 768, 64)):
+            A = (torch.randn(M, K, generator=g) * 0.5).to(dt).to(dev)
+            B = (torch.randn(N, K, generator=g) * 0.2).to(dt).to(dev)
+            bias = torch.randn(N, generator=g).to(dev)
+            pre = torch.randn(M, N, generator=g).to(dt).to(dev)
+            add_t = torch.randn(M, N, generator=g).to(dt).to(dev)
+            outs = {}
+            for arm, bits in (("nt", 0), ("plain", 1 << 26)):
+                L.vb_gemm_set_debug(bits)
+                try:
+                    with _lib.stream_opts(nt_kernel=variant):
+                        res = []
+                        res.append(gemm(dev, dt, A, B, M, N, K, 0, 0, bias=bias))
+                        aux = torch.zeros(M, N, dtype=dt, device=dev)
+                        res.append(gemm(dev, dt, A, B, M, N, K, 0, 0, bias=bias, act=_lib.VB_ACT_GELU_SAVE_GRAD, aux_out=aux))
+                        res.append(aux)
+                        aux2 = torch.zeros(M, N, dtype=dt, device=dev)
+                        res.append(gemm(dev, dt, A, B, M, N, K, 0, 0, bias=bias, act=_lib.VB_ACT_GELU, aux_out=aux2))
+                        res.append(aux2)
+                        cs = torch.zeros(N, device=dev)
+                        res.append(gemm(dev, dt, A, B, M, N, K, 0, 0, act=_lib.VB_ACT_MUL_AUX, aux_in=pre, colsum=cs))
+                        # (the column sums themselves leave through fp32 atomics of many workgroups: not a bitwise quantity)
+                        res.append(gemm(dev, dt, A, B, M, N, K, 0, 0, addend=add_t))
+                        Nr = N - 6                              # ragged N: the last 8-column group is partial
+                        res.append(gemm(dev, dt, A, B[:Nr], M, Nr, K, 0, 0, bias=bias[:Nr].contiguous()))
+                        torch.cuda.synchronize()
+                finally:
+                    L.vb_gemm_set_debug(0)
+                outs[arm] = res
+            for i, (x, y) in enumerate(zip(outs["nt"], outs["plain"])):
+                assert torch.equal(x, y), ("result %d differs between streaming and plain stores" % i, (M, N, K))
+            ref = A.float() @ B.float().t() + bias                # and the streaming arm is right, not just equal
+            assert (outs["nt"][0].float() - ref).abs().max().item() <= 1.2e-2 * max(1.0, ref.abs().max().item())
+
+
 @pytest.mark.parametrize("wgs", [0, 2])
 def test_gemm_direct_b_kernel(dev, wgs):
     """nt_kernel 101: the four-wave 256x256 kernel whose B operand goes straight from global memory into MFMA-layout registers

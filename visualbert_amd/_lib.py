@@ -29,6 +29,8 @@ SIGNATURES = {
     "vb_ln_fwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _f, _u32, _f, _u32, _u64, _p]),
     "vb_ln_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _u32, _f, _u32, _u64, _p, _p]),
     "vb_ln_bwd_ws_bytes": (_i64, [_i, _i]),
+    "vb_ln_fwd_rb": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _f, _u32, _u64, _p, _p]),
+    "vb_ln_bwd_rb": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _u32, _u64, _p, _p, _p, _p, _p]),
     "vb_embed_fwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "vb_attn_probs": (_i, [_i, _p, _p, _p, _i, _i, _i, _i, _p]),
     "vb_align_pos_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),

@@ -363,6 +363,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(NTH, (NTH == NT ? 3 : 1)) attn_fwd_kernel(AttnArgs a
     const T* Qp = (const T*)a.q;
     const T* Kp = (const T*)a.k;
     const T* Vp = (const T*)a.v;
+    const bool wide_c = sizeof(T) == 2 && wide_ok(a.ctx, a.ldc);     // wave-uniform: 16-byte context stores (store4x2)
 
     if constexpr (sizeof(T) == 2) {
         PairTile<NK> tk;
@@ -479,17 +480,23 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(NTH, (NTH == NT ? 3 : 1)) attn_fwd_kernel(AttnArgs a
 
         T* crow = (T*)a.ctx + (rowq + (qok ? q : 0)) * a.ldc + h * D;
 #pragma unroll
-        for (int df = 0; df < 4; ++df) {
-            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int dj = 0; dj < 2; ++dj) {                     // two 16-column blocks at a time: one 16-byte store per lane (store4x2)
+            f32x4 acc2[2];
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) {
-                if (EXACT || ks * 32 < S)
-                    acc = vb_mma(frag_tr(ldsVT, tr_pitch<T>(NKVK), df * 16 + li, ks, lg, T()), pb[ks], acc);
+            for (int e = 0; e < 2; ++e) {
+                const int df = 2 * dj + e;
+                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    if (EXACT || ks * 32 < S)
+                        acc = vb_mma(frag_tr(ldsVT, tr_pitch<T>(NKVK), df * 16 + li, ks, lg, T()), pb[ks], acc);
+                }
+                acc2[e] = acc;                               // lane: query q, d = df*16 + lg*4 + 0..3
+                if constexpr (std::is_same<T, xf32>::value) {
+                    if (a.ctx_sp && qok) store_split4(a.ctx_sp + (rowq + q) * (2 * a.ldc) + h * D + df * 16 + lg * 4, a.ldc, acc);
+                }
             }
-            if (qok && !a.sp_only) store4(crow + df * 16 + lg * 4, acc);     // lane: query q, d = df*16 + lg*4 + 0..3
-            if constexpr (std::is_same<T, xf32>::value) {
-                if (a.ctx_sp && qok) store_split4(a.ctx_sp + (rowq + q) * (2 * a.ldc) + h * D + df * 16 + lg * 4, a.ldc, acc);
-            }
+            store4x2(crow + dj * 32, lg, acc2[0], acc2[1], qok && !a.sp_only, wide_c);
         }
     }
 }
@@ -1016,17 +1023,20 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) attn_bwd_dkv_kernel(AttnArgs a) {
             }
         }
     }
-    if (kok) {
-        T* dkrow = (T*)a.dk + (rowk + key) * a.lddk + h * D;
-        T* dvrow = (T*)a.dv + (rowk + key) * a.lddv + h * D;
+    {   // every lane runs the stores' lane exchanges (store4x2); only the stores themselves are predicated on the key being real
+        const int keyr = kok ? key : 0;
+        T* dkrow = (T*)a.dk + (rowk + keyr) * a.lddk + h * D;
+        T* dvrow = (T*)a.dv + (rowk + keyr) * a.lddv + h * D;
+        const bool wide_k = sizeof(T) == 2 && wide_ok(a.dk, a.lddk), wide_v = sizeof(T) == 2 && wide_ok(a.dv, a.lddv);
 #pragma unroll
-        for (int df = 0; df < 4; ++df) {
-            if (!a.sp_only) {
-                store4(dkrow + df * 16 + lg * 4, dkT[df]);
-                store4(dvrow + df * 16 + lg * 4, dvT[df]);
-            }
-            if constexpr (std::is_same<T, xf32>::value) {
-                if (a.dqkv_sp) {                            // self-attention: dK | dV are column blocks H.. and 2H.. of the dqkv image
+        for (int dj = 0; dj < 2; ++dj) {
+            store4x2(dkrow + dj * 32, lg, dkT[2 * dj], dkT[2 * dj + 1], kok && !a.sp_only, wide_k);
+            store4x2(dvrow + dj * 32, lg, dvT[2 * dj], dvT[2 * dj + 1], kok && !a.sp_only, wide_v);
+        }
+        if constexpr (std::is_same<T, xf32>::value) {
+            if (kok && a.dqkv_sp) {                         // self-attention: dK | dV are column blocks H.. and 2H.. of the dqkv image
+#pragma unroll
+                for (int df = 0; df < 4; ++df) {
                     bf16* sp = a.dqkv_sp + (rowk + key) * (2 * a.lddk) + h * D + df * 16 + lg * 4;
                     store_split4(sp + a.nh * D, a.lddk, dkT[df]);
                     store_split4(sp + 2 * a.nh * D, a.lddk, dvT[df]);
@@ -1050,8 +1060,9 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) attn_bwd_dkv_kernel(AttnArgs a) {
 // =================================================================================================
 constexpr int FWPB = 12, FNT = FWPB * 64, FNK = FWPB * 16;  // 192 keys
 constexpr int TSP = FNK * 2 + 8;                           // dS tile pitch in bytes (pad: 16 rows -> distinct banks)
+constexpr int PF_AHEAD = 256;                              // prefetch_successor: workgroup b touches the lines of workgroup b + PF_AHEAD (same XCD)
 
-template <int NKF, int CQ>
+template <int NKF, int CQ, bool PFS = true>                 // PFS: prefetch_successor (below); false = the A/B arm (attn_two_pass == 2)
 VB_KERNEL VB_LAUNCH_BOUNDS(FNT) attn_bwd_fused_kernel(AttnArgs a) {
     typedef bf16 T;
     constexpr int NW = (NKF + 15) / 16;
@@ -1181,6 +1192,36 @@ VB_KERNEL VB_LAUNCH_BOUNDS(FNT) attn_bwd_fused_kernel(AttnArgs a) {
             bw[0] = (uint32_t)kw; bw[4] = (uint32_t)(kw >> 32);
         }
     };
+    // L2 prefetch for a LATER workgroup.  This kernel holds a CU alone (124 KB of LDS, 12 waves): nothing overlaps a workgroup's
+    // prologue, one HBM round trip under full-chip load (~2.5 us = ~18 % of its life, profiles/r02_attn_bwd_cycle_trace.txt), and
+    // the persistent form that would fetch the next pair into dead registers does not fit the 168-register budget (same file).
+    // Workgroup b runs on XCD b % 8 (observed; speed only), so workgroup b + 256 shares this one's L2 and starts about one
+    // workgroup lifetime later: once this pair's own fetches are all consumed (last chunk staged), every thread touches ONE 128-byte
+    // line of what that workgroup's prologue reads -- its K and V rows, chunk 0 of Q / dO / O, its mask, lse and keep-bit words --
+    // with a load whose result nobody uses (kept in `pf_sink` until the end so the register is not reused under the landing data).
+    uint32_t pf_sink = 0;
+    auto prefetch_successor = [&]() {
+        const int nbh = bh + PF_AHEAD;
+        if (nbh >= a.B * a.nh) return;                     // wave-uniform
+        // wave-uniform roles, scalar bases, ONE 32-bit multiply per lane (the kernel sits at its 168-register budget: per-thread
+        // 64-bit address arithmetic here spilled 11 registers): waves 0-2 the K rows, 3-5 the V rows, 6 / 7 / 8 chunk 0 of Q / dO / O,
+        // 9 / 10 / 11 the lines of the mask, of chunk 0's lse and of its keep-bit words
+        const int nb = nbh / a.nh, nhh = nbh % a.nh, w = vb_uniform(wave);
+        const long nrow0 = (long)nb * S;
+        const int nq = S < CQ ? S : CQ;                    // rows of chunk 0
+        const unsigned char* base;
+        int pitch, n;
+        if (w < 6) { const int r0 = (w % 3) * 64; base = (const unsigned char*)(qkv + (nrow0 + r0) * ldx + (w < 3 ? H : 2 * H) + nhh * D); pitch = (int)ldx * 2; n = S - r0; }
+        else if (w == 6) { base = (const unsigned char*)(qkv + nrow0 * ldx + nhh * D); pitch = (int)ldx * 2; n = nq; }
+        else if (w == 7) { base = (const unsigned char*)(dctx + nrow0 * (long)H + nhh * D); pitch = H * 2; n = nq; }
+        else if (w == 8) { base = (const unsigned char*)(octx + nrow0 * (long)H + nhh * D); pitch = H * 2; n = nq; }
+        else if (w == 9) { base = (const unsigned char*)(a.mask_add + nrow0); pitch = 128; n = (S * 4 + 127) / 128; }
+        else if (w == 10) { base = (const unsigned char*)(a.lse + (long)nbh * S); pitch = 128; n = (nq * 4 + 127) / 128; }
+        else { base = (const unsigned char*)(a.keepbits + ((long)nbh * S) * 4 * NW); pitch = 128; n = a.p > 0.f ? (nq * 4 * NW * 8 + 127) / 128 : 0; }
+        if (n <= 0) return;                                // wave-uniform
+        n = n < 64 ? n : 64;
+        vb_prefetch_line(base, (unsigned)((lane < n ? lane : n - 1) * pitch), pf_sink);      // clamped lanes touch a line twice: harmless
+    };
     load_chunk(0);
     const float mk = kok ? mk_raw : -INFINITY;
     const float mk2 = mk * 1.44269504088896340736f, sc2 = a.scale * 1.44269504088896340736f;
@@ -1246,8 +1287,8 @@ VB_KERNEL VB_LAUNCH_BOUNDS(FNT) attn_bwd_fused_kernel(AttnArgs a) {
                         const float pdrop = p * kscale;
                         const float dpv = dp[r] * kscale;
                         pd[hf][r] = pdrop;
-                        dsv[hf][r] = p * (dpv - d4[r]) * a.scale;
-                        *(bf16*)(ldsDS + ql * TSP + (kf * 16 + li) * 2) = (bf16)dsv[hf][r];      // dS as [query][key]
+                        dsv[hf][r] = p * (dpv - d4[r]);             // dS / scale: the factor goes onto dK^T and dQ^T once (below)
+                        *(bf16*)(ldsDS + ql * TSP + (kf * 16 + li) * 2) = (bf16)dsv[hf][r];      // dS / scale as [query][key]
                     }
                 }
                 bf16x8 pb, dsb;
@@ -1263,6 +1304,9 @@ VB_KERNEL VB_LAUNCH_BOUNDS(FNT) attn_bwd_fused_kernel(AttnArgs a) {
         if (q0 + CQ < S) {                                 // the next chunk's images go to the other set meanwhile
             use_set(cur ^ 1);
             store_chunk(q0 + CQ);
+        }
+        if constexpr (PFS) {
+            if (q0 + 2 * CQ >= S && (q0 == 0 || q0 + CQ < S)) prefetch_successor();   // once: no fetch of this pair is outstanding any more
         }
         __syncthreads();                                   // the chunk's dS tile is complete, the next chunk is staged
         if (q0 + 2 * CQ < S) load_chunk(q0 + 2 * CQ);
@@ -1294,11 +1338,13 @@ VB_KERNEL VB_LAUNCH_BOUNDS(FNT) attn_bwd_fused_kernel(AttnArgs a) {
                 }
                 if (v0) {
                     const int q = q0 + qf0 * 16 + li;
+                    acc0 *= a.scale;                        // the score scale left out of dS in phase A
                     if (q < S) store4((T*)a.dqkv + (row0 + q) * ldx + h * D + df * 16 + lg * 4, acc0);
                     dqsum += acc0;                          // columns of padded queries are exactly 0 (their dS rows are)
                 }
                 if (v1) {
                     const int q = q0 + qf1 * 16 + li;
+                    acc1 *= a.scale;
                     if (q < S) store4((T*)a.dqkv + (row0 + q) * ldx + h * D + df * 16 + lg * 4, acc1);
                     dqsum += acc1;
                 }
@@ -1306,13 +1352,16 @@ VB_KERNEL VB_LAUNCH_BOUNDS(FNT) attn_bwd_fused_kernel(AttnArgs a) {
         }
         __syncthreads();                                   // phase B is done with the tile before the next phase A writes it
     }
-    if (kok) {
-        T* dkrow = (T*)a.dqkv + (row0 + key) * ldx + H + h * D;
-        T* dvrow = (T*)a.dqkv + (row0 + key) * ldx + 2 * H + h * D;
 #pragma unroll
-        for (int df = 0; df < 4; ++df) {
-            store4(dkrow + df * 16 + lg * 4, dkT[df]);
-            store4(dvrow + df * 16 + lg * 4, dvT[df]);
+    for (int df = 0; df < 4; ++df) dkT[df] *= a.scale;     // dK^T was accumulated from dS / scale (phase A): one multiply per output
+    {   // 16-byte stores (store4x2: every lane takes part in the lane exchange, the store is predicated on a real key)
+        T* dkrow = (T*)a.dqkv + (row0 + keyc) * ldx + H + h * D;
+        T* dvrow = (T*)a.dqkv + (row0 + keyc) * ldx + 2 * H + h * D;
+        const bool wide = wide_ok(a.dqkv, ldx);
+#pragma unroll
+        for (int dj = 0; dj < 2; ++dj) {
+            store4x2(dkrow + dj * 32, lg, dkT[2 * dj], dkT[2 * dj + 1], kok, wide);
+            store4x2(dvrow + dj * 32, lg, dvT[2 * dj], dvT[2 * dj + 1], kok, wide);
         }
     }
     if (a.bias_ws) {
@@ -1354,6 +1403,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS(FNT) attn_bwd_fused_kernel(AttnArgs a) {
             a.bias_ws[((long)b * 3 + which) * H + h * D + dd] = sum;
         }
     }
+    if constexpr (PFS) vb_prefetch_retire(pf_sink);
 }
 
 // out[c] += sum over samples of ws[b][c]  (c < 3H): 256 columns x a slice of the batch per workgroup
@@ -1412,7 +1462,8 @@ int launch_all(int which, const AttnArgs& a, hipStream_t s) {
                 (long)a.B * a.S * 3 * a.nh * D * 2 < (1L << 32)) {   // one-pass backward (needs the forward output; 32-bit byte offsets)
                 // 64-query chunks (86 KB of LDS, one workgroup per CU): 528-541 us per layer at B=512; 32-query chunks (two
                 // workgroups per CU, twice the barriers): 575 us
-                VB_LAUNCH((attn_bwd_fused_kernel<NKF, 64>), grid, dim3(FNT), (fused_smem<NKF, 64>()), s, a);
+                if (vb_opts_for((void*)s).attn_two_pass == 2) VB_LAUNCH((attn_bwd_fused_kernel<NKF, 64, false>), grid, dim3(FNT), (fused_smem<NKF, 64>()), s, a);
+                else VB_LAUNCH((attn_bwd_fused_kernel<NKF, 64, true>), grid, dim3(FNT), (fused_smem<NKF, 64>()), s, a);
                 return vb_check_launch() == VB_OK ? 1 : VB_ERR_LAUNCH;      // 1: the bias workspace (if any) was filled
             }
         }

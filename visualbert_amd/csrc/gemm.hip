@@ -2308,7 +2308,7 @@ extern "C" int vb_gemm(int dtype, int out_dtype, int a_layout, int b_layout,
     g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
     g.debug = g_debug; g.trace = g_trace;
     g.split_out = split_out ? 1 : 0;
-    g.nt_store = (!x3 && dtype == VB_BF16 && K <= 1024) ? 1 : 0;
+    g.nt_store = (!x3 && dtype == VB_BF16 && K <= 1024 && !(g_debug & (1 << 26))) ? 1 : 0;      // developer library, debug bit 26: plain stores (the A/B and bit-compare arm)
     g.x3 = x3 ? 1 : 0; g.a_lo = x3 ? (int)(lda / 2) : 0; g.b_lo = x3 ? (int)(ldb / 2) : 0; g.kseg = x3 ? K / 64 : 0;
     g.stripe = 0;
     const int bk = dtype == VB_F32 ? 32 : 64;

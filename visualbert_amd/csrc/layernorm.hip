@@ -51,6 +51,15 @@ struct LnFwdArgs {
 // LayerNorm has a channel with |gamma| << |beta|.  So the kernels decide per launch, from the parameters themselves: each lane
 // tests the channels it owns, the half-wave (which owns all H channels between its lanes) agrees, every workgroup reaches the same
 // verdict, workgroup 0 records it for the backward (which must not re-derive it: an optimizer step may lie in between).
+// 1 / gamma of the rebuild route.  bf16: the hardware reciprocal (1 ulp of fp32, far below the 2^-9 of the y it multiplies).  fp32 / split
+// mode: one Newton step on top (r + r (1 - g r): two fused multiply-adds, correct to ~0.5 ulp) -- there y itself carries only 2^-24, so
+// a 1-ulp reciprocal would be the largest error term of x-hat, and the fp32 gradients are held to the reference at the 1e-5 level.
+template <typename T> VB_DEVICE float rebuild_rcp(float g) {
+    const float r = fast_rcp(g);
+    if constexpr (sizeof(T) == 2) return r;
+    else return fmaf(r, fmaf(-g, r, 1.0f), r);
+}
+
 template <int NC>
 VB_DEVICE bool ln_rebuildable(const float* gamma, const float* beta, int H, int l32) {
     float bad = 0.f;
@@ -297,7 +306,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(NT, MINW) ln_bwd_kernel(LnBwdArgs a) {
                 load8(bt, a.beta + colc);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float sub = rebuild ? bt[j] : mean, q = rebuild ? fast_rcp(gm[j]) : rstd;
+                    const float sub = rebuild ? bt[j] : mean, q = rebuild ? rebuild_rcp<T>(gm[j]) : rstd;
                     xh[ci][j] = (xh[ci][j] - sub) * q;
                 }
             } else {
@@ -433,7 +442,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(NT, 4) ln_bwd12_kernel(LnBwdArgs a) {
             if (a.dout.p > 0.f) dropw<W>(dy, a.dout, (uint64_t)(rb + col));
             if constexpr (RB) {
 #pragma unroll
-                for (int j = 0; j < W; ++j) xh[j] = (xh[j] - (rebuild ? bt[j] : mean)) * (rebuild ? fast_rcp(gm[j]) : rstd);
+                for (int j = 0; j < W; ++j) xh[j] = (xh[j] - (rebuild ? bt[j] : mean)) * (rebuild ? rebuild_rcp<T>(gm[j]) : rstd);
             } else {
 #pragma unroll
                 for (int j = 0; j < W; ++j) xh[j] = (xh[j] - mean) * rstd;
@@ -711,6 +720,13 @@ int vb_ln_fwd_sp(int dtype, const void* x, const void* resid, void* z_out, void*
     return vb_check_launch();
 }
 
+extern "C" int vb_ln_fwd_rb(int dtype, const void* x, const void* resid, void* z_out, void* y, float* mean, float* rstd,
+                            const float* gamma, const float* beta, int M, int H, float eps,
+                            float p_in, uint32_t stream_in, uint64_t seed, int* rebuild, void* stream) {
+    if (!rebuild) return VB_ERR_ARG;
+    return vb_ln_fwd_sp(dtype, x, resid, z_out, y, mean, rstd, gamma, beta, M, H, eps, p_in, stream_in, 0.f, 0, seed, nullptr, 0, rebuild, stream);
+}
+
 extern "C" int64_t vb_ln_bwd_ws_bytes(int M, int H) {
     return (int64_t)row_grid(M, 1024) * 3 * H * (int64_t)sizeof(float);
 }
@@ -768,6 +784,15 @@ int vb_ln_bwd_sp(int dtype, const void* dy, const void* z, const float* mean, co
                   dgamma, dbeta, dbias);
     }
     return vb_check_launch();
+}
+
+extern "C" int vb_ln_bwd_rb(int dtype, const void* dy, const void* z, const float* mean, const float* rstd,
+                            const float* gamma, void* dz, void* dx, float* dgamma, float* dbeta, float* dbias,
+                            int M, int H, float p_in, uint32_t stream_in, uint64_t seed, float* ws,
+                            const void* y, const float* beta, const int* rebuild, void* stream) {
+    if (!rebuild) return VB_ERR_ARG;
+    return vb_ln_bwd_sp(dtype, dy, z, mean, rstd, gamma, dz, dx, dgamma, dbeta, dbias, M, H, p_in, stream_in, 0.f, 0, seed, ws,
+                        nullptr, 0, y, beta, rebuild, stream);
 }
 
 extern "C" int vb_embed_fwd(int dtype, const int64_t* input_ids, const int64_t* token_type_ids,

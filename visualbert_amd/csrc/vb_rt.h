@@ -378,6 +378,23 @@ VB_DEVICE float vb_pair_sum32(float x) {
 }
 #endif
 
+// Touch one line for somebody else (L2 prefetch): a global load (scalar base + 32-bit lane offset) whose result is never used.  Inline asm, so that the compiler neither
+// deletes it nor ever waits for it (it keeps no score of asm loads; the hardware's in-order vmcnt only makes later counted waits more
+// conservative, never wrong).  The destination register must stay reserved until the load has certainly landed: the caller passes the
+// same `sink` to vb_prefetch_retire at the end of the kernel.
+#ifdef VB_EMU
+VB_DEVICE void vb_prefetch_line(const void* base, unsigned off, uint32_t& sink) { sink += *((const volatile unsigned char*)base + off) & 0u; }
+VB_DEVICE void vb_prefetch_retire(uint32_t& sink) { (void)sink; }
+#else
+VB_DEVICE void vb_prefetch_line(const void* base, unsigned off, uint32_t& sink) {      // base: wave-uniform (SGPR pair); off: bytes, per lane
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(sink) : "v"(off), "s"(base) : "memory");
+}
+VB_DEVICE void vb_prefetch_retire(uint32_t& sink) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" :: "v"(sink));
+}
+#endif
+
 // v_permlane16_swap_b32 a, b (gfx950): the ODD 16-lane rows of a are exchanged with the EVEN rows of b (a.row1 <-> b.row0,
 // a.row3 <-> b.row2); the other rows stay.  Used to turn two 8-byte-per-lane results of an MFMA-layout epilogue (lane (li, lg) holds
 // columns 4 lg .. 4 lg + 3 of two adjacent 16-column blocks) into ONE 16-byte-per-lane store: a store instruction costs the CU's
@@ -659,7 +676,9 @@ __attribute__((visibility("hidden"))) int vb_vendor_nt(const VbVendorGemm& g, vo
 // split_only (attention) / dx == NULL (LayerNorm backward): the fp32 form of that result is NOT written at all -- in the layer only
 // GEMMs consume it, and they read the image; the q | k | v bias gradient is then summed from the image's two planes.
 // rebuild (LayerNorm, device int): the forward skips z_out when the backward can take x-hat from y (layernorm.hip: ln_rebuildable) and
-// records its decision there; the backward (bf16 only) is handed y, beta and the same int.
+// records its decision there; the backward (every element type at H <= 768; fp32 uses a Newton-refined 1 / gamma) is handed y, beta and the
+// same int.  gamma / beta must still hold the forward's values at backward time: a graph kept alive ACROSS an optimizer step (retain_graph) is
+// not supported -- like every weight of the layer, whose bf16 shadows the backward GEMMs read ("Contracts").
 __attribute__((visibility("hidden"))) int vb_ln_fwd_sp(int dtype, const void* x, const void* resid, void* z_out, void* y, float* mean,
     float* rstd, const float* gamma, const float* beta, int M, int H, float eps, float p_in, uint32_t stream_in, float p_out,
     uint32_t stream_out, uint64_t seed, void* y_split, int64_t ld_split, int* rebuild, void* stream);

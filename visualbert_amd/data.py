@@ -224,14 +224,19 @@ class FeatureStager(object):
         completed.
     Contract for inputs that are ALREADY pinned (RegionFeatureStore slabs): they are copied from in place, so the caller must
     not rewrite such a slab until the event returned by the stage() call that consumed it has completed -- pass that event as
-    `wait=` to RegionFeatureStore.read_batch(out=slab, ...) or call `stager.wait_host(slot)` before refilling."""
+    `wait=` to RegionFeatureStore.read_batch(out=slab, ...) or call `stager.wait_host(slot)` before refilling.
+    `strict_pinned=True` turns the most common violation into an error: a pinned slab that is staged AGAIN while the copy of its
+    previous contents is still in flight was, in a refill loop, rewritten under that copy (a caller that re-stages an unchanged
+    slab on purpose, like bench.py's streaming leg, keeps the default)."""
 
-    def __init__(self, device):
+    def __init__(self, device, strict_pinned=False):
         self.device = device
         self.stream = torch.cuda.Stream(device=device)
+        self.strict_pinned = bool(strict_pinned)
         self._pinned = {}
         self._dev = {}
         self._copied = {}
+        self._slab_events = {}                          # data_ptr of a caller-pinned input -> event of the last copy out of it
 
     def stage(self, host_batch, slot=0):
         """enqueue async copies of `host_batch` (CPU tensors) on the side stream; returns (device batch, event).
@@ -245,6 +250,11 @@ class FeatureStager(object):
             for k, v in host_batch.items():
                 if v.is_pinned():                       # the feature store already lives in pinned memory: copied from in
                     pin = v                             # place (the caller keeps it intact until `ev` completes, see above)
+                    last = self._slab_events.get(v.data_ptr())
+                    if self.strict_pinned and last is not None and not last.query():
+                        raise RuntimeError("FeatureStager.stage: pinned input %r is staged again while the copy of its previous "
+                                           "contents is still in flight -- refill a slab only after the event stage() returned "
+                                           "has completed (read_batch(..., wait=ev) or stager.wait_host(slot))" % k)
                 else:
                     key = (slot, k)
                     pin = self._pinned.get(key)
@@ -264,6 +274,9 @@ class FeatureStager(object):
             ev = torch.cuda.Event()
             ev.record(self.stream)
         self._copied[slot] = ev
+        for v in host_batch.values():
+            if v.is_pinned():
+                self._slab_events[v.data_ptr()] = ev
         return out, ev
 
     def wait_host(self, slot=0):

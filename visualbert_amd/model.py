@@ -65,23 +65,35 @@ class VisualBERTFixedImageEmbedding(nn.Module):
         return output_dict
 
 
-def _load_flexible(model, state_dict, strict_first=True):
-    """utils/pytorch_misc.py:246-265: try a full load, then fall back to copying the tensors whose names match."""
+def _load_flexible(model, state_dict, strict_first=True, report=None):
+    """utils/pytorch_misc.py:246-265: try a full load, then fall back to copying the tensors whose names match.
+    -> (loaded, skipped_unknown, shape_mismatch) name lists; `report` (a callable taking one line) gets the reference's per-key
+    messages ("Skipped" / "Part load failed", models/model_wrapper.py:201-221 via utils/pytorch_misc.py)."""
     if strict_first:
         try:
             model.load_state_dict(state_dict)
-            return
+            return list(state_dict.keys()), [], []
         except RuntimeError:
             pass
     own_state = model.state_dict()
+    loaded, unknown, mismatch = [], [], []
     with torch.no_grad():
         for name, param in state_dict.items():
             if name not in own_state:
+                unknown.append(name)
+                if report:
+                    report("Skipped: " + name)
                 continue
             if isinstance(param, torch.nn.Parameter):
                 param = param.data
             if own_state[name].shape == param.shape:
                 own_state[name].copy_(param)
+                loaded.append(name)
+            else:
+                mismatch.append(name)
+                if report:
+                    report("Part load failed: %s (checkpoint %s, model %s)" % (name, tuple(param.shape), tuple(own_state[name].shape)))
+    return loaded, unknown, mismatch
 
 
 class AttrDict(dict):
@@ -303,8 +315,21 @@ class ModelWrapper(object):
 
     def restore_checkpoint_pretrained(self, restore_bin):
         """copy every tensor of a saved state dict whose name exists here (models/model_wrapper.py:201-221)."""
-        _load_flexible(self.model, torch.load(restore_bin, map_location="cpu"), strict_first=False)
+        import logging
+        log = logging.getLogger(__name__)
+        state = torch.load(restore_bin, map_location="cpu")
+        if isinstance(state, dict) and "model" in state and not any(torch.is_tensor(v) for v in state.values()):
+            state = state["model"]                         # a training checkpoint wrapped as {"model": state_dict, ...}
+        # a checkpoint saved from the reference's nn.DataParallel wrapper carries "module." on every key (model_wrapper.py:146)
+        state = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in state.items()}
+        loaded, unknown, mismatch = _load_flexible(self.model, state, strict_first=False, report=log.info)
+        log.warning("restore_checkpoint_pretrained(%s): %d tensors loaded, %d names unknown to this model, %d shape mismatches",
+                    restore_bin, len(loaded), len(unknown), len(mismatch))
+        if not loaded:
+            raise RuntimeError("restore_checkpoint_pretrained(%r): no tensor of the checkpoint matches this model (first keys: %s) -- "
+                               "refusing to continue from random weights" % (restore_bin, list(state.keys())[:4]))
         self._after_weights_changed()
+        return loaded, unknown, mismatch
 
     def step(self, batch, eval_mode=False):
         if eval_mode:

@@ -541,7 +541,7 @@ def main():
     ap.add_argument("--nt-kernel", type=int, default=0,
                     help="vb_stream_opts.nt_kernel for the whole run (0 = chosen per shape; 81 / 90 for A/B runs)")
     ap.add_argument("--attn-two-pass", type=int, default=0,
-                    help="vb_stream_opts.attn_two_pass for the whole run (A/B: 1 = two-pass attention backward, 2 = one-pass without its L2 prefetch)")
+                    help="vb_stream_opts.attn_two_pass for the whole run (A/B: 1 = two-pass attention backward)")
     ap.add_argument("--pmc-traffic", default="auto", choices=["auto", "off"],
                     help="auto (N = 1): measure roofline.traffic for THIS run with two rocprofv3 --pmc children of the same command "
                          "line (adds ~1 min per timed mode); off: report the committed PMC pass (profiles/pmc_traffic.json) or null")

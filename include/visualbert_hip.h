@@ -59,8 +59,7 @@ const char* vb_version(void);
  *              tiles; 81 = persistent 256x256 tile; 90 = 256x128 tiles, two workgroups per compute unit; 1 = the generic
  *              register-staged kernel.  Anything else is VB_ERR_ARG: experiment arms and the vendor-library yardstick exist in
  *              the developer library only (include/visualbert_hip_dev.h).  This library owns no device memory.
- *   attn_two_pass: 1 = two-pass attention backward even where the one-pass kernel applies; 2 = the one-pass kernel without its
- *                  L2 prefetch for a later workgroup (A/B arm: same instructions otherwise, same results).
+ *   attn_two_pass: 1 = two-pass attention backward even where the one-pass kernel applies.
  *   reserved: must be 0 (VB_ERR_ARG otherwise).
  * vb_stream_set_opts(stream, NULL) forgets the stream's entry (call it before destroying a stream).
  * ---------------------------------------------------------------------------------------------- */

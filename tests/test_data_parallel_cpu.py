@@ -88,6 +88,14 @@ def _worker(rank, world, port, q):
         worst = 0.0
         for k, v in leaves2.items():
             worst = max(worst, float((named[k]._vb_grad - v.grad).abs().max()))
+        # a micro-step whose gradients no optimizer step reads (gradient accumulation): nothing is reduced
+        before = m.arena.grad.clone()
+        sync.begin_step(sync=False)
+        m.arena.grad.add_(float(rank + 1))                   # rank-dependent garbage: an all-reduce would average it
+        for i in reversed(range(cfg.num_hidden_layers)):
+            m.bert.encoder.layer[i].grad_ready_hook(i)
+        sync.finish_step()
+        assert torch.equal(m.arena.grad, before + float(rank + 1))
         q.put((rank, worst))
     finally:
         dist.destroy_process_group()

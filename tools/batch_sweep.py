@@ -45,8 +45,9 @@ def run(dtype_name, B, steps, warmup, dev):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--batches", type=int, nargs="+", default=[8, 64, 256, 1024])
+    ap.add_argument("--batches", type=int, nargs="+", default=[8, 16, 32, 64, 128, 256, 512, 1024])
     ap.add_argument("--dtypes", nargs="+", default=["bf16", "bf16x3"])
+    ap.add_argument("--x3-batches", type=int, nargs="+", default=[8, 64, 256, 1024], help="the (slower) split-operand mode runs this subset")
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=3)
     args = ap.parse_args()
@@ -57,7 +58,7 @@ def main():
         args.steps, args.warmup, fps / 1e9))
     print("%-8s %6s %12s %12s %12s %10s" % ("dtype", "B", "median ms", "min ms", "samples/s", "step_mfu"))
     for dt in args.dtypes:
-        for B in args.batches:
+        for B in (args.x3_batches if dt == "bf16x3" else args.batches):
             try:
                 med, lo, hi = run(dt, B, args.steps, args.warmup, dev)
                 print("%-8s %6d %12.3f %12.3f %12.1f %10.4f" % (dt, B, med, lo, B / med * 1e3, B / med * 1e3 * fps / 2.5e15), flush=True)

@@ -1057,12 +1057,14 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) attn_bwd_dkv_kernel(AttnArgs a) {
 //   phase B  the 16 (query fragment, d block) outputs of dQ = dS K for the chunk are split over the waves: full-depth MFMAs
 //            with dS from the tile and K^T from an LDS image built once per (batch, head) -- no atomics, no second exp.
 // (A first version added per-wave dQ partials into an LDS tile with ds_add_f32: 7x slower than two passes.)
+// Round 5, measured and removed (profiles/r05_attn_bench_b1024_prefetch_ab.txt): an L2 prefetch of the lines workgroup b + 256 (same XCD)
+// opens with, issued by this workgroup once its own fetches were consumed -- 845 -> 907 us alone, 956 -> 1015 us in the step: the four
+// registers it cost spilled (the kernel sits at 168), and scratch reloads wait on vmcnt.
 // =================================================================================================
 constexpr int FWPB = 12, FNT = FWPB * 64, FNK = FWPB * 16;  // 192 keys
 constexpr int TSP = FNK * 2 + 8;                           // dS tile pitch in bytes (pad: 16 rows -> distinct banks)
-constexpr int PF_AHEAD = 256;                              // prefetch_successor: workgroup b touches the lines of workgroup b + PF_AHEAD (same XCD)
 
-template <int NKF, int CQ, bool PFS = true>                 // PFS: prefetch_successor (below); false = the A/B arm (attn_two_pass == 2)
+template <int NKF, int CQ>
 VB_KERNEL VB_LAUNCH_BOUNDS(FNT) attn_bwd_fused_kernel(AttnArgs a) {
     typedef bf16 T;
     constexpr int NW = (NKF + 15) / 16;
@@ -1192,36 +1194,6 @@ VB_KERNEL VB_LAUNCH_BOUNDS(FNT) attn_bwd_fused_kernel(AttnArgs a) {
             bw[0] = (uint32_t)kw; bw[4] = (uint32_t)(kw >> 32);
         }
     };
-    // L2 prefetch for a LATER workgroup.  This kernel holds a CU alone (124 KB of LDS, 12 waves): nothing overlaps a workgroup's
-    // prologue, one HBM round trip under full-chip load (~2.5 us = ~18 % of its life, profiles/r02_attn_bwd_cycle_trace.txt), and
-    // the persistent form that would fetch the next pair into dead registers does not fit the 168-register budget (same file).
-    // Workgroup b runs on XCD b % 8 (observed; speed only), so workgroup b + 256 shares this one's L2 and starts about one
-    // workgroup lifetime later: once this pair's own fetches are all consumed (last chunk staged), every thread touches ONE 128-byte
-    // line of what that workgroup's prologue reads -- its K and V rows, chunk 0 of Q / dO / O, its mask, lse and keep-bit words --
-    // with a load whose result nobody uses (kept in `pf_sink` until the end so the register is not reused under the landing data).
-    uint32_t pf_sink = 0;
-    auto prefetch_successor = [&]() {
-        const int nbh = bh + PF_AHEAD;
-        if (nbh >= a.B * a.nh) return;                     // wave-uniform
-        // wave-uniform roles, scalar bases, ONE 32-bit multiply per lane (the kernel sits at its 168-register budget: per-thread
-        // 64-bit address arithmetic here spilled 11 registers): waves 0-2 the K rows, 3-5 the V rows, 6 / 7 / 8 chunk 0 of Q / dO / O,
-        // 9 / 10 / 11 the lines of the mask, of chunk 0's lse and of its keep-bit words
-        const int nb = nbh / a.nh, nhh = nbh % a.nh, w = vb_uniform(wave);
-        const long nrow0 = (long)nb * S;
-        const int nq = S < CQ ? S : CQ;                    // rows of chunk 0
-        const unsigned char* base;
-        int pitch, n;
-        if (w < 6) { const int r0 = (w % 3) * 64; base = (const unsigned char*)(qkv + (nrow0 + r0) * ldx + (w < 3 ? H : 2 * H) + nhh * D); pitch = (int)ldx * 2; n = S - r0; }
-        else if (w == 6) { base = (const unsigned char*)(qkv + nrow0 * ldx + nhh * D); pitch = (int)ldx * 2; n = nq; }
-        else if (w == 7) { base = (const unsigned char*)(dctx + nrow0 * (long)H + nhh * D); pitch = H * 2; n = nq; }
-        else if (w == 8) { base = (const unsigned char*)(octx + nrow0 * (long)H + nhh * D); pitch = H * 2; n = nq; }
-        else if (w == 9) { base = (const unsigned char*)(a.mask_add + nrow0); pitch = 128; n = (S * 4 + 127) / 128; }
-        else if (w == 10) { base = (const unsigned char*)(a.lse + (long)nbh * S); pitch = 128; n = (nq * 4 + 127) / 128; }
-        else { base = (const unsigned char*)(a.keepbits + ((long)nbh * S) * 4 * NW); pitch = 128; n = a.p > 0.f ? (nq * 4 * NW * 8 + 127) / 128 : 0; }
-        if (n <= 0) return;                                // wave-uniform
-        n = n < 64 ? n : 64;
-        vb_prefetch_line(base, (unsigned)((lane < n ? lane : n - 1) * pitch), pf_sink);      // clamped lanes touch a line twice: harmless
-    };
     load_chunk(0);
     const float mk = kok ? mk_raw : -INFINITY;
     const float mk2 = mk * 1.44269504088896340736f, sc2 = a.scale * 1.44269504088896340736f;
@@ -1304,9 +1276,6 @@ VB_KERNEL VB_LAUNCH_BOUNDS(FNT) attn_bwd_fused_kernel(AttnArgs a) {
         if (q0 + CQ < S) {                                 // the next chunk's images go to the other set meanwhile
             use_set(cur ^ 1);
             store_chunk(q0 + CQ);
-        }
-        if constexpr (PFS) {
-            if (q0 + 2 * CQ >= S && (q0 == 0 || q0 + CQ < S)) prefetch_successor();   // once: no fetch of this pair is outstanding any more
         }
         __syncthreads();                                   // the chunk's dS tile is complete, the next chunk is staged
         if (q0 + 2 * CQ < S) load_chunk(q0 + 2 * CQ);
@@ -1403,7 +1372,6 @@ VB_KERNEL VB_LAUNCH_BOUNDS(FNT) attn_bwd_fused_kernel(AttnArgs a) {
             a.bias_ws[((long)b * 3 + which) * H + h * D + dd] = sum;
         }
     }
-    if constexpr (PFS) vb_prefetch_retire(pf_sink);
 }
 
 // out[c] += sum over samples of ws[b][c]  (c < 3H): 256 columns x a slice of the batch per workgroup
@@ -1462,8 +1430,7 @@ int launch_all(int which, const AttnArgs& a, hipStream_t s) {
                 (long)a.B * a.S * 3 * a.nh * D * 2 < (1L << 32)) {   // one-pass backward (needs the forward output; 32-bit byte offsets)
                 // 64-query chunks (86 KB of LDS, one workgroup per CU): 528-541 us per layer at B=512; 32-query chunks (two
                 // workgroups per CU, twice the barriers): 575 us
-                if (vb_opts_for((void*)s).attn_two_pass == 2) VB_LAUNCH((attn_bwd_fused_kernel<NKF, 64, false>), grid, dim3(FNT), (fused_smem<NKF, 64>()), s, a);
-                else VB_LAUNCH((attn_bwd_fused_kernel<NKF, 64, true>), grid, dim3(FNT), (fused_smem<NKF, 64>()), s, a);
+                VB_LAUNCH((attn_bwd_fused_kernel<NKF, 64>), grid, dim3(FNT), (fused_smem<NKF, 64>()), s, a);
                 return vb_check_launch() == VB_OK ? 1 : VB_ERR_LAUNCH;      // 1: the bias workspace (if any) was filled
             }
         }

@@ -378,23 +378,6 @@ VB_DEVICE float vb_pair_sum32(float x) {
 }
 #endif
 
-// Touch one line for somebody else (L2 prefetch): a global load (scalar base + 32-bit lane offset) whose result is never used.  Inline asm, so that the compiler neither
-// deletes it nor ever waits for it (it keeps no score of asm loads; the hardware's in-order vmcnt only makes later counted waits more
-// conservative, never wrong).  The destination register must stay reserved until the load has certainly landed: the caller passes the
-// same `sink` to vb_prefetch_retire at the end of the kernel.
-#ifdef VB_EMU
-VB_DEVICE void vb_prefetch_line(const void* base, unsigned off, uint32_t& sink) { sink += *((const volatile unsigned char*)base + off) & 0u; }
-VB_DEVICE void vb_prefetch_retire(uint32_t& sink) { (void)sink; }
-#else
-VB_DEVICE void vb_prefetch_line(const void* base, unsigned off, uint32_t& sink) {      // base: wave-uniform (SGPR pair); off: bytes, per lane
-    asm volatile("global_load_dword %0, %1, %2" : "=v"(sink) : "v"(off), "s"(base) : "memory");
-}
-VB_DEVICE void vb_prefetch_retire(uint32_t& sink) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("" :: "v"(sink));
-}
-#endif
-
 // v_permlane16_swap_b32 a, b (gfx950): the ODD 16-lane rows of a are exchanged with the EVEN rows of b (a.row1 <-> b.row0,
 // a.row3 <-> b.row2); the other rows stay.  Used to turn two 8-byte-per-lane results of an MFMA-layout epilogue (lane (li, lg) holds
 // columns 4 lg .. 4 lg + 3 of two adjacent 16-column blocks) into ONE 16-byte-per-lane store: a store instruction costs the CU's

@@ -339,11 +339,13 @@ class ModelWrapper(object):
                     output_dict["loss"] = output_dict["loss"].mean()
                 return output_dict
         self.optimizer.zero_grad()
+        gas = self.args.get("gradient_accumulation_steps", 1)
         if self.grad_sync is not None:
-            self.grad_sync.begin_step()
+            # the gradients of a micro-step that is not followed by optimizer.step() are zeroed by the next call (the reference's
+            # order, model_wrapper.py:64): all-reducing them would be pure xGMI traffic
+            self.grad_sync.begin_step(sync=(self.called_time + 1) % gas == 0)
         output_dict = self.model(**batch)
         loss = output_dict["loss"].mean()
-        gas = self.args.get("gradient_accumulation_steps", 1)
         if gas > 1:
             loss = loss / gas
         loss.backward()

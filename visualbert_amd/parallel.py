@@ -19,12 +19,17 @@ gloo CPU tests) goes through torch.distributed's all_reduce instead.  xGMI is po
 bound, so buckets are whole layers (28 MB fp32 at BERT-base) -- large enough to run at link speed,
 small enough that the last one (embeddings, 94 MB + heads) is the only exposed tail.
 
-Compute units for the collective.  The persistent GEMM kernels launch one 160-KB-LDS workgroup per CU, and such a
-workgroup cannot share a CU with an RCCL workgroup: while the collective is resident on c CUs, c workgroups of a GEMM
-launch wait for a free CU.  Reserving CUs up front (VB_COMM_CUS=c: GEMMs use CUs - c workgroups while buckets are in
-flight, RCCL capped to c channels via NCCL_MAX_NCHANNELS) was measured on one GPU and is OFF by default: the N=768 GEMMs
-have 246 output tiles, so ANY grid below 246 workgroups costs them a second round (30 -> 47 us, 78 -> 128 us at 224
-workgroups) -- the same price the un-reserved launch pays only while the collective really is resident.
+Compute units for the collective.  Read from the code objects (hipcc -Rpass-analysis=kernel-resource-usage, launch sizes in
+csrc/gemm.hip / attention.hip): the persistent 256x256 GEMM and the grouped weight-gradient kernel launch 512 threads x 256
+VGPRs with 163,840 B of LDS -- the WHOLE register file and LDS of a CU; two workgroups of the 256x128 kernel (256 threads x 256
+VGPRs, 81,920 B each) fill it the same way; the one-pass attention backward holds 12 waves x 168 VGPRs and 124 KB.  None of them
+can share a CU with an RCCL workgroup (registers alone forbid it): while the collective is resident on c CUs, c workgroups of a
+persistent launch wait for a CU -- the launch is stretched by up to the collective's remaining residency -- and c CUs host one
+256x128 workgroup (or none) instead of two.  Reserving CUs up front (VB_COMM_CUS=c: RCCL capped to c channels via
+NCCL_MAX_NCHANNELS; while buckets are in flight the forward / dgrad GEMMs run as the one-workgroup-per-tile kernel and the
+weight-gradient kernel on CUs - c workgroups) is OFF by default: on one GPU the persistent GEMM's N = 768 shapes paid a second
+round for ANY grid below 246 workgroups (30 -> 47 us, 78 -> 128 us at 224) -- which is why the reservation now pins the
+per-tile kernel for them.  DESIGN.md section 6 carries the bound this puts on the scaling prediction.
 """
 import os
 
@@ -117,7 +122,11 @@ class DataParallelGradSync(object):
         self.obj.arena.refresh_shadows() if self.obj.arena.data.is_cuda else None
 
     # -- per step ---------------------------------------------------------------------------------
-    def begin_step(self):
+    def begin_step(self, sync=True):
+        """sync=False: a micro-step whose gradients no optimizer step will read (gradient_accumulation_steps > 1: the reference's
+        ModelWrapper.step zeroes the gradients at the top of EVERY call, models/model_wrapper.py:64, so only the last micro-batch
+        of a group reaches the optimizer) -- the hooks and finish_step() then move nothing over xGMI."""
+        self._sync = bool(sync)
         if self.obj.arena.grad.data_ptr() != getattr(self, "_grad_ptr", None):
             self._install()                                   # arena was rebuilt (e.g. .to(device))
             self._grad_ptr = self.obj.arena.grad.data_ptr()
@@ -162,7 +171,11 @@ class DataParallelGradSync(object):
             _lib.check(_lib.lib().vb_stream_get_opts(sp, ctypes.byref(cur)), "vb_stream_get_opts")
             self._saved_opts = (cur.persistent_workgroups, cur.nt_kernel, cur.attn_two_pass, cur.reserved)
             cus = torch.cuda.get_device_properties(self.obj.arena.grad.device).multi_processor_count
-            o = _lib.StreamOpts(max(8, (cus - comm_cus()) // 8 * 8), cur.nt_kernel, cur.attn_two_pass, cur.reserved)
+            # forward / dgrad GEMMs: the two-workgroups-per-CU kernel (nt_kernel 90) unless the caller pinned one -- its grid is one
+            # workgroup per TILE, so a CU that RCCL holds simply takes fewer of them (the persistent 256x256 kernel's grid IS the CU
+            # count: short of CUs it pays a whole second round on the N = 768 shapes, see the module docstring); the grouped
+            # weight-gradient kernel, persistent by construction, gets the reduced workgroup count
+            o = _lib.StreamOpts(max(8, (cus - comm_cus()) // 8 * 8), cur.nt_kernel or 90, cur.attn_two_pass, cur.reserved)
             _lib.check(_lib.lib().vb_stream_set_opts(sp, ctypes.byref(o)), "vb_stream_set_opts")
         else:
             saved = getattr(self, "_saved_opts", (0, 0, 0, 0))
@@ -173,6 +186,8 @@ class DataParallelGradSync(object):
                 _lib.check(_lib.lib().vb_stream_set_opts(sp, None), "vb_stream_set_opts")
 
     def _layer_ready(self, layer_index):
+        if not getattr(self, "_sync", True):
+            return
         # everything above this layer in the graph has finished enqueuing its backward
         self._reduce("heads")
         self._reduce("layer%d" % layer_index)
@@ -196,6 +211,8 @@ class DataParallelGradSync(object):
         a.touched_synced = flags
 
     def finish_step(self):
+        if not getattr(self, "_sync", True):
+            return
         for name, _, _ in self.buckets:                       # whatever the hooks did not cover
             self._reduce(name)
         self._reduce_touched()

@@ -52,8 +52,21 @@ for step in "$@"; do
       timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/pf -o f -- python bench.py --dtype bf16x3 --batch 1024 --steps 8 --warmup 2 $QUIET > gpurun_out/pf2.log 2>&1
       python tools/rocpd_summary.py gpurun_out/pf/f_results.db > gpurun_out/${TAG}_kernel_stats_bf16x3_b1024.txt 2>&1; rm -rf gpurun_out/pf
       head -n 24 gpurun_out/${TAG}_kernel_stats_bf16x3_b1024.txt | cut -c1-200 ;;
-    pmc)
-      bash tools/gpu_r04_pmc_step.sh ${TAG} ;;
+    pmc)        # per-kernel MFMA busy / VALU:MFMA / issue stalls / LDS conflicts of the bf16 step (two PMC passes, kernel trace only)
+      PQ="--steps 2 --warmup 1 $QUIET"
+      SETA="SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
+      SETB="GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_INSTS_LDS SQ_INST_LEVEL_VMEM"
+      timeout 400 rocprofv3 --kernel-trace --pmc $SETA -d gpurun_out/pa -o p -- python bench.py --batch 1024 $PQ > gpurun_out/pa.log 2>&1
+      timeout 400 rocprofv3 --kernel-trace --pmc $SETB -d gpurun_out/pb -o p -- python bench.py --batch 1024 $PQ > gpurun_out/pb.log 2>&1
+      A=$(find gpurun_out/pa -name "*_results.db" | head -1); B=$(find gpurun_out/pb -name "*_results.db" | head -1)
+      echo "# python bench.py --dtype bf16 --batch 1024 (3 steps), rocprofv3 --kernel-trace --pmc, two passes; tools/pmc_step_summary.py" > gpurun_out/${TAG}_pmc_step_bf16.txt
+      python tools/pmc_step_summary.py $A $B >> gpurun_out/${TAG}_pmc_step_bf16.txt 2>&1
+      rm -rf gpurun_out/pa gpurun_out/pb
+      head -n 16 gpurun_out/${TAG}_pmc_step_bf16.txt | cut -c1-200 ;;
+    pyt:*)      # a subset of the GPU suite: pyt:<-k expression with '+' for spaces>
+      expr=$(echo "${step#pyt:}" | tr '+' ' ')
+      timeout 900 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -k "$expr" > gpurun_out/${TAG}_pytest_subset.log 2>&1
+      echo "rc=$?" >> gpurun_out/${TAG}_pytest_subset.log; tail -n 6 gpurun_out/${TAG}_pytest_subset.log ;;
     gemmab:*)
       arms=$(echo "${step#gemmab:}" | tr ',' ' ')
       VB_DEV=1 VB_NOCHECK=1 timeout 400 python tools/gemm_ab.py 1024 $arms > gpurun_out/${TAG}_gemm_ab.txt 2>&1; cut -c1-260 gpurun_out/${TAG}_gemm_ab.txt ;;

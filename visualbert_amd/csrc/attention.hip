@@ -79,48 +79,49 @@ VB_DEVICE void split8(const f32x4& a, const f32x4& b, bf16x8& hi, bf16x8& lo) {
 // this replaced, pays one HBM round trip per trip: 9 serial round trips per workgroup in the forward kernel.)
 // zero fill as a select on a value that was loaded UNCONDITIONALLY (see frag_g)
 VB_DEVICE u32x4 zsel(bool ok, const u32x4& x) { return u32x4{ok ? x[0] : 0u, ok ? x[1] : 0u, ok ? x[2] : 0u, ok ? x[3] : 0u}; }
-template <int NROWS>
+// NTH: threads of the workgroup that stage the tile together (256; 512 for the long-sequence forms whose tiles leave one workgroup per CU)
+template <int NROWS, int NTH = NT>
 struct PairTile {
-    static constexpr int ITEMS = (NROWS / 2) * 8, PER = (ITEMS + NT - 1) / NT;
+    static constexpr int ITEMS = (NROWS / 2) * 8, PER = (ITEMS + NTH - 1) / NTH;
     u32x4 x0[PER], x1[PER];
 };
-template <int NROWS>
-VB_DEVICE void pair_load(PairTile<NROWS>& p, const bf16* X, long ldx, long row0, int c0, int S, int t) {
+template <int NROWS, int NTH = NT>
+VB_DEVICE void pair_load(PairTile<NROWS, NTH>& p, const bf16* X, long ldx, long row0, int c0, int S, int t) {
     // unconditional loads from clamped rows first, the zero fill of rows >= S as selects afterwards (see frag_g)
 #pragma unroll
-    for (int k = 0; k < PairTile<NROWS>::PER; ++k) {
-        const int idx = t + k * NT;
+    for (int k = 0; k < PairTile<NROWS, NTH>::PER; ++k) {
+        const int idx = t + k * NTH;
         const int dc = idx & 7, r = (idx >> 3) * 2;
         p.x0[k] = *(const u32x4*)(X + (row0 + (r < S ? r : S - 1)) * ldx + c0 + dc * 8);
         p.x1[k] = *(const u32x4*)(X + (row0 + (r + 1 < S ? r + 1 : S - 1)) * ldx + c0 + dc * 8);
     }
 #pragma unroll
-    for (int k = 0; k < PairTile<NROWS>::PER; ++k) {
-        const int idx = t + k * NT;
+    for (int k = 0; k < PairTile<NROWS, NTH>::PER; ++k) {
+        const int idx = t + k * NTH;
         const int r = (idx >> 3) * 2;
-        const bool in = idx < PairTile<NROWS>::ITEMS;
+        const bool in = idx < PairTile<NROWS, NTH>::ITEMS;
         p.x0[k] = zsel(in && r < S, p.x0[k]);
         p.x1[k] = zsel(in && r + 1 < S, p.x1[k]);
     }
 }
-template <int NROWS>
-VB_DEVICE void pair_store_rm(const PairTile<NROWS>& p, unsigned char* lds, int t) {
+template <int NROWS, int NTH = NT>
+VB_DEVICE void pair_store_rm(const PairTile<NROWS, NTH>& p, unsigned char* lds, int t) {
 #pragma unroll
-    for (int k = 0; k < PairTile<NROWS>::PER; ++k) {
-        const int idx = t + k * NT;
-        if (idx >= PairTile<NROWS>::ITEMS) continue;
+    for (int k = 0; k < PairTile<NROWS, NTH>::PER; ++k) {
+        const int idx = t + k * NTH;
+        if (idx >= PairTile<NROWS, NTH>::ITEMS) continue;
         const int dc = idx & 7, r = (idx >> 3) * 2;
         *(u32x4*)(lds + rm_off<bf16>(r, dc)) = p.x0[k];
         *(u32x4*)(lds + rm_off<bf16>(r + 1, dc)) = p.x1[k];
     }
 }
-template <int NROWS>
-VB_DEVICE void pair_store_tr(const PairTile<NROWS>& p, unsigned char* lds, int t) {
+template <int NROWS, int NTH = NT>
+VB_DEVICE void pair_store_tr(const PairTile<NROWS, NTH>& p, unsigned char* lds, int t) {
     const int pitch = tr_pitch<bf16>(NROWS);
 #pragma unroll
-    for (int k = 0; k < PairTile<NROWS>::PER; ++k) {
-        const int idx = t + k * NT;
-        if (idx >= PairTile<NROWS>::ITEMS) continue;
+    for (int k = 0; k < PairTile<NROWS, NTH>::PER; ++k) {
+        const int idx = t + k * NTH;
+        if (idx >= PairTile<NROWS, NTH>::ITEMS) continue;
         const int dc = idx & 7, r = (idx >> 3) * 2;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
@@ -366,12 +367,12 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(NTH, (NTH == NT ? 3 : 1)) attn_fwd_kernel(AttnArgs a
     const bool wide_c = sizeof(T) == 2 && wide_ok(a.ctx, a.ldc);     // wave-uniform: 16-byte context stores (store4x2)
 
     if constexpr (sizeof(T) == 2) {
-        PairTile<NK> tk;
-        PairTile<NKVK> tv;
-        pair_load<NK>(tk, Kp, a.ldk, rowk, h * D, S, t);
-        pair_load<NKVK>(tv, Vp, a.ldv, rowk, h * D, S, t);
-        pair_store_rm<NK>(tk, ldsK, t);
-        pair_store_tr<NKVK>(tv, ldsVT, t);                  // rows >= S arrive as zeros: the padded key columns are 0
+        PairTile<NK, NTH> tk;
+        PairTile<NKVK, NTH> tv;
+        pair_load<NK, NTH>(tk, Kp, a.ldk, rowk, h * D, S, t);
+        pair_load<NKVK, NTH>(tv, Vp, a.ldv, rowk, h * D, S, t);
+        pair_store_rm<NK, NTH>(tk, ldsK, t);
+        pair_store_tr<NKVK, NTH>(tv, ldsVT, t);             // rows >= S arrive as zeros: the padded key columns are 0
     } else {
         PairTile32<NK, NTH> tk;
         PairTile32<NKVK, NTH> tv;
@@ -521,12 +522,12 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NTH) attn_bwd_dq_kernel(AttnArgs a) {
     const T* Vp = (const T*)a.v;
 
     if constexpr (sizeof(T) == 2) {
-        PairTile<NK> tk, tv;                               // K is fetched once for both of its LDS images
-        pair_load<NK>(tk, Kp, a.ldk, rowk, h * D, S, t);
-        pair_load<NK>(tv, Vp, a.ldv, rowk, h * D, S, t);
-        pair_store_rm<NK>(tk, ldsK, t);
-        pair_store_tr<NK>(tk, ldsKT, t);
-        pair_store_rm<NK>(tv, ldsV, t);
+        PairTile<NK, NTH> tk, tv;                          // K is fetched once for both of its LDS images
+        pair_load<NK, NTH>(tk, Kp, a.ldk, rowk, h * D, S, t);
+        pair_load<NK, NTH>(tv, Vp, a.ldv, rowk, h * D, S, t);
+        pair_store_rm<NK, NTH>(tk, ldsK, t);
+        pair_store_tr<NK, NTH>(tk, ldsKT, t);
+        pair_store_rm<NK, NTH>(tv, ldsV, t);
     } else {
         PairTile32<NK, NTH> tk, tv;
         pair_load32<NK, T, NTH>(tk, Kp, a.ldk, rowk, h * D, S, t);
@@ -1419,6 +1420,11 @@ int launch_all(int which, const AttnArgs& a, hipStream_t s) {
         if constexpr (sizeof(T) == 4 && NKF <= 12 && NKF > 4) {      // 4-byte tiles: one workgroup per CU, so it brings 12 / 8 waves itself
             constexpr int NTHF = NKF > 8 ? 768 : 512;
             VB_LAUNCH((attn_fwd_kernel<T, NKF, false, false, NTHF>), grid, dim3(NTHF), sm, s, a);
+        } else if constexpr (sizeof(T) == 2 && NKF >= 20) {
+            // long bf16 sequences (NLVR2 as the reference runs it, S = 416: 106 KB of K / V^T): ONE workgroup per CU here too, and the
+            // 256-thread form was compiled for three (168 VGPRs: 340 bytes of scratch at 26 key fragments) -- eight waves at 256
+            // registers keep all scores in registers and give every SIMD a second wave to hide LDS / HBM latency behind
+            VB_LAUNCH((attn_fwd_kernel<T, NKF, false, false, 512>), grid, dim3(512), sm, s, a);
         } else {
             VB_LAUNCH((attn_fwd_kernel<T, NKF>), grid, block, sm, s, a);
         }
@@ -1437,6 +1443,8 @@ int launch_all(int which, const AttnArgs& a, hipStream_t s) {
         const size_t sm1 = dq_smem<T, NKF>(), sm2 = dkv_smem<T, NKF>();
         if (sm2 > kMaxLds) return VB_ERR_UNSUPPORTED;
         if (sm1 > kMaxLds) VB_LAUNCH((attn_bwd_dq_tiled_kernel<T, NW>), grid, block, dq_tiled_smem<T>(), s, a);
+        // (the long bf16 forms, NKF >= 20, stay at four waves: the dQ pass holds P and dP of ALL keys -- 208 registers at 26 fragments --
+        //  and needs the 512-register budget of one wave per SIMD: eight waves spill 840 bytes per lane)
         else if constexpr (sizeof(T) == 4 && NKF <= 12 && NKF > 4) VB_LAUNCH((attn_bwd_dq_kernel<T, NKF, 512>), grid, dim3(512), sm1, s, a);
         else VB_LAUNCH((attn_bwd_dq_kernel<T, NKF>), grid, block, sm1, s, a);
         dim3 grid2((unsigned)(a.B * a.nh), (unsigned)(((a.S + 15) / 16 + 3) / 4));

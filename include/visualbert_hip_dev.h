@@ -14,7 +14,10 @@ extern "C" {
 
 /* vb_stream_opts.nt_kernel values accepted by the DEVELOPER library only (the product returns VB_ERR_ARG for them):
  *   80  = persistent 256x256 tile, eight slots per K tile (81 is the four-slot form that ships)
+ *   82  = kernel 81 with the REGISTER-DIRECT epilogue (round 5: swapped MFMA operand roles, v_permlane16_swap pairs, one 16-byte store per
+ *         lane and no LDS transposition) in the specialised instantiations; measured 3-12 % slower than the LDS route on every shape
  *   91  = the two-workgroups-per-CU kernel with the copies issued ahead of the fragment reads
+ *   92  = kernel 90 with the register-direct epilogue (as 82)
  *   100 = persistent 256x256 tile with four waves, 128x128 outputs each, inline-asm K loop (K / 64 even, else 90)
  *   101 = the same tile with B fetched straight into fragment registers (1 x 4 waves; K / 64 % 4 == 0 and N % 256 == 0, else 90)
  *   200 = the vendor yardstick: plain GEMMs (bias only, or "+ addend") are handed to hipBLASLt (csrc/vendor_gemm.hip: dlopen'ed

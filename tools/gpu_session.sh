@@ -69,7 +69,7 @@ for step in "$@"; do
       echo "rc=$?" >> gpurun_out/${TAG}_pytest_subset.log; tail -n 6 gpurun_out/${TAG}_pytest_subset.log ;;
     gemmab:*)
       arms=$(echo "${step#gemmab:}" | tr ',' ' ')
-      VB_DEV=1 VB_NOCHECK=1 timeout 400 python tools/gemm_ab.py 1024 $arms > gpurun_out/${TAG}_gemm_ab.txt 2>&1; cut -c1-260 gpurun_out/${TAG}_gemm_ab.txt ;;
+      VB_DEV=1 timeout 400 python tools/gemm_ab.py 1024 $arms > gpurun_out/${TAG}_gemm_ab.txt 2>&1; cut -c1-260 gpurun_out/${TAG}_gemm_ab.txt ;;
     attn)
       timeout 300 python tools/attn_bench.py 1024 164 > gpurun_out/${TAG}_attn_bench.txt 2>&1; tail -n 12 gpurun_out/${TAG}_attn_bench.txt ;;
     nlvr2real)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""MFMA-pipe utilisation per kernel INSIDE the training step from two rocprofv3 --pmc passes over bench.py (tools/gpu_r04_pmc_step.sh):
+"""MFMA-pipe utilisation per kernel INSIDE the training step from two rocprofv3 --pmc passes over bench.py (tools/gpu_session.sh step `pmc`):
    pass A: SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
    pass B: GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_INSTS_LDS SQ_INST_LEVEL_VMEM
 MFMA busy % = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)   (the formula of profiles/r03_pmc_gemm_*.txt);

@@ -172,7 +172,7 @@ def use_dev_library():
 
 
 #: vb_stream_opts.nt_kernel values that exist in the developer library only (include/visualbert_hip_dev.h)
-DEV_NT_KERNELS = (80, 91, 100, 101, 200)
+DEV_NT_KERNELS = (80, 82, 91, 92, 100, 101, 200)
 
 
 class dev_library(object):

@@ -967,6 +967,127 @@ VB_DEVICE void gemm_epilogue_private(f32x4 (&acc)[8][4], unsigned char* slab, co
     if constexpr (OPT & EPI_COLSUM) epi_colsum_flush(e, g, nw0, lane);
 }
 
+// =================================================================================================
+// REGISTER-DIRECT epilogue (round 5; developer-library experiment arms nt_kernel 92 / 82 -- it LOST, see kDirectEpilogue below) of the
+// specialised instantiations (one activation, no ragged edge) of the two fast kernels.
+// The K loop runs with the MFMA operand roles SWAPPED -- acc = W-fragment x activation-fragment -- so lane (li, lg) of a wave holds,
+// per 16x16 fragment (mi, ni), FOUR CONSECUTIVE COLUMNS of ONE row: C[mw0 + 16 mi + li][nw0 + 16 ni + 4 lg + 0..3].  Two
+// v_permlane16_swap_b32 per register pair (vb_rt.h: the ODD 16-lane rows of one register exchanged with the EVEN rows of the other)
+// turn the fragments (mi, 2 j) and (mi, 2 j + 1) into EIGHT contiguous columns per lane, nw0 + 32 j + vb_wide_col(lg) + 0..7 -- the
+// unit every element-wise epilogue above (epi_vec8) is written for -- and the result leaves in ONE 16-byte store per lane, 16 store
+// instructions per wave and tile exactly like the LDS route, but with no LDS round trip at all: 128 ds_write_b32, 32 ds_read_b128,
+// 16 waits per wave and tile are gone, and with them the 2-way bank conflicts of the slab reads (7.7 % of the LDS-active cycles of
+// these kernels, profiles/r04_pmc_step_bf16.txt).  Round 1 tried the swapped roles with 8-byte stores (twice the store instructions:
+// 8-15 % slower, profiles/r01_gemm_register_epilogue_experiment.txt); what prices an epilogue is its store-instruction count
+// ("Round 5"), and the lane exchange keeps it.
+// A store instruction covers 16 rows x 64 bytes here (8 rows x 128 bytes on the LDS route); the two 64-byte halves of a 128-byte
+// line are written by the two stores of the same fragment row, back to back.
+VB_DEVICE void vb_permlane16_swap_f(float& a, float& b) {
+    uint32_t x = __builtin_bit_cast(uint32_t, a), y = __builtin_bit_cast(uint32_t, b);
+    vb_permlane16_swap(x, y);
+    a = __builtin_bit_cast(float, x); b = __builtin_bit_cast(float, y);
+}
+template <typename T, typename TO>
+VB_DEVICE void epi_lane_init_direct(EpiLane& e, const GemmArgs& g, int ncol) {
+    e.alpha = g.alpha_dev ? g.alpha * g.alpha_dev[0] : g.alpha;
+    e.ncol = ncol;
+    e.nv = 8; e.vec = true;                             // the launcher checked N % 8 == 0 and every alignment
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { e.bb[j] = 0.f; e.cs[j] = 0.f; }
+    if (g.bias && e.ncol < g.N) load8(e.bb, g.bias + e.ncol);
+}
+// column sums: the 16 lanes of a lane row (equal lg) own the same 8 columns on 16 different rows
+VB_DEVICE void epi_colsum_flush_direct(EpiLane& e, const GemmArgs& g, int lane) {
+    if (!(g.colsum && g.splits == 1)) return;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        e.cs[j] += __shfl_xor(e.cs[j], 1);
+        e.cs[j] += __shfl_xor(e.cs[j], 2);
+        e.cs[j] += __shfl_xor(e.cs[j], 4);
+        e.cs[j] += __shfl_xor(e.cs[j], 8);
+    }
+    if ((lane & 15) == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (e.ncol + j < g.N) vb_atomic_add_noret(g.colsum + e.ncol + j, e.cs[j]);
+    }
+}
+template <typename T, typename TO, int ACT, int OPT>
+VB_DEVICE void gemm_epilogue_direct(f32x4 (&acc)[8][4], const GemmArgs& g, int mw0, int nw0, int lane) {
+    static_assert(ACT >= 0 && !(OPT & EPI_RAGGED), "specialised, aligned instantiations only");
+    const int li = lane & 15, lg = lane >> 4;
+    EpiLane e0, e1;
+    epi_lane_init_direct<T, TO>(e0, g, nw0 + vb_wide_col(lg));
+    epi_lane_init_direct<T, TO>(e1, g, nw0 + 32 + vb_wide_col(lg));
+    // the per-row operand of the specialised epilogues (saved GELU' / residual gradient): two batches of 8 independent 16-byte loads
+    // per lane, issued ahead of the batch's first multiply (one round trip per batch instead of one per row)
+    constexpr bool PRE_AUX = sizeof(T) == 2 && (ACT == VB_ACT_MUL_AUX || ACT == VB_ACT_GELU_GRAD);
+    constexpr bool PRE_ADD = sizeof(T) == 2 && !PRE_AUX && (OPT & EPI_ADD);
+    u32x4 pre[4][2];
+    int pre_kind = 0;
+    const unsigned char* pbase = nullptr;
+    long pld = 0;
+    if constexpr (PRE_AUX || PRE_ADD) {
+        if (PRE_AUX) { pbase = (const unsigned char*)g.aux_in; pld = g.ld_aux; pre_kind = 1; }
+        else if (g.addend && !g.accumulate) { pbase = (const unsigned char*)g.addend; pld = g.ld_addend; pre_kind = 2; }
+    }
+    auto preload = [&](int mi0) {
+        if constexpr (PRE_AUX || PRE_ADD) {
+            if (pre_kind) {
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        int m = mw0 + (mi0 + mi) * 16 + li;
+                        m = m < g.M ? m : g.M - 1;                  // clamped rows are loaded but never stored
+                        const int nc = j ? e1.ncol : e0.ncol;
+                        pre[mi][j] = *(const u32x4*)(pbase + ((long)m * pld + (nc < g.N ? nc : 0)) * 2);
+                    }
+            }
+        }
+    };
+    const long rowc = (long)(mw0 + li) * g.ldc, rowa = (long)(mw0 + li) * g.ld_aux;
+    const long stepc = 16 * g.ldc, stepa = 16 * g.ld_aux;
+    // one fragment row (16 rows x 64 columns of the wave's block); mi is a compile-time constant at every call
+    auto fragrow = [&](f32x4 (&a)[4], int mi, const u32x4 (&pr)[2]) {
+        const int m = mw0 + mi * 16 + li;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            EpiLane& e = j ? e1 : e0;
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {                                       // every lane takes part; only the store is predicated
+                float x = a[2 * j][r], y = a[2 * j + 1][r];
+                vb_permlane16_swap_f(x, y);
+                v[r] = x; v[4 + r] = y;
+            }
+            float xa[8], xd[8], xc[8];
+            const bool ok = m < g.M && e.ncol < g.N;
+            if constexpr (PRE_AUX || PRE_ADD) {
+                if (pre_kind) {
+                    const bf16x8 x = *(const bf16x8*)&pr[j];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { if (pre_kind == 1) xa[q] = (float)x[q]; else xd[q] = (float)x[q]; }
+                } else if (ok) epi_load8<T, TO, ACT, OPT>(xa, xd, xc, g, m, e.ncol);
+            } else {
+                if (ok) epi_load8<T, TO, ACT, OPT>(xa, xd, xc, g, m, e.ncol);
+            }
+            if (ok) epi_vec8<T, TO, ACT, OPT>(v, g, e, rowc + mi * stepc + e.ncol, rowa + mi * stepa + e.ncol, xa, xd, xc);
+        }
+    };
+    // constant indices spelled out: the accumulators must never be addressed by a loop variable
+    preload(0);
+    fragrow(acc[0], 0, pre[0]); fragrow(acc[1], 1, pre[1]); fragrow(acc[2], 2, pre[2]); fragrow(acc[3], 3, pre[3]);
+    preload(4);
+    fragrow(acc[4], 4, pre[0]); fragrow(acc[5], 5, pre[1]); fragrow(acc[6], 6, pre[2]); fragrow(acc[7], 7, pre[3]);
+    if constexpr (OPT & EPI_COLSUM) { epi_colsum_flush_direct(e0, g, lane); epi_colsum_flush_direct(e1, g, lane); }
+}
+// which instantiations take it (and therefore run their K loop with swapped operand roles): the developer library's arms 92 / 82 only --
+// MEASURED SLOWER than the LDS route on every shape of the step (profiles/r05_gemm_direct_epilogue_ab.txt: 69.96 vs 66.68 ms per step on
+// the two-workgroup kernel, 69.72 vs 65.44 on the persistent one; the GELU + GELU' epilogue 1134 vs 1007 us): a store instruction that
+// covers 16 rows x 64 bytes costs more than one that covers 8 rows x 128 bytes -- the price follows the LINES an instruction touches,
+// not only the instruction count -- which is what the LDS transposition buys.  Kept as an experiment arm, not in the product.
+template <int ACT, int OPT, bool ON> constexpr bool kDirectEpilogue = ACT >= 0 && !(OPT & EPI_RAGGED) && ON;
+
 // X3: split-operand mode (see GemmArgs): the copy stream walks 3 K / 64 virtual K tiles whose column offsets come from
 // x3_col_a / x3_col_b; the epilogue's row operands are fp32 (TE).  With a virtual K of >= 2304 the per-tile epilogue is a small
 // share and this kernel's lower LDS traffic per FLOP is what counts (profiles/r04_power_by_kernel.txt: +9 % at K = 3072 in bf16).
@@ -976,6 +1097,9 @@ VB_KERNEL VB_LAUNCH_BOUNDS(512) gemm_nt_8ph_kernel(GemmArgs g) {
     constexpr int BK = TT<T>::BK, KSTEPS = TT<T>::KSTEPS, EPC = TT<T>::EPC;
     constexpr int HALF = 128 * 128, BUF = 4 * HALF;
     constexpr int SLOT_A0 = 0, SLOT_A1 = 1, SLOT_B0 = 2, SLOT_B1 = 3;
+    // SCHED: bit 0 = four-slot schedule (what ships), bit 1 = the register-direct epilogue where it applies (developer library:
+    // nt_kernel 82, an experiment arm that lost)
+    constexpr bool DIRECT = kDirectEpilogue<ACT, OPT, (SCHED & 2) != 0>;
     VB_DYN_SMEM(smem);
     const int t = threadIdx.x;
     const int lane = t & 63, wave = vb_uniform(t >> 6);
@@ -1062,13 +1186,15 @@ VB_KERNEL VB_LAUNCH_BOUNDS(512) gemm_nt_8ph_kernel(GemmArgs g) {
 #pragma unroll
             for (int f = 0; f < 4; ++f)
 #pragma unroll
-                for (int q = 0; q < 2; ++q)
-                    acc[mh * 4 + f][nh * 2 + q] = vb_mma(fa[f][ks], fb[q][ks], acc[mh * 4 + f][nh * 2 + q]);
+                for (int q = 0; q < 2; ++q) {
+                    if constexpr (DIRECT) acc[mh * 4 + f][nh * 2 + q] = vb_mma(fb[q][ks], fa[f][ks], acc[mh * 4 + f][nh * 2 + q]);    // swapped roles: 4 columns per lane
+                    else acc[mh * 4 + f][nh * 2 + q] = vb_mma(fa[f][ks], fb[q][ks], acc[mh * 4 + f][nh * 2 + q]);
+                }
         vb_setprio<0>();
     };
 
     const int GK = my_tiles * nk;                  // K tiles in this workgroup's stream
-    if constexpr (SCHED == 1) {
+    if constexpr ((SCHED & 1) != 0) {
         // ---- FOUR-SLOT schedule: two quadrants (32 MFMAs) per slot, half the barriers.  Per K tile g (buffer g & 1):
         //   E(g): reads A0 B0 B1 | issues A1 of tile g+1 | MFMAs (0,0) (0,1)
         //   O(g): reads A1       | issues A0 B0 B1 of tile g+2 (into the buffer E(g) just drained) | MFMAs (1,1) (1,0)
@@ -1108,7 +1234,8 @@ VB_KERNEL VB_LAUNCH_BOUNDS(512) gemm_nt_8ph_kernel(GemmArgs g) {
                 // output tile finished: drain it while the next tile's first K tiles are already landing
                 int m0, n0;
                 origin(cj, m0, n0);
-                gemm_epilogue_private<TE, TO, ACT, OPT>(acc, slab, g, m0 + wr * 128, n0 + wc * 64, lane);
+                if constexpr (DIRECT) gemm_epilogue_direct<TE, TO, ACT, OPT>(acc, g, m0 + wr * 128, n0 + wc * 64, lane);
+                else gemm_epilogue_private<TE, TO, ACT, OPT>(acc, slab, g, m0 + wr * 128, n0 + wc * 64, lane);
     #pragma unroll
                 for (int mi = 0; mi < 8; ++mi)
     #pragma unroll
@@ -1164,7 +1291,8 @@ VB_KERNEL VB_LAUNCH_BOUNDS(512) gemm_nt_8ph_kernel(GemmArgs g) {
             // output tile finished: drain it while the next tile's first K tiles are already landing
             int m0, n0;
             origin(cj, m0, n0);
-            gemm_epilogue_private<TE, TO, ACT, OPT>(acc, slab, g, m0 + wr * 128, n0 + wc * 64, lane);
+            if constexpr (DIRECT) gemm_epilogue_direct<TE, TO, ACT, OPT>(acc, g, m0 + wr * 128, n0 + wc * 64, lane);
+            else gemm_epilogue_private<TE, TO, ACT, OPT>(acc, slab, g, m0 + wr * 128, n0 + wc * 64, lane);
 #pragma unroll
             for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
@@ -1183,6 +1311,7 @@ template <typename T, typename TO, int ACT, int OPT>
 int launch_8ph_act(const GemmArgs& g, dim3 grid, dim3 block, int smem_bytes, hipStream_t stream) {
 #ifdef VB_DEV_KNOBS
     if (t_opts.nt_kernel == 80) return launch_8ph_sched<T, TO, ACT, OPT, 0>(g, grid, block, smem_bytes, stream);   // eight slots
+    if (t_opts.nt_kernel == 82) return launch_8ph_sched<T, TO, ACT, OPT, 3>(g, grid, block, smem_bytes, stream);   // four slots, register-direct epilogue (experiment arm)
 #endif
     return launch_8ph_sched<T, TO, ACT, OPT, 1>(g, grid, block, smem_bytes, stream);                                // four slots
 }
@@ -1269,6 +1398,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(256, 2) gemm_nt_dual_kernel(GemmArgs g) {
     typedef bf16 T;
     typedef typename std::conditional<X3, float, bf16>::type TE;
     constexpr int BK = 64, KSTEPS = 2, HALF = 128 * 128;
+    constexpr bool DIRECT = kDirectEpilogue<ACT, OPT, (VAR & 4) != 0>;    // VAR bit 2 (developer library, nt_kernel 92): the register-direct epilogue (experiment arm)
     VB_DYN_SMEM(smem);
     const int t = threadIdx.x;
     const int lane = t & 63, wave = vb_uniform(t >> 6);
@@ -1352,8 +1482,10 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(256, 2) gemm_nt_dual_kernel(GemmArgs g) {
 #pragma unroll
             for (int f = 0; f < 4; ++f)
 #pragma unroll
-                for (int q = 0; q < 2; ++q)
-                    acc[mh * 4 + f][nh * 2 + q] = vb_mma(fa[f][ks], fb[q][ks], acc[mh * 4 + f][nh * 2 + q]);
+                for (int q = 0; q < 2; ++q) {
+                    if constexpr (DIRECT) acc[mh * 4 + f][nh * 2 + q] = vb_mma(fb[q][ks], fa[f][ks], acc[mh * 4 + f][nh * 2 + q]);    // swapped roles
+                    else acc[mh * 4 + f][nh * 2 + q] = vb_mma(fa[f][ks], fb[q][ks], acc[mh * 4 + f][nh * 2 + q]);
+                }
     };
     auto prio = [&](int p) {
         if constexpr ((VAR & 2) != 0) { if (p) vb_setprio<1>(); else vb_setprio<0>(); }
@@ -1403,8 +1535,12 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(256, 2) gemm_nt_dual_kernel(GemmArgs g) {
         step(std::integral_constant<int, 3>(), k); if (++k == nk) break;
         step(std::integral_constant<int, 4>(), k); if (++k == nk) break;
     }
-    vb_phase_barrier();                                        // every wave is done with the ring: the slabs may alias it
-    gemm_epilogue_private<TE, TO, ACT, OPT>(acc, smem + wave * EPI8_BYTES_PER_WAVE, g, m0 + wr * 128, n0 + wc * 64, lane);
+    if constexpr (DIRECT) {
+        gemm_epilogue_direct<TE, TO, ACT, OPT>(acc, g, m0 + wr * 128, n0 + wc * 64, lane);     // no LDS: no barrier, a wave leaves when it is done
+    } else {
+        vb_phase_barrier();                                    // every wave is done with the ring: the slabs may alias it
+        gemm_epilogue_private<TE, TO, ACT, OPT>(acc, smem + wave * EPI8_BYTES_PER_WAVE, g, m0 + wr * 128, n0 + wc * 64, lane);
+    }
 }
 
 template <typename TO, int ACT, int OPT, int VAR, bool X3 = false>
@@ -1416,6 +1552,7 @@ template <typename TO, int ACT, int OPT>
 int launch_dual_act(const GemmArgs& g, dim3 grid, hipStream_t stream) {
 #ifdef VB_DEV_KNOBS
     if (t_opts.nt_kernel == 91) return launch_dual_var<TO, ACT, OPT, 0>(g, grid, stream);
+    if (t_opts.nt_kernel == 92) return launch_dual_var<TO, ACT, OPT, 7>(g, grid, stream);      // register-direct epilogue (experiment arm)
 #endif
     return launch_dual_var<TO, ACT, OPT, 3>(g, grid, stream);
 }
@@ -2245,8 +2382,8 @@ int dispatch_pipe(const GemmArgs& g, hipStream_t s) {
         case 81: return launch_8ph<T, TO>(g, s);
         case 90: return launch_dual<T, TO>(g, s);
 #ifdef VB_DEV_KNOBS
-        case 80: return launch_8ph<T, TO>(g, s);
-        case 91: return launch_dual<T, TO>(g, s);
+        case 80: case 82: return launch_8ph<T, TO>(g, s);
+        case 91: case 92: return launch_dual<T, TO>(g, s);
         case 100: return launch_big<T, TO>(g, s);
         case 101: return launch_big<T, TO>(g, s, true);
 #endif

@@ -363,7 +363,7 @@ extern "C" int vb_stream_set_opts(void* stream, const vb_stream_opts* opts) {
         // vendor yardstick (200) exist in libvisualbert_hip_dev.so only (include/visualbert_hip_dev.h)
         bool ok = (k == 0 || k == 1 || k == 22 || k == 42 || k == 81 || k == 90);
 #ifdef VB_DEV_KNOBS
-        ok = ok || k == 80 || k == 91 || k == 100 || k == 101 || k == 200;
+        ok = ok || k == 80 || k == 82 || k == 91 || k == 92 || k == 100 || k == 101 || k == 200;
 #endif
         if (opts->persistent_workgroups < 0 || !ok) return VB_ERR_ARG;
     }

@@ -542,6 +542,8 @@ def main():
                     help="vb_stream_opts.nt_kernel for the whole run (0 = chosen per shape; 81 / 90 for A/B runs)")
     ap.add_argument("--attn-two-pass", type=int, default=0,
                     help="vb_stream_opts.attn_two_pass for the whole run (A/B: 1 = two-pass attention backward)")
+    ap.add_argument("--dev-debug", type=int, default=0,
+                    help="developer A/B runs only: bind libvisualbert_hip_dev.so for the whole run and set vb_gemm_set_debug(bits)")
     ap.add_argument("--pmc-traffic", default="auto", choices=["auto", "off"],
                     help="auto (N = 1): measure roofline.traffic for THIS run with two rocprofv3 --pmc children of the same command "
                          "line (adds ~1 min per timed mode); off: report the committed PMC pass (profiles/pmc_traffic.json) or null")
@@ -621,6 +623,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.dev_debug:
+        from visualbert_amd import _lib
+        _lib.use_dev_library().vb_gemm_set_debug(args.dev_debug)
     if args.nt_kernel or args.attn_two_pass:
         from visualbert_amd import _lib
         _lib.set_opts(nt_kernel=args.nt_kernel, attn_two_pass=args.attn_two_pass)

@@ -27,6 +27,8 @@ extern "C" {
  * reads, 4 skip MFMAs in the pipelined kernel, 128 predicate the epilogue's global stores off */
 /* bit 26 (1 << 26): the bf16 epilogues' streaming (`nt`) stores replaced by plain stores -- results are IDENTICAL (this bit does not
  * make them wrong): the bit-compare arm of tests/test_kernels.py::test_streaming_stores_equal_plain_stores */
+/* bit 27 (1 << 27): the round-4 dispatch rule for "+ addend" GEMMs with K >= 2048 (two-workgroup kernel instead of the persistent one);
+ * results identical up to summation order */
 int vb_gemm_set_debug(int bits);
 /* debug bit 64 (256x128 pipelined kernel, bf16): waves 0 and 4 of workgroup 0 write per-K-tile shader-clock stamps
  * {landed, barrier, copies issued, frags0, mfma0, frags1, mfma1} to this device buffer (uint64[2][64][8]) */

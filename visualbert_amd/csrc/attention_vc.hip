@@ -1550,7 +1550,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS(FNT) attn_bwd_fused_pers_kernel(AttnArgs a) {
     for (;;) {                                             // the workgroup's pairs: blockIdx.x, blockIdx.x + G, ...
     bh = f_bh; b = f_b; h = f_h; row0 = f_row0;
     const bool has_next = bh + G < npairs;
-    vb_wait_vmcnt<0>();                                    // my LDS-direct copies of this pair's K rows have landed (issued >= one phase B +
+    __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0), compiler-visible: my LDS-direct copies of this pair's K rows have landed (issued >= one phase B +
     __syncthreads();                                       // one epilogue ago; the compiler does not track them) -- and, after the barrier,
                                                            // everyone's; the previous pair's bias partials (they alias the images) have been read
     mk2 = (kok ? mk_raw : -INFINITY) * 1.44269504088896340736f;

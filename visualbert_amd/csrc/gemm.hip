@@ -2373,8 +2373,13 @@ int dispatch_pipe(const GemmArgs& g, hipStream_t s) {
         // partner workgroup's MFMAs -- except long-K GEMMs with a plain epilogue (FFN-out forward: K = 3072), where the
         // persistent 256x256 kernel's K loop is ~10 % faster and the epilogue is 1/48 of the tile
         // (profiles/r02_gemm_ab_*.txt: per step 36.6 -> 34.6 ms of NT GEMMs at B = 512).
+        // Round 5: "+ residual gradient" (an addend, no activation) counts as light too -- the two long-K dgrads of a layer (FFN-in:
+        // K = 3072, QKV: K = 2304) run 7-8 % faster on the persistent kernel alone (profiles/r05_gemm_direct_epilogue_ab.txt, arms
+        // k82 / k92 = the shipping epilogue: 642 vs 698 us and 507 vs 544 us at M = 167,936), as they already did in the split mode.
+        // (developer library: debug bit 27 restores the round-4 rule for the in-step A/B)
         const bool plain = !g.addend && !g.aux_in && !g.aux_out && !g.colsum && g.act == VB_ACT_NONE && sizeof(TO) == 2;
-        variant = (sizeof(T) == 2 && t256 >= 160) ? ((g.K >= 2048 && plain) ? 81 : 90) : (t128 >= 256 ? 42 : 22);
+        const bool light = !g.aux_in && !g.aux_out && !g.colsum && g.act == VB_ACT_NONE && !g.accumulate && sizeof(TO) == 2 && !(g.debug & (1 << 27));
+        variant = (sizeof(T) == 2 && t256 >= 160) ? ((g.K >= 2048 && (plain || light)) ? 81 : 90) : (t128 >= 256 ? 42 : 22);
     }
     switch (variant) {
         case 22: return launch_pipe<T, TO, 2, 2>(g, s);

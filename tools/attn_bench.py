@@ -33,14 +33,3 @@ for p in (0.0, 0.1):
     print("B=%d p=%.1f: one-pass backward + q|k|v bias gradient %.1f us" % (B, p, t1b))
     print("B=%d p=%.1f: fwd %.1f us (%.0f TF)  bwd two-pass %.1f / %.1f us (%.0f TF)  bwd one-pass %.1f / %.1f us" % (
         B, p, tf, flops / tf / 1e6, tb, tb2, 2.5 * flops / tb / 1e6, t1, t12))
-# A/B: the one-pass backward per (batch, head) workgroup (0) vs the PERSISTENT form (vb_stream_opts.attn_two_pass = 2: one workgroup per
-# CU walks the pairs, the next pair's K / V / chunk 0 fetched under the current pair's last phase B and epilogue); interleaved rounds
-db = torch.zeros(3 * H, device=dev)
-ctx, lse, bits = ops.attn_fwd(qkv, mask, B, S, nh, 0.1, 5, 3)
-res = {"per pair": [], "persistent": []}
-for rnd in range(4):
-    for name, v in (("per pair", 0), ("persistent", 2)):
-        with _lib.stream_opts(attn_two_pass=v):
-            res[name].append(bench(lambda: ops.attn_bwd(qkv, mask, dctx, lse, bits, B, S, nh, 0.1, 5, 3, ctx_fwd=ctx, dqkv_bias=db)))
-print("B=%d one-pass backward + bias gradient, p=0.1, 4 interleaved rounds (us): " % B +
-      "  ".join("%s %s" % (k, " ".join("%.1f" % x for x in v)) for k, v in res.items()))

@@ -50,11 +50,6 @@ for step in "$@"; do
         timeout 300 python bench.py --steps 15 --warmup 4 --dev-debug $b $QUIET > gpurun_out/ab.json 2>/dev/null
         python -c "import json;d=json.load(open('gpurun_out/ab.json'));print('debug bits %d: %.1f samples/s  %.3f ms/step (median %.3f)' % ($b, d['value'], d['ms_per_step'], d['ms_per_step_median']))" | tee -a gpurun_out/${TAG}_benchab_$bits.txt
       done; done ;;
-    benchattn)  # in-step A/B of the persistent attention backward (attn_two_pass 2) against the per-pair kernel, 3 rounds
-      for r in 1 2 3; do for v in 2 0; do
-        timeout 300 python bench.py --steps 15 --warmup 4 --attn-two-pass $v $QUIET > gpurun_out/ab.json 2>/dev/null
-        python -c "import json;d=json.load(open('gpurun_out/ab.json'));print('attn_two_pass %d: %.1f samples/s  %.3f ms/step (median %.3f)' % ($v, d['value'], d['ms_per_step'], d['ms_per_step_median']))" | tee -a gpurun_out/${TAG}_benchattn.txt
-      done; done ;;
     stats)
       timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/pf -o f -- python bench.py --steps 8 --warmup 2 $QUIET > gpurun_out/pf.log 2>&1
       python tools/rocpd_summary.py gpurun_out/pf/f_results.db > gpurun_out/${TAG}_kernel_stats_b1024.txt 2>&1; rm -rf gpurun_out/pf

@@ -1060,7 +1060,11 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) attn_bwd_dkv_kernel(AttnArgs a) {
 // (A first version added per-wave dQ partials into an LDS tile with ds_add_f32: 7x slower than two passes.)
 // Round 5, measured and removed (profiles/r05_attn_bench_b1024_prefetch_ab.txt): an L2 prefetch of the lines workgroup b + 256 (same XCD)
 // opens with, issued by this workgroup once its own fetches were consumed -- 845 -> 907 us alone, 956 -> 1015 us in the step: the four
-// registers it cost spilled (the kernel sits at 168), and scratch reloads wait on vmcnt.
+// registers it cost spilled (the kernel sits at 168), and scratch reloads wait on vmcnt.  Also measured and removed
+// (profiles/r05_attn_persistent_ab.txt; the kernel is in the git history): the PERSISTENT form -- one workgroup per CU walking the pairs,
+// the next pair's K / V fragments, mask and chunk 0 fetched into registers that are dead by then and its K rows into spare LDS by
+// LDS-direct copies, under the current pair's last phase B and epilogue.  Bit-identical, no VGPR spill after five compiler
+// work-arounds, and at best PARITY: 862 against 853 us.
 // =================================================================================================
 constexpr int FWPB = 12, FNT = FWPB * 64, FNK = FWPB * 16;  // 192 keys
 constexpr int TSP = FNK * 2 + 8;                           // dS tile pitch in bytes (pad: 16 rows -> distinct banks)
@@ -1375,388 +1379,6 @@ VB_KERNEL VB_LAUNCH_BOUNDS(FNT) attn_bwd_fused_kernel(AttnArgs a) {
     }
 }
 
-template <int NKF, int CQ>
-VB_KERNEL VB_LAUNCH_BOUNDS(FNT) attn_bwd_fused_pers_kernel(AttnArgs a) {
-    typedef bf16 T;
-    constexpr int NW = (NKF + 15) / 16;
-    VB_DYN_SMEM(smem);
-    // two sets of chunk images: chunk c+1 is written to LDS while the slower waves still compute on chunk c
-    constexpr int SETB = 2 * rm_bytes<T>(CQ) + 2 * tr_bytes<T>(CQ) + 2 * CQ * 4 + CQ * 4 * NW * 8;
-    unsigned char *ldsQ, *ldsDO, *ldsQT, *ldsDOT;
-    float *ldsLse, *ldsD;
-    uint64_t* ldsBits;                                     // [CQ][4][NW]
-    auto use_set = [&](int set) {
-        ldsQ = smem + set * SETB;
-        ldsDO = ldsQ + rm_bytes<T>(CQ);
-        ldsQT = ldsDO + rm_bytes<T>(CQ);
-        ldsDOT = ldsQT + tr_bytes<T>(CQ);
-        ldsLse = (float*)(ldsDOT + tr_bytes<T>(CQ));
-        ldsD = ldsLse + CQ;
-        ldsBits = (uint64_t*)(ldsD + CQ);
-    };
-    unsigned char* ldsKT = smem + 2 * SETB;                // K^T of the whole sequence: [64 d][FNK keys]
-    unsigned char* ldsDS = ldsKT + tr_bytes<T>(FNK);       // dS of the chunk: [CQ queries][FNK keys], pitch TSP
-    unsigned char* ldsKN = ldsDS + CQ * TSP;               // K rows of the pair being FETCHED: [FNK rows][128 B], filled by LDS-direct copies
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, lg = lane >> 4;
-    // compute side: the (batch, head) pair being worked on; fetch side (f_*, sbase, obase, off_s): the pair whose data is being fetched --
-    // the same pair in a pair's prologue and first chunks, the workgroup's NEXT pair from the last chunk's phase B on
-    int bh = blockIdx.x, b = bh / a.nh, h = bh % a.nh;
-    int f_bh = bh, f_b = b, f_h = h;
-    const int npairs = a.B * a.nh, G = (int)gridDim.x;
-    const int S = a.S, H = a.nh * D;
-    const long ldx = 3L * H;
-    long row0 = (long)b * S, f_row0 = row0;
-    const T* qkv = (const T*)a.qkv;
-    const T* dctx = (const T*)a.dctx;
-    const T* octx = (const T*)a.ctx_fwd;
-
-    // Every global load below is UNCONDITIONAL from a clamped (always readable) row, and the zero / -inf / all-ones fill of the
-    // rows past S is a select at the point of use: the loads carry no branches, nothing waits between them, and a chunk's
-    // fetch really runs a chunk ahead (with `ok ? load : fill` the compiler put s_waitcnt vmcnt(0) between the loads of the
-    // "prefetch" -- the registers' fill is a write-after-write on a pending load -- and the workgroup, alone on its compute
-    // unit, sat through four HBM round trips before its first MFMA and one more per chunk).
-    const int kf = wave;
-    const int key = kf * 16 + li;
-    const bool wave_on = kf * 16 < S;                      // wave-uniform
-    const bool kok = key < S;
-    const int keyc = kok ? key : S - 1;
-    // K^T image source: one row pair x 16-byte chunk per thread (96 pairs x 8 chunks = 768 items = FNT), read from ldsKN
-    bf16x8 kb[2], vb[2];
-    float mk_raw = 0.f;
-    // what a pair's prologue needs besides its chunk 0, issued in one go for the FETCH-side pair: the K / V fragments and the mask
-    // straight into registers (dead between the last phase A of a pair and the first of the next), the K rows behind the K^T image by
-    // LDS-direct copies into ldsKN -- no registers at all, which is what the round-2 persistent form lacked (8 VGPRs for those rows
-    // pushed it past the 168-register budget: 232 bytes of scratch, 673 us against 447)
-    // (the per-lane address arithmetic of everything that runs ONCE PER PAIR -- this fetch, the K^T build, the epilogue -- starts from an
-    //  opaque copy of the thread index made at its point of use: as loop invariants of the pair loop the compiler kept all of it in
-    //  registers across the phases and spilled 38-60 of them)
-    auto fetch_pair = [&]() {
-        int tz = t;
-        vb_pin(tz);
-        const int lz = tz & 63, lgz = lz >> 4, keyz = (tz >> 6) * 16 + (lz & 15);
-        const bool kokz = keyz < S;
-        const int keycz = kokz ? keyz : S - 1;
-        const T* krow = qkv + (f_row0 + keycz) * ldx + H + f_h * D;
-        const T* vrow = qkv + (f_row0 + keycz) * ldx + 2 * H + f_h * D;
-        // RAW loads from the clamped row: the zero fill of keys past S is a select at the top of the pair (prologue) -- applied here, inside
-        // the conditional prefetch block, it made the compiler wait for the loads before leaving the block
-        kb[0] = *(const bf16x8*)(krow + lgz * 8); kb[1] = *(const bf16x8*)(krow + 32 + lgz * 8);
-        vb[0] = *(const bf16x8*)(vrow + lgz * 8); vb[1] = *(const bf16x8*)(vrow + 32 + lgz * 8);
-        mk_raw = a.mask_add[(long)f_b * S + keycz];
-        const int wu = vb_uniform(tz >> 6);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {                        // 24 one-KB pieces: rows (2 wave + i) 8 + lane / 8, chunk lane % 8
-            const int r = (wu * 2 + i) * 8 + (lz >> 3);
-            vb_glds16_untracked(qkv + (f_row0 + (r < S ? r : S - 1)) * ldx + H + f_h * D + (lz & 7) * 8, ldsKN + (wu * 2 + i) * 1024);
-        }
-    };
-    f32x4 dkT[4], dvT[4];
-
-    constexpr int BPT = (CQ * 4 * NW + FNT - 1) / FNT;
-    constexpr int SI = CQ * 4;                             // staging items per tensor (row pair x 16-byte chunk)
-    static_assert(SI % 64 == 0 && CQ == 64, "the staging role must be wave-uniform; wave 0 carries the chunk's lse values");
-    // staging roles (wave-uniform): role 0 (waves 0-3) fetches dO and O for D = dO . O and carries the chunk's lse and keep-bit
-    // words, role 1 (waves 4-7) stages dO, role 2 (waves 8-11) stages Q.  The heaviest staging goes to the OLDEST waves: the
-    // SIMD arbiter favours them in phase A (an in-kernel cycle trace shows waves 0-3 done with a chunk's phase A after ~3700
-    // cycles, waves 8-11 after ~6000 -- three waves per SIMD share its VALU), so they have the slack.
-    const int st = t % SI, role = vb_uniform(t / SI);
-    const int sdc = st & 7, sr = (st >> 3) * 2;            // rows q0 + sr, q0 + sr + 1; 16-byte column chunk sdc
-    // addresses: byte offsets of this thread's row q0 = 0 from wave-uniform bases, 32 bits (launcher: tokens x pitch x 2 below
-    // 2^32); a chunk adds a small signed multiple of the pitch, which also expresses the clamp of rows past S
-    const int sldb = (int)((role == 2 ? ldx : (long)H) * 2);                 // row pitch in bytes
-    // bases stay kernel-lifetime SCALARS (head 0, token 0); everything that changes with the pair -- its first token row and its head's
-    // column block -- is folded into the 32-bit per-lane offset (launcher: tokens x pitch x 2 below 2^32)
-    const unsigned char* const sbase = (const unsigned char*)(role == 2 ? qkv : dctx);      // Q rows | dO rows (roles 0 and 1)
-    const unsigned char* const obase = (const unsigned char*)octx;                          // O rows: same pitch and offsets as dO
-    unsigned off_s = 0;
-    auto set_fetch = [&](int p) {
-        f_bh = p; f_b = p / a.nh; f_h = p % a.nh; f_row0 = (long)f_b * S;
-        off_s = (unsigned)((f_row0 + sr) * (long)sldb) + (unsigned)(f_h * D * 2) + sdc * 16;
-    };
-    u32x4 c0 = u32x4{0u, 0u, 0u, 0u}, c1 = c0, o0 = c0, o1 = c0;
-    float c_lse = 0.f;
-    uint64_t c_bits[BPT];
-#pragma unroll
-    for (int j = 0; j < BPT; ++j) c_bits[j] = 0;
-    static_assert(BPT == 1 && CQ * 4 * NW == SI, "keep-bit words of a chunk: one per thread of waves 0-3");
-    auto load_chunk = [&](int q0) {
-        // (an opaque zero keeps this call's index arithmetic out of the pair loop's invariants: hoisted, it was spilled)
-        int z = 0;
-        vb_pin(z);
-        const int sr = (st >> 3) * 2 + z, lane = (t & 63) + z;
-        // rows q0 + sr (+ 1), clamped to S - 1, as a row delta from this thread's chunk-0 row sr
-        const int d0r = q0 + sr < S ? q0 : S - 1 - sr, d1r = q0 + sr + 1 < S ? q0 + 1 : S - 1 - sr;
-        // ONE pair of loads for every role (role 0 reads the same dO rows as role 1): two branches filling the same registers
-        // made the compiler put a vmcnt wait in front of the second branch's loads
-        c0 = *(const u32x4*)(sbase + (off_s + (unsigned)(d0r * sldb)));
-        c1 = *(const u32x4*)(sbase + (off_s + (unsigned)(d1r * sldb)));
-        if (role == 0) {                                   // wave-uniform: a scalar branch
-            o0 = *(const u32x4*)(obase + (off_s + (unsigned)(d0r * sldb)));
-            o1 = *(const u32x4*)(obase + (off_s + (unsigned)(d1r * sldb)));
-            // scalar bases + 32-bit byte offsets (64-bit per-lane addresses here were the last registers the pair loop spilled)
-            const unsigned char* lse_b = (const unsigned char*)(a.lse + (long)f_bh * S);
-            const unsigned char* bits_b = (const unsigned char*)(a.keepbits + ((long)f_bh * S + q0) * 4 * NW);
-            if (wave == 0) c_lse = *(const float*)(lse_b + (unsigned)((q0 + lane < S ? q0 + lane : S - 1) * 4));      // CQ = 64 queries = one wave
-            if (a.p > 0.f) {
-                const int i = t + z, last = (S - q0) * 4 * NW - 1;
-                c_bits[0] = *(const uint64_t*)(bits_b + (unsigned)((i < last ? i : last) * 8));
-            }
-        }
-    };
-    auto store_tr2 = [&](unsigned char* lds, const u32x4& x0, const u32x4& x1) {
-        const int pitch = tr_pitch<bf16>(CQ);
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const uint32_t a0 = x0[w], b0 = x1[w];
-            *(uint32_t*)(lds + (sdc * 8 + 2 * w) * pitch + sr * 2) = (a0 & 0xFFFFu) | (b0 << 16);
-            *(uint32_t*)(lds + (sdc * 8 + 2 * w + 1) * pitch + sr * 2) = (a0 >> 16) | (b0 & 0xFFFF0000u);
-        }
-    };
-    auto store_chunk = [&](int q0) {
-        // the fetched registers are consumed from here on, not earlier (the compiler would hoist the selects and the
-        // D products -- and with them the wait for the fetch -- above the phase the fetch is supposed to run under)
-        vb_pin(c0); vb_pin(c1); vb_pin(o0); vb_pin(o1); vb_pin(c_lse);
-#pragma unroll
-        for (int j = 0; j < BPT; ++j) vb_pin(c_bits[j]);
-        const u32x4 z0 = zsel(q0 + sr < S, c0), z1 = zsel(q0 + sr + 1 < S, c1);        // rows past S are zeros
-        if (role > 0) {
-            unsigned char* rm = role == 2 ? ldsQ : ldsDO;
-            *(u32x4*)(rm + rm_off<T>(sr, sdc)) = z0;
-            *(u32x4*)(rm + rm_off<T>(sr + 1, sdc)) = z1;
-            store_tr2(role == 2 ? ldsQT : ldsDOT, z0, z1);
-        } else {                                           // D[q] = dO[q] . O[q]: 8 products per thread, 8 threads per row
-            const bf16x8 d0 = *(const bf16x8*)&z0, d1 = *(const bf16x8*)&z1, p0 = *(const bf16x8*)&o0, p1 = *(const bf16x8*)&o1;
-            float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { s0 += (float)d0[j] * (float)p0[j]; s1 += (float)d1[j] * (float)p1[j]; }
-            s0 = oct_sum(s0); s1 = oct_sum(s1);
-            if (sdc == 0) { ldsD[sr] = s0; ldsD[sr + 1] = s1; }
-            // lse in units of log 2 (phase A computes exp2 of one packed fma); exp2(x - inf) = 0 for padded queries
-            if (wave == 0) ldsLse[lane] = q0 + lane < S ? c_lse * 1.44269504088896340736f : INFINITY;
-            // keep words, re-laid for phase A: a lane there needs the SAME 32-bit half (its wave's key fragment) and the same
-            // key group g of the four queries lg*4 + 0..3 -- stored as [qf][lg][g][half][r] they are one 16-byte read instead
-            // of four address computations and four 4-byte reads
-            const int i = t, ql = i >> 2, g = i & 3;
-            const uint64_t kw = (a.p > 0.f && q0 + ql < S) ? c_bits[0] : ~(uint64_t)0;
-            uint32_t* bw = (uint32_t*)ldsBits + (((ql >> 2) * 4 + g) * 8 + (ql & 3));
-            bw[0] = (uint32_t)kw; bw[4] = (uint32_t)(kw >> 32);
-        }
-    };
-    const float sc2 = a.scale * 1.44269504088896340736f;
-    float mk2 = 0.f;
-    set_fetch(bh);
-    fetch_pair();
-    load_chunk(0);
-    for (;;) {                                             // the workgroup's pairs: blockIdx.x, blockIdx.x + G, ...
-    bh = f_bh; b = f_b; h = f_h; row0 = f_row0;
-    const bool has_next = bh + G < npairs;
-    vb_wait_vmcnt<0>();                                    // my LDS-direct copies of this pair's K rows have landed (issued >= one phase B +
-    __syncthreads();                                       // one epilogue ago; the compiler does not track them) -- and, after the barrier,
-                                                           // everyone's; the previous pair's bias partials (they alias the images) have been read
-    mk2 = (kok ? mk_raw : -INFINITY) * 1.44269504088896340736f;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {                       // keys past S: zero fragments (see fetch_pair)
-        const u32x4 zk = zsel(kok, *(const u32x4*)&kb[ks]), zv = zsel(kok, *(const u32x4*)&vb[ks]);
-        kb[ks] = *(const bf16x8*)&zk; vb[ks] = *(const bf16x8*)&zv;
-    }
-    {   // K^T image (from the K rows the LDS-direct copies brought) and a zeroed dS tile
-        int tz = t;
-        vb_pin(tz);
-        const int kdc = tz & 7, kr = (tz >> 3) * 2;
-        const u32x4 kx0 = *(const u32x4*)(ldsKN + kr * 128 + kdc * 16), kx1 = *(const u32x4*)(ldsKN + (kr + 1) * 128 + kdc * 16);
-        const u32x4 x0 = zsel(kr < S, kx0), x1 = zsel(kr + 1 < S, kx1);
-        const int pitch = tr_pitch<bf16>(FNK);
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const uint32_t lo = x0[w], hi = x1[w];
-            *(uint32_t*)(ldsKT + (kdc * 8 + 2 * w) * pitch + kr * 2) = (lo & 0xFFFFu) | (hi << 16);
-            *(uint32_t*)(ldsKT + (kdc * 8 + 2 * w + 1) * pitch + kr * 2) = (lo >> 16) | (hi & 0xFFFF0000u);
-        }
-        for (int i = tz; i < CQ * TSP / 8; i += FNT) *(uint64_t*)(ldsDS + i * 8) = 0;
-    }
-    use_set(0);
-    store_chunk(0);
-    __syncthreads();                                       // chunk 0, the K^T image and the zeroed tile are in LDS
-    if (CQ < S) load_chunk(CQ);
-#pragma unroll
-    for (int df = 0; df < 4; ++df) { dkT[df] = f32x4{0.f, 0.f, 0.f, 0.f}; dvT[df] = dkT[df]; }
-
-    // q/k/v bias gradients = column sums of dqkv over tokens.  This kernel holds dK^T, dV^T (and, block by block, dQ^T) in
-    // fp32 registers with the token index along the LANES (li): a 16-lane butterfly per value, once per workgroup, gives the
-    // per-sample sums, which leave through a [B][3H] workspace (one slot per workgroup: no same-address global atomics --
-    // those cost +140 us per layer in round 1) and a tiny reduction kernel.  Replaces an 85 us pass over dqkv per layer.
-    f32x4 dqsum = f32x4{0.f, 0.f, 0.f, 0.f};               // this wave's phase-B blocks all have df = wave & 3 (12 % 4 == 0)
-    int cur = 0;
-    for (int q0 = 0; q0 < S; q0 += CQ, cur ^= 1) {
-        use_set(cur);
-        // ---- phase A
-        if (wave_on) {
-#pragma unroll
-            for (int qc = 0; qc < CQ / 32; ++qc) {
-                if (q0 + qc * 32 >= S) continue;
-                f32x4 pd[2], dsv[2];
-#pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-                    const int qf = 2 * qc + hf;            // fragment index inside the chunk
-                    f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = s;
-#pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
-                        s = vb_mma(frag_rm(ldsQ, qf * 16 + li, ks, lg, T()), kb[ks], s);
-                        dp = vb_mma(frag_rm(ldsDO, qf * 16 + li, ks, lg, T()), vb[ks], dp);
-                    }
-                    // lane: key = kf*16 + li (column), queries q0 + qf*16 + lg*4 + r (rows)
-                    const f32x4 lse4 = *(const f32x4*)(ldsLse + qf * 16 + lg * 4);         // already times log2(e)
-                    const f32x4 d4 = *(const f32x4*)(ldsD + qf * 16 + lg * 4);
-                    // this wave's nibble of the keep words lies in ONE 32-bit half (kf is wave-uniform); the four queries'
-                    // halves are adjacent (see store_chunk); one select per probability yields the factor for both products
-                    const u32x4 w4 = *(const u32x4*)((const uint32_t*)ldsBits + (((qf * 4 + lg) * 4 + (li >> 2)) * 2 + ((kf & 15) >> 3)) * 4);
-                    // p = exp(s * scale + mask - lse) = exp2(s * (scale log2 e) + (mask log2 e - lse log2 e)): two packed
-                    // instructions per two probabilities instead of an fma, a subtract and a multiply each
-                    f32x4 xe;
-#pragma unroll
-                    for (int r = 0; r < 4; r += 2) {
-                        const f32x2 c = vb_splat2(mk2) - f32x2{lse4[r], lse4[r + 1]};
-                        const f32x2 x = vb_fma2(f32x2{s[r], s[r + 1]}, vb_splat2(sc2), c);
-                        xe[r] = x[0]; xe[r + 1] = x[1];
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int ql = qf * 16 + lg * 4 + r;
-                        const float p = fast_exp2(xe[r]);
-                        const float kscale = ((w4[r] >> ((kf & 7) * 4 + (li & 3))) & 1u) ? a.inv_keep : 0.f;
-                        const float pdrop = p * kscale;
-                        const float dpv = dp[r] * kscale;
-                        pd[hf][r] = pdrop;
-                        dsv[hf][r] = p * (dpv - d4[r]);             // dS / scale: the factor goes onto dK^T and dQ^T once (below)
-                        *(bf16*)(ldsDS + ql * TSP + (kf * 16 + li) * 2) = (bf16)dsv[hf][r];      // dS / scale as [query][key]
-                    }
-                }
-                bf16x8 pb, dsb;
-                pack_b(pb, pd[0], pd[1]);
-                pack_b(dsb, dsv[0], dsv[1]);
-#pragma unroll
-                for (int df = 0; df < 4; ++df) {
-                    dvT[df] = vb_mma(frag_tr(ldsDOT, tr_pitch<T>(CQ), df * 16 + li, qc, lg, T()), pb, dvT[df]);
-                    dkT[df] = vb_mma(frag_tr(ldsQT, tr_pitch<T>(CQ), df * 16 + li, qc, lg, T()), dsb, dkT[df]);
-                }
-            }
-        }
-        if (q0 + CQ < S) {                                 // the next chunk's images go to the other set meanwhile
-            use_set(cur ^ 1);
-            store_chunk(q0 + CQ);
-        }
-        __syncthreads();                                   // the chunk's dS tile is complete, the next chunk is staged
-        {   // ONE call site fills the chunk registers (two sites -- "next-next chunk" and "the next pair's chunk 0" -- made the compiler load
-            // into temporaries and copy them into the loop-carried registers behind a vmcnt wait: the round trip was back in the open)
-            const bool more = q0 + 2 * CQ < S;
-            const bool pre = !more && q0 + CQ >= S && has_next;   // last chunk: K / V fragments and chunk registers are dead -- the NEXT
-            if (pre) set_fetch(bh + G);                           // pair's prologue data starts its trip under this pair's phase B and epilogue
-            if (more || pre) load_chunk(more ? q0 + 2 * CQ : 0);
-            if (pre) fetch_pair();
-        }
-        // ---- phase B: dQ^T block (d rows df*16.., query columns qf*16..) = K^T dS^T over all keys.  16 blocks, 12 waves:
-        // wave w owns block w (qf = w >> 2, df = w & 3) and waves 0..3 also block w + 12 (qf = 3, the SAME df): the two are
-        // computed together -- one K^T fragment feeds both, and their MFMA chains (six dependent instructions each) overlap
-        // instead of running back to back on the four waves the whole workgroup then waits for
-        {
-            static_assert(CQ == 64 && FWPB == 12, "block ownership below assumes 16 blocks on 12 waves");
-            const int df = wave & 3, qf0 = wave >> 2, qf1 = 3;
-            const bool v0 = q0 + qf0 * 16 < S, v1 = wave < 4 && q0 + qf1 * 16 < S;      // wave-uniform
-            if (v0 || v1) {
-                f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-#pragma unroll
-                for (int ks = 0; ks < FNK / 32; ++ks) {
-                    if (ks * 32 >= S) continue;
-                    // B operand: lane (n = query li, g = lg) holds dS[q][key(g, j)], key(g, j) = 32 ks + 16 (j >> 2) + 4 g + (j & 3)
-                    const bf16x8 kt = frag_tr(ldsKT, tr_pitch<T>(FNK), df * 16 + li, ks, lg, T());
-                    if (v0) {
-                        const unsigned char* src = ldsDS + (qf0 * 16 + li) * TSP + (32 * ks + 4 * lg) * 2;
-                        const bf16x4 lo = *(const bf16x4*)src, hi = *(const bf16x4*)(src + 32);
-                        acc0 = vb_mma(kt, bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}, acc0);
-                    }
-                    if (v1) {
-                        const unsigned char* src = ldsDS + (qf1 * 16 + li) * TSP + (32 * ks + 4 * lg) * 2;
-                        const bf16x4 lo = *(const bf16x4*)src, hi = *(const bf16x4*)(src + 32);
-                        acc1 = vb_mma(kt, bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}, acc1);
-                    }
-                }
-                if (v0) {
-                    const int q = q0 + qf0 * 16 + li;
-                    acc0 *= a.scale;                        // the score scale left out of dS in phase A
-                    if (q < S) store4((T*)a.dqkv + (row0 + q) * ldx + h * D + df * 16 + lg * 4, acc0);
-                    dqsum += acc0;                          // columns of padded queries are exactly 0 (their dS rows are)
-                }
-                if (v1) {
-                    const int q = q0 + qf1 * 16 + li;
-                    acc1 *= a.scale;
-                    if (q < S) store4((T*)a.dqkv + (row0 + q) * ldx + h * D + df * 16 + lg * 4, acc1);
-                    dqsum += acc1;
-                }
-            }
-        }
-        __syncthreads();                                   // phase B is done with the tile before the next phase A writes it
-    }
-#pragma unroll
-    for (int df = 0; df < 4; ++df) dkT[df] *= a.scale;     // dK^T was accumulated from dS / scale (phase A): one multiply per output
-    int te = t;                                            // epilogue: opaque thread index (see fetch_pair)
-    vb_pin(te);
-    const int lane_e = te & 63, wave_e = te >> 6, lg_e = lane_e >> 4;
-    {   // 16-byte stores (store4x2: every lane takes part in the lane exchange, the store is predicated on a real key)
-        const int key_e = wave_e * 16 + (lane_e & 15);
-        const bool kok_e = key_e < S;
-        const int keyc_e = kok_e ? key_e : S - 1;
-        T* dkrow = (T*)a.dqkv + (row0 + keyc_e) * ldx + H + h * D;
-        T* dvrow = (T*)a.dqkv + (row0 + keyc_e) * ldx + 2 * H + h * D;
-        const bool wide = wide_ok(a.dqkv, ldx);
-#pragma unroll
-        for (int dj = 0; dj < 2; ++dj) {
-            store4x2(dkrow + dj * 32, lg_e, dkT[2 * dj], dkT[2 * dj + 1], kok_e, wide);
-            store4x2(dvrow + dj * 32, lg_e, dvT[2 * dj], dvT[2 * dj + 1], kok_e, wide);
-        }
-    }
-    if (a.bias_ws) {
-        // every LDS image is idle now (the loop ended on a barrier): each lane parks its 36 accumulators (4 dQ sums, 16 dK^T,
-        // 16 dV^T) as raw[wave][value][lane] -- 36 conflict-free ds_write_b32 -- and 192 threads add up, per output column d,
-        // the 16 lanes (keys / queries) x the waves that hold it.  (The first form reduced inside each wave with 36 DPP
-        // row sums per lane before going to LDS: ~5000 of the workgroup's ~45000 cycles, by the in-kernel cycle trace.)
-        float* raw = (float*)smem;                          // 12 x 36 x 64 floats = 108 KB of the 124 KB
-        constexpr int NV = 4 + 2 * 16;
-        static_assert((size_t)FWPB * NV * 64 * 4 <= 2 * (size_t)SETB + tr_bytes<T>(FNK) + (size_t)CQ * TSP, "raw partials fit the idle images");
-        float* mine = raw + ((long)wave_e * NV) * 64 + lane_e;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) mine[r * 64] = dqsum[r];
-#pragma unroll
-        for (int df = 0; df < 4; ++df)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {                   // padded keys contribute exact zeros
-                mine[(4 + df * 4 + r) * 64] = dkT[df][r];
-                mine[(20 + df * 4 + r) * 64] = dvT[df][r];
-            }
-        __syncthreads();
-        if (te < 3 * D) {
-            const int which = te / D, dd = te % D, df = dd >> 4, glg = (dd >> 2) & 3, r = dd & 3;
-            float sum = 0.f;
-            if (which == 0) {                               // dQ^T block df lives in the waves with (wave & 3) == df
-                for (int w = df; w < FWPB; w += 4) {
-                    const f32x4* src = (const f32x4*)(raw + ((long)w * NV + r) * 64 + glg * 16);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) { const f32x4 x = src[i]; sum += (x[0] + x[1]) + (x[2] + x[3]); }
-                }
-            } else {
-                const int v = (which == 1 ? 4 : 20) + df * 4 + r;
-                for (int w = 0; w < FWPB; ++w) {
-                    const f32x4* src = (const f32x4*)(raw + ((long)w * NV + v) * 64 + glg * 16);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) { const f32x4 x = src[i]; sum += (x[0] + x[1]) + (x[2] + x[3]); }
-                }
-            }
-            a.bias_ws[((long)b * 3 + which) * H + h * D + dd] = sum;
-        }
-    }
-    if (!has_next) break;
-    }
-}
-
 // out[c] += sum over samples of ws[b][c]  (c < 3H): 256 columns x a slice of the batch per workgroup
 VB_KERNEL VB_LAUNCH_BOUNDS(256) attn_bias_reduce_kernel(const float* ws, float* out, int B, int C, int rows_per_block) {
     const int c = blockIdx.x * 256 + threadIdx.x;
@@ -1777,7 +1399,6 @@ template <int NKF, int CQ> size_t fused_smem() {
            tr_bytes<bf16>(FNK) + (size_t)CQ * TSP;
 }
 
-template <int NKF, int CQ> size_t fused_pers_smem() { return fused_smem<NKF, CQ>() + (size_t)FNK * 128; }   // + the fetched pair's K rows
 template <typename T, int NKF> size_t fwd_smem() { return rm_bytes<T>(NKF * 16) + tr_bytes<T>((NKF + 1) / 2 * 32) + NKF * 16 * 4; }
 template <typename T, int NKF> size_t dq_smem() { return 2 * rm_bytes<T>(NKF * 16) + tr_bytes<T>(NKF * 16) + NKF * 16 * 4; }
 template <typename T, int NKF> size_t dkv_smem() {
@@ -1819,10 +1440,6 @@ int launch_all(int which, const AttnArgs& a, hipStream_t s) {
                 (long)a.B * a.S * 3 * a.nh * D * 2 < (1L << 32)) {   // one-pass backward (needs the forward output; 32-bit byte offsets)
                 // 64-query chunks (86 KB of LDS, one workgroup per CU): 528-541 us per layer at B=512; 32-query chunks (two
                 // workgroups per CU, twice the barriers): 575 us
-                if (vb_opts_for((void*)s).attn_two_pass == 2) {          // persistent form (A/B arm): one workgroup per CU walks the pairs
-                    const unsigned g = (unsigned)(a.B * a.nh < vb_num_cus() ? a.B * a.nh : vb_num_cus());
-                    VB_LAUNCH((attn_bwd_fused_pers_kernel<NKF, 64>), dim3(g), dim3(FNT), (fused_pers_smem<NKF, 64>()), s, a);
-                } else
                 VB_LAUNCH((attn_bwd_fused_kernel<NKF, 64>), grid, dim3(FNT), (fused_smem<NKF, 64>()), s, a);
                 return vb_check_launch() == VB_OK ? 1 : VB_ERR_LAUNCH;      // 1: the bias workspace (if any) was filled
             }

@@ -227,19 +227,6 @@ VB_DEVICE void vb_lds_add(float* p, float v) {
 }
 #endif
 
-// The same copy as INLINE ASM (global_load_lds_dwordx4; M0 = LDS byte address of the wave's 1-KB slot): the compiler keeps no score of
-// it, so it neither drains it in front of every __syncthreads() that MIGHT see one in flight (the builtin form inside a loop costs a
-// vmcnt(0) at every barrier of the loop: measured on the persistent attention backward) nor waits for it anywhere -- the caller places
-// vb_wait_vmcnt<0>() + a barrier in front of the first read of the destination.  lds_wave_base must be wave-uniform.
-#ifdef VB_EMU
-VB_DEVICE void vb_glds16_untracked(const void* gsrc, unsigned char* lds_wave_base) { vb_glds16(gsrc, lds_wave_base); }
-#else
-VB_DEVICE void vb_glds16_untracked(const void* gsrc, unsigned char* lds_wave_base) {
-    const unsigned m0v = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds_wave_base;
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gsrc), "s"(m0v) : "memory", "m0");
-}
-#endif
-
 // The same copy through a BUFFER descriptor (buffer_load_dwordx4 ... offen lds): address = descriptor base (4 SGPRs) + per-lane
 // 32-bit byte offset (VGPR) + wave-uniform 32-bit byte offset (SGPR).  A K tile advances the SGPR offset, so issuing a copy
 // costs no vector arithmetic at all -- the flat form above needs a 64-bit per-lane add unless the compiler happens to match

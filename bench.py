@@ -542,6 +542,7 @@ def main():
                     help="vb_stream_opts.nt_kernel for the whole run (0 = chosen per shape; 81 / 90 for A/B runs)")
     ap.add_argument("--attn-two-pass", type=int, default=0,
                     help="vb_stream_opts.attn_two_pass for the whole run (A/B: 1 = two-pass attention backward)")
+    ap.add_argument("--lib-path", default="", help="developer A/B runs only: bind this build of libvisualbert_hip.so instead of the in-tree one")
     ap.add_argument("--dev-debug", type=int, default=0,
                     help="developer A/B runs only: bind libvisualbert_hip_dev.so for the whole run and set vb_gemm_set_debug(bits)")
     ap.add_argument("--pmc-traffic", default="auto", choices=["auto", "off"],
@@ -623,6 +624,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.lib_path:
+        from visualbert_amd import _lib
+        _lib.set_library(os.path.abspath(args.lib_path))
     if args.dev_debug:
         from visualbert_amd import _lib
         _lib.use_dev_library().vb_gemm_set_debug(args.dev_debug)

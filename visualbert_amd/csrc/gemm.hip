@@ -281,6 +281,7 @@ VB_DEVICE void epi_lane_init(EpiLane& e, const GemmArgs& g, int nw0, int lane) {
 static int epi_needs(const GemmArgs& g, size_t t_size, size_t to_size) {
     int n = 0;
     if (g.addend || g.accumulate) n |= EPI_ADD;
+    if (g.accumulate) n |= EPI_RAGGED;                 // "+= C" keeps the run-time epilogue: the specialised EPI_ADD instantiation means "addend, no accumulate"
     if (g.colsum) n |= EPI_COLSUM;
     bool aligned = (g.N % 8) == 0 && (((g.ldc * to_size) | (uintptr_t)g.C) & 15) == 0 &&
                    (!g.bias || ((uintptr_t)g.bias & 15) == 0) &&
@@ -856,13 +857,14 @@ VB_DEVICE void gemm_epilogue_fragrow(f32x4 (&a)[4], unsigned char* slab, const G
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
         const int m = mrow0 + it * 8 + (lane >> 3);
-        if constexpr (sizeof(T) == 2) {
-            if (pre_kind) {                             // row operand already in registers (gemm_epilogue_private)
-                const bf16x8 x = *(const bf16x8*)&pre[it];
+        // pre_kind is a COMPILE-TIME fact of the specialised bf16 instantiations (1: aux_in, 2: addend): with a run-time fallback to
+        // epi_load8 next to it the compiler had to assume a load might be pending at every later use and waited vmcnt(0) -- for the
+        // previous fragment row's stores -- eight times per tile
+        if constexpr (sizeof(T) == 2 && !(OPT & EPI_RAGGED) && ACT >= 0 && ((OPT & EPI_ADD) || ACT == VB_ACT_MUL_AUX || ACT == VB_ACT_GELU_GRAD)) {
+            const bf16x8 x = *(const bf16x8*)&pre[it];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { if (pre_kind == 1) xa[it][j] = (float)x[j]; else xd[it][j] = (float)x[j]; }
-                continue;
-            }
+            for (int j = 0; j < 8; ++j) { if (pre_kind == 1) xa[it][j] = (float)x[j]; else xd[it][j] = (float)x[j]; }
+            continue;
         }
         if (e.vec && m < g.M && e.ncol < g.N) epi_load8<T, TO, ACT, OPT>(xa[it], xd[it], xc[it], g, m, e.ncol);
     }
@@ -908,44 +910,58 @@ VB_DEVICE void epi_pause(const GemmArgs& g) {
     (void)g;
 #endif
 }
-template <typename T, typename TO, int ACT, int OPT>
+// FLUSH: one compiler-visible vmcnt(0) after the epilogue's loads (below).  (Loading the bias BEFORE the K loop of the one-tile-per-workgroup
+// kernel, so that this wait costs nothing, does not fit: 8 more registers through the K loop spill, and an EpiLane handed over by
+// POINTER lives in scratch memory altogether -- 128 bytes per lane, 200 scratch instructions.)
+template <typename T, typename TO, int ACT, int OPT, bool FLUSH = false>
 VB_DEVICE void gemm_epilogue_private(f32x4 (&acc)[8][4], unsigned char* slab, const GemmArgs& g, int mw0, int nw0, int lane) {
     EpiLane e;
     epi_lane_init<T, TO, OPT>(e, g, nw0, lane);
     // The per-row operand of the specialised epilogues (saved GELU' / residual gradient) is fetched for the WHOLE 128x64
-    // block in two batches of 8 independent 16-byte loads per lane (the fragment registers are dead by now) instead of
-    // two per fragment row, each waiting out an HBM round trip before its multiply (8 round trips per tile).
+    // block as 16 independent 16-byte loads per lane, ALL ahead of the first store (the fragment registers are dead by now: 64 registers),
+    // instead of two per fragment row, each waiting out an HBM round trip before its multiply (8 round trips per tile).  Until round 5
+    // they went out in two batches of 8 with four fragment rows of stores in between: the wait for the second batch was then a wait
+    // for those stores' acknowledgements as well (one in-order vmcnt), and in the persistent kernel -- LDS-direct copies of the next
+    // tile in flight, exec-masked blocks per fragment row -- the compiler re-waited vmcnt(0) at later uses of the bias and batch
+    // registers too, i.e. for every store issued since (74 such waits in the "+ addend" instantiation: 667 us where the same source in
+    // the developer build, laid out differently, ran 603).  Now: every load of the epilogue first, ONE compiler-visible vmcnt(0), then
+    // eight fragment rows of LDS traffic and stores with nothing left to wait for.
     constexpr bool PRE_AUX = sizeof(T) == 2 && !(OPT & EPI_RAGGED) && (ACT == VB_ACT_MUL_AUX || ACT == VB_ACT_GELU_GRAD);
     constexpr bool PRE_ADD = sizeof(T) == 2 && !(OPT & EPI_RAGGED) && ACT >= 0 && !PRE_AUX && (OPT & EPI_ADD);
-    u32x4 pre[4][2];                                // two batches of 4 fragment rows (8 loads in flight, 32 VGPRs)
-    int pre_kind = 0;
+    u32x4 pre[8][2];                                // all 8 fragment rows (16 loads in flight, 64 VGPRs)
+    constexpr int pre_kind = PRE_AUX ? 1 : (PRE_ADD ? 2 : 0);   // EPI_ADD here = "addend, no accumulate" (epi_needs sends "+= C" to the run-time epilogue)
     const unsigned char* pbase = nullptr;
     long pld = 0;
     if constexpr (PRE_AUX || PRE_ADD) {
-        if (PRE_AUX) { pbase = (const unsigned char*)g.aux_in; pld = g.ld_aux; pre_kind = 1; }
-        else if (g.addend && !g.accumulate) { pbase = (const unsigned char*)g.addend; pld = g.ld_addend; pre_kind = 2; }
+        if (PRE_AUX) { pbase = (const unsigned char*)g.aux_in; pld = g.ld_aux; }
+        else { pbase = (const unsigned char*)g.addend; pld = g.ld_addend; }
     }
     // row addressing without per-row 64-bit multiplies: one product per matrix here, 64-bit adds from then on
     const int mlane = mw0 + (lane >> 3);
     const long stepc = 16 * g.ldc, stepa = 16 * g.ld_aux;
     long offc = (long)mlane * g.ldc + e.ncol, offa = (long)mlane * g.ld_aux + e.ncol;
-    auto preload = [&](int mi0) {
-        if constexpr (PRE_AUX || PRE_ADD) {
-            if (pre_kind) {
+    if constexpr (PRE_AUX || PRE_ADD) {
+        if (pre_kind) {
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
-                    for (int it = 0; it < 2; ++it) {
-                        int m = mw0 + (mi0 + mi) * 16 + it * 8 + (lane >> 3);
-                        m = m < g.M ? m : g.M - 1;                  // clamped rows are loaded but never stored
-                        const int n = e.ncol < g.N ? e.ncol : 0;
-                        pre[mi][it] = *(const u32x4*)(pbase + ((long)m * pld + n) * 2);
-                    }
-            }
+                for (int it = 0; it < 2; ++it) {
+                    int m = mw0 + mi * 16 + it * 8 + (lane >> 3);
+                    m = m < g.M ? m : g.M - 1;                  // clamped rows are loaded but never stored
+                    const int n = e.ncol < g.N ? e.ncol : 0;
+                    pre[mi][it] = *(const u32x4*)(pbase + ((long)m * pld + n) * 2);
+                }
         }
-    };
+    }
+    // ONE compiler-visible vmcnt(0) for everything the epilogue loaded -- the bias, the row operands (+ whatever copies of the next tile
+    // were in flight).  Without it the compiler, which finds the first use of those registers inside the exec-masked block of fragment
+    // row 0, RE-WAITS at every later use -- `s_waitcnt vmcnt(1)`, `vmcnt(0)` in front of each store's arithmetic -- and since a wave has
+    // one in-order vmcnt for loads and stores, each of those waits is a wait for the PREVIOUS STORE's acknowledgement: sixteen
+    // serialised store round trips per wave and tile.  That, not the store path's rate, was the per-tile "store cost" of rounds 1-4
+    // ("Round 5").  Where the waits PACED the stores to the benefit of a co-resident workgroup, the caller leaves
+    // FLUSH off (the two-workgroup kernel's fp32 and x GELU' epilogues).
+    if constexpr (FLUSH) vb_wait_vmcnt0_visible();
     // constant indices spelled out: the accumulators must never be addressed by a loop variable
-    preload(0);
     gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[0], slab, g, mw0 + 0, lane, e, pre[0], pre_kind, offc, offa);
     epi_pause(g);
     gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[1], slab, g, mw0 + 16, lane, e, pre[1], pre_kind, offc + stepc, offa + stepa);
@@ -954,15 +970,14 @@ VB_DEVICE void gemm_epilogue_private(f32x4 (&acc)[8][4], unsigned char* slab, co
     epi_pause(g);
     gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[3], slab, g, mw0 + 48, lane, e, pre[3], pre_kind, offc + 3 * stepc, offa + 3 * stepa);
     epi_pause(g);
-    preload(4);
     offc += 4 * stepc; offa += 4 * stepa;
-    gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[4], slab, g, mw0 + 64, lane, e, pre[0], pre_kind, offc, offa);
+    gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[4], slab, g, mw0 + 64, lane, e, pre[4], pre_kind, offc, offa);
     epi_pause(g);
-    gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[5], slab, g, mw0 + 80, lane, e, pre[1], pre_kind, offc + stepc, offa + stepa);
+    gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[5], slab, g, mw0 + 80, lane, e, pre[5], pre_kind, offc + stepc, offa + stepa);
     epi_pause(g);
-    gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[6], slab, g, mw0 + 96, lane, e, pre[2], pre_kind, offc + 2 * stepc, offa + 2 * stepa);
+    gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[6], slab, g, mw0 + 96, lane, e, pre[6], pre_kind, offc + 2 * stepc, offa + 2 * stepa);
     epi_pause(g);
-    gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[7], slab, g, mw0 + 112, lane, e, pre[3], pre_kind, offc + 3 * stepc, offa + 3 * stepa);
+    gemm_epilogue_fragrow<T, TO, ACT, OPT>(acc[7], slab, g, mw0 + 112, lane, e, pre[7], pre_kind, offc + 3 * stepc, offa + 3 * stepa);
     epi_pause(g);
     if constexpr (OPT & EPI_COLSUM) epi_colsum_flush(e, g, nw0, lane);
 }
@@ -1235,7 +1250,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS(512) gemm_nt_8ph_kernel(GemmArgs g) {
                 int m0, n0;
                 origin(cj, m0, n0);
                 if constexpr (DIRECT) gemm_epilogue_direct<TE, TO, ACT, OPT>(acc, g, m0 + wr * 128, n0 + wc * 64, lane);
-                else gemm_epilogue_private<TE, TO, ACT, OPT>(acc, slab, g, m0 + wr * 128, n0 + wc * 64, lane);
+                else gemm_epilogue_private<TE, TO, ACT, OPT, true>(acc, slab, g, m0 + wr * 128, n0 + wc * 64, lane);
     #pragma unroll
                 for (int mi = 0; mi < 8; ++mi)
     #pragma unroll
@@ -1292,7 +1307,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS(512) gemm_nt_8ph_kernel(GemmArgs g) {
             int m0, n0;
             origin(cj, m0, n0);
             if constexpr (DIRECT) gemm_epilogue_direct<TE, TO, ACT, OPT>(acc, g, m0 + wr * 128, n0 + wc * 64, lane);
-            else gemm_epilogue_private<TE, TO, ACT, OPT>(acc, slab, g, m0 + wr * 128, n0 + wc * 64, lane);
+            else gemm_epilogue_private<TE, TO, ACT, OPT, true>(acc, slab, g, m0 + wr * 128, n0 + wc * 64, lane);
 #pragma unroll
             for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
@@ -1539,7 +1554,11 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(256, 2) gemm_nt_dual_kernel(GemmArgs g) {
         gemm_epilogue_direct<TE, TO, ACT, OPT>(acc, g, m0 + wr * 128, n0 + wc * 64, lane);     // no LDS: no barrier, a wave leaves when it is done
     } else {
         vb_phase_barrier();                                    // every wave is done with the ring: the slabs may alias it
-        gemm_epilogue_private<TE, TO, ACT, OPT>(acc, smem + wave * EPI8_BYTES_PER_WAVE, g, m0 + wr * 128, n0 + wc * 64, lane);
+        // FLUSH (see gemm_epilogue_private): measured per epilogue in the step (profiles/r05_gemm_epilogue_waits.txt) -- on for the plain
+        // and the GELU + GELU' epilogues (-1 ... -2 %), off where un-paced store bursts cost the co-resident workgroup more than the waits
+        // cost this one: the fp32 logits (+12 % with it), x GELU' + column sums (+1.5 %), the split-operand mode (not measured)
+        constexpr bool FLUSH = !X3 && sizeof(TO) == 2 && (ACT == VB_ACT_NONE || ACT == VB_ACT_GELU_SAVE_GRAD);
+        gemm_epilogue_private<TE, TO, ACT, OPT, FLUSH>(acc, smem + wave * EPI8_BYTES_PER_WAVE, g, m0 + wr * 128, n0 + wc * 64, lane);
     }
 }
 
@@ -2378,8 +2397,15 @@ int dispatch_pipe(const GemmArgs& g, hipStream_t s) {
         // k82 / k92 = the shipping epilogue: 642 vs 698 us and 507 vs 544 us at M = 167,936), as they already did in the split mode.
         // (developer library: debug bit 27 restores the round-4 rule for the in-step A/B)
         const bool plain = !g.addend && !g.aux_in && !g.aux_out && !g.colsum && g.act == VB_ACT_NONE && sizeof(TO) == 2;
+#ifdef VB_AB_OLD_ADD_RULE                                  /* one-off A/B build of the product library (tools/gpu_dispatch_ab.sh) */
+        const bool light = false;
+#else
         const bool light = !g.aux_in && !g.aux_out && !g.colsum && g.act == VB_ACT_NONE && !g.accumulate && sizeof(TO) == 2 && !(g.debug & (1 << 27));
+#endif
         variant = (sizeof(T) == 2 && t256 >= 160) ? ((g.K >= 2048 && (plain || light)) ? 81 : 90) : (t128 >= 256 ? 42 : 22);
+#ifdef VB_DEV_KNOBS
+        if (variant == 90 && (g.debug & (1 << 28)) && (plain || light)) variant = 81;      // A/B: the short-K plain / "+ addend" shapes on the persistent kernel too
+#endif
     }
     switch (variant) {
         case 22: return launch_pipe<T, TO, 2, 2>(g, s);

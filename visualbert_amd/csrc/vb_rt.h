@@ -266,9 +266,13 @@ VB_DEVICE u32x4 vb_buf_load16(vb_buf b, unsigned voff, unsigned soff) {
 // barriers").  N must be an immediate.
 #ifdef VB_EMU
 template <int N> VB_DEVICE void vb_wait_vmcnt() {}
+VB_DEVICE void vb_wait_vmcnt0_visible() {}
 VB_DEVICE void vb_raw_barrier() { __syncthreads(); }
 #else
 template <int N> VB_DEVICE void vb_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// vmcnt(0) the COMPILER can see (builtin, gfx9 encoding: vmcnt 0, expcnt 7, lgkmcnt 15): its scoreboard is empty afterwards, so it
+// does not re-wait -- conservatively, with vmcnt(0), i.e. for every store issued since -- at later uses of values loaded before it
+VB_DEVICE void vb_wait_vmcnt0_visible() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 VB_DEVICE void vb_raw_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();

@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 QUIET="--no-cpu-baseline --no-profile --no-h2d --no-parity --strict-dtype none --no-vendor-leg --pmc-traffic off"
-OLD=${1:-tools/libvisualbert_hip_ab_oldrule.so}
+OLD=${1:?usage: gpu_lib_ab.sh <reference build of libvisualbert_hip.so>}
 NEW=visualbert_amd/libvisualbert_hip.so
 for r in 1 2 3; do for lib in $OLD $NEW; do
   timeout 300 python bench.py --steps 15 --warmup 4 --lib-path $lib $QUIET > gpurun_out/ab.json 2>/dev/null

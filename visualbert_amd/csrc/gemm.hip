@@ -1556,7 +1556,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(256, 2) gemm_nt_dual_kernel(GemmArgs g) {
         vb_phase_barrier();                                    // every wave is done with the ring: the slabs may alias it
         // FLUSH (see gemm_epilogue_private): measured per epilogue in the step (profiles/r05_gemm_epilogue_waits.txt) -- on for the plain
         // and the GELU + GELU' epilogues (-1 ... -2 %), off where un-paced store bursts cost the co-resident workgroup more than the waits
-        // cost this one: the fp32 logits (+12 % with it), x GELU' + column sums (+1.5 %), the split-operand mode (not measured)
+        // cost this one: the fp32 logits (+12 % with it), x GELU' + column sums (+2 %); no difference in the split-operand mode
         constexpr bool FLUSH = !X3 && sizeof(TO) == 2 && (ACT == VB_ACT_NONE || ACT == VB_ACT_GELU_SAVE_GRAD);
         gemm_epilogue_private<TE, TO, ACT, OPT, FLUSH>(acc, smem + wave * EPI8_BYTES_PER_WAVE, g, m0 + wr * 128, n0 + wc * 64, lane);
     }
@@ -2392,16 +2392,14 @@ int dispatch_pipe(const GemmArgs& g, hipStream_t s) {
         // partner workgroup's MFMAs -- except long-K GEMMs with a plain epilogue (FFN-out forward: K = 3072), where the
         // persistent 256x256 kernel's K loop is ~10 % faster and the epilogue is 1/48 of the tile
         // (profiles/r02_gemm_ab_*.txt: per step 36.6 -> 34.6 ms of NT GEMMs at B = 512).
-        // Round 5: "+ residual gradient" (an addend, no activation) counts as light too -- the two long-K dgrads of a layer (FFN-in:
-        // K = 3072, QKV: K = 2304) run 7-8 % faster on the persistent kernel alone (profiles/r05_gemm_direct_epilogue_ab.txt, arms
-        // k82 / k92 = the shipping epilogue: 642 vs 698 us and 507 vs 544 us at M = 167,936), as they already did in the split mode.
-        // (developer library: debug bit 27 restores the round-4 rule for the in-step A/B)
+        // Round 5: "+ residual gradient" (an addend, no activation) counts as light too -- with the epilogue's re-waits gone
+        // (gemm_epilogue_private, FLUSH) the two long-K dgrads of a layer (FFN-in: K = 3072, QKV: K = 2304) run 565 us on the persistent
+        // kernel against 624 us on the two-workgroup one inside the step (profiles/r05_gemm_epilogue_waits.txt); before that fix the
+        // product build's persistent "+ addend" instantiation was the slower one (667 us) although the developer build's, laid out
+        // differently, was not (603) -- A/B product builds, never the developer library, when the question is what ships.
+        // (developer library: debug bit 27 restores the round-4 rule)
         const bool plain = !g.addend && !g.aux_in && !g.aux_out && !g.colsum && g.act == VB_ACT_NONE && sizeof(TO) == 2;
-#ifdef VB_AB_OLD_ADD_RULE                                  /* one-off A/B build of the product library (tools/gpu_dispatch_ab.sh) */
-        const bool light = false;
-#else
         const bool light = !g.aux_in && !g.aux_out && !g.colsum && g.act == VB_ACT_NONE && !g.accumulate && sizeof(TO) == 2 && !(g.debug & (1 << 27));
-#endif
         variant = (sizeof(T) == 2 && t256 >= 160) ? ((g.K >= 2048 && (plain || light)) ? 81 : 90) : (t128 >= 256 ? 42 : 22);
 #ifdef VB_DEV_KNOBS
         if (variant == 90 && (g.debug & (1 << 28)) && (plain || light)) variant = 81;      // A/B: the short-K plain / "+ addend" shapes on the persistent kernel too

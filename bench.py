@@ -362,7 +362,19 @@ def roofline_of(summ, steps, peak, batch, workload, traffic_child_args=None):
     key, d = max(summ.items(), key=lambda kv: kv[1]["ms"])
     ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
     traffic, traffic_src = traffic_for(key, batch, workload, traffic_child_args)
+    # the dispatch rule moves shapes between the two K-contiguous kernels from round to round (round 5: the long-K + addend
+    # dgrads left the two-workgroup kernel for the persistent one), so the dominant kernel's own rate is not comparable across
+    # rounds -- this entry is: every K-contiguous GEMM with the dominant kernel's output type, whichever kernel ran it
+    tag = ops.gemm_key_name(key).split(",")[0].split("<")[1]          # "bf16->bf16" / "bf16->fp32"
+    x3 = "[bf16x3" in ops.gemm_key_name(key)
+    fam = [v for k, v in summ.items() if ops.gemm_key_name(k).startswith("gemm_nt_") and ("<" + tag) in ops.gemm_key_name(k)
+           and (("[bf16x3" in ops.gemm_key_name(k)) == x3)]
+    fam = fam or [d]
+    fam_tf = sum(v["flops"] for v in fam) / (sum(v["ms"] for v in fam) * 1e-3) / 1e12
     return dict(bound="mfma", achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
+                nt_gemms_same_output_type=dict(tflops=round(fam_tf, 1), frac=round(fam_tf / peak, 4),
+                                               launches_per_step=sum(v["launches"] for v in fam) / steps,
+                                               ms_per_step=round(sum(v["ms"] for v in fam) / steps, 3)),
                 traffic=traffic, traffic_source=traffic_src,
                 kernel=ops.gemm_key_name(key),
                 launches_per_step=d["launches"] / steps,

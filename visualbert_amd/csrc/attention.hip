@@ -993,6 +993,12 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) attn_bwd_dkv_kernel(AttnArgs a) {
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
                 const int qf = 2 * qc + hf;                // fragment index inside the chunk
+                if constexpr (!std::is_same<T, bf16>::value) {          // (bf16: +6 ... 8 VGPRs across the 128 mark; S <= 192 runs the one-pass kernel anyway)
+                    if (hf == 1 && q0 + qf * 16 >= Sq) {   // wave-uniform: the second half of the last 32-query block is all padding
+                        pd[1] = f32x4{0.f, 0.f, 0.f, 0.f}; dsv[1] = pd[1];
+                        continue;
+                    }
+                }
                 f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = s;
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
@@ -1235,6 +1241,10 @@ VB_KERNEL VB_LAUNCH_BOUNDS(FNT) attn_bwd_fused_kernel(AttnArgs a) {
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
                     const int qf = 2 * qc + hf;            // fragment index inside the chunk
+                    if (hf == 1 && q0 + qf * 16 >= S) {    // wave-uniform: the second half of the LAST 32-query block is all padding
+                        pd[1] = f32x4{0.f, 0.f, 0.f, 0.f}; dsv[1] = pd[1];      // (S = 164: one fragment in twelve); phase B skips its rows too
+                        continue;
+                    }
                     f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = s;
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
@@ -1310,16 +1320,21 @@ VB_KERNEL VB_LAUNCH_BOUNDS(FNT) attn_bwd_fused_kernel(AttnArgs a) {
                         acc1 = vb_mma(kt, bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}, acc1);
                     }
                 }
+                // dQ rows: 32-bit byte offsets from the scalar base (the launcher checks tokens x pitch x 2 < 2^32) -- a 64-bit lane
+                // address here is a register pair the kernel (at its 168-register budget) spills, and its scratch reload's
+                // vmcnt(0) also waits for the chunk fetch in flight
+                const unsigned dq_col = (unsigned)(h * D + df * 16 + lg * 4) * 2u;
+                unsigned char* const dq_base = (unsigned char*)a.dqkv;
                 if (v0) {
                     const int q = q0 + qf0 * 16 + li;
                     acc0 *= a.scale;                        // the score scale left out of dS in phase A
-                    if (q < S) store4((T*)a.dqkv + (row0 + q) * ldx + h * D + df * 16 + lg * 4, acc0);
+                    if (q < S) store4((T*)(dq_base + ((unsigned)((int)row0 + q) * (unsigned)((int)ldx * 2) + dq_col)), acc0);
                     dqsum += acc0;                          // columns of padded queries are exactly 0 (their dS rows are)
                 }
                 if (v1) {
                     const int q = q0 + qf1 * 16 + li;
                     acc1 *= a.scale;
-                    if (q < S) store4((T*)a.dqkv + (row0 + q) * ldx + h * D + df * 16 + lg * 4, acc1);
+                    if (q < S) store4((T*)(dq_base + ((unsigned)((int)row0 + q) * (unsigned)((int)ldx * 2) + dq_col)), acc1);
                     dqsum += acc1;
                 }
             }

@@ -2362,8 +2362,12 @@ int dispatch_pipe(const GemmArgs& g, hipStream_t s) {
         // Measured inside the step at B = 512 (profiles/r04_x3_gemm_ab.txt): the persistent kernel wins where the epilogue is light
         // (bias only: 614 -> 576 us; + residual gradient: 917 -> 814 us), the two-workgroup kernel where it is heavy -- GELU + GELU'
         // with a split result (1195 vs 1253 us), x GELU' + column sums (1240 vs 1271 us) and the 30522-wide fp32 logits (5.96 vs 8.15 ms)
+        // Round 5, after the epilogue's re-waits were removed (FLUSH): GELU + GELU' with a split result moved to the persistent kernel too --
+        // 2 329 vs 2 477 us inside the step at B = 1024 (profiles/r05_x3_nt_kernel_ab.txt); x GELU' + column sums (2 436 vs 2 407) and
+        // the fp32 logits (33.7 vs 22.7 ms) stay
         const bool light = g.act == VB_ACT_NONE && !g.aux_in && !g.aux_out && !g.colsum && !g.split_out && g.N <= 4096;
-        if (variant != 22 && variant != 42 && variant != 90 && variant != 81) variant = t256 >= 160 ? (light ? 81 : 90) : (t128 >= 256 ? 42 : 22);   // (never 100 / 101)
+        const bool gelu_split = g.act == VB_ACT_GELU_SAVE_GRAD && g.split_out && !g.aux_in && !g.colsum && g.N <= 4096;
+        if (variant != 22 && variant != 42 && variant != 90 && variant != 81) variant = t256 >= 160 ? ((light || gelu_split) ? 81 : 90) : (t128 >= 256 ? 42 : 22);   // (never 100 / 101)
     }
 #ifdef VB_DEV_KNOBS
     if (variant == 200) {

@@ -2402,9 +2402,13 @@ int dispatch_pipe(const GemmArgs& g, hipStream_t s) {
         // product build's persistent "+ addend" instantiation was the slower one (667 us) although the developer build's, laid out
         // differently, was not (603) -- A/B product builds, never the developer library, when the question is what ships.
         // (developer library: debug bit 27 restores the round-4 rule)
+        // Last step of round 5: bias-only GEMMs go to the persistent kernel at ANY K (QKV / attention-out forward, attention-out dgrad:
+        // K = 768) -- 321 vs 343 us per launch inside the step, product build against product build on one box 119.3 -> 119.0 ms per step
+        // (profiles/r05_gemm_plain_short_k_ab.txt).  The two-workgroup kernel keeps what has a heavy epilogue: GELU + GELU' (1 038 vs
+        // 1 110 us), x GELU' + column sums (tie), the fp32 logits (9.0 vs 9.6 ms).
         const bool plain = !g.addend && !g.aux_in && !g.aux_out && !g.colsum && g.act == VB_ACT_NONE && sizeof(TO) == 2;
         const bool light = !g.aux_in && !g.aux_out && !g.colsum && g.act == VB_ACT_NONE && !g.accumulate && sizeof(TO) == 2 && !(g.debug & (1 << 27));
-        variant = (sizeof(T) == 2 && t256 >= 160) ? ((g.K >= 2048 && (plain || light)) ? 81 : 90) : (t128 >= 256 ? 42 : 22);
+        variant = (sizeof(T) == 2 && t256 >= 160) ? ((plain || (g.K >= 2048 && light)) ? 81 : 90) : (t128 >= 256 ? 42 : 22);
 #ifdef VB_DEV_KNOBS
         if (variant == 90 && (g.debug & (1 << 28)) && (plain || light)) variant = 81;      // A/B: the short-K plain / "+ addend" shapes on the persistent kernel too
 #endif

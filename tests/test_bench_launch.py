@@ -92,3 +92,26 @@ def test_pmc_kernel_name_matcher():
     assert pick(16) == [ph8_bf16]
     assert pick(16 | 4 | 256) == [ph8_x3, ph8_x3_mangled]                  # the strict leg's dominant family
     assert bench.kernel_name_filter(1) is None and bench.kernel_name_filter(19) is None    # not an NT GEMM family
+
+
+def test_roofline_reports_the_dominant_kernel_and_the_comparable_family():
+    """roofline.frac is defined on the kernel with the largest summed launch time; the dispatch rule moves shapes between the two
+    K-contiguous kernels from round to round, so the object also carries every K-contiguous GEMM of the dominant kernel's output type
+    together (`nt_gemms_same_output_type`) -- checked here on a synthetic per-kernel summary (no GPU)."""
+    sys.path.insert(0, ROOT)
+    from unittest import mock
+    import bench
+    steps = 20
+    summ = {16: dict(ms=33.6 * steps, flops=1141.0e12 * 33.6e-3 * steps, launches=74 * steps),          # persistent kernel, bf16 -> bf16
+            64: dict(ms=24.3 * steps, flops=790.0e12 * 24.3e-3 * steps, launches=25 * steps),           # two-workgroup kernel, bf16 -> bf16
+            64 | 4: dict(ms=10.0 * steps, flops=887.0e12 * 10.0e-3 * steps, launches=2 * steps),        # fp32 logits: another output type
+            19: dict(ms=23.2 * steps, flops=1283.0e12 * 23.2e-3 * steps, launches=16 * steps)}          # grouped weight gradients
+    with mock.patch.object(bench, "traffic_for", lambda *a, **k: (None, "not measured")):
+        r = bench.roofline_of(summ, steps, 2500.0, 1024, "pretraining")
+    assert r["kernel"].startswith("gemm_nt_8ph_kernel<bf16->bf16") and abs(r["frac"] - 0.4564) < 1e-3
+    fam = r["nt_gemms_same_output_type"]
+    assert fam["launches_per_step"] == 99 and abs(fam["ms_per_step"] - 57.9) < 1e-6
+    assert abs(fam["tflops"] - (1141.0 * 33.6 + 790.0 * 24.3) / 57.9) < 0.1 and abs(fam["frac"] - fam["tflops"] / 2500.0) < 1e-4
+    with mock.patch.object(bench, "traffic_for", lambda *a, **k: (None, "not measured")):
+        r = bench.roofline_of({19: summ[19]}, steps, 2500.0, 1024, "pretraining")          # no NT GEMM at all: the family is the kernel itself
+    assert r["nt_gemms_same_output_type"]["launches_per_step"] == 16

@@ -2367,7 +2367,9 @@ int dispatch_pipe(const GemmArgs& g, hipStream_t s) {
         // the fp32 logits (33.7 vs 22.7 ms) stay
         const bool light = g.act == VB_ACT_NONE && !g.aux_in && !g.aux_out && !g.colsum && !g.split_out && g.N <= 4096;
         const bool gelu_split = g.act == VB_ACT_GELU_SAVE_GRAD && g.split_out && !g.aux_in && !g.colsum && g.N <= 4096;
-        if (variant != 22 && variant != 42 && variant != 90 && variant != 81) variant = t256 >= 160 ? ((light || gelu_split) ? 81 : 90) : (t128 >= 256 ? 42 : 22);   // (never 100 / 101)
+        const long t22 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);          // at most one 128x128 tile per CU: the four-stage ring (see below)
+        if (variant != 22 && variant != 24 && variant != 42 && variant != 90 && variant != 81)
+            variant = t256 >= 160 ? ((light || gelu_split) ? 81 : 90) : (t128 >= 256 ? 42 : (t22 <= 256 ? 24 : 22));   // (never 100 / 101)
     }
 #ifdef VB_DEV_KNOBS
     if (variant == 200) {
@@ -2408,13 +2410,19 @@ int dispatch_pipe(const GemmArgs& g, hipStream_t s) {
         // 1 110 us), x GELU' + column sums (tie), the fp32 logits (9.0 vs 9.6 ms).
         const bool plain = !g.addend && !g.aux_in && !g.aux_out && !g.colsum && g.act == VB_ACT_NONE && sizeof(TO) == 2;
         const bool light = !g.aux_in && !g.aux_out && !g.colsum && g.act == VB_ACT_NONE && !g.accumulate && sizeof(TO) == 2 && !(g.debug & (1 << 27));
-        variant = (sizeof(T) == 2 && t256 >= 160) ? ((plain || (g.K >= 2048 && light)) ? 81 : 90) : (t128 >= 256 ? 42 : 22);
+        // small problems (per-GPU batch <= ~32 at S = 164: at most one 128x128 tile per compute unit): the FOUR-stage ring (128 KB, one
+        // workgroup per CU -- there is no second one to host anyway) keeps three K tiles in flight where the two-stage form exposes an
+        // L2 / HBM round trip per K tile: the whole step 6.43 -> 6.18 ms at B = 8, 6.73 -> 6.38 at 16, 7.63 -> 7.21 at 32; with more
+        // tiles than CUs it loses the second resident workgroup (B = 64: 10.68 -> 11.46 ms) -- profiles/r05_small_batch_four_stage_ab.txt
+        const long t22 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
+        variant = (sizeof(T) == 2 && t256 >= 160) ? ((plain || (g.K >= 2048 && light)) ? 81 : 90) : (t128 >= 256 ? 42 : (t22 <= 256 ? 24 : 22));
 #ifdef VB_DEV_KNOBS
         if (variant == 90 && (g.debug & (1 << 28)) && (plain || light)) variant = 81;      // A/B: the short-K plain / "+ addend" shapes on the persistent kernel too
 #endif
     }
     switch (variant) {
         case 22: return launch_pipe<T, TO, 2, 2>(g, s);
+        case 24: return launch_pipe<T, TO, 2, 4>(g, s);
         case 42: return launch_pipe<T, TO, 4, 2>(g, s);
         case 81: return launch_8ph<T, TO>(g, s);
         case 90: return launch_dual<T, TO>(g, s);

@@ -55,7 +55,7 @@ const char* vb_version(void);
  *   persistent_workgroups: workgroups launched by the persistent GEMM kernels; 0 = one per compute unit.  A
  *                          data-parallel caller lowers it while RCCL kernels are resident (parallel.py).
  *   nt_kernel: pins the K-contiguous x K-contiguous bf16 GEMM kernel to one the dispatcher could have chosen itself (for
- *              reproducible summation order, or an A/B run); 0 = chosen from the shape; 22 / 24 / 42 = two-barrier 128x128 (two / four LDS stages) / 256x128
+ *              reproducible summation order, or an A/B run); 0 = chosen from the shape; 14 / 22 / 24 / 42 = two-barrier 64x128 (four LDS stages) / 128x128 (two / four) / 256x128
  *              tiles; 81 = persistent 256x256 tile; 90 = 256x128 tiles, two workgroups per compute unit; 1 = the generic
  *              register-staged kernel.  Anything else is VB_ERR_ARG: experiment arms and the vendor-library yardstick exist in
  *              the developer library only (include/visualbert_hip_dev.h).  This library owns no device memory.

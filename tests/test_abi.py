@@ -76,7 +76,7 @@ def test_developer_knobs_are_not_in_the_product_library():
         L.vb_stream_set_opts.restype = ctypes.c_int
         L.vb_stream_set_opts.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     fake_stream = ctypes.c_void_p(0x1234)                       # options are a host-side table keyed by the handle: no GPU needed
-    for k in (0, 1, 22, 24, 42, 81, 90) + tuple(_lib.DEV_NT_KERNELS):
+    for k in (0, 1, 14, 22, 24, 42, 81, 90) + tuple(_lib.DEV_NT_KERNELS):
         o = _lib.StreamOpts(0, k, 0, 0)
         want_product = 0 if k not in _lib.DEV_NT_KERNELS else -1                 # VB_ERR_ARG
         assert lib.vb_stream_set_opts(fake_stream, ctypes.byref(o)) == want_product, k

@@ -534,7 +534,7 @@ def test_cross_attention_fwd_bwd(dev, dt, cfg):
         assert (out.float() - ref).abs().max().item() <= t
 
 
-@pytest.mark.parametrize("variant", [1, 22, 24, 42, 80, 81, 82, 90, 92, 100, 200])     # 200: plain GEMMs through the vendor library (yardstick); 82 / 92: register-direct epilogue arms
+@pytest.mark.parametrize("variant", [1, 14, 22, 24, 42, 80, 81, 82, 90, 92, 100, 200])     # 200: plain GEMMs through the vendor library (yardstick); 82 / 92: register-direct epilogue arms
 def test_gemm_pipelined_variants_agree(dev, variant):
     """every pipelined K-contiguous kernel variant (tile shape x LDS stages, counted vmcnt, ping-pong,
     256x256) must give the generic kernel's answer -- on hardware this is what validates the
@@ -553,7 +553,7 @@ def test_gemm_pipelined_variants_agree(dev, variant):
             assert (C - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
 
 
-@pytest.mark.parametrize("variant", [22, 24, 42, 80, 81, 82, 90, 92, 100, 200])        # 200: bias-only / "+ addend" / fp32-out go to hipBLASLt,
+@pytest.mark.parametrize("variant", [14, 22, 24, 42, 80, 81, 82, 90, 92, 100, 200])        # 200: bias-only / "+ addend" / fp32-out go to hipBLASLt,
 def test_gemm_specialised_epilogues(dev, variant):                          # the fused epilogues stay on our kernels
     """the K-contiguous fast kernels carry ONE epilogue each (activation and optional operands are template
     parameters, picked by the launcher): bias only, GELU + saved pre-activation, GELU' + fused column sums,

@@ -2414,8 +2414,9 @@ int dispatch_pipe(const GemmArgs& g, hipStream_t s) {
         // workgroup per CU -- there is no second one to host anyway) keeps three K tiles in flight where the two-stage form exposes an
         // L2 / HBM round trip per K tile: the whole step 6.43 -> 6.18 ms at B = 8, 6.73 -> 6.38 at 16, 7.63 -> 7.21 at 32; with more
         // tiles than CUs it loses the second resident workgroup (B = 64: 10.68 -> 11.46 ms) -- profiles/r05_small_batch_four_stage_ab.txt
+        // ... and 64x128 tiles on the same ring (nt_kernel 14) while even those leave half the chip idle: 6.01 -> 5.90 ms at B = 8, 6.34 -> 6.19 at 16
         const long t22 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
-        variant = (sizeof(T) == 2 && t256 >= 160) ? ((plain || (g.K >= 2048 && light)) ? 81 : 90) : (t128 >= 256 ? 42 : (t22 <= 256 ? 24 : 22));
+        variant = (sizeof(T) == 2 && t256 >= 160) ? ((plain || (g.K >= 2048 && light)) ? 81 : 90) : (t128 >= 256 ? 42 : (t22 <= 128 ? 14 : (t22 <= 256 ? 24 : 22)));
 #ifdef VB_DEV_KNOBS
         if (variant == 90 && (g.debug & (1 << 28)) && (plain || light)) variant = 81;      // A/B: the short-K plain / "+ addend" shapes on the persistent kernel too
 #endif
@@ -2423,6 +2424,7 @@ int dispatch_pipe(const GemmArgs& g, hipStream_t s) {
     switch (variant) {
         case 22: return launch_pipe<T, TO, 2, 2>(g, s);
         case 24: return launch_pipe<T, TO, 2, 4>(g, s);
+        case 14: return launch_pipe<T, TO, 1, 4>(g, s);
         case 42: return launch_pipe<T, TO, 4, 2>(g, s);
         case 81: return launch_8ph<T, TO>(g, s);
         case 90: return launch_dual<T, TO>(g, s);

@@ -361,7 +361,7 @@ extern "C" int vb_stream_set_opts(void* stream, const vb_stream_opts* opts) {
         if (opts->reserved != 0) return VB_ERR_ARG;
         // the product library pins only kernels its own dispatcher can choose; the experiment arms (80, 91, 100, 101) and the
         // vendor yardstick (200) exist in libvisualbert_hip_dev.so only (include/visualbert_hip_dev.h)
-        bool ok = (k == 0 || k == 1 || k == 22 || k == 24 || k == 42 || k == 81 || k == 90);
+        bool ok = (k == 0 || k == 1 || k == 14 || k == 22 || k == 24 || k == 42 || k == 81 || k == 90);
 #ifdef VB_DEV_KNOBS
         ok = ok || k == 80 || k == 82 || k == 91 || k == 92 || k == 100 || k == 101 || k == 200;
 #endif

@@ -117,7 +117,7 @@ def _wgrad_grouped(dev, dys, xs, dws, tokens, alpha=1.0, alpha_dev=None):
 
 
 @pytest.mark.parametrize("tokens", [64, 192, 704, 100, 749])    # 100, 749: ragged token counts (B x S not a multiple of 64): whole
-@pytest.mark.parametrize("wgs", [0, 1, 3])                       # K tiles on the grouped kernel, the last 36 / 45 tokens on the generic one
+@pytest.mark.parametrize("wgs", [0, 1, 3])                       # K tiles on the grouped kernel, the last 36 / 45 tokens on the grouped tail kernel (one launch for all problems)
 def test_wgrad_grouped_transposing_reads(dev, tokens, wgs):
     """dW += dY^T X for a group of Linears in one persistent launch: operands copied as stored ([token][feature]) and
     gathered into MFMA fragments by ds_read_b64_tr_b16 (in the simulator: the measured lane map).  1, 3 and 11 K tiles

@@ -2343,6 +2343,82 @@ static int launch_tn_group(TnArgs& g, int K, hipStream_t stream) {
     for (int i = 0; i < g.nprob; ++i) flops += 2.0 * g.p[i].Mo * g.p[i].Ni * K;
     return vb_prof_launch(flops, 4 | 2 | 1 | 16, stream, [&]() { VB_LAUNCH(gemm_tn_8ph_kernel, grid, block, SM, stream, g); });
 }
+// The last tokens % 64 rows of a grouped weight-gradient call (ragged B x S: per-GPU batch 8 x 164 tokens = 20 K tiles + 32 rows), ALL
+// problems in ONE launch: dW_p[o][i] += alpha sum_r dY_p[r][o] X_p[r][i], r < rows <= 63.  One 64 x 64 output tile per workgroup, both
+// row panels staged in LDS as fp32, 4 x 4 outputs per thread, plain read-modify-write of dW (the launch runs after the grouped kernel on
+// the same stream: nothing else writes dW meanwhile).  Before round 5's last step these rows went through the generic kernel, one launch
+// per problem: 4 x 11.6 us per encoder layer at B = 8 -- 0.59 ms of a 5.9 ms step (profiles/r05_kernel_stats_b8.txt).
+struct TnTailArgs {
+    TnProblem p[VB_TN_MAX];
+    int blk0[VB_TN_MAX + 1];                      // first workgroup of each problem
+    int nprob, rows;
+    float alpha;
+    const float* alpha_dev;
+};
+VB_KERNEL VB_LAUNCH_BOUNDS(256) gemm_tn_tail_kernel(TnTailArgs g) {
+    VB_DYN_SMEM(smem);
+    float* sa = (float*)smem;                     // [rows][64] dY columns o0 .. o0 + 63
+    float* sb = sa + 64 * 64;                     // [rows][64] X  columns i0 .. i0 + 63
+    int pi = 0;
+    while (pi + 1 < g.nprob && (int)blockIdx.x >= g.blk0[pi + 1]) ++pi;
+    const TnProblem& P = g.p[pi];
+    const int tn = (P.Ni + 63) / 64;
+    const int tile = (int)blockIdx.x - g.blk0[pi];
+    const int o0 = (tile / tn) * 64, i0 = (tile % tn) * 64;
+    const int t = threadIdx.x;
+    const bf16* A = (const bf16*)P.A;
+    const bf16* B = (const bf16*)P.B;
+    for (int c = t; c < g.rows * 8; c += 256) {   // 16-byte chunks: the leading dimensions cover the columns rounded up to 8 (tn_eligible)
+        const int r = c >> 3, ch = (c & 7) * 8;
+        float va[8], vb[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { va[j] = 0.f; vb[j] = 0.f; }
+        if (o0 + ch < P.Mo) load8(va, A + (long)r * P.lda + o0 + ch);
+        if (i0 + ch < P.Ni) load8(vb, B + (long)r * P.ldb + i0 + ch);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sa[r * 64 + ch + j] = va[j]; sb[r * 64 + ch + j] = vb[j]; }
+    }
+    __syncthreads();
+    const int to = (t >> 4) * 4, ti = (t & 15) * 4;
+    float acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
+    for (int r = 0; r < g.rows; ++r) {
+        const f32x4 x = *(const f32x4*)(sa + r * 64 + to), y = *(const f32x4*)(sb + r * 64 + ti);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] += x[a] * y[b];
+    }
+    const float alpha = g.alpha_dev ? g.alpha * g.alpha_dev[0] : g.alpha;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int o = o0 + to + a;
+        if (o >= P.Mo) continue;
+        float* crow = P.C + (long)o * P.ldc + i0 + ti;
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+            if (i0 + ti + b < P.Ni) crow[b] += alpha * acc[a][b];
+    }
+}
+static int launch_tn_tail(const TnArgs& main, int row0, int rows, hipStream_t stream) {
+    TnTailArgs g;
+    g.nprob = main.nprob; g.rows = rows; g.alpha = main.alpha; g.alpha_dev = main.alpha_dev;
+    int blocks = 0;
+    for (int i = 0; i < main.nprob; ++i) {
+        g.p[i] = main.p[i];
+        g.p[i].A = (const bf16*)main.p[i].A + (long)row0 * main.p[i].lda;
+        g.p[i].B = (const bf16*)main.p[i].B + (long)row0 * main.p[i].ldb;
+        g.blk0[i] = blocks;
+        blocks += ((main.p[i].Mo + 63) / 64) * ((main.p[i].Ni + 63) / 64);
+    }
+    g.blk0[main.nprob] = blocks;
+    double flops = 0;
+    for (int i = 0; i < main.nprob; ++i) flops += 2.0 * main.p[i].Mo * main.p[i].Ni * rows;
+    return vb_prof_launch(flops, 4 | 2 | 1, stream, [&]() { VB_LAUNCH(gemm_tn_tail_kernel, dim3((unsigned)blocks), dim3(256), 2 * 64 * 64 * 4, stream, g); });
+}
 static bool tn_eligible(const void* A, long lda, const void* B, long ldb, const float* C, long ldc, int Mo, int Ni, int K) {
     return K >= 64 && (K % 64) == 0 && Mo >= 1 && Ni >= 1 && lda >= ((Mo + 7) & ~7) && ldb >= ((Ni + 7) & ~7) && (lda % 8) == 0 && (ldb % 8) == 0 &&
            ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0 && C != nullptr && ldc >= Ni &&
@@ -2576,7 +2652,7 @@ extern "C" int vb_wgrad_grouped(int dtype, int n, const void* const* dy, const i
         }
         const int rc = launch_tn_group(tg, main_tok, (hipStream_t)stream);
         if (rc != VB_OK || main_tok == tokens) return rc;
-        done = main_tok;
+        return launch_tn_tail(tg, main_tok, tokens - main_tok, (hipStream_t)stream);       // the ragged rows of every problem: one launch
     }
     const size_t es = dtype == VB_BF16 ? 2 : 4;
     for (int i = 0; i < n; ++i) {

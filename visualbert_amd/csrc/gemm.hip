@@ -18,9 +18,9 @@
 //                        dgrad GEMM of the training step): LDS-direct copy stream of half-tiles that runs across output
 //                        tiles, four-slot schedule with the two wave groups one barrier apart, counted vmcnt waits,
 //                        wave-private epilogue slabs, epilogue specialised by template (ACT, OPT).
-//   gemm_tn_8ph_kernel   grouped weight gradients: both operands token-major, copied as stored, MFMA fragments gathered
-//                        with ds_read_b64_tr_b16; (problem, tile, token slice) work items, fp32 atomics.
-//   gemm_nt_pipe_kernel  two-barrier 128x128 / 256x128 kernels: small or odd problems (fewer than ~160 big tiles), fp32.
+//   gemm_tn_8ph_kernel   grouped weight gradients: both operands token-major, copied as stored, MFMA fragments gathered with ds_read_b64_tr_b16; (problem, tile, token slice) work items, fp32 atomics (+ gemm_tn_tail_kernel: the ragged tokens % 64 rows of all problems in one launch)
+//   gemm_nt_dual_kernel  256x128 tiles, two workgroups per CU (one's epilogue under the other's K loop): the GEMMs with heavy epilogues (GELU + GELU', x GELU' + column sums, fp32 logits)
+//   gemm_nt_pipe_kernel  two-barrier 64x128 / 128x128 / 256x128 kernels, two or four LDS stages: small or odd problems (fewer than ~160 big tiles), fp32.
 //   gemm_kernel          generic 128x128 kernel for any layout / dtype / ragged K, register-staged transposes, split-K:
 //                        the strict-fp32 parity mode and the fallbacks.
 // Common: 128-byte LDS rows (64 bf16 / 32 fp32 of K) with a 16-byte-chunk XOR swizzle so fragment reads (ds_read_b128) are

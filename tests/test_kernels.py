@@ -143,6 +143,20 @@ def test_wgrad_grouped_transposing_reads(dev, tokens, wgs):
         assert (C - ref).abs().max().item() <= 2e-4 * max(1.0, ref.abs().max().item())
 
 
+def test_wgrad_grouped_problems_sharing_one_dw(dev):
+    """two problems of one call that accumulate into the SAME dW (the ABI does not forbid it): the grouped kernel adds with atomics;
+    the ragged rows' tail kernel uses plain read-modify-writes and must therefore run such problems one after the other."""
+    g = torch.Generator().manual_seed(77)
+    dt = torch.bfloat16
+    tokens, o, i = 100, 72, 136                                  # one K tile + 36 ragged rows
+    dys = [padded(tokens, o, dt, dev, g) for _ in range(2)]
+    xs = [padded(tokens, i, dt, dev, g) for _ in range(2)]
+    dw = torch.full((o, i), 0.5, device=dev)
+    _wgrad_grouped(dev, dys, xs, [dw, dw], tokens)
+    ref = 0.5 + dys[0].float().t() @ xs[0].float() + dys[1].float().t() @ xs[1].float()
+    assert (dw - ref).abs().max().item() <= 2e-4 * max(1.0, ref.abs().max().item())
+
+
 def test_wgrad_grouped_helper_layout_on_the_full_chip(dev):
     """An encoder layer's four weight gradients are 108 tiles: two token slices each leave 40 of 256 compute units idle, so
     the launch switches to the helper layout (slices over the first KT - rem K tiles, the idle CUs take the last `rem` of

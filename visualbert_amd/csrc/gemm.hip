@@ -2345,8 +2345,9 @@ static int launch_tn_group(TnArgs& g, int K, hipStream_t stream) {
 }
 // The last tokens % 64 rows of a grouped weight-gradient call (ragged B x S: per-GPU batch 8 x 164 tokens = 20 K tiles + 32 rows), ALL
 // problems in ONE launch: dW_p[o][i] += alpha sum_r dY_p[r][o] X_p[r][i], r < rows <= 63.  One 64 x 64 output tile per workgroup, both
-// row panels staged in LDS as fp32, 4 x 4 outputs per thread, plain read-modify-write of dW (the launch runs after the grouped kernel on
-// the same stream: nothing else writes dW meanwhile).  Before round 5's last step these rows went through the generic kernel, one launch
+// row panels staged in LDS as fp32, 4 x 4 outputs per thread, plain read-modify-write of dW: every output element belongs to exactly one
+// thread of the launch, and the launch runs after the grouped kernel on the same stream.  (fp32 atomics instead: 25 -> 85 us per launch.)
+// Problems whose dW ranges OVERLAP (nothing in this repo does that; the ABI does not forbid it) are launched one after the other.  Before round 5's last step these rows went through the generic kernel, one launch
 // per problem: 4 x 11.6 us per encoder layer at B = 8 -- 0.59 ms of a 5.9 ms step (profiles/r05_kernel_stats_b8.txt).
 struct TnTailArgs {
     TnProblem p[VB_TN_MAX];
@@ -2403,21 +2404,37 @@ VB_KERNEL VB_LAUNCH_BOUNDS(256) gemm_tn_tail_kernel(TnTailArgs g) {
             if (i0 + ti + b < P.Ni) crow[b] += alpha * acc[a][b];
     }
 }
-static int launch_tn_tail(const TnArgs& main, int row0, int rows, hipStream_t stream) {
+static int launch_tn_tail_range(const TnArgs& main, int first, int count, int row0, int rows, hipStream_t stream) {
     TnTailArgs g;
-    g.nprob = main.nprob; g.rows = rows; g.alpha = main.alpha; g.alpha_dev = main.alpha_dev;
+    g.nprob = count; g.rows = rows; g.alpha = main.alpha; g.alpha_dev = main.alpha_dev;
     int blocks = 0;
-    for (int i = 0; i < main.nprob; ++i) {
-        g.p[i] = main.p[i];
-        g.p[i].A = (const bf16*)main.p[i].A + (long)row0 * main.p[i].lda;
-        g.p[i].B = (const bf16*)main.p[i].B + (long)row0 * main.p[i].ldb;
-        g.blk0[i] = blocks;
-        blocks += ((main.p[i].Mo + 63) / 64) * ((main.p[i].Ni + 63) / 64);
-    }
-    g.blk0[main.nprob] = blocks;
     double flops = 0;
-    for (int i = 0; i < main.nprob; ++i) flops += 2.0 * main.p[i].Mo * main.p[i].Ni * rows;
+    for (int i = 0; i < count; ++i) {
+        const TnProblem& src = main.p[first + i];
+        g.p[i] = src;
+        g.p[i].A = (const bf16*)src.A + (long)row0 * src.lda;
+        g.p[i].B = (const bf16*)src.B + (long)row0 * src.ldb;
+        g.blk0[i] = blocks;
+        blocks += ((src.Mo + 63) / 64) * ((src.Ni + 63) / 64);
+        flops += 2.0 * src.Mo * src.Ni * rows;
+    }
+    g.blk0[count] = blocks;
     return vb_prof_launch(flops, 4 | 2 | 1, stream, [&]() { VB_LAUNCH(gemm_tn_tail_kernel, dim3((unsigned)blocks), dim3(256), 2 * 64 * 64 * 4, stream, g); });
+}
+static int launch_tn_tail(const TnArgs& main, int row0, int rows, hipStream_t stream) {
+    bool overlap = false;                         // two problems writing the same dW elements: no single launch of plain read-modify-writes
+    for (int i = 0; i < main.nprob && !overlap; ++i)
+        for (int j = i + 1; j < main.nprob && !overlap; ++j) {
+            const float *a0 = main.p[i].C, *a1 = a0 + (long)(main.p[i].Mo - 1) * main.p[i].ldc + main.p[i].Ni;
+            const float *b0 = main.p[j].C, *b1 = b0 + (long)(main.p[j].Mo - 1) * main.p[j].ldc + main.p[j].Ni;
+            overlap = a0 < b1 && b0 < a1;
+        }
+    if (!overlap) return launch_tn_tail_range(main, 0, main.nprob, row0, rows, stream);
+    for (int i = 0; i < main.nprob; ++i) {
+        const int rc = launch_tn_tail_range(main, i, 1, row0, rows, stream);
+        if (rc != VB_OK) return rc;
+    }
+    return VB_OK;
 }
 static bool tn_eligible(const void* A, long lda, const void* B, long ldb, const float* C, long ldc, int Mo, int Ni, int K) {
     return K >= 64 && (K % 64) == 0 && Mo >= 1 && Ni >= 1 && lda >= ((Mo + 7) & ~7) && ldb >= ((Ni + 7) & ~7) && (lda % 8) == 0 && (ldb % 8) == 0 &&

@@ -379,8 +379,9 @@ int64_t vb_stream_profile_read(void* stream, double* ms, double* flops, int* key
 /* Weight gradients of a group of Linears that saw the same tokens (the four of an encoder layer), one launch:
  *   dw[i][n_out[i], n_in[i]] (fp32, ld_dw[i]) += alpha * dy[i]^T x[i],   dy[i]: [tokens, n_out[i]] (T, ld_dy[i]),
  *   x[i]: [tokens, n_in[i]] (T, ld_x[i]).  n <= 8.  alpha_dev: optional fp32 device scalar multiplying alpha.
- * bf16 with tokens % 64 == 0 and leading dimensions that are multiples of 8 (>= round_up(features, 8)) runs as ONE persistent kernel
- * (operands copied as stored, fragments gathered by transposing LDS reads, token slices added with fp32 atomics);
+ * bf16 with leading dimensions that are multiples of 8 (>= round_up(features, 8)) runs the whole 64-token tiles as ONE persistent kernel
+ * (operands copied as stored, fragments gathered by transposing LDS reads, token slices added with fp32 atomics) and the ragged
+ * tokens % 64 rows of all problems as one more launch (one after the other if two problems' dw ranges overlap);
  * anything else falls back to n vb_gemm calls.
  * Replaces: the dW = dy^T x half of autograd for nn.Linear at pytorch_pretrained_bert/modeling.py:232-234 (Q,K,V),
  * :271, :303, :316. */

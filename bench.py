@@ -47,7 +47,7 @@ PEAK_HBM_GBPS = 8000.0
 DTYPES = {"bf16": "bfloat16", "fp32": "float32", "bf16x3": "bf16x3"}
 # the short re-run of this command line that the PMC passes profile (measure_traffic)
 PMC_CHILD_FLAGS = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-profile", "--no-h2d", "--no-parity", "--strict-dtype", "none",
-                   "--no-vendor-leg", "--pmc-traffic", "off"]
+                   "--no-vendor-leg", "--pmc-traffic", "off", "--no-batch-curve"]
 
 # BASELINE.json configs -> (head, text tokens, regions, feature width, label for config.workload)
 WORKLOADS = {
@@ -506,6 +506,35 @@ def hbm_bound_kernels(model, M, H, dev, optimizer=None, V=0):
     return out
 
 
+BATCH_CURVE = [8, 16, 32, 64, 128, 256, 512]
+
+
+def batch_curve(dev, head, T, R, Dv, V, dtype_name, fps, peak, steps=12, warmup=3):
+    """the same training step at the per-GPU batches the reference's own configs live in (global batch 48-64 over 8 GPUs =
+    6-8 per GPU: configs/vqa/coco-pre-train.json:17, models/train.py:146) up to 512: ms per step = median of `steps` per-step HIP
+    events after `warmup` steps, a fresh model per batch size.  VERDICT r05 item 1: the driver's record keeps this curve."""
+    import torch
+    from visualbert_amd.data import synthetic_batch
+    from visualbert_amd.model import AttrDict, ModelWrapper, VisualBERTFixedImageEmbedding
+    from visualbert_amd.modeling import BertConfig
+    out = {}
+    for B in BATCH_CURVE:
+        torch.manual_seed(1234)
+        config = BertConfig(V, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072)
+        model = VisualBERTFixedImageEmbedding(config=config, training_head_type=head, visual_embedding_dim=Dv,
+                                              compute_dtype=compute_dtype_of(dtype_name)).to(dev)
+        model.train()
+        mw = ModelWrapper(AttrDict(train_batch_size=B, learning_rate=5e-5, warmup_proportion=0.1, num_train_epochs=1,
+                                   gradient_accumulation_steps=1), (steps + warmup + 20) * B, model=model)
+        b = synthetic_batch(head, B, T, R, Dv, V, seed=0, device=dev)
+        _, med, _ = timed_steps(mw, b, steps, warmup, torch.cuda.synchronize, profile=False)
+        out[B] = dict(ms_per_step=round(med, 3), samples_per_s=round(B / med * 1e3, 1),
+                      step_mfu=round(B / med * 1e3 * fps / (peak * 1e12), 4))
+        del mw, model, b
+        torch.cuda.empty_cache()
+    return out
+
+
 def selftest_launch():
     """plumbing check of the self-launch path without a GPU (tests/test_bench_launch.py): every rank joins a gloo group,
     all-reduces a one, and rank 0 prints the JSON line."""
@@ -560,6 +589,8 @@ def main():
     ap.add_argument("--pmc-traffic", default="auto", choices=["auto", "off"],
                     help="auto (N = 1): measure roofline.traffic for THIS run with two rocprofv3 --pmc children of the same command "
                          "line (adds ~1 min per timed mode); off: report the committed PMC pass (profiles/pmc_traffic.json) or null")
+    ap.add_argument("--no-batch-curve", action="store_true",
+                    help="skip the per-GPU batch sweep 8 ... 512 (N = 1, pre-training workload; ~15 s) reported as roofline.batch_curve")
     ap.add_argument("--selftest-launch", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -645,7 +676,15 @@ def main():
     if args.nt_kernel or args.attn_two_pass:
         from visualbert_amd import _lib
         _lib.set_opts(nt_kernel=args.nt_kernel, attn_two_pass=args.attn_two_pass)
+    # the matrix pipes' ceiling on THIS box right before and right after the timed loop (boxes differ by +-3.5 %, a kernel gain of
+    # 2 % is invisible in `value` alone): roofline.all_gemm_frac_of_measured_ceiling divides by the mean of the two
+    ceil_before = None
+    if dtype == torch.bfloat16 and not args.no_profile:
+        for _ in range(min(args.warmup, 3)):
+            mw.step(batch)                                     # clocks and caches in the state the loop will see
+        ceil_before = measured_mfma_ceiling(dev)
     elapsed, median_ms, summ = timed_steps(mw, batch, args.steps, args.warmup, barrier, profile=not args.no_profile)
+    ceil_after = measured_mfma_ceiling(dev) if ceil_before else None
     et = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(et, op=dist.ReduceOp.MAX)
@@ -671,7 +710,13 @@ def main():
         h2d = B * world * args.steps / float(e2.item())
 
     allreduce = None
+    replicas_same = None
     if sync is not None:
+        # replicas must have stayed bit-identical through the synchronised steps: every rank's parameter arena, summed in fp64
+        mine = model.bert.arena.data.double().sum().reshape(1)
+        sums = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(sums, mine)
+        replicas_same = all(bool(torch.equal(x, sums[0])) for x in sums)
         allreduce = sync.measure_allreduce(barrier)             # stand-alone all-reduce of the whole gradient arena
 
     sparse = None
@@ -730,13 +775,17 @@ def main():
                             step_mfu_executed=round((gemm_flops + attn_flops) / (elapsed / args.steps) / (peak * 1e12), 4),
                             note="step_mfu prices SURVEY 8d's 3 x forward FLOPs per sample; this is the arithmetic the step really ran")
             roofline = roofline_of(summ, args.steps, peak, B, args.workload)
-            if dtype == torch.bfloat16:
-                ceil_tf = measured_mfma_ceiling(dev)
-                if ceil_tf:
-                    roofline["mfma_ceiling_measured"] = round(ceil_tf, 1)
-                    roofline["frac_of_measured_ceiling"] = round(roofline["achieved"] / ceil_tf, 4)
-                    roofline["mfma_ceiling_note"] = ("register-only bf16 MFMA loop, operands changing every instruction, all "
-                                                     "CUs: what the chip sustains at the clock it holds under real data")
+            if ceil_before and ceil_after:
+                ceil_tf = 0.5 * (ceil_before + ceil_after)
+                roofline["mfma_ceiling_measured"] = round(ceil_tf, 1)
+                roofline["mfma_ceiling_before_loop"] = round(ceil_before, 1)
+                roofline["mfma_ceiling_after_loop"] = round(ceil_after, 1)
+                roofline["frac_of_measured_ceiling"] = round(roofline["achieved"] / ceil_tf, 4)
+                # the round-to-round, box-independent figure: every GEMM launch of the step against what THIS chip's matrix
+                # pipes sustained around the loop
+                roofline["all_gemm_frac_of_measured_ceiling"] = round(roofline["all_gemm_tflops"] / ceil_tf, 4)
+                roofline["mfma_ceiling_note"] = ("register-only bf16 MFMA loop, operands changing every instruction, all "
+                                                 "CUs, run right before and right after the timed loop (mean of the two)")
             if dtype == torch.bfloat16:
                 roofline["hbm_bound"] = hbm_bound_kernels(model, B * S, H, dev, optimizer=mw.optimizer,
                                                             V=30522 if head == "pretraining" else 0)
@@ -771,6 +820,36 @@ def main():
             for extra in kinds[1:]:                         # the exact fp32 kernels: a short run (they are 3x slower still)
                 strict[extra + "_kernels"] = strict_mode(dev, head, T, R, Dv, V, min(args.strict_batch, 256), 6, 2, extra, fps,
                                                          args.workload, full=False)
+        curve = None
+        if world == 1 and not args.no_batch_curve and args.workload == "pretrain" and roofline is not None:
+            batch = mw = model = None
+            torch.cuda.empty_cache()
+            curve = batch_curve(dev, head, T, R, Dv, V, args.dtype, fps, peak)
+            if B not in curve:
+                curve[B] = dict(ms_per_step=round(median_ms, 3), samples_per_s=round(B / median_ms * 1e3, 1),
+                                step_mfu=round(B / median_ms * 1e3 * fps / (peak * 1e12), 4))
+        if roofline is not None:
+            # the driver's record keeps the SCALAR entries of `roofline` (nested objects and the other top-level objects of this line
+            # survive by name only -- VERDICT r05 item 4): what a reader needs to judge the round goes here, flat
+            if par is not None:
+                roofline["parity_bf16_max_dlogit"] = par["max_dlogit_vs_fp32_ref"]
+            if strict is not None:
+                roofline["strict_dtype"] = strict["dtype"]
+                roofline["strict_value"] = strict["value"]
+                roofline["strict_ms_per_step"] = strict["ms_per_step"]
+                roofline["strict_max_dlogit"] = strict["max_dlogit"]
+                roofline["strict_meets_tolerance"] = strict["meets_tolerance"]
+                if "roofline" in strict:
+                    roofline["strict_frac"] = strict["roofline"]["frac"]
+                    roofline["strict_all_gemm_tflops"] = strict["roofline"]["all_gemm_tflops"]
+                roofline["strict_mode"] = dict(value=strict["value"], ms_per_step=strict["ms_per_step"], max_dlogit=strict["max_dlogit"],
+                                               frac=strict.get("roofline", {}).get("frac"))
+            if h2d is not None:
+                roofline["value_with_h2d"] = round(h2d, 2)
+            if curve:
+                roofline["batch_curve"] = {str(k): v for k, v in sorted(curve.items())}
+                for k, v in sorted(curve.items()):
+                    roofline["batch_curve_b%d_ms" % k] = v["ms_per_step"]
         if not args.no_cpu_baseline:
             cpu = cpu_baseline(args.cpu_batch, T, R, head)
         metric = {"pretrain": "pretrain samples/sec (BERT-base, 36 regions+128 tok)",
@@ -785,6 +864,8 @@ def main():
             "config": {"workload": "BASELINE.json %s: BERT-base 12L/768 VisualBERT, %d regions x %d-d + %d text tokens (S=%d), %s"
                                    % (wl["cfg"], R, Dv, T, S, wl["what"]),
                        "per_gpu_batch": B, "global_batch": B * world, "seq_len": S, "parallelism": "dp%d" % world,
+                       "h2d": "excluded from `value` (batch resident in HBM, the bench contract); roofline.value_with_h2d = the same loop with "
+                              "every batch streamed from pinned host memory (SURVEY 8d's definition)",
                        "grad_allreduce": ("fp32 %s (%s), %s" % ("gloo" if one_device else "RCCL", comm_kind, "overlapped with backward" if not args.no_overlap
                                                                   else "after backward")) if use_dist else "none (1 rank)"},
             "value_with_h2d": round(h2d, 2) if h2d is not None else None,
@@ -794,6 +875,7 @@ def main():
             "executed": executed,
             "final_loss": round(loss, 4),
             "rccl_ranks_seen": ranks_seen,
+            "replicas_bit_identical": replicas_same,
             "allreduce": allreduce,
             "roofline": roofline,
             "cpu_baseline": cpu,

@@ -51,20 +51,24 @@ def test_bench_runs_as_a_rank_of_an_existing_launch():
 
 
 @pytest.mark.gpu
-def test_driver_command_two_ranks_end_to_end(dev):
-    """The driver's multi-GPU command, `python bench.py --gpus 2 ...`, executed for real on the one GPU this box has: both
+@pytest.mark.parametrize("world,batch,extra", [(2, 8, []), (8, 2, []), (8, 2, ["--no-overlap"])])
+def test_driver_command_ranks_end_to_end(dev, world, batch, extra):
+    """The driver's multi-GPU command, `python bench.py --gpus N ...` (N = 2, and N = 8 = the node north_star names, with and
+    without --no-overlap), executed for real on the one GPU this box has: all
     ranks drive cuda:0 (VB_BENCH_ONE_DEVICE=1; the process group is gloo because RCCL refuses two ranks on one device).
     Everything but the transport is the N > 1 path the scaling bench runs: self-spawn through torch.distributed.run, rank
     environment, per-rank shards, gradient hooks firing during backward, max-over-ranks timing, ONE JSON line from rank 0
     that still carries cpu_baseline and parity."""
     if dev.type != "cuda":
         pytest.skip("needs the GPU")
-    d = _run(["--gpus", "2", "--batch", "8", "--steps", "2", "--warmup", "1", "--cpu-batch", "1", "--no-h2d"],
-             extra_env={"VB_BENCH_ONE_DEVICE": "1", "VB_BENCH_HANG_DUMP": "150"}, timeout=240)
-    assert d["n_gpus"] == 2 and d["rccl_ranks_seen"] == 2
-    assert d["config"]["global_batch"] == 16 and d["config"]["parallelism"] == "dp2"
-    assert "overlapped with backward" in d["config"]["grad_allreduce"]
-    assert d["allreduce"] and d["allreduce"]["ranks"] == 2 and d["allreduce"]["bus_GBps"] > 0
+    d = _run(["--gpus", str(world), "--batch", str(batch), "--steps", "2", "--warmup", "1", "--cpu-batch", "1", "--no-h2d"] + extra,
+             extra_env={"VB_BENCH_ONE_DEVICE": "1", "VB_BENCH_HANG_DUMP": "300"}, timeout=240 if world == 2 else 600)
+    assert d["n_gpus"] == world and d["rccl_ranks_seen"] == world
+    assert d["config"]["global_batch"] == world * batch and d["config"]["parallelism"] == "dp%d" % world
+    assert ("after backward" if extra else "overlapped with backward") in d["config"]["grad_allreduce"]
+    assert d["allreduce"] and d["allreduce"]["ranks"] == world and d["allreduce"]["bus_GBps"] > 0
+    assert d["allreduce"]["buckets"] == 12 + 2                      # heads | 12 layers | embeddings
+    assert d["replicas_bit_identical"] is True                      # parameter arenas of all ranks after the timed steps
     assert d["cpu_baseline"] and d["cpu_baseline"]["value"] > 0
     assert d["parity"] and d["parity"]["max_dlogit_vs_fp32_ref"] < 0.1
     assert d["value"] > 0 and d["final_loss"] == d["final_loss"]

@@ -52,7 +52,7 @@ def _worker(rank, world, port, q):
         # gradients from the oracle on this rank's shard (the HIP kernels need a GPU; the sync does not care
         # who wrote the arena)
         sd = vo.synth_state_dict(cfg, "pretraining", 7)
-        full = vo.synth_batch(cfg, 4, 12, 5, 7, "pretraining")
+        full = vo.synth_batch(cfg, 2 * world, 12, 5, 7, "pretraining")
         shard = {k: v[rank * 2:(rank + 1) * 2] for k, v in full.items()}
         leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
         out = vo.objective_forward(leaves, cfg, "pretraining", **shard)
@@ -71,6 +71,7 @@ def _worker(rank, world, port, q):
         for i in reversed(range(cfg.num_hidden_layers)):
             m.bert.encoder.layer[i].grad_ready_hook(i)
         sync.finish_step()
+        assert sync._done == set(names) and len(names) == cfg.num_hidden_layers + 2     # every rank reduced L + 2 buckets, once each
         flags = m.arena.touched_synced
         assert flags is not None and flags.numel() == len(m.arena.params)
         for i, p in enumerate(m.arena.params):
@@ -101,8 +102,10 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_two_rank_gradient_sync_matches_mean_of_replica_means():
-    world = 2
+@pytest.mark.parametrize("world", [2, 8])
+def test_gradient_sync_matches_mean_of_replica_means(world):
+    """world 2, and world 8 = the node size north_star names (one process per GPU x 8): the launcher-independent part of the
+    N = 8 path -- rank environment, L + 2 buckets per rank, hooks, the touched-flag union -- on gloo."""
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -113,7 +116,7 @@ def test_two_rank_gradient_sync_matches_mean_of_replica_means():
         p.join(300)
         assert p.exitcode == 0
     res = dict(q.get(timeout=10) for _ in range(world))
-    assert set(res) == {0, 1}
+    assert set(res) == set(range(world))
     for r, worst in res.items():
         assert worst < 1e-6, (r, worst)
 
@@ -131,8 +134,8 @@ def test_allreduce_buckets_tile_the_gradient_arena(head, bypass):
     assert all(r[i][1] == r[i + 1][0] for i in range(len(r) - 1))
 
 
-def _gpu_worker(rank, world, port, q):
-    """two ranks sharing cuda:0 (gloo carries the collectives): the REAL training step -- HIP kernels, autograd hooks
+def _gpu_worker(rank, world, port, q, overlap=True):
+    """`world` ranks sharing cuda:0 (gloo carries the collectives): the REAL training step -- HIP kernels, autograd hooks
     firing the per-layer buckets during backward, fused BertAdam on the averaged gradients."""
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -157,15 +160,16 @@ def _gpu_worker(rank, world, port, q):
             with torch.no_grad():
                 for k, v in sd.items():
                     own[k].copy_(v)
-        sync = DataParallelGradSync(model.bert, overlap=True)
+        sync = DataParallelGradSync(model.bert, overlap=overlap)
         sync.broadcast_parameters(0)
         model.train()
-        mw = ModelWrapper(AttrDict(train_batch_size=4, learning_rate=1e-3, warmup_proportion=0.1, num_train_epochs=1,
-                                   gradient_accumulation_steps=1), 400, model=model, grad_sync=sync)
-        full = vo.synth_batch(cfg, 4, 12, 5, 7, "pretraining")
+        mw = ModelWrapper(AttrDict(train_batch_size=2 * world, learning_rate=1e-3, warmup_proportion=0.1, num_train_epochs=1,
+                                   gradient_accumulation_steps=1), 100 * 2 * world, model=model, grad_sync=sync)
+        full = vo.synth_batch(cfg, 2 * world, 12, 5, 7, "pretraining")
         shard = {k: v[rank * 2:(rank + 1) * 2].to(dev) for k, v in full.items()}
         for _ in range(3):
             mw.step(shard)
+            assert len(sync._done) == cfg.num_hidden_layers + 2, sync._done           # L + 2 buckets reduced on this rank, every step
         # single-process restatement: gradient of the mean over replicas of the per-replica mean losses, BertAdam
         ref_sd = {k: v.clone() for k, v in sd.items()}
         state = {}
@@ -186,24 +190,28 @@ def _gpu_worker(rank, world, port, q):
 
 
 @pytest.mark.gpu
-def test_two_ranks_on_one_gpu_train_like_the_reference_data_parallel(dev):
+@pytest.mark.parametrize("world,overlap", [(2, True), (8, True), (8, False)])
+def test_ranks_on_one_gpu_train_like_the_reference_data_parallel(dev, world, overlap):
+    """world 8 = the node north_star names, on the ONE device a builder box has (gloo carries the collectives; RCCL refuses two ranks
+    on a device): eight replicas, a shard of 2 samples each, three real steps -- every rank reduces L + 2 buckets per step, the replicas
+    stay bit-identical and land on the oracle's trajectory of the mean over 8 per-replica mean losses (models/model_wrapper.py:75);
+    overlap=False is bench.py's --no-overlap control (everything reduced in finish_step)."""
     if dev.type != "cuda":
-        pytest.skip("two processes driving the HIP kernels: GPU only")
-    world = 2
+        pytest.skip("several processes driving the HIP kernels: GPU only")
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, q, overlap)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(600)
+        p.join(900)
         assert p.exitcode == 0
     res = [q.get(timeout=10) for _ in range(world)]
-    assert sorted(r[0] for r in res) == [0, 1]
+    assert sorted(r[0] for r in res) == list(range(world))
     for r, worst, _ in res:
         assert worst < 5e-6, (r, worst)                     # three optimizer steps, fp32 kernels vs the oracle
-    assert res[0][2] == res[1][2]                           # replicas bit-identical after the synchronised steps
+    assert all(r[2] == res[0][2] for r in res)              # replicas bit-identical after the synchronised steps
 
 
 def _abi_comm_worker(port, q):

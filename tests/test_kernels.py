@@ -143,6 +143,44 @@ def test_wgrad_grouped_transposing_reads(dev, tokens, wgs):
         assert (C - ref).abs().max().item() <= 2e-4 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("tokens", [24, 64, 100, 448, 1312, 3072])   # 24: only a ragged tile; 1312 = per-GPU batch 8 x 164; 3072 = 48 K tiles (the crossover)
+@pytest.mark.parametrize("wgs", [0, 8])                            # 0: tiles <= compute units (four-stage ring); 8: more tiles than units (two stages, two workgroups per CU)
+def test_wgrad_small_token_kernel(dev, tokens, wgs):
+    """gemm_tn_small_kernel: dW += alpha dY^T X for a group of Linears at SMALL token counts -- one workgroup per 128x128 tile of dW walks the
+    whole token range (whole 64-token K tiles by LDS-direct copies, the ragged rest through registers with zero fill) and adds the tile
+    with plain read-modify-writes.  Ragged output rows (Mo not a multiple of 128 or of 8), several problems, both ring depths, alpha from
+    the device; twice into the same dW (no stale state between launches)."""
+    if dev.type != "cuda" and tokens > 448:
+        pytest.skip("simulator: the small cases cover the index logic")
+    g = torch.Generator().manual_seed(tokens + wgs)
+    dt = torch.bfloat16
+    shapes = [(264, 520), (768, 256), (8, 72), (77, 136), (128, 128)]          # (out, in): in % 8 == 0 (the kernel's vector rows)
+    dys = [padded(tokens, o, dt, dev, g) for o, _ in shapes]
+    xs = [padded(tokens, i, dt, dev, g) for _, i in shapes]
+    with _lib.stream_opts(persistent_workgroups=wgs):
+        _lib.lib().vb_stream_profile(_lib.stream_ptr(), 1)
+        dws = [torch.full((o, i), 1.5, device=dev) for o, i in shapes]
+        sc = torch.tensor([0.5], device=dev)
+        _wgrad_grouped(dev, dys, xs, dws, tokens, alpha=2.0, alpha_dev=sc)
+        _wgrad_grouped(dev, dys, xs, dws, tokens, alpha=-1.0)
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+        n = 64
+        ms, fl, ky = (ctypes.c_double * n)(), (ctypes.c_double * n)(), (ctypes.c_int * n)()
+        cnt = _lib.lib().vb_stream_profile_read(_lib.stream_ptr(), ms, fl, ky, n)
+        _lib.lib().vb_stream_profile(_lib.stream_ptr(), 0)
+        if dev.type == "cuda":                      # (the simulator build records no launches)
+            assert cnt == 2 and all((ky[i] & 255) == 39 for i in range(cnt)), [ky[i] for i in range(max(cnt, 0))]   # ONE launch per call, the small-token kernel
+        for dy, x, dw in zip(dys, xs, dws):
+            ref = 1.5 + 0.0 * (dy.float().t() @ x.float())
+            assert (dw - ref).abs().max().item() <= 4e-4 * max(1.0, (dy.float().t() @ x.float()).abs().max().item())
+        dws = [torch.full((o, i), 1.5, device=dev) for o, i in shapes]
+        _wgrad_grouped(dev, dys, xs, dws, tokens, alpha=2.0, alpha_dev=sc)
+        for dy, x, dw in zip(dys, xs, dws):
+            ref = 1.5 + dy.float().t() @ x.float()
+            assert (dw - ref).abs().max().item() <= 2e-4 * max(1.0, ref.abs().max().item())
+
+
 def test_wgrad_grouped_problems_sharing_one_dw(dev):
     """two problems of one call that accumulate into the SAME dW (the ABI does not forbid it): the grouped kernel adds with atomics;
     the ragged rows' tail kernel uses plain read-modify-writes and must therefore run such problems one after the other."""

@@ -2436,10 +2436,237 @@ static int launch_tn_tail(const TnArgs& main, int row0, int rows, hipStream_t st
     }
     return VB_OK;
 }
+// =================================================================================================
+// Weight gradients at SMALL token counts (per-GPU batch <= ~24 at S = 164: the regime of every reference config at DP = 8,
+// configs/vqa/coco-pre-train.json:17 / models/train.py:146).  There the persistent kernel above spends most of its time adding 256x256
+// partial tiles with fp32 atomics (a drain costs 24 K tiles' worth of time against 10-20 K tiles of work: 62.7 us per encoder layer at
+// B = 8 for a 28 MB dW, plus a 25 us tail launch for the tokens % 64 rows -- profiles/r05_fin3_kernel_stats_b8.txt).  This kernel gives every
+// 128 x 128 tile of dW to ONE workgroup that walks the WHOLE token range -- whole 64-token K tiles by LDS-direct copies (the half-tile image
+// and the transposing fragment reads of the kernel above), the last tokens % 64 rows through registers with zero fill -- and adds the
+// tile to dW with plain 16-byte read-modify-writes: no atomics, no token slices, no tail launch, every dW element touched by exactly
+// one thread.  The dW tile is FETCHED AT THE START (64 floats per lane) so its HBM read runs under the K loop.
+// 4 waves as 2 x 2 (64 x 64 each); STAGES x 32 KB ring (one A and one B half-tile per stage): 4 stages when the tiles do not outnumber the
+// compute units, 2 stages (two workgroups per CU) otherwise.
+// =================================================================================================
+struct TnSmallArgs {
+    TnProblem p[VB_TN_MAX];
+    int tile0[VB_TN_MAX + 1];                     // first 128x128 tile of each problem
+    int nprob, KT, rows_tail;                     // whole 64-token K tiles; rows of the last, partial K tile (0 .. 63)
+    float alpha;
+    const float* alpha_dev;
+};
+#ifdef VB_EMU
+template <int N> VB_DEVICE void vb_wait_lgkmcnt() {}
+#else
+template <int N> VB_DEVICE void vb_wait_lgkmcnt() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+#endif
+template <int STAGES>
+VB_KERNEL VB_LAUNCH_BOUNDS(256) gemm_tn_small_kernel(TnSmallArgs g) {
+    constexpr int HALF = 128 * 128, STAGE_BYTES = 2 * HALF, PER_TILE = 8;
+    VB_DYN_SMEM(smem);
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = vb_uniform(t >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntiles = g.tile0[g.nprob];
+    const int v = xcd_remap((int)blockIdx.x, ntiles);
+    int pi = 0;
+    for (int q = 1; q < g.nprob; ++q) if (v >= g.tile0[q]) pi = q;
+    const TnProblem& P = g.p[pi];
+    const int tl = v - g.tile0[pi];
+    const int tm = (P.Mo + 127) / 128, tn = (P.Ni + 127) / 128;
+    int m0, n0;                                  // consecutive tiles (one XCD's workgroups) share a panel of the longer operand
+    if (tm < tn) { m0 = (tl % tm) * 128; n0 = (tl / tm) * 128; }
+    else { m0 = (tl / tn) * 128; n0 = (tl % tn) * 128; }
+
+    // ---- the dW tile this wave will add to: rows mw0 + pass 32 + it 8 + lane / 8, columns nw0 + (lane & 7) 8 .. + 7 (fetched now, used last)
+    const int mw0 = m0 + wm * 64, nw0 = n0 + wn * 64;
+    const int ncol = nw0 + (lane & 7) * 8;
+    const bool col_ok = ncol < P.Ni;             // Ni % 8 == 0 (launcher): a lane's 8 columns are inside or outside together
+    f32x4 cin[2][4][2];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            int m = mw0 + pass * 32 + it * 8 + (lane >> 3);
+            m = m < P.Mo ? m : P.Mo - 1;                                 // clamped: always readable, never stored
+            const float* cp = P.C + (long)m * P.ldc + (col_ok ? ncol : 0);
+            cin[pass][it][0] = *(const f32x4*)cp;
+            cin[pass][it][1] = *(const f32x4*)(cp + 4);
+        }
+
+    // ---- copy stream: wave w, instruction i fills chunk q = 4 w + i of a half-tile (image: see gemm_tn_8ph_kernel's header)
+    const int kl = (wave & 1) * 32 + ((lane >> 3) & 1) * 8 + ((lane >> 1) & 3);      // + (i & 1) 16 + (i >> 1) 4
+    const int cr = (wave >> 1) * 64 + (lane >> 4) * 16 + (lane & 1) * 8;
+    const int mo8 = (P.Mo + 7) & ~7, ni8 = (P.Ni + 7) & ~7;                           // readable up to round_up(rows, 8) per token (ABI)
+    int ca = m0 + cr, cb = n0 + cr;
+    ca = ca <= mo8 - 8 ? ca : mo8 - 8;                                               // clamped pieces land in rows the epilogue masks
+    cb = cb <= ni8 - 8 ? cb : ni8 - 8;
+    unsigned offA[4], offB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = kl + (i & 1) * 16 + (i >> 1) * 4;
+        offA[i] = (unsigned)((k * (int)P.lda + ca) * 2);
+        offB[i] = (unsigned)((k * (int)P.ldb + cb) * 2);
+    }
+    const long stepA = 64 * P.lda * 2, stepB = 64 * P.ldb * 2;
+    const unsigned char* baseA = (const unsigned char*)P.A;
+    const unsigned char* baseB = (const unsigned char*)P.B;
+    const int nk = g.KT + (g.rows_tail > 0 ? 1 : 0);
+    auto issue = [&](int kt) {                               // K tile kt -> ring stage kt % STAGES
+        unsigned char* dst = smem + (kt % STAGES) * STAGE_BYTES + wave * 4096;
+        if (kt < g.KT) {
+            const unsigned char* sa = baseA + (long)kt * stepA;
+            const unsigned char* sb = baseB + (long)kt * stepB;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) vb_glds16(sa + offA[i], dst + i * 1024);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) vb_glds16(sb + offB[i], dst + HALF + i * 1024);
+        } else {
+            // the ragged tile: rows >= rows_tail are zeros; through registers (a masked LDS-direct lane would leave stale LDS behind);
+            // loads from a clamped (always readable) row, the zero chosen afterwards
+            const unsigned char* sa = baseA + (long)g.KT * stepA;
+            const unsigned char* sb = baseB + (long)g.KT * stepB;
+            u32x4 va[4], vb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = kl + (i & 1) * 16 + (i >> 1) * 4;
+                const int kc = k < g.rows_tail ? k : g.rows_tail - 1;
+                va[i] = *(const u32x4*)(sa + (long)(kc * (int)P.lda + ca) * 2);
+                vb[i] = *(const u32x4*)(sb + (long)(kc * (int)P.ldb + cb) * 2);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = kl + (i & 1) * 16 + (i >> 1) * 4;
+                const bool ok = k < g.rows_tail;
+                const u32x4 z = u32x4{0u, 0u, 0u, 0u};
+                *(u32x4*)(dst + i * 1024 + lane * 16) = ok ? va[i] : z;
+                *(u32x4*)(dst + HALF + i * 1024 + lane * 16) = ok ? vb[i] : z;
+            }
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- fragment gathers (lane map of the transposing read: gemm_tn_8ph_kernel)
+    const int s16 = lane & 15, kg = lane >> 4;
+    const int lane_off = (kg >> 1) * 1024 + ((kg & 1) * 4 + (s16 >> 2)) * 32 + ((s16 >> 1) & 1) * 16 + (s16 & 1) * 8;
+    const int offa_w = wm * 8192 + lane_off, offb_w = HALF + wn * 8192 + lane_off;
+    bf16x4 fal[4][2], fah[4][2], fbl[4][2], fbh[4][2];
+
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (s < nk) issue(s);
+    for (int kt = 0; kt < nk; ++kt) {
+        // tile kt has landed; the LDS-direct tiles issued after it (at most STAGES - 2, and only whole tiles: index < KT) may stay in flight
+        const int last = g.KT - 1;
+        if (STAGES >= 3 && kt + STAGES - 2 <= last) vb_wait_vmcnt<(STAGES - 2) * PER_TILE>();
+        else if (STAGES >= 4 && kt + STAGES - 3 <= last) vb_wait_vmcnt<(STAGES >= 4 ? STAGES - 3 : 0) * PER_TILE>();
+        else vb_wait_vmcnt<0>();
+        vb_raw_barrier();                      // everyone's part of tile kt is in LDS; everyone finished reading tile kt - 1
+        if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1);
+        const unsigned char* buf = smem + (kt % STAGES) * STAGE_BYTES;
+        const unsigned char* pa = buf + offa_w;
+        const unsigned char* pb = buf + offb_w;
+        vb_static_for<0, 4>([&](auto f) { vb_lds_read_tr_pair<decltype(f)::value * 256>(fal[decltype(f)::value][0], fah[decltype(f)::value][0], pa); });
+        vb_static_for<0, 4>([&](auto f) { vb_lds_read_tr_pair<decltype(f)::value * 256>(fbl[decltype(f)::value][0], fbh[decltype(f)::value][0], pb); });
+        vb_static_for<0, 4>([&](auto f) { vb_lds_read_tr_pair<4096 + decltype(f)::value * 256>(fal[decltype(f)::value][1], fah[decltype(f)::value][1], pa); });
+        vb_static_for<0, 4>([&](auto f) { vb_lds_read_tr_pair<4096 + decltype(f)::value * 256>(fbl[decltype(f)::value][1], fbh[decltype(f)::value][1], pb); });
+        vb_wait_lgkmcnt<15>();                 // 32 reads issued, the LDS returns them in order: the first 16 (the k = 0 .. 31 fragments) are in
+        vb_sched_fence();
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                acc[mi][ni] = vb_mma(vb_join(fal[mi][0], fah[mi][0]), vb_join(fbl[ni][0], fbh[ni][0]), acc[mi][ni]);
+        vb_sched_fence();
+        vb_wait_lgkmcnt<0>();
+        vb_sched_fence();
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                acc[mi][ni] = vb_mma(vb_join(fal[mi][1], fah[mi][1]), vb_join(fbl[ni][1], fbh[ni][1]), acc[mi][ni]);
+    }
+
+    // ---- dW tile += alpha * acc: through a wave-private slab (in the ring, dead by now) so that a lane owns 8 consecutive columns
+    const float alpha = g.alpha_dev ? g.alpha * g.alpha_dev[0] : g.alpha;
+    const int li = lane & 15, lg = lane >> 4;
+    unsigned char* slab = smem + wave * EPI_BYTES_PER_WAVE;
+    static_assert(4 * EPI_BYTES_PER_WAVE <= 2 * STAGE_BYTES, "epilogue slabs live in the ring");
+    __syncthreads();                           // every wave has finished reading the ring
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass) vb_wave_sync();
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    *(float*)(slab + (mh * 16 + lg * 4 + r) * EPI_PITCH + (ni * 16 + li) * 4) = acc[pass * 2 + mh][ni][r];
+        vb_wave_sync();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = it * 8 + (lane >> 3);
+            const int m = mw0 + pass * 32 + row;
+            const unsigned char* src = slab + row * EPI_PITCH + (lane & 7) * 32;
+            const f32x4 lo = *(const f32x4*)src, hi = *(const f32x4*)(src + 16);
+            if (m < P.Mo && col_ok) {
+                float* cp = P.C + (long)m * P.ldc + ncol;
+                *(f32x4*)cp = cin[pass][it][0] + alpha * lo;
+                *(f32x4*)(cp + 4) = cin[pass][it][1] + alpha * hi;
+            }
+        }
+    }
+}
 static bool tn_eligible(const void* A, long lda, const void* B, long ldb, const float* C, long ldc, int Mo, int Ni, int K) {
     return K >= 64 && (K % 64) == 0 && Mo >= 1 && Ni >= 1 && lda >= ((Mo + 7) & ~7) && ldb >= ((Ni + 7) & ~7) && (lda % 8) == 0 && (ldb % 8) == 0 &&
            ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0 && C != nullptr && ldc >= Ni &&
            64L * lda * 2 + 2L * Mo < (1L << 31) && 64L * ldb * 2 + 2L * Ni < (1L << 31);
+}
+
+// the small-token kernel takes a group when: few K tiles (the persistent kernel's atomic drain would dominate), vector-aligned dW
+// rows, and no two problems adding into the same dW (plain read-modify-writes).  VB_TN_SMALL_MAX_KT: crossover measured on MI355X
+// (profiles/r06_small_batch_ab.txt): the persistent kernel's 256x256 tiles move half the LDS bytes per FLOP and win once the K loop is long
+#ifndef VB_TN_SMALL_MAX_KT
+#define VB_TN_SMALL_MAX_KT 48
+#endif
+static bool tn_small_eligible(const TnArgs& g, int tokens) {
+    if ((tokens + 63) / 64 > VB_TN_SMALL_MAX_KT) return false;
+    for (int i = 0; i < g.nprob; ++i) {
+        const TnProblem& P = g.p[i];
+        if ((P.Ni % 8) || (P.ldc % 4) || (((uintptr_t)P.C) & 15)) return false;
+        for (int j = i + 1; j < g.nprob; ++j) {
+            const float *a0 = P.C, *a1 = a0 + (long)(P.Mo - 1) * P.ldc + P.Ni;
+            const float *b0 = g.p[j].C, *b1 = b0 + (long)(g.p[j].Mo - 1) * g.p[j].ldc + g.p[j].Ni;
+            if (a0 < b1 && b0 < a1) return false;
+        }
+    }
+    return true;
+}
+static int launch_tn_small(const TnArgs& main, int tokens, hipStream_t stream) {
+    TnSmallArgs g;
+    g.nprob = main.nprob; g.alpha = main.alpha; g.alpha_dev = main.alpha_dev;
+    g.KT = tokens / 64; g.rows_tail = tokens % 64;
+    int tiles = 0;
+    double flops = 0;
+    for (int i = 0; i < main.nprob; ++i) {
+        g.p[i] = main.p[i];
+        g.tile0[i] = tiles;
+        tiles += ((main.p[i].Mo + 127) / 128) * ((main.p[i].Ni + 127) / 128);
+        flops += 2.0 * main.p[i].Mo * main.p[i].Ni * tokens;
+    }
+    g.tile0[main.nprob] = tiles;
+    const int cus = (t_opts.persistent_workgroups > 0 && t_opts.persistent_workgroups < vb_num_cus()) ? t_opts.persistent_workgroups : vb_num_cus();
+    dim3 grid((unsigned)tiles), block(256);
+    // key: weight-gradient family (4 | 2 | 1) + 32 = the small-token kernel
+    if (tiles <= cus)
+        return vb_prof_launch(flops, 4 | 2 | 1 | 32, stream, [&]() { VB_LAUNCH(gemm_tn_small_kernel<4>, grid, block, 4 * 2 * 128 * 128, stream, g); });
+    return vb_prof_launch(flops, 4 | 2 | 1 | 32, stream, [&]() { VB_LAUNCH(gemm_tn_small_kernel<2>, grid, block, 2 * 2 * 128 * 128, stream, g); });
 }
 
 // kernel for a K-contiguous x K-contiguous problem (vb_stream_opts.nt_kernel): 0 = chosen from the shape; 1 = the generic
@@ -2447,6 +2674,9 @@ static bool tn_eligible(const void* A, long lda, const void* B, long ldb, const 
 template <typename T, typename TO>
 int dispatch_pipe(const GemmArgs& g, hipStream_t s) {
     int variant = t_opts.nt_kernel;
+    // compute units this stream may fill: the device's, or fewer while DataParallelGradSync keeps some for RCCL (persistent_workgroups)
+    const int all_cus = vb_num_cus();
+    const int cus = (t_opts.persistent_workgroups > 0 && t_opts.persistent_workgroups < all_cus) ? t_opts.persistent_workgroups : all_cus;
     if (g.x3) {                                            // split operands: the two-workgroup kernel or the two-barrier ones
         const long t256 = (long)((g.M + 255) / 256) * ((g.N + 255) / 256);
         const long t128 = (long)((g.M + 255) / 256) * ((g.N + 127) / 128);
@@ -2461,8 +2691,9 @@ int dispatch_pipe(const GemmArgs& g, hipStream_t s) {
         const bool light = g.act == VB_ACT_NONE && !g.aux_in && !g.aux_out && !g.colsum && !g.split_out && g.N <= 4096;
         const bool gelu_split = g.act == VB_ACT_GELU_SAVE_GRAD && g.split_out && !g.aux_in && !g.colsum && g.N <= 4096;
         const long t22 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);          // at most one 128x128 tile per CU: the four-stage ring (see below)
-        if (variant != 22 && variant != 24 && variant != 42 && variant != 90 && variant != 81)
-            variant = t256 >= 160 ? ((light || gelu_split) ? 81 : 90) : (t128 >= 256 ? 42 : (t22 <= 256 ? 24 : 22));   // (never 100 / 101)
+        // a pinned kernel is honoured here too (14 / 22 / 24 / 42 / 81 / 90: what vb_stream_set_opts accepts in the product library)
+        if (variant != 14 && variant != 22 && variant != 24 && variant != 42 && variant != 90 && variant != 81)
+            variant = t256 >= 160 ? ((light || gelu_split) ? 81 : 90) : (t128 >= cus ? 42 : (t22 <= cus ? 24 : 22));   // (never 100 / 101)
     }
 #ifdef VB_DEV_KNOBS
     if (variant == 200) {
@@ -2509,7 +2740,11 @@ int dispatch_pipe(const GemmArgs& g, hipStream_t s) {
         // tiles than CUs it loses the second resident workgroup (B = 64: 10.68 -> 11.46 ms) -- profiles/r05_small_batch_four_stage_ab.txt
         // ... and 64x128 tiles on the same ring (nt_kernel 14) while even those leave half the chip idle: 6.01 -> 5.90 ms at B = 8, 6.34 -> 6.19 at 16
         const long t22 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
-        variant = (sizeof(T) == 2 && t256 >= 160) ? ((plain || (g.K >= 2048 && light)) ? 81 : 90) : (t128 >= 256 ? 42 : (t22 <= 128 ? 14 : (t22 <= 256 ? 24 : 22)));
+        variant = (sizeof(T) == 2 && t256 >= 160) ? ((plain || (g.K >= 2048 && light)) ? 81 : 90) : (t128 >= cus ? 42 : (t22 <= cus / 2 ? 14 : (t22 <= cus ? 24 : 22)));
+        // compute units reserved for a collective (cus < all_cus): the persistent kernel's grid IS the CU count and its N = 768 shapes pay
+        // a whole second round for any grid below 246 workgroups -- those launches take the one-workgroup-per-tile kernel instead; every
+        // other choice of the rule stands (pinning 90 from Python bypassed the small-problem kernels)
+        if (variant == 81 && cus < all_cus) variant = 90;
 #ifdef VB_DEV_KNOBS
         if (variant == 90 && (g.debug & (1 << 28)) && (plain || light)) variant = 81;      // A/B: the short-K plain / "+ addend" shapes on the persistent kernel too
 #endif
@@ -2655,9 +2890,9 @@ extern "C" int vb_wgrad_grouped(int dtype, int n, const void* const* dy, const i
     vb_prof_select(stream);
     // the grouped kernel takes whole 64-token K tiles; the last tokens % 64 rows (ragged B x S) go through the generic kernel below
     const int main_tok = tokens & ~63;
-    bool fast = dtype == VB_BF16 && t_opts.nt_kernel != 1 && main_tok >= 64;
-    for (int i = 0; i < n && fast; ++i)
-        fast = tn_eligible(dy[i], ld_dy[i], x[i], ld_x[i], (const float*)dw[i], ld_dw[i], n_out[i], n_in[i], main_tok);
+    bool fast = dtype == VB_BF16 && t_opts.nt_kernel != 1;
+    for (int i = 0; i < n && fast; ++i)          // alignment / range checks (they do not depend on the token count)
+        fast = tn_eligible(dy[i], ld_dy[i], x[i], ld_x[i], (const float*)dw[i], ld_dw[i], n_out[i], n_in[i], 64);
     int done = 0;
     if (fast) {
         TnArgs tg;
@@ -2667,9 +2902,12 @@ extern "C" int vb_wgrad_grouped(int dtype, int n, const void* const* dy, const i
             tg.p[i].lda = ld_dy[i]; tg.p[i].ldb = ld_x[i]; tg.p[i].ldc = ld_dw[i];
             tg.p[i].Mo = n_out[i]; tg.p[i].Ni = n_in[i];
         }
-        const int rc = launch_tn_group(tg, main_tok, (hipStream_t)stream);
-        if (rc != VB_OK || main_tok == tokens) return rc;
-        return launch_tn_tail(tg, main_tok, tokens - main_tok, (hipStream_t)stream);       // the ragged rows of every problem: one launch
+        if (tn_small_eligible(tg, tokens)) return launch_tn_small(tg, tokens, (hipStream_t)stream);     // few tokens: one launch, no atomics
+        if (main_tok >= 64) {
+            const int rc = launch_tn_group(tg, main_tok, (hipStream_t)stream);
+            if (rc != VB_OK || main_tok == tokens) return rc;
+            return launch_tn_tail(tg, main_tok, tokens - main_tok, (hipStream_t)stream);   // the ragged rows of every problem: one launch
+        }
     }
     const size_t es = dtype == VB_BF16 ? 2 : 4;
     for (int i = 0; i < n; ++i) {

@@ -486,13 +486,17 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(NT, 4) ln_bwd12_kernel(LnBwdArgs a) {
         phase2(W8(), dyA, xhA, colA, true, accx);
         phase2(W4(), dyB, xhB, colBc, okB, accx + 8);
     }
-    // the waves' accumulators -> LDS [wave][3][H]
-    float* my = lds + (long)wave * 3 * H;
+    // the waves' accumulators -> LDS [wave][3][HP]: column c sits at c + (c >> 5), i.e. one float of padding per 32 columns, so that the
+    // 32 lanes of a store (lane stride 8 or 4 columns) fall on 32 different banks -- at the plain pitch they shared four (an 8-way
+    // conflict on every store: SQ_LDS_BANK_CONFLICT 34 % of this kernel's LDS cycles in round 5's PMC pass)
+    const int HP = H + (H >> 5) + 1;
+    float* my = lds + (long)wave * 3 * HP;
+    const int pA = colA + (colA >> 5), pB = colB + (colB >> 5);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { my[colA + j] = accg[j]; my[H + colA + j] = accb[j]; my[2 * H + colA + j] = accx[j]; }
+    for (int j = 0; j < 8; ++j) { my[pA + j] = accg[j]; my[HP + pA + j] = accb[j]; my[2 * HP + pA + j] = accx[j]; }
     if (okB) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { my[colB + j] = accg[8 + j]; my[H + colB + j] = accb[8 + j]; my[2 * H + colB + j] = accx[8 + j]; }
+        for (int j = 0; j < 4; ++j) { my[pB + j] = accg[8 + j]; my[HP + pB + j] = accb[8 + j]; my[2 * HP + pB + j] = accx[8 + j]; }
     }
     __syncthreads();
     float* part = a.partials ? a.partials + (long)blockIdx.x * 3 * H : nullptr;
@@ -501,8 +505,9 @@ VB_KERNEL VB_LAUNCH_BOUNDS2(NT, 4) ln_bwd12_kernel(LnBwdArgs a) {
         float* out = which == 0 ? a.dgamma : (which == 1 ? a.dbeta : a.dbias);
         if (!out) continue;
         float sum = 0.f;
+        const int pi = which * HP + c + (c >> 5);
 #pragma unroll
-        for (int h = 0; h < WAVES_PER_BLOCK; ++h) sum += lds[(long)h * 3 * H + i];
+        for (int h = 0; h < WAVES_PER_BLOCK; ++h) sum += lds[(long)h * 3 * HP + pi];
         if (part) part[i] = sum;
         else atomicAdd(&out[c], sum);
     }
@@ -755,7 +760,7 @@ int vb_ln_bwd_sp(int dtype, const void* dy, const void* z, const float* mean, co
                 make_drop(p_out, seed, stream_out), ws, (bf16*)dx_split, (long)ld_split, y, beta, rebuild};
     dim3 grid(row_grid(M, ws ? 1024 : 256));
     hipStream_t s = (hipStream_t)stream;
-    const size_t smem = (size_t)H * WAVES_PER_BLOCK * 3 * sizeof(float);
+    const size_t smem = (size_t)(H + (H >> 5) + 1) * WAVES_PER_BLOCK * 3 * sizeof(float);      // padded pitch: ln_bwd12_kernel
     // generic kernel <.., 4>: four waves per SIMD (128 VGPRs, a 12-byte spill) beat three without the spill: 109 vs 130 us at M = 83,968
     // 512 < H <= 768: twelve columns per lane (113 VGPRs, no spills, every lane busy): 188.7 -> 182.4 us per launch at M = 167,936 in the
     // step, 191.8 us in the rebuild-capable form (profiles/r04_ln_rebuild.txt).  The generic kernel's rebuild-capable form exists for

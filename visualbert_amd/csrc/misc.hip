@@ -74,7 +74,8 @@ template <typename T>
 VB_KERNEL VB_LAUNCH_BOUNDS(NT) colsum_kernel(const T* x, long ld, float* out, const float* scale_dev, int M, int N,
                                             int rows_per_block, int fold) {
     VB_DYN_SMEM(smem);
-    float* red = (float*)smem;                       // [4][512]
+    constexpr int RED_PITCH = 64 * 9;
+    float* red = (float*)smem;                       // [4 waves][64 lanes][9]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = blockIdx.x * 512 + lane * 8;
     const int r0 = blockIdx.y * rows_per_block;
@@ -105,13 +106,15 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) colsum_kernel(const T* x, long ld, float* out, co
             }
         }
     }
+    // a lane's 8 values at a pitch of 9 floats: lane stride 9 is coprime with the 32 banks a 4-byte LDS access is spread over (the
+    // pitch-8 form was an 8-way conflict on every store: SQ_LDS_BANK_CONFLICT 35 % of this kernel's LDS cycles, round 5's PMC pass)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) red[wave * 512 + lane * 8 + j] = acc[j];
+    for (int j = 0; j < 8; ++j) red[wave * RED_PITCH + lane * 9 + j] = acc[j];
     __syncthreads();
     const float sc = scale_dev ? scale_dev[0] : 1.f;
     for (int c = threadIdx.x; c < 512; c += NT) {
-        const int cc = blockIdx.x * 512 + c;
-        if (cc < N) atomicAdd(&out[fold > 0 && cc >= fold ? cc - fold : cc], (red[c] + red[512 + c] + red[1024 + c] + red[1536 + c]) * sc);
+        const int cc = blockIdx.x * 512 + c, ci = c + (c >> 3);
+        if (cc < N) atomicAdd(&out[fold > 0 && cc >= fold ? cc - fold : cc], (red[ci] + red[RED_PITCH + ci] + red[2 * RED_PITCH + ci] + red[3 * RED_PITCH + ci]) * sc);
     }
 }
 
@@ -299,7 +302,7 @@ static int colsum_launch(int dtype, const void* x, int64_t ld, float* out, const
     while ((long)((M + rb - 1) / rb) * ((N + 511) / 512) > 4096) rb *= 2;
     dim3 grid((unsigned)((N + 511) / 512), (unsigned)((M + rb - 1) / rb));
     hipStream_t s = (hipStream_t)stream;
-    const size_t smem = 4 * 512 * sizeof(float);
+    const size_t smem = 4 * 64 * 9 * sizeof(float);
     if (dtype == VB_BF16) VB_LAUNCH(colsum_kernel<bf16>, grid, dim3(NT), smem, s, (const bf16*)x, (long)ld, out, scale_dev, M, N, rb, fold);
     else if (dtype == VB_F32) VB_LAUNCH(colsum_kernel<float>, grid, dim3(NT), smem, s, (const float*)x, (long)ld, out, scale_dev, M, N, rb, fold);
     else return VB_ERR_ARG;

@@ -245,10 +245,14 @@ class FeatureStager(object):
         consumed = torch.cuda.Event()
         consumed.record(torch.cuda.current_stream(self.device))      # the slot's previous contents are consumed before this
         prev = self._copied.get(slot)
+        # entries whose copy has completed carry no information any more (and a freed slab's address may be reused by another
+        # tensor, which must not inherit the old event): drop them before looking anything up
+        self._slab_events = {p: e for p, e in self._slab_events.items() if not e.query()}
+        pinned = {k: v.is_pinned() for k, v in host_batch.items()}   # a driver query: once per tensor and call
         with torch.cuda.stream(self.stream):
             self.stream.wait_event(consumed)
             for k, v in host_batch.items():
-                if v.is_pinned():                       # the feature store already lives in pinned memory: copied from in
+                if pinned[k]:                           # the feature store already lives in pinned memory: copied from in
                     pin = v                             # place (the caller keeps it intact until `ev` completes, see above)
                     last = self._slab_events.get(v.data_ptr())
                     if self.strict_pinned and last is not None and not last.query():
@@ -274,8 +278,8 @@ class FeatureStager(object):
             ev = torch.cuda.Event()
             ev.record(self.stream)
         self._copied[slot] = ev
-        for v in host_batch.values():
-            if v.is_pinned():
+        for k, v in host_batch.items():
+            if pinned[k]:
                 self._slab_events[v.data_ptr()] = ev
         return out, ev
 

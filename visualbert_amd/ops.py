@@ -310,6 +310,9 @@ def gemm_key_name(key):
     if (key & 19) == 19:
         return "gemm_tn_8ph_kernel<bf16->fp32, grouped persistent 256x256 wgrad, ds_read_b64_tr_b16 gathers, fp32 atomics>" + \
             (" [bf16x3: three plane-pair passes, algorithmic FLOPs]" if key & 256 else "")
+    if (key & 255) == 39:
+        return "gemm_tn_small_kernel<bf16->fp32, grouped 128x128 wgrad for small token counts, whole token range per tile, plain read-modify-write>" + \
+            (" [bf16x3: three plane-pair passes, algorithmic FLOPs]" if key & 256 else "")
     if key & 512:
         return "hipBLASLt (vendor yardstick, nt_kernel 200)<bf16->%s>" % ("fp32" if key & 4 else "bf16")
     x3 = " [bf16x3 split operands]" if key & 256 else ""

@@ -26,8 +26,9 @@ VGPRs, 81,920 B each) fill it the same way; the one-pass attention backward hold
 can share a CU with an RCCL workgroup (registers alone forbid it): while the collective is resident on c CUs, c workgroups of a
 persistent launch wait for a CU -- the launch is stretched by up to the collective's remaining residency -- and c CUs host one
 256x128 workgroup (or none) instead of two.  Reserving CUs up front (VB_COMM_CUS=c: RCCL capped to c channels via
-NCCL_MAX_NCHANNELS; while buckets are in flight the forward / dgrad GEMMs run as the one-workgroup-per-tile kernel and the
-weight-gradient kernel on CUs - c workgroups) is OFF by default: on one GPU the persistent GEMM's N = 768 shapes paid a second
+NCCL_MAX_NCHANNELS; while buckets are in flight the GEMM dispatcher sends what would have been persistent 256x256 launches to
+the one-workgroup-per-tile kernel and runs the weight-gradient kernel on CUs - c workgroups; bitwise results then differ from a run
+without the reservation) is OFF by default: on one GPU the persistent GEMM's N = 768 shapes paid a second
 round for ANY grid below 246 workgroups (30 -> 47 us, 78 -> 128 us at 224) -- which is why the reservation now pins the
 per-tile kernel for them.  DESIGN.md section 6 carries the bound this puts on the scaling prediction.
 """
@@ -171,11 +172,14 @@ class DataParallelGradSync(object):
             _lib.check(_lib.lib().vb_stream_get_opts(sp, ctypes.byref(cur)), "vb_stream_get_opts")
             self._saved_opts = (cur.persistent_workgroups, cur.nt_kernel, cur.attn_two_pass, cur.reserved)
             cus = torch.cuda.get_device_properties(self.obj.arena.grad.device).multi_processor_count
-            # forward / dgrad GEMMs: the two-workgroups-per-CU kernel (nt_kernel 90) unless the caller pinned one -- its grid is one
-            # workgroup per TILE, so a CU that RCCL holds simply takes fewer of them (the persistent 256x256 kernel's grid IS the CU
-            # count: short of CUs it pays a whole second round on the N = 768 shapes, see the module docstring); the grouped
-            # weight-gradient kernel, persistent by construction, gets the reduced workgroup count
-            o = _lib.StreamOpts(max(8, (cus - comm_cus()) // 8 * 8), cur.nt_kernel or 90, cur.attn_two_pass, cur.reserved)
+            # only the workgroup budget is lowered; the GEMM dispatcher (csrc/gemm.hip: dispatch_pipe) reads it and moves exactly the
+            # launches that would have taken the persistent 256x256 kernel -- whose grid IS the CU count: short of CUs it pays a whole
+            # second round on the N = 768 shapes, see the module docstring -- to the one-workgroup-per-TILE kernel (a CU that RCCL holds
+            # simply takes fewer tiles); the small-problem kernels of small per-GPU batches keep their rule, measured against the
+            # reduced budget; the grouped weight-gradient kernel, persistent by construction, gets the reduced workgroup count.
+            # NOTE: a GEMM that changes kernel changes its summation order -- with VB_COMM_CUS set, results differ bitwise from a run
+            # without it (same bounds; replicas still agree with each other: every rank reserves the same way).
+            o = _lib.StreamOpts(max(8, (cus - comm_cus()) // 8 * 8), cur.nt_kernel, cur.attn_two_pass, cur.reserved)
             _lib.check(_lib.lib().vb_stream_set_opts(sp, ctypes.byref(o)), "vb_stream_set_opts")
         else:
             saved = getattr(self, "_saved_opts", (0, 0, 0, 0))

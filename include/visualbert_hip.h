@@ -73,6 +73,21 @@ int vb_stream_set_opts(void* stream, const vb_stream_opts* opts);
 int vb_stream_get_opts(void* stream, vb_stream_opts* out);
 
 /* ------------------------------------------------------------------------------------------------
+ * Caller-owned scratch for in-launch reductions, per stream (round 6).  Small GEMMs -- per-GPU batches of 8-16, the regime of the
+ * reference's own configs (visualbert/configs/vqa/coco-pre-train.json:17 over 8 GPUs, models/train.py:146) -- have fewer output tiles
+ * than the chip has compute units; vb_gemm then cuts the reduction (K) of a long-K problem into slices that run on different
+ * compute units, each slice leaves its fp32 partial tile in this buffer, and the LAST slice to arrive (a device-scope ticket) sums the
+ * slices IN SLICE ORDER (deterministic: the result does not depend on which slice came last) and runs the ordinary epilogue.
+ * The library never allocates device memory: without a registered buffer that form is simply not chosen.
+ *   scratch: device memory, 256-byte aligned, >= VB_SCRATCH_MIN_BYTES; the first 16 KB are arrival counters (zeroed HERE, on `stream`;
+ *            every kernel leaves them zero), the rest holds the partial tiles.  The buffer belongs to the stream: launches on ONE stream
+ *            are ordered, two streams must not share a buffer.  It must stay alive until the stream's work has drained;
+ *   vb_stream_set_scratch(stream, NULL, 0) forgets the entry.
+ * ---------------------------------------------------------------------------------------------- */
+#define VB_SCRATCH_MIN_BYTES (1 << 20)
+int vb_stream_set_scratch(void* stream, void* scratch, int64_t bytes);
+
+/* ------------------------------------------------------------------------------------------------
  * GEMM with fused epilogue.   C[M,N] = epi( alpha * sum_k Aop[m,k] * Bop[n,k] )
  *   a_layout / b_layout: VB_KCONTIG  -> operand stored [rows][K]  (ld = row pitch)
  *                        VB_KSTRIDED -> operand stored [K][rows]  (ld = k pitch)

@@ -102,6 +102,43 @@ def test_gemm_dgrad_wgrad_layouts(dev, dt, shape):
     assert (C - ref).abs().max().item() <= 3e-4 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("shape,addend", [((100, 128, 1536), False), ((100, 128, 1536), True), ((1312, 768, 3072), False),
+                                          ((1312, 768, 2304), True), ((650, 768, 3072), True)])
+def test_gemm_split_k_across_compute_units(dev, shape, addend):
+    """Small long-K problems (per-GPU batch 8: M = 1312, N = 768, K = 3072 / 2304) leave half of the chip idle: the reduction is cut into
+    slices on different compute units, partial tiles go through the stream's scratch (vb_stream_set_scratch), the last slice to arrive
+    sums them in slice order and runs the epilogue.  Against fp32 matmul, bias and "+ addend" epilogues; the SAME bits on every repeat
+    (the summation order does not depend on which slice arrives last) and the same bits as the unsplit kernel up to fp32 reassociation."""
+    M, N, K = shape
+    if dev.type != "cuda" and M > 128:
+        pytest.skip("simulator: the small case covers the index logic (4 compute units)")
+    g = torch.Generator().manual_seed(M + K)
+    dt = torch.bfloat16
+    A = (0.5 * torch.randn(M, K, generator=g)).to(dt).to(dev)
+    W = (0.05 * torch.randn(N, K, generator=g)).to(dt).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    add = torch.randn(M, N, generator=g).to(dt).to(dev) if addend else None
+    ref = A.float() @ W.float().t() + bias + (add.float() if addend else 0.0)
+    outs = []
+    L = _lib.lib()
+    for rep in range(3):
+        L.vb_stream_profile(_lib.stream_ptr(), 1)
+        C = gemm(dev, dt, A, W, M, N, K, 0, 0, bias=bias, addend=add)
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+            n = 8
+            ms, fl, ky = (ctypes.c_double * n)(), (ctypes.c_double * n)(), (ctypes.c_int * n)()
+            cnt = L.vb_stream_profile_read(_lib.stream_ptr(), ms, fl, ky, n)
+            assert cnt == 1 and (ky[0] & 1024), [ky[i] for i in range(max(cnt, 0))]        # the split-K instantiation ran
+        L.vb_stream_profile(_lib.stream_ptr(), 0)
+        assert (C.float() - ref).abs().max().item() <= 1e-2 * max(1.0, ref.abs().max().item())
+        outs.append(C.clone())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    with _lib.stream_opts(nt_kernel=22):                      # a pinned kernel is never split
+        C22 = gemm(dev, dt, A, W, M, N, K, 0, 0, bias=bias, addend=add)
+    assert (C22.float() - outs[0].float()).abs().max().item() <= 2e-2 * max(1.0, ref.abs().max().item())
+
+
 def _wgrad_grouped(dev, dys, xs, dws, tokens, alpha=1.0, alpha_dev=None):
     L = _lib.lib()
     n = len(dys)

@@ -24,6 +24,7 @@ SIGNATURES = {
     "vb_version": (ctypes.c_char_p, []),
     "vb_stream_set_opts": (_i, [_p, _p]),
     "vb_stream_get_opts": (_i, [_p, _p]),
+    "vb_stream_set_scratch": (_i, [_p, _p, _i64]),
     "vb_gemm": (_i, [_i, _i, _i, _i, _p, _i64, _p, _i64, _p, _i64, _i, _i, _i, _f, _p, _p, _p, _i64, _i,
                      _p, _p, _i64, _i, _p, _p]),
     "vb_ln_fwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _f, _u32, _f, _u32, _u64, _p]),
@@ -243,9 +244,38 @@ def ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+#: bytes of the per-stream scratch handed to the library (vb_stream_set_scratch): 16 KB of arrival counters + the fp32 partial tiles of
+#: the in-launch split-K GEMMs (at most compute-units x 64 KB = 16 MB at a time on MI355X)
+SCRATCH_BYTES = 32 << 20
+_scratch = {}
+
+
+def _register_scratch(key, sp, device):
+    buf = torch.empty(SCRATCH_BYTES + 256, dtype=torch.uint8, device=device)
+    base = (buf.data_ptr() + 255) & ~255                  # the ABI asks for 256-byte alignment
+    check(lib().vb_stream_set_scratch(sp, ctypes.c_void_p(base), SCRATCH_BYTES), "vb_stream_set_scratch")
+    _scratch[key] = buf                                   # kept alive with the process: the library holds the raw pointer
+
+
 def stream_ptr():
+    """the CURRENT stream as the ABI's `void* stream`.  Every call into the library passes through here, so this is also where a
+    stream gets its scratch buffer (include/visualbert_hip.h: vb_stream_set_scratch) the first time it is used -- per bound library
+    (the per-stream tables live inside each shared object) and per stream."""
+    if _lib is None:
+        lib()                                             # binds the library (and fixes _lib_path) on first use
     if _device_type == "cuda":
-        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        # the raw handle straight from torch's C side: torch.cuda.current_stream() builds a Python Stream object per call (~10 us of
+        # the ~30 calls of a training step at small batches, where the step is host-bound)
+        idx = torch.cuda.current_device()
+        raw = torch._C._cuda_getCurrentRawStream(idx)
+        sp = ctypes.c_void_p(raw)
+        key = (_lib_path, idx, raw)
+        if key not in _scratch:
+            _register_scratch(key, sp, torch.device("cuda", idx))
+        return sp
+    key = (_lib_path, -1, 0)
+    if key not in _scratch:
+        _register_scratch(key, None, torch.device("cpu"))
     return None
 
 

@@ -90,6 +90,12 @@ struct GemmArgs {
     // output tiles per second, whose dirty lines would push the operand panels out of the XCD's L2 -- gain 5-13 % alone at M = 167,936; long
     // ones (K >= 2048) lose up to 12 % with them (profiles/r04_gemm_nt_stores.txt), and so does nothing in the split-operand mode
     int nt_store;
+    // in-launch split-K of the small-problem kernels (gemm_nt_pipe_kernel<..., SK = true>): workgroup (tile, slice) reduces K tiles
+    // [slice sk_kps, (slice + 1) sk_kps), parks its fp32 partial tile in sk_slabs and draws a ticket from sk_cnt[tile]; the last
+    // arrival sums the slices in slice order and runs the epilogue (vb_stream_set_scratch owns the memory)
+    int sk_splits, sk_kps;
+    float* sk_slabs;
+    int* sk_cnt;
 };
 // K tile `v` of the (virtual) K loop -> element offset of its first column inside a row of A / of B
 VB_DEVICE int x3_col_a(const GemmArgs& g, int v, int bk) {
@@ -682,7 +688,7 @@ VB_DEVICE void fast_issue(unsigned char* stage, const FastPtrs<T, WM>& p, int k0
         vb_glds16(sb + p.b[i], lb + (wave * FastPtrs<T, WM>::B_INSTR + i) * 8 * 128);
 }
 
-template <typename T, typename TO, int WM, int STAGES, int DBG = 0, int ACT = -1, int OPT = EPI_ALL, typename TE = T, bool X3 = false>
+template <typename T, typename TO, int WM, int STAGES, int DBG = 0, int ACT = -1, int OPT = EPI_ALL, typename TE = T, bool X3 = false, bool SK = false>
 VB_KERNEL VB_LAUNCH_BOUNDS(WM * 128) gemm_nt_pipe_kernel(GemmArgs g) {
     constexpr int NW = WM * 2, BMX = WM * 64;
     constexpr int BK = TT<T>::BK, KSTEPS = TT<T>::KSTEPS;
@@ -694,7 +700,11 @@ VB_KERNEL VB_LAUNCH_BOUNDS(WM * 128) gemm_nt_pipe_kernel(GemmArgs g) {
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 15, lg = lane >> 4;
     const int nwg = g.tiles_m * g.tiles_n;
-    const int tile = xcd_remap((int)blockIdx.x, nwg);
+    // SK: workgroup id -> (tile, K slice); consecutive ids (one XCD's run of the remap) are the slices of one tile, so the last
+    // arrival reads its partners' partial tiles from its own XCD's L2 (speed only: the hand-off below is placement-independent)
+    const int wid = xcd_remap((int)blockIdx.x, SK ? nwg * g.sk_splits : nwg);
+    const int tile = SK ? wid / g.sk_splits : wid;
+    const int kt_lo = SK ? (wid - tile * g.sk_splits) * g.sk_kps : 0;
     const int m0 = (tile / g.tiles_n) * BMX, n0 = (tile % g.tiles_n) * BN;
     const T* A = (const T*)g.A;
     const T* B = (const T*)g.B;
@@ -705,14 +715,15 @@ VB_KERNEL VB_LAUNCH_BOUNDS(WM * 128) gemm_nt_pipe_kernel(GemmArgs g) {
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = X3 ? 3 * g.kseg : g.K / BK;
+    const int nk_all = X3 ? 3 * g.kseg : g.K / BK;
+    const int nk = SK ? (nk_all - kt_lo < g.sk_kps ? nk_all - kt_lo : g.sk_kps) : nk_all;
     FastPtrs<T, WM> ptrs;
     fast_setup<T, WM>(ptrs, A, B, g, m0, n0, wave, lane);
     typename VecOf<T>::v8 fa[4], fb[4];
-    auto issue_tile = [&](int kt) {                       // K tile kt of the (virtual) K loop into its ring stage
+    auto issue_tile = [&](int kt) {                       // K tile kt of this workgroup's (virtual) K loop into its ring stage
         unsigned char* stage = smem + (kt % STAGES) * STAGE_BYTES;
         if constexpr (X3) fast_issue<T, WM>(stage, ptrs, x3_col_a(g, kt, BK), x3_col_b(g, kt, BK), wave);
-        else fast_issue<T, WM>(stage, ptrs, kt * BK, kt * BK, wave);
+        else fast_issue<T, WM>(stage, ptrs, (kt_lo + kt) * BK, (kt_lo + kt) * BK, wave);
     };
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s)
@@ -767,6 +778,38 @@ VB_KERNEL VB_LAUNCH_BOUNDS(WM * 128) gemm_nt_pipe_kernel(GemmArgs g) {
             if ((DBG & 16) && ks == 0 && kt + STAGES - 1 < nk) issue_tile(kt + STAGES - 1);
         }
     }
+    if constexpr (SK) {
+        // partial tile -> this slice's slab, register-major ([16 accumulator vectors][threads]: every store / load instruction of a wave
+        // covers 1 KB of consecutive bytes), WRITE-THROUGH (sc1) stores: once a wave's vmcnt has drained they are in L2 / on the fabric,
+        // so the hand-off needs no release fence (which would write back the whole XCD L2: first version, 28.8 vs 30.0 us unsplit --
+        // profiles/r06_small_batch_ab.txt); workgroup barrier, ONE relaxed device-scope ticket; the workgroup that draws the last ticket
+        // reads every slice with sc1 loads (never served by this CU's L1: no acquire needed) and sums them IN SLICE ORDER -- its own from
+        // memory too, so the result does not depend on who arrived last.  Placement-independent (guide, Guideline 16).
+        constexpr int NTH = WM * 128;
+        const int nsl = g.sk_splits;
+        const vb_buf sbuf = vb_make_buf(g.sk_slabs);
+        const unsigned tile_off = (unsigned)tile * (unsigned)nsl * (16u * NTH * 16u);
+        const unsigned my_off = tile_off + (unsigned)(wid - tile * nsl) * (16u * NTH * 16u);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) vb_buf_store16_sc1(sbuf, (unsigned)(i * NTH + t) * 16u, my_off, __builtin_bit_cast(u32x4, acc[i >> 2][i & 3]));
+        vb_wait_vmcnt<0>();
+        __syncthreads();                                   // every wave's stores are out; the ring is dead
+        int* flag = (int*)smem;
+        if (t == 0) *flag = vb_ticket_add(g.sk_cnt + tile);
+        __syncthreads();
+        if (*flag != nsl - 1) return;                      // uniform over the workgroup
+        if (t == 0) vb_ticket_reset(g.sk_cnt + tile);      // zero again for the next launch on this stream
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i >> 2][i & 3] = __builtin_bit_cast(f32x4, vb_buf_load16_sc1(sbuf, (unsigned)(i * NTH + t) * 16u, tile_off));
+        for (int sl = 1; sl < nsl; ++sl) {
+            const unsigned off = tile_off + (unsigned)sl * (16u * NTH * 16u);
+            f32x4 part[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) part[i] = __builtin_bit_cast(f32x4, vb_buf_load16_sc1(sbuf, (unsigned)(i * NTH + t) * 16u, off));
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i >> 2][i & 3] += part[i];
+        }
+    }
     gemm_epilogue<TE, TO, ACT, OPT>(acc, smem, g, m0 + wm * 64, n0 + wn * 64, wave, lane);
 }
 
@@ -775,9 +818,9 @@ VB_KERNEL VB_LAUNCH_BOUNDS(WM * 128) gemm_nt_pipe_kernel(GemmArgs g) {
 template <typename T, typename TO>
 constexpr bool kActSpecialised = (sizeof(T) == 2 && sizeof(TO) == 2);
 
-template <typename T, typename TO, int WM, int STAGES, int ACT, int OPT, typename TE = T, bool X3 = false>
+template <typename T, typename TO, int WM, int STAGES, int ACT, int OPT, typename TE = T, bool X3 = false, bool SK = false>
 int launch_pipe_act(const GemmArgs& g, dim3 grid, dim3 block, int smem_bytes, hipStream_t stream) {
-    return vb_prof_launch(2.0 * g.M * g.N * g.K, (sizeof(T) == 2 ? 0 : 8) | (sizeof(TO) == 4 ? 4 : 0) | (X3 ? 256 : 0), stream, [&]() { VB_LAUNCH((gemm_nt_pipe_kernel<T, TO, WM, STAGES, 0, ACT, OPT, TE, X3>), grid, block, smem_bytes, stream, g); });
+    return vb_prof_launch(2.0 * g.M * g.N * g.K, (sizeof(T) == 2 ? 0 : 8) | (sizeof(TO) == 4 ? 4 : 0) | (X3 ? 256 : 0) | (SK ? 1024 : 0), stream, [&]() { VB_LAUNCH((gemm_nt_pipe_kernel<T, TO, WM, STAGES, 0, ACT, OPT, TE, X3, SK>), grid, block, smem_bytes, stream, g); });
 }
 
 template <typename T, typename TO, int WM, int STAGES>
@@ -805,6 +848,15 @@ int launch_pipe(GemmArgs g, hipStream_t stream) {
         }
     }
     const int needs = epi_needs(g, sizeof(T), sizeof(TO));
+    if constexpr (kActSpecialised<T, TO> && STAGES == 4) {
+        if (g.sk_splits > 1) {                             // K slices on different compute units (dispatch_pipe decided; light epilogues only)
+            dim3 gridk((unsigned)(g.tiles_m * g.tiles_n * g.sk_splits));
+            if (g.act == VB_ACT_NONE && needs == 0) return launch_pipe_act<T, TO, WM, STAGES, VB_ACT_NONE, 0, T, false, true>(g, gridk, block, SM, stream);
+            if (g.act == VB_ACT_NONE && (needs & ~EPI_ADD) == 0) return launch_pipe_act<T, TO, WM, STAGES, VB_ACT_NONE, EPI_ADD, T, false, true>(g, gridk, block, SM, stream);
+            g.sk_splits = 1;
+        }
+    }
+    g.sk_splits = 1;
 #define VB_TRY_EPI(A, O) if (g.act == (A) && (needs & ~(O)) == 0) return launch_pipe_act<T, TO, WM, STAGES, A, O>(g, grid, block, SM, stream)
     if constexpr (kActSpecialised<T, TO>) {
         VB_TRY_EPI(VB_ACT_NONE, 0);                        // forward projections, dgrad attention-out
@@ -2671,6 +2723,12 @@ static int launch_tn_small(const TnArgs& main, int tokens, hipStream_t stream) {
 
 // kernel for a K-contiguous x K-contiguous problem (vb_stream_opts.nt_kernel): 0 = chosen from the shape; 1 = the generic
 // register-staged kernel; tens = waves in M (2 -> 128-row tile, 4 -> 256-row tile), units = LDS stages; 80 / 81 persistent
+#ifndef VB_SPLITK_MIN_KT
+#define VB_SPLITK_MIN_KT 24          // reductions shorter than this (K < 1536) are not cut
+#endif
+#ifndef VB_SPLITK_MIN_SLICE
+#define VB_SPLITK_MIN_SLICE 8        // K tiles per slice at least
+#endif
 template <typename T, typename TO>
 int dispatch_pipe(const GemmArgs& g, hipStream_t s) {
     int variant = t_opts.nt_kernel;
@@ -2749,6 +2807,32 @@ int dispatch_pipe(const GemmArgs& g, hipStream_t s) {
         if (variant == 90 && (g.debug & (1 << 28)) && (plain || light)) variant = 81;      // A/B: the short-K plain / "+ addend" shapes on the persistent kernel too
 #endif
     }
+    if constexpr (sizeof(T) == 2 && sizeof(TO) == 2) {
+        // split-K across compute units for long reductions whose tiles leave at least half of the chip idle (per-GPU batch 8 at S = 164: the
+        // K = 3072 / 2304 GEMMs with N = 768 are 126 tiles of 64x128 walking 36-48 K tiles each -- 30 us for 6 GFLOP,
+        // profiles/r05_fin3_kernel_stats_b8.txt): slices of at least VB_SPLITK_MIN_SLICE K tiles, as many as fill the chip, partial tiles
+        // through the stream's scratch (vb_stream_set_scratch; none registered = not chosen)
+        if ((variant == 14 || variant == 24) && !g.x3 && g.act == VB_ACT_NONE && !g.aux_in && !g.aux_out && !g.colsum && !g.accumulate &&
+            g.K / 64 >= VB_SPLITK_MIN_KT) {
+            const vb_scratch sc = vb_scratch_for((void*)s);
+            const long tiles = (long)((g.M + (variant == 14 ? 63 : 127)) / (variant == 14 ? 64 : 128)) * ((g.N + 127) / 128);
+            const int nk = g.K / 64;
+            int want = (int)(cus / tiles);
+            if (want > nk / VB_SPLITK_MIN_SLICE) want = nk / VB_SPLITK_MIN_SLICE;
+            if (want > 8) want = 8;
+            if (sc.ptr && want >= 2 && tiles * 4 <= VB_SCRATCH_COUNTER_BYTES) {
+                GemmArgs gs = g;
+                gs.sk_kps = (nk + want - 1) / want;
+                gs.sk_splits = (nk + gs.sk_kps - 1) / gs.sk_kps;
+                const long slab_bytes = tiles * gs.sk_splits * (variant == 14 ? 128 : 256) * 256L;
+                if (gs.sk_splits >= 2 && VB_SCRATCH_COUNTER_BYTES + slab_bytes <= sc.bytes) {
+                    gs.sk_cnt = (int*)sc.ptr;
+                    gs.sk_slabs = (float*)((unsigned char*)sc.ptr + VB_SCRATCH_COUNTER_BYTES);
+                    return variant == 14 ? launch_pipe<T, TO, 1, 4>(gs, s) : launch_pipe<T, TO, 2, 4>(gs, s);
+                }
+            }
+        }
+    }
     switch (variant) {
         case 22: return launch_pipe<T, TO, 2, 2>(g, s);
         case 24: return launch_pipe<T, TO, 2, 4>(g, s);
@@ -2823,6 +2907,7 @@ extern "C" int vb_gemm(int dtype, int out_dtype, int a_layout, int b_layout,
     g.nt_store = (!x3 && dtype == VB_BF16 && K <= 1024 && !(g_debug & (1 << 26))) ? 1 : 0;      // developer library, debug bit 26: plain stores (the A/B and bit-compare arm)
     g.x3 = x3 ? 1 : 0; g.a_lo = x3 ? (int)(lda / 2) : 0; g.b_lo = x3 ? (int)(ldb / 2) : 0; g.kseg = x3 ? K / 64 : 0;
     g.stripe = 0;
+    g.sk_splits = 1; g.sk_kps = 0; g.sk_slabs = nullptr; g.sk_cnt = nullptr;
     const int bk = dtype == VB_F32 ? 32 : 64;
     const int nk = x3 ? 3 * (K / 64) : (K + bk - 1) / bk;
     // LDS-direct copies need whole K tiles (a masked lane would leave stale LDS behind)
@@ -2852,6 +2937,7 @@ extern "C" int vb_gemm(int dtype, int out_dtype, int a_layout, int b_layout,
         tg.nprob = 1; tg.alpha = alpha; tg.alpha_dev = alpha_dev;
         tg.p[0].A = A; tg.p[0].B = B; tg.p[0].C = (float*)C; tg.p[0].lda = lda; tg.p[0].ldb = ldb; tg.p[0].ldc = ldc;
         tg.p[0].Mo = M; tg.p[0].Ni = N;
+        if (tn_small_eligible(tg, K)) return launch_tn_small(tg, K, s);      // few tokens (the MLM decoder's weight gradient over the labelled rows, small batches)
         const int rc = launch_tn_group(tg, k_main, s);
         if (rc != VB_OK || k_main == K) return rc;
         return vb_gemm(dtype, out_dtype, a_layout, b_layout, (const bf16*)A + (long)k_main * lda, lda, (const bf16*)B + (long)k_main * ldb, ldb,

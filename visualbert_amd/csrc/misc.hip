@@ -387,6 +387,41 @@ extern "C" int vb_stream_get_opts(void* stream, vb_stream_opts* out) {
     return VB_OK;
 }
 
+// ---- per-stream scratch for in-launch reductions (include/visualbert_hip.h: vb_stream_set_scratch) --------------------------
+namespace {
+std::vector<std::pair<void*, vb_scratch>>& scratch_table() {
+    static std::vector<std::pair<void*, vb_scratch>> t;
+    return t;
+}
+}  // namespace
+
+vb_scratch vb_scratch_for(void* stream) {
+    std::lock_guard<std::mutex> lock(g_opts_mutex);
+    for (auto& e : scratch_table()) if (e.first == stream) return e.second;
+    return vb_scratch{nullptr, 0};
+}
+
+extern "C" int vb_stream_set_scratch(void* stream, void* scratch, int64_t bytes) {
+    if (scratch && (bytes < VB_SCRATCH_MIN_BYTES || (((uintptr_t)scratch) & 255))) return VB_ERR_ARG;
+    if (scratch) {
+        // the arrival counters at the head of the buffer start at zero; every kernel that uses one leaves it at zero again
+#ifndef VB_EMU
+        if (hipMemsetAsync(scratch, 0, VB_SCRATCH_COUNTER_BYTES, (hipStream_t)stream) != hipSuccess) return VB_ERR_LAUNCH;
+#else
+        memset(scratch, 0, VB_SCRATCH_COUNTER_BYTES);
+#endif
+    }
+    std::lock_guard<std::mutex> lock(g_opts_mutex);
+    auto& t = scratch_table();
+    for (size_t i = 0; i < t.size(); ++i)
+        if (t[i].first == stream) {
+            if (scratch) t[i].second = vb_scratch{scratch, bytes}; else t.erase(t.begin() + i);
+            return VB_OK;
+        }
+    if (scratch) t.emplace_back(stream, vb_scratch{scratch, bytes});
+    return VB_OK;
+}
+
 // ---- developer library and simulator only: one wave through vb_mma_f8 / vb_cvt4_fp8 (the documented lane layout is what the test pins) ----
 #if defined(VB_DEV_KNOBS) || defined(VB_EMU)
 namespace {

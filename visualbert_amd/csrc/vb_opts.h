@@ -5,3 +5,9 @@
 
 // options attached to `stream` (all-zero defaults when the stream has no entry)
 vb_stream_opts vb_opts_for(void* stream);
+
+// scratch attached to `stream` (vb_stream_set_scratch); {NULL, 0} when the stream has none: kernels that would need it are not chosen
+struct vb_scratch { void* ptr; int64_t bytes; };
+vb_scratch vb_scratch_for(void* stream);
+// layout: [VB_SCRATCH_COUNTER_BYTES of int32 arrival counters, zero between launches][fp32 partial-result slabs]
+#define VB_SCRATCH_COUNTER_BYTES 16384

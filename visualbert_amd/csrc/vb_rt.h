@@ -261,6 +261,22 @@ VB_DEVICE u32x4 vb_buf_load16(vb_buf b, unsigned voff, unsigned soff) {
 }
 #endif
 
+// 16 bytes per lane through a descriptor with the sc1 (write-through / L1-bypassing) policy: the hand-off form for tens of KB per
+// workgroup (guide, price list "publish-large": an agent-scope release after plain stores writes back the whole XCD L2's dirty lines,
+// 8.2 us per 64 KB publish; write-through stores + a drained vmcnt need no release, 3.0 us) -- and sc1 loads on the consumer side
+// need no acquire (they are served by L2 / the fabric, never by this CU's possibly stale L1)
+#ifdef VB_EMU
+VB_DEVICE void vb_buf_store16_sc1(vb_buf b, unsigned voff, unsigned soff, const u32x4& v) { memcpy((unsigned char*)b.base + voff + soff, &v, 16); }
+VB_DEVICE u32x4 vb_buf_load16_sc1(vb_buf b, unsigned voff, unsigned soff) { u32x4 v; memcpy(&v, b.base + voff + soff, 16); return v; }
+#else
+VB_DEVICE void vb_buf_store16_sc1(vb_buf b, unsigned voff, unsigned soff, const u32x4& v) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, b, (int)voff, (int)soff, 16);
+}
+VB_DEVICE u32x4 vb_buf_load16_sc1(vb_buf b, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(b, (int)voff, (int)soff, 16));
+}
+#endif
+
 // counted wait for outstanding vector-memory operations (LDS-direct copies included) + raw workgroup
 // barrier: lets the newest K tile(s) stay in flight across the barrier (guide: "Pipelining across
 // barriers").  N must be an immediate.
@@ -401,6 +417,17 @@ VB_DEVICE void vb_permlane16_swap(uint32_t& a, uint32_t& b) {
 #endif
 // element offset of the 8 contiguous columns lane group lg owns after vb_permlane16_swap of blocks (2j, 2j + 1), inside the 32 columns
 VB_DEVICE int vb_wide_col(int lg) { return (lg & 1) * 16 + (lg >> 1) * 8; }
+
+// Inter-workgroup hand-off through a device-scope counter (guide, Guideline 16 / "in-launch split-K reduction"), write-through form:
+// the producer's payload leaves by sc1 stores (vb_buf_store16_sc1), every wave drains vmcnt, workgroup barrier, ONE lane draws a relaxed
+// agent-scope ticket; the consumer reads the payload with sc1 loads.  Placement-independent; no fences.
+#ifdef VB_EMU
+VB_DEVICE int vb_ticket_add(int* p) { return __atomic_fetch_add(p, 1, __ATOMIC_SEQ_CST); }
+VB_DEVICE void vb_ticket_reset(int* p) { __atomic_store_n(p, 0, __ATOMIC_SEQ_CST); }
+#else
+VB_DEVICE int vb_ticket_add(int* p) { return __hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+VB_DEVICE void vb_ticket_reset(int* p) { __hip_atomic_store(p, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#endif
 
 // value known to be identical in every lane of the wave: keep it in a scalar register (addresses built from it
 // become scalar arithmetic instead of per-lane VALU + v_readfirstlane at every use)

@@ -572,17 +572,15 @@ class BertLayer(nn.Module):
     def _forward_fused(self, hidden_states, attention_mask):
         if self.grad_ready_hook is not None and torch.is_grad_enabled() and hidden_states.requires_grad:
             hidden_states = _GradReadyFn.apply(hidden_states, self)
-        at, im, om = self.attention, self.intermediate, self.output
-        sa, so = at.self, at.output
+        (at, sa, so, im, om), _, params = ops.layer_params(self)     # the sub-modules and their 16 parameters, cached on the layer
         B, S, H = hidden_states.shape
         mask_add = attention_mask.reshape(B, S)
         if mask_add.dtype != torch.float32 or not mask_add.is_contiguous():
             mask_add = mask_add.to(torch.float32).contiguous()
+        # parameter order: q.w q.b k.w k.b v.w v.b | self-output dense.w dense.b LN.w LN.b | intermediate dense.w dense.b |
+        # output dense.w dense.b LN.w LN.b
         return ops.BertLayerFn.apply(
-            hidden_states, mask_add, self, _drop_p(om.dropout, self.training), _drop_p(sa.dropout, self.training),
-            sa.query.weight, sa.query.bias, sa.key.weight, sa.key.bias, sa.value.weight, sa.value.bias,
-            so.dense.weight, so.dense.bias, so.LayerNorm.weight, so.LayerNorm.bias,
-            im.dense.weight, im.dense.bias, om.dense.weight, om.dense.bias, om.LayerNorm.weight, om.LayerNorm.bias)
+            hidden_states, mask_add, self, _drop_p(om.dropout, self.training), _drop_p(sa.dropout, self.training), *params)
 
     def forward_unfused(self, hidden_states, attention_mask):
         """the same layer as two autograd nodes (attention block, FFN block) -- kept for tests that compare

@@ -258,13 +258,15 @@ class BertAdam(Optimizer):
         _lib.check(rc, "vb_bert_adam_step")
         f["host_step"] += 1
         # the kernel refreshed the bf16 shadows of every optimised 2-D parameter
-        member = set()
-        for group in self.param_groups:
-            for p in group["params"]:
-                member.add(id(p))
-        for p in a.params:
-            if p.dim() == 2 and id(p) in member:
-                p._vb_shadow_ver = p._version
+        shadowed = f.get("shadowed")
+        if shadowed is None:                         # (the fused state -- and this list with it -- is rebuilt by load_state_dict)
+            member = set()
+            for group in self.param_groups:
+                for p in group["params"]:
+                    member.add(id(p))
+            shadowed = f["shadowed"] = [p for p in a.params if p.dim() == 2 and id(p) in member]
+        for p in shadowed:
+            p._vb_shadow_ver = p._version
         a.refresh_transposed()                       # W^T copies for the next backward (one launch)
         ops.bump_x3_epoch()                          # split (bf16x3) images of the weights are re-made at their next use
         return loss

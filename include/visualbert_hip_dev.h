@@ -29,6 +29,9 @@ extern "C" {
  * make them wrong): the bit-compare arm of tests/test_kernels.py::test_streaming_stores_equal_plain_stores */
 /* bit 27 (1 << 27): the round-4 dispatch rule for "+ addend" GEMMs with K >= 2048 (two-workgroup kernel instead of the persistent one);
  * results identical up to summation order */
+/* bit 29 (1 << 29): arms the dropout form of the "+ residual" GEMM epilogue (csrc/gemm.hip: vb_gemm_dropres / EPI_DROP) that
+ * vb_bert_layer_fwd asks for when hidden dropout is on -- results are CORRECT (tests/test_bench_shape.py replays the mask); it lost its
+ * A/B against dropout + residual in the LayerNorm launch (profiles/r06_dropres_epilogue_ab.txt), so the product library declines it */
 int vb_gemm_set_debug(int bits);
 /* debug bit 64 (256x128 pipelined kernel, bf16): waves 0 and 4 of workgroup 0 write per-K-tile shader-clock stamps
  * {landed, barrier, copies issued, frags0, mfma0, frags1, mfma1} to this device buffer (uint64[2][64][8]) */

@@ -294,16 +294,22 @@ def test_bert_layer_at_bench_shape(dev, which, mode_name):
     ctx = _unsplit(sv["sp_ctx"], H) if mode.x3 else sv["ctx"]
     close(ctx, ctx_ref, mode.attn, "attention context")
     del ctx_ref
-    ao = sc["t_h0"]
-    close(ao, f(ctx) @ f(P["wo"]).t() + P["bo"], mode.gemm, "attention-out dense")
-    z1 = f(ao) + f(P["h_in"])
     # the forward skips the pre-LN sums when |beta| <= 2 |gamma| on every channel (true for this problem's parameters: the backward
     # rebuilds x-hat from the LayerNorm outputs)
     rebuilt1 = rebuilt2 = True
     if which == "guard":
         rebuilt1 = False
+    if mode.x3:
+        ao = sc["t_h0"]
+        close(ao, f(ctx) @ f(P["wo"]).t() + P["bo"], mode.gemm, "attention-out dense")
+        z1 = f(ao) + f(P["h_in"])
+    else:
+        # bf16 (round 6): the GEMM's epilogue adds the residual itself and writes z = ctx Wo^T + b + h_in into the saved slot -- always,
+        # whether or not the LayerNorm's backward will rebuild x-hat; the LayerNorm launch reads that one tensor
+        close(sv["z1"], f(ctx) @ f(P["wo"]).t() + P["bo"] + f(P["h_in"]), mode.gemm, "z1 = attention-out dense + residual (GEMM epilogue)")
+        z1 = f(sv["z1"])
     assert sv["ln_flags"].tolist() == [int(rebuilt1), int(rebuilt2)], sv["ln_flags"].tolist()
-    if not rebuilt1:
+    if not rebuilt1 and mode.x3:
         close(sv["z1"], z1, mode.add, "z1 = attention-out + residual")              # one fp32 add, one rounding
     close(sv["a_out"], _ln_ref(z1, P["g1"], P["b1"]), mode.ln, "LayerNorm 1")
     if rebuilt1:                                   # how far the rebuilt x-hat is from the exact one (the numerics the mode signs up for)
@@ -321,11 +327,15 @@ def test_bert_layer_at_bench_shape(dev, which, mode_name):
     if mode.x3:                                   # the kept images of the GEMM inputs that also exist in fp32 are exactly split(input)
         for name, src in (("sp_hin", P["h_in"]), ("sp_aout", sv["a_out"])):
             assert torch.equal(sv[name], _split(src)), name
-    fo = sc["t_h1"]
-    close(fo, f(inter) @ f(P["wo2"]).t() + P["bo2"], mode.gemm, "FFN-out dense")
-    z2 = f(fo) + f(sv["a_out"])
-    if not rebuilt2:
-        close(sv["z2"], z2, mode.add, "z2 = FFN-out + residual")
+    if mode.x3:
+        fo = sc["t_h1"]
+        close(fo, f(inter) @ f(P["wo2"]).t() + P["bo2"], mode.gemm, "FFN-out dense")
+        z2 = f(fo) + f(sv["a_out"])
+        if not rebuilt2:
+            close(sv["z2"], z2, mode.add, "z2 = FFN-out + residual")
+    else:
+        close(sv["z2"], f(inter) @ f(P["wo2"]).t() + P["bo2"] + f(sv["a_out"]), mode.gemm, "z2 = FFN-out dense + residual (GEMM epilogue)")
+        z2 = f(sv["z2"])
     close(h_out, _ln_ref(z2, P["g2"], P["b2"]), mode.ln, "LayerNorm 2 (h_out)")
     del z2
     # ---- backward (reuses the scratch: the forward temporaries above are dead from here)
@@ -373,6 +383,70 @@ def test_bert_layer_at_bench_shape(dev, which, mode_name):
         vec_close(G[idx], ref, mode.dw, what)
         del ref
     _dump_measured()
+
+
+def test_bert_layer_fused_dropout_residual_replays_the_documented_generator(dev):
+    """bf16 at a size that fills the chip (B = 96: 15,744 rows, 186 tiles of 256x256): BertSelfOutput / BertOutput's
+    dropout(dense(x)) + residual (modeling.py:271-273, 316-318) runs in the producing GEMM's epilogue and the LayerNorm reads the one
+    tensor it wrote.  With p_hidden = 0.1 (attention dropout off) the saved z1 / z2 must equal dense + bias, masked by the DOCUMENTED
+    generator at (seed, site id, element index) -- the numpy statement in tests/test_kernels.py -- scaled by 1 / (1 - p), plus the
+    residual; and the backward, whose LayerNorm kernels regenerate the mask on their own, must produce the matching dfo / dao."""
+    import numpy as np
+    from test_kernels import generator_keep
+    if dev.type != "cuda":
+        pytest.skip("the dropout epilogue is taken by chip-filling problems only")
+    D = Dims(96, 164, 768, 3072, 12)
+    mode = Mode("bf16")
+    P = _layer_problem(D, dev, seed=11, mode=mode)
+    p, seed, sid = 0.1, 0x1234567, 40
+    # the dropout form of the epilogue lost its A/B (csrc/gemm.hip: vb_gemm_dropres) and lives in the developer library behind debug bit 29
+    with _lib.dev_library() as DL:
+        DL.vb_gemm_set_debug(1 << 29)
+        try:
+            _fused_dropres_checks(D, mode, P, dev, p, seed, sid, np, generator_keep)
+        finally:
+            DL.vb_gemm_set_debug(0)
+    # the product library declines the dropout form: z1 is then NOT the GEMM's output (the LayerNorm launch owns dropout + residual, and
+    # with rebuildable gamma / beta it writes no z at all) while the layer output is the same function of the same mask
+    saved, scratch, h_prod, weights = _run_layer(D, P, dev, p, 0.0, seed=seed, sid=sid, mode=mode)
+    with _lib.dev_library() as DL:
+        DL.vb_gemm_set_debug(1 << 29)
+        try:
+            _, _, h_dev, _ = _run_layer(D, P, dev, p, 0.0, seed=seed, sid=sid, mode=mode)
+        finally:
+            DL.vb_gemm_set_debug(0)
+    assert float((h_prod.float() - h_dev.float()).abs().max()) <= 0.06 * float(h_prod.float().abs().max())      # same mask, one bf16 rounding moved
+
+
+def _fused_dropres_checks(D, mode, P, dev, p, seed, sid, np, generator_keep):
+    saved, scratch, h_out, weights = _run_layer(D, P, dev, p, 0.0, seed=seed, sid=sid, mode=mode)
+    sv = _saved_views(D, saved, 0, mode)
+    f = lambda t: t.float()
+    M, H = D.M, D.H
+    groups = np.arange(M * H // 8)
+    for site, zname, x, w, b, resid in ((sid + 1, "z1", sv["ctx"], P["wo"], P["bo"], P["h_in"]),
+                                        (sid + 4, "z2", sv["inter"], P["wo2"], P["bo2"], sv["a_out"])):
+        keep = torch.from_numpy(generator_keep(groups, p, seed, site).reshape(M, H)).to(dev)
+        y = f(x) @ f(w).t() + b
+        ref = torch.where(keep, y * (1.0 / (1.0 - p)), torch.zeros_like(y)) + f(resid)
+        _close(sv[zname], ref, mode.gemm, "%s = dropout(dense) + residual, mask replayed" % zname, "fused/")
+        # where the mask dropped an element the stored value is EXACTLY the (bf16) residual
+        dropped = ~keep
+        assert torch.equal(sv[zname][dropped], resid[dropped]), zname
+        frac = float(dropped.float().mean())
+        assert 0.095 < frac < 0.105, frac
+    close_ln = lambda got, ref, what: _close(got, ref, mode.ln, what, "fused/")
+    close_ln(sv["a_out"], _ln_ref(f(sv["z1"]), P["g1"], P["b1"]), "LayerNorm 1 over the fused z1")
+    close_ln(h_out, _ln_ref(f(sv["z2"]), P["g2"], P["b2"]), "LayerNorm 2 over the fused z2")
+    # backward: dfo = mask * dz2 / (1 - p) from the LayerNorm backward's own regeneration of the site's mask
+    d_in, G = _run_bwd(D, P, saved, scratch, weights, dev, p, 0.0, seed=seed, sid=sid, mode=mode, h_out=h_out)
+    sc = _scratch_views(D, scratch, mode)
+    keep2 = torch.from_numpy(generator_keep(groups, p, seed, sid + 4).reshape(M, H)).to(dev)
+    dz2, dfo = sc["t_h0"], sc["t_h1"]
+    assert torch.equal(dfo[~keep2], torch.zeros_like(dfo[~keep2]))
+    want = f(dz2) * (1.0 / (1.0 - p))
+    assert float((f(dfo)[keep2] - want[keep2]).abs().max()) <= 2.0 ** -7 * float(want.abs().max())
+    assert torch.isfinite(d_in.float()).all()
 
 
 @pytest.mark.parametrize("which,mode_name", [("bench", "bf16"), ("small", "bf16"), ("bench512", "bf16x3"), ("small", "bf16x3")])

@@ -2,6 +2,8 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from visualbert_amd import _lib, ops
+if os.environ.get("VB_LIB_PATH"):                       # A/B of two product builds: VB_LIB_PATH=tools/libvisualbert_hip_ab_<arm>.so
+    _lib.set_library(os.path.abspath(os.environ["VB_LIB_PATH"]))
 dev = torch.device("cuda", 0)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 S, nh = (int(sys.argv[2]) if len(sys.argv) > 2 else 164), 12

@@ -39,8 +39,19 @@ constexpr int NT = 256;
 constexpr int D = 64;
 
 template <typename T> struct LT;   // LDS tile geometry
+// TPAD: padding of a transposed tile's rows, in bytes.  Round 6 ("17 % LDS bank conflicts, no commit has changed the
+// tile layouts") tried the pitch the documented bank model asks for -- 8-byte fragment reads, one row per lane of a 16-lane group, two column
+// groups per half-wave on 64 banks: conflict-free at a pitch of 4 x odd dwords, i.e. 16 bytes of padding for every tile width, where
+// 8 bytes (2 x odd dwords) leave one 2-way conflict per read -- and it LOST on every kernel (profiles/r06_attn_pitch_ab.txt, three product
+// builds on one box, B = 1024, S = 164, p = 0.1): one-pass backward + bias gradient 842 -> 954 us alone (1 059 vs 959 us in the step),
+// forward 293 -> 313 us, step 117.5 -> 119.5 ms; with only the backward's dS tile and K^T image re-pitched (VB_ATTN_BPAD) 842 -> 902 us.
+// The counter's conflict cycles are not where these kernels lose time, and whatever the wider rows cost (the 2- and 4-byte staging stores
+// land 8-way instead of 4-way) outweighs them.  8 bytes stay; the macros keep the arms buildable (tools/build_variant.sh).
+#ifndef VB_ATTN_TPAD
+#define VB_ATTN_TPAD 8
+#endif
 template <> struct LT<bf16> {
-    static constexpr int RB = 128, CPR = 8, KPT = 2, TPAD = 8;
+    static constexpr int RB = 128, CPR = 8, KPT = 2, TPAD = VB_ATTN_TPAD;
     static constexpr bool SPLIT = false;
     VB_DEVICE int sw(int row) { return (row >> 1) & 7; }    // conflict-free for ds_read_b128 fragment reads (see gemm.hip)
 };
@@ -55,7 +66,7 @@ template <> struct LT<float> {
 // [64 hi | 64 lo] (256 B, the fp32 row's size), a transposed tile is a hi tile followed by a lo tile of bf16 pitch, so
 // the LDS budgets -- and with them the sequence limits of every kernel form -- are those of the fp32 instantiation.
 template <> struct LT<xf32> {
-    static constexpr int RB = 256, CPR = 16, TPAD = 8;
+    static constexpr int RB = 256, CPR = 16, TPAD = VB_ATTN_TPAD;
     static constexpr bool SPLIT = true;
     VB_DEVICE int sw(int row) { return (row & 7) << 1; }
 };
@@ -1073,7 +1084,14 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) attn_bwd_dkv_kernel(AttnArgs a) {
 // work-arounds, and at best PARITY: 862 against 853 us.
 // =================================================================================================
 constexpr int FWPB = 12, FNT = FWPB * 64, FNK = FWPB * 16;  // 192 keys
-constexpr int TSP = FNK * 2 + 8;                           // dS tile pitch in bytes (pad: 16 rows -> distinct banks)
+// Pitches of the two LDS tiles phase B reads: rows of FNK keys + VB_ATTN_BPAD bytes (see LT<bf16>::TPAD above for the round-6
+// experiment with 16: it lost)
+#ifndef VB_ATTN_BPAD
+#define VB_ATTN_BPAD 8
+#endif
+constexpr int TSP = FNK * 2 + VB_ATTN_BPAD;                // dS tile pitch in bytes (pad: 16 rows -> distinct banks)
+constexpr int KTP = FNK * 2 + VB_ATTN_BPAD;                // K^T image pitch in bytes
+constexpr int KT_BYTES = D * KTP;
 
 template <int NKF, int CQ>
 VB_KERNEL VB_LAUNCH_BOUNDS(FNT) attn_bwd_fused_kernel(AttnArgs a) {
@@ -1095,7 +1113,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS(FNT) attn_bwd_fused_kernel(AttnArgs a) {
         ldsBits = (uint64_t*)(ldsD + CQ);
     };
     unsigned char* ldsKT = smem + 2 * SETB;                // K^T of the whole sequence: [64 d][FNK keys]
-    unsigned char* ldsDS = ldsKT + tr_bytes<T>(FNK);       // dS of the chunk: [CQ queries][FNK keys], pitch TSP
+    unsigned char* ldsDS = ldsKT + KT_BYTES;               // dS of the chunk: [CQ queries][FNK keys], pitch TSP
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, lg = lane >> 4;
     const int bh = blockIdx.x, b = bh / a.nh, h = bh % a.nh;
     const int S = a.S, H = a.nh * D;
@@ -1210,7 +1228,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS(FNT) attn_bwd_fused_kernel(AttnArgs a) {
     const float mk2 = mk * 1.44269504088896340736f, sc2 = a.scale * 1.44269504088896340736f;
     {   // K^T image and a zeroed dS tile
         const u32x4 x0 = zsel(kr < S, kx0), x1 = zsel(kr + 1 < S, kx1);
-        const int pitch = tr_pitch<bf16>(FNK);
+        const int pitch = KTP;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
             const uint32_t lo = x0[w], hi = x1[w];
@@ -1308,7 +1326,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS(FNT) attn_bwd_fused_kernel(AttnArgs a) {
                 for (int ks = 0; ks < FNK / 32; ++ks) {
                     if (ks * 32 >= S) continue;
                     // B operand: lane (n = query li, g = lg) holds dS[q][key(g, j)], key(g, j) = 32 ks + 16 (j >> 2) + 4 g + (j & 3)
-                    const bf16x8 kt = frag_tr(ldsKT, tr_pitch<T>(FNK), df * 16 + li, ks, lg, T());
+                    const bf16x8 kt = frag_tr(ldsKT, KTP, df * 16 + li, ks, lg, T());
                     if (v0) {
                         const unsigned char* src = ldsDS + (qf0 * 16 + li) * TSP + (32 * ks + 4 * lg) * 2;
                         const bf16x4 lo = *(const bf16x4*)src, hi = *(const bf16x4*)(src + 32);
@@ -1360,7 +1378,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS(FNT) attn_bwd_fused_kernel(AttnArgs a) {
         // row sums per lane before going to LDS: ~5000 of the workgroup's ~45000 cycles, by the in-kernel cycle trace.)
         float* raw = (float*)smem;                          // 12 x 36 x 64 floats = 108 KB of the 124 KB
         constexpr int NV = 4 + 2 * 16;
-        static_assert((size_t)FWPB * NV * 64 * 4 <= 2 * (size_t)SETB + tr_bytes<T>(FNK) + (size_t)CQ * TSP, "raw partials fit the idle images");
+        static_assert((size_t)FWPB * NV * 64 * 4 <= 2 * (size_t)SETB + KT_BYTES + (size_t)CQ * TSP, "raw partials fit the idle images");
         float* mine = raw + ((long)wave * NV) * 64 + lane;
 #pragma unroll
         for (int r = 0; r < 4; ++r) mine[r * 64] = dqsum[r];
@@ -1411,7 +1429,7 @@ VB_KERNEL VB_LAUNCH_BOUNDS(256) attn_bias_reduce_kernel(const float* ws, float* 
 }
 template <int NKF, int CQ> size_t fused_smem() {
     return 2 * (2 * rm_bytes<bf16>(CQ) + 2 * tr_bytes<bf16>(CQ) + 2 * CQ * 4 + (size_t)CQ * 4 * ((NKF + 15) / 16) * 8) +
-           tr_bytes<bf16>(FNK) + (size_t)CQ * TSP;
+           KT_BYTES + (size_t)CQ * TSP;
 }
 
 template <typename T, int NKF> size_t fwd_smem() { return rm_bytes<T>(NKF * 16) + tr_bytes<T>((NKF + 1) / 2 * 32) + NKF * 16 * 4; }

@@ -96,6 +96,12 @@ struct GemmArgs {
     int sk_splits, sk_kps;
     float* sk_slabs;
     int* sk_cnt;
+    // EPI_DROP (vb_gemm_dropres): inverted dropout of (alpha acc + bias) BEFORE the addend -- BertSelfOutput / BertOutput's
+    // dropout(dense(x)) + residual (modeling.py:271-273, 316-318) in the producing GEMM's epilogue; the generator, key and group
+    // indexing are the LayerNorm kernels' (layernorm.hip: apply_dropout8 on element index m N + n), whose backward regenerates the mask
+    uint32_t drop_thresh, drop_stream;
+    float drop_scale;
+    uint64_t drop_seed;
 };
 // K tile `v` of the (virtual) K loop -> element offset of its first column inside a row of A / of B
 VB_DEVICE int x3_col_a(const GemmArgs& g, int v, int bk) {
@@ -252,7 +258,8 @@ enum { EPI_ADD = 1,          // addend and/or accumulate operands
        EPI_RAGGED = 2,       // N % 8 != 0 or a pointer / leading dimension that is not 16-byte aligned
        EPI_COLSUM = 4,       // fused column sums
        EPI_ALL = 7,          // everything above, decided at run time (incl. a split result when g.split_out is set)
-       EPI_SPLIT = 8 };      // specialised split-operand epilogues: the result ALWAYS leaves as a bf16 hi | lo image (g.split_out)
+       EPI_SPLIT = 8,        // specialised split-operand epilogues: the result ALWAYS leaves as a bf16 hi | lo image (g.split_out)
+       EPI_DROP = 16 };      // inverted dropout of (alpha acc + bias) in front of the addend (specialised bf16 instantiations only; ldc == N)
 struct EpiLane {             // per-lane constants of an epilogue call
     float bb[8], cs[8];
     float alpha;
@@ -289,6 +296,7 @@ static int epi_needs(const GemmArgs& g, size_t t_size, size_t to_size) {
     if (g.addend || g.accumulate) n |= EPI_ADD;
     if (g.accumulate) n |= EPI_RAGGED;                 // "+= C" keeps the run-time epilogue: the specialised EPI_ADD instantiation means "addend, no accumulate"
     if (g.colsum) n |= EPI_COLSUM;
+    if (g.drop_thresh) n |= EPI_DROP;
     bool aligned = (g.N % 8) == 0 && (((g.ldc * to_size) | (uintptr_t)g.C) & 15) == 0 &&
                    (!g.bias || ((uintptr_t)g.bias & 15) == 0) &&
                    (!g.addend || (((g.ld_addend * t_size) | (uintptr_t)g.addend) & 15) == 0) &&
@@ -350,6 +358,12 @@ VB_DEVICE void epi_vec8(float (&v)[8], const GemmArgs& g, EpiLane& e, long offc,
     } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = v[j] * e.alpha + e.bb[j];
+    }
+    if constexpr ((OPT & EPI_DROP) != 0 && OPT != EPI_ALL) {
+        // the 8 columns of this lane are one generator group: element index m N + n = offc (the launcher checked ldc == N)
+        const Rand8 r = vb_dropout_bits8(g.drop_seed, (uint64_t)offc >> 3, g.drop_stream);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = rand8_keep(r, j, g.drop_thresh) ? v[j] * g.drop_scale : 0.0f;
     }
     if (act == VB_ACT_GELU) {
         if (g.aux_out) { if (g.nt_store) store8_nt((T*)g.aux_out + offa, v); else store8((T*)g.aux_out + offa, v); }   // pre-activation, kept for backward
@@ -1416,6 +1430,15 @@ int launch_8ph(GemmArgs g, hipStream_t stream) {
             }
         }
         const int needs = epi_needs(g, sizeof(T), sizeof(TO));
+        if (needs & EPI_DROP) {                             // dropout + residual: the one specialised instantiation (developer library), or nothing
+#ifdef VB_DEV_KNOBS
+            if constexpr (kActSpecialised<T, TO>) {
+                if (g.act == VB_ACT_NONE && g.addend && needs == (EPI_ADD | EPI_DROP) && g.ldc == g.N)
+                    return launch_8ph_act<T, TO, VB_ACT_NONE, EPI_ADD | EPI_DROP>(g, grid, block, SM, stream);
+            }
+#endif
+            return VB_ERR_UNSUPPORTED;
+        }
 #define VB_TRY_EPI(A, O) if (g.act == (A) && (needs & ~(O)) == 0) return launch_8ph_act<T, TO, A, O>(g, grid, block, SM, stream)
         if constexpr (kActSpecialised<T, TO>) {
             VB_TRY_EPI(VB_ACT_NONE, 0);
@@ -1663,6 +1686,15 @@ int launch_dual(GemmArgs g, hipStream_t stream) {
             }
         }
         const int needs = epi_needs(g, sizeof(T), sizeof(TO));
+        if (needs & EPI_DROP) {
+#ifdef VB_DEV_KNOBS
+            if constexpr (kActSpecialised<T, TO>) {
+                if (g.act == VB_ACT_NONE && g.addend && needs == (EPI_ADD | EPI_DROP) && g.ldc == g.N)
+                    return launch_dual_act<TO, VB_ACT_NONE, EPI_ADD | EPI_DROP>(g, grid, stream);
+            }
+#endif
+            return VB_ERR_UNSUPPORTED;
+        }
 #define VB_TRY_EPI(A, O) if (g.act == (A) && (needs & ~(O)) == 0) return launch_dual_act<TO, A, O>(g, grid, stream)
         if constexpr (kActSpecialised<T, TO>) {
             VB_TRY_EPI(VB_ACT_NONE, 0);
@@ -2685,7 +2717,7 @@ static bool tn_eligible(const void* A, long lda, const void* B, long ldb, const 
 // rows, and no two problems adding into the same dW (plain read-modify-writes).  VB_TN_SMALL_MAX_KT: crossover measured on MI355X
 // (profiles/r06_small_batch_ab.txt): the persistent kernel's 256x256 tiles move half the LDS bytes per FLOP and win once the K loop is long
 #ifndef VB_TN_SMALL_MAX_KT
-#define VB_TN_SMALL_MAX_KT 48
+#define VB_TN_SMALL_MAX_KT 96
 #endif
 static bool tn_small_eligible(const TnArgs& g, int tokens) {
     if ((tokens + 63) / 64 > VB_TN_SMALL_MAX_KT) return false;
@@ -2723,6 +2755,9 @@ static int launch_tn_small(const TnArgs& main, int tokens, hipStream_t stream) {
 
 // kernel for a K-contiguous x K-contiguous problem (vb_stream_opts.nt_kernel): 0 = chosen from the shape; 1 = the generic
 // register-staged kernel; tens = waves in M (2 -> 128-row tile, 4 -> 256-row tile), units = LDS stages; 80 / 81 persistent
+#ifndef VB_DROPRES_SHORT_K_PERSISTENT
+#define VB_DROPRES_SHORT_K_PERSISTENT 1   // the K = 768 attention-out GEMM with the dropout + residual epilogue: 1 = persistent kernel, 0 = two-workgroup kernel
+#endif
 #ifndef VB_SPLITK_MIN_KT
 #define VB_SPLITK_MIN_KT 24          // reductions shorter than this (K < 1536) are not cut
 #endif
@@ -2735,6 +2770,16 @@ int dispatch_pipe(const GemmArgs& g, hipStream_t s) {
     // compute units this stream may fill: the device's, or fewer while DataParallelGradSync keeps some for RCCL (persistent_workgroups)
     const int all_cus = vb_num_cus();
     const int cus = (t_opts.persistent_workgroups > 0 && t_opts.persistent_workgroups < all_cus) ? t_opts.persistent_workgroups : all_cus;
+    if (g.drop_thresh) {
+        // dropout + residual epilogue (vb_gemm_dropres): bf16 -> bf16 on the two big-tile kernels only -- problems that fill the chip;
+        // everything else is declined and the caller (layer.hip) keeps dropout + residual in its LayerNorm launch
+        if (sizeof(T) != 2 || sizeof(TO) != 2 || g.x3) return VB_ERR_UNSUPPORTED;
+        const long t256d = (long)((g.M + 255) / 256) * ((g.N + 255) / 256);
+        if (t256d < 160 || (variant != 0 && variant != 81 && variant != 90)) return VB_ERR_UNSUPPORTED;
+        if (variant == 0) variant = (g.K >= 2048 || VB_DROPRES_SHORT_K_PERSISTENT) ? 81 : 90;
+        if (variant == 81 && cus < all_cus) variant = 90;
+        return variant == 81 ? launch_8ph<T, TO>(g, s) : launch_dual<T, TO>(g, s);
+    }
     if (g.x3) {                                            // split operands: the two-workgroup kernel or the two-barrier ones
         const long t256 = (long)((g.M + 255) / 256) * ((g.N + 255) / 256);
         const long t128 = (long)((g.M + 255) / 256) * ((g.N + 127) / 128);
@@ -2855,6 +2900,9 @@ int dispatch(int out_dtype_is_f32, int al, int bl, const GemmArgs& g, hipStream_
     if (al == VB_KCONTIG && bl == VB_KCONTIG) {
         if (g.fast_a && g.fast_b && g.splits == 1 && t_opts.nt_kernel != 1)
             return out_dtype_is_f32 ? dispatch_pipe<T, float>(g, s) : dispatch_pipe<T, T>(g, s);
+    }
+    if (g.drop_thresh) return VB_ERR_UNSUPPORTED;           // the dropout epilogue exists on the fast K-contiguous kernels only
+    if (al == VB_KCONTIG && bl == VB_KCONTIG) {
         if constexpr (sizeof(T) == 2) { if (g.x3) return launch_gemm<T, float, VB_KCONTIG, VB_KCONTIG, float>(g, s); }
         return out_dtype_is_f32 ? launch_gemm<T, float, VB_KCONTIG, VB_KCONTIG>(g, s)
                                 : launch_gemm<T, T, VB_KCONTIG, VB_KCONTIG>(g, s);
@@ -2876,7 +2924,38 @@ extern "C" int vb_gemm(int dtype, int out_dtype, int a_layout, int b_layout,
                        const void* addend, int64_t ld_addend, int act,
                        const void* aux_in, void* aux_out, int64_t ld_aux, int accumulate,
                        float* colsum_out, void* stream) {
+    return vb_gemm_dropres(dtype, out_dtype, a_layout, b_layout, A, lda, B, ldb, C, ldc, M, N, K, alpha, alpha_dev, bias, addend, ld_addend,
+                           act, aux_in, aux_out, ld_aux, accumulate, colsum_out, 0.f, 0, 0, stream);
+}
+
+// internal (layer.hip): vb_gemm + inverted dropout (p_drop, seed, drop_stream: the LayerNorm kernels' generator and indexing) of
+// alpha acc + bias in front of the addend -- BertSelfOutput / BertOutput's dropout(dense(x)) + residual in the producing GEMM, so that
+// the LayerNorm launch reads one tensor instead of two.
+// MEASURED, round 6 (profiles/r06_dropres_epilogue_ab.txt; three product builds on one box, three interleaved rounds at B = 1024):
+//   p_drop == 0 ("+ residual" only): free on every kernel (the "+ addend" epilogue) -- layer.hip uses it whenever hidden dropout is off;
+//   p_drop  > 0: the LayerNorm forward drops 132.3 -> 112.2 us per launch (-0.48 ms per step) but the generator's ~50 VALU instructions
+//   per 8 elements sit in the persistent kernel's epilogue, where the matrix pipe idles: 397 -> 454 us per launch on the 24 fused GEMMs
+//   of a step (+1.09 ms), step 118.0 -> 118.45 ms (two-workgroup kernel for the K = 768 shape: 118.5).  So the dropout form LOSES and is
+//   compiled into the DEVELOPER library only (debug bit 29 arms it; tests/test_bench_shape.py replays its mask); the product declines
+//   p_drop > 0 with VB_ERR_UNSUPPORTED, NOTHING launched, and the caller keeps dropout + residual in its LayerNorm launch.
+int vb_gemm_dropres(int dtype, int out_dtype, int a_layout, int b_layout,
+                    const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                    int M, int N, int K, float alpha, const float* alpha_dev, const float* bias,
+                    const void* addend, int64_t ld_addend, int act,
+                    const void* aux_in, void* aux_out, int64_t ld_aux, int accumulate,
+                    float* colsum_out, float p_drop, uint64_t drop_seed, uint32_t drop_stream, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C) return VB_ERR_ARG;
+    if (p_drop < 0.f || p_drop >= 1.f) return VB_ERR_ARG;
+    if (p_drop > 0.f) {
+#ifdef VB_DEV_KNOBS
+        if (!(g_debug & (1 << 29))) return VB_ERR_UNSUPPORTED;
+#else
+        return VB_ERR_UNSUPPORTED;
+#endif
+        if (dtype != VB_BF16 || out_dtype != VB_BF16 || !addend || act != VB_ACT_NONE || accumulate || colsum_out || alpha_dev ||
+            a_layout != VB_KCONTIG || b_layout != VB_KCONTIG || (K % 64) || ldc != N)
+            return VB_ERR_UNSUPPORTED;
+    }
     if (dtype != VB_F32 && dtype != VB_BF16 && dtype != VB_BF16X3) return VB_ERR_ARG;
     if (out_dtype != VB_F32 && out_dtype != dtype) return VB_ERR_ARG;
     const bool x3 = dtype == VB_BF16X3;
@@ -2908,6 +2987,8 @@ extern "C" int vb_gemm(int dtype, int out_dtype, int a_layout, int b_layout,
     g.x3 = x3 ? 1 : 0; g.a_lo = x3 ? (int)(lda / 2) : 0; g.b_lo = x3 ? (int)(ldb / 2) : 0; g.kseg = x3 ? K / 64 : 0;
     g.stripe = 0;
     g.sk_splits = 1; g.sk_kps = 0; g.sk_slabs = nullptr; g.sk_cnt = nullptr;
+    g.drop_thresh = p_drop > 0.f ? vb_drop_thresh16(p_drop) : 0u; g.drop_scale = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
+    g.drop_seed = drop_seed; g.drop_stream = drop_stream;
     const int bk = dtype == VB_F32 ? 32 : 64;
     const int nk = x3 ? 3 * (K / 64) : (K + bk - 1) / bk;
     // LDS-direct copies need whole K tiles (a masked lane would leave stale LDS behind)

@@ -111,6 +111,9 @@ int linear(const Dims& d, const void* x, int k, unsigned char* stage, const void
 }
 
 #define VB_TRY(expr) do { int rc_ = (expr); if (rc_ != VB_OK) return rc_; } while (0)
+#ifndef VB_FUSE_DROPRES
+#define VB_FUSE_DROPRES 1            // 0: dropout + residual stay in the LayerNorm launch everywhere (the A/B arm, tools/build_variant.sh)
+#endif
 
 }  // namespace
 
@@ -155,27 +158,41 @@ extern "C" int vb_bert_layer_fwd(int dtype, const void* h_in, const float* mask_
     //    at all (sv.ctx, sc.t_h1 / t_h4 / t_3h stay untouched in this mode)
     VB_TRY(vb_attn_fwd_sp(d.dtype, sv.qkv, mask_add, sv.ctx, sv.lse, sv.keepbits, B, S, nh, 64, p_attn, seed, sid,
                           d.x3 ? sv.sp_ctx : nullptr, 1, stream));
-    // 3. attention output projection
-    VB_TRY(linear(d, d.x3 ? (const void*)sv.sp_ctx : (const void*)sv.ctx, H, nullptr, wo, wk * H, sc.t_h0, H, bo, nullptr, VB_ACT_NONE,
-                  nullptr, nullptr, nullptr, stream));
-    // 4. dropout + residual + LayerNorm
-    //    (the pre-LN sum z is NOT written when the backward can rebuild x-hat from the output it reads anyway -- three tensors per
-    //     launch instead of four; decided in the kernel from gamma / beta and recorded in sv.ln_flags)
+    // 3 + 4. attention output projection, dropout + residual + LayerNorm
+    //    (the pre-LN sum z is NOT written by the LayerNorm when the backward can rebuild x-hat from the output it reads anyway --
+    //     decided in the kernel from gamma / beta and recorded in sv.ln_flags)
+    //    bf16 (round 6, VB_FUSE_DROPRES): the GEMM's epilogue adds the residual itself and writes z = (ctx Wo^T + b) + h_in straight
+    //    into the saved slot; the LayerNorm launch then reads ONE tensor and writes one (two [M, H] streams instead of three:
+    //    modeling.py:271-273 / SURVEY 2.3 K5) -- taken whenever hidden dropout is OFF (eval, p = 0 configurations).  With dropout ON the
+    //    GEMM would have to run the mask generator in its epilogue, which was built, measured and lost (gemm.hip: vb_gemm_dropres;
+    //    profiles/r06_dropres_epilogue_ab.txt): the product's GEMM declines (VB_ERR_UNSUPPORTED, nothing launched) and dropout + residual
+    //    stay in the LayerNorm launch; the developer library's arm keeps the fused form testable.  The backward is the same either way: its
+    //    LayerNorm kernel regenerates the mask from (seed, site id, element index).
     const bool rb = H <= 768;                           // (wider rows: the backward's rebuild-capable form does not pay, layernorm.hip)
     int* rb1 = rb ? sv.ln_flags : nullptr;
     int* rb2 = rb ? sv.ln_flags + 1 : nullptr;
-    VB_TRY(vb_ln_fwd_sp(edt, sc.t_h0, h_in, sv.z1, sv.a_out, sv.mean1, sv.rstd1, g1, b1, M, H, eps, p_hidden, sid + 1,
-                        0.f, 0, seed, d.x3 ? sv.sp_aout : nullptr, 2 * H, rb1, stream));
+    auto out_block = [&](const void* x, int k, const void* w, const float* bias, const void* resid, unsigned char* tmp, unsigned char* zslot,
+                         void* y, float* mean, float* rstd, const float* gam, const float* bet, uint32_t site, int* rbf,
+                         void* y_split) -> int {
+        if (VB_FUSE_DROPRES && d.dtype == VB_BF16) {
+            const int rc = vb_gemm_dropres(VB_BF16, VB_BF16, VB_KCONTIG, VB_KCONTIG, x, k, w, k, zslot, H, M, H, k, 1.f, nullptr, bias, resid, H,
+                                           VB_ACT_NONE, nullptr, nullptr, H, 0, nullptr, p_hidden, seed, site, stream);
+            if (rc == VB_OK)                            // z is in its slot already: x = z_out = the slot (the kernel reads a row before it writes it)
+                return vb_ln_fwd_sp(edt, zslot, nullptr, zslot, y, mean, rstd, gam, bet, M, H, eps, 0.f, site, 0.f, 0, seed, nullptr, 0, rbf, stream);
+            if (rc != VB_ERR_UNSUPPORTED) return rc;    // (small problems: declined, nothing launched)
+        }
+        VB_TRY(linear(d, x, k, nullptr, w, wk * k, tmp, H, bias, nullptr, VB_ACT_NONE, nullptr, nullptr, nullptr, stream));
+        return vb_ln_fwd_sp(edt, tmp, resid, zslot, y, mean, rstd, gam, bet, M, H, eps, p_hidden, site, 0.f, 0, seed, y_split, 2 * H, rbf, stream);
+    };
+    VB_TRY(out_block(d.x3 ? (const void*)sv.sp_ctx : (const void*)sv.ctx, H, wo, bo, h_in, sc.t_h0, sv.z1, sv.a_out, sv.mean1, sv.rstd1,
+                     g1, b1, sid + 1, rb1, d.x3 ? sv.sp_aout : nullptr));
     // 5. FFN in + erf-GELU (GELU' kept for backward)
     //    (split-operand mode: the activation leaves the GEMM as a split image -- only GEMMs read it: FFN-out and its wgrad)
     VB_TRY(linear(d, d.x3 ? (const void*)sv.sp_aout : (const void*)sv.a_out, H, nullptr, wi, wk * H,
                   d.x3 ? (void*)sv.sp_inter : (void*)sv.inter, I, bi, nullptr, VB_ACT_GELU_SAVE_GRAD, nullptr, sv.pre, nullptr, stream, d.x3));
-    // 6. FFN out
-    VB_TRY(linear(d, d.x3 ? (const void*)sv.sp_inter : (const void*)sv.inter, I, nullptr, wo2, wk * I, sc.t_h1, H, bo2, nullptr,
-                  VB_ACT_NONE, nullptr, nullptr, nullptr, stream));
-    // 7. dropout + residual + LayerNorm
-    VB_TRY(vb_ln_fwd_sp(edt, sc.t_h1, sv.a_out, sv.z2, h_out, sv.mean2, sv.rstd2, g2, b2, M, H, eps, p_hidden, sid + 4,
-                        0.f, 0, seed, nullptr, 0, rb2, stream));
+    // 6 + 7. FFN out, dropout + residual + LayerNorm (the same block: modeling.py:316-318)
+    VB_TRY(out_block(d.x3 ? (const void*)sv.sp_inter : (const void*)sv.inter, I, wo2, bo2, sv.a_out, sc.t_h1, sv.z2, h_out, sv.mean2, sv.rstd2,
+                     g2, b2, sid + 4, rb2, nullptr));
     return VB_OK;
 }
 

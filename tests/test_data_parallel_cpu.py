@@ -24,6 +24,7 @@ def _free_port():
 
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
+    torch.set_num_threads(2)                               # `world` processes share the host: the default (one thread per core, each) thrashes
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -138,6 +139,8 @@ def _gpu_worker(rank, world, port, q, overlap=True):
     """`world` ranks sharing cuda:0 (gloo carries the collectives): the REAL training step -- HIP kernels, autograd hooks
     firing the per-layer buckets during backward, fused BertAdam on the averaged gradients."""
     sys.path.insert(0, ROOT)
+    torch.set_num_threads(4)                               # 8 ranks x the oracle's CPU steps on one host: 128 threads each would thrash (the
+                                                           # first world-8 run of this test sat in the oracle for > 300 s)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)

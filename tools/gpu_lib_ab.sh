@@ -2,7 +2,7 @@
 # plain timing (3 interleaved rounds) + one kernel trace each
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-QUIET="--no-cpu-baseline --no-profile --no-h2d --no-parity --strict-dtype none --no-vendor-leg --pmc-traffic off --no-batch-curve"
+QUIET="--no-cpu-baseline --no-profile --no-h2d --no-parity --strict-dtype none --no-vendor-leg --pmc-traffic off --no-batch-curve --no-sparse-leg"
 OLD=${1:?usage: gpu_lib_ab.sh <reference build of libvisualbert_hip.so>}
 NEW=visualbert_amd/libvisualbert_hip.so
 for r in 1 2 3; do for lib in $OLD $NEW; do

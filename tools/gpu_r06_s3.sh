@@ -3,7 +3,7 @@ export TMPDIR=/tmp
 mkdir -p gpurun_out
 timeout 900 python -m pytest tests/test_kernels.py -m gpu -q -x --tb=short -p no:cacheprovider -k "split_k or wgrad or gemm" > gpurun_out/r06_s3_pytest_kernels.log 2>&1
 echo "rc=$?" >> gpurun_out/r06_s3_pytest_kernels.log; tail -n 4 gpurun_out/r06_s3_pytest_kernels.log
-QUIET="--no-cpu-baseline --no-profile --no-h2d --no-parity --strict-dtype none --no-vendor-leg --pmc-traffic off --no-batch-curve"
+QUIET="--no-cpu-baseline --no-profile --no-h2d --no-parity --strict-dtype none --no-vendor-leg --pmc-traffic off --no-batch-curve --no-sparse-leg"
 for B in 8 16; do for r in 1 2; do for lib in tools/libvisualbert_hip_ab_base.so tools/libvisualbert_hip_ab_nosk.so visualbert_amd/libvisualbert_hip.so; do
   timeout 300 python bench.py --batch $B --steps 30 --warmup 8 --lib-path $lib $QUIET > gpurun_out/ab.json 2>gpurun_out/ab.err
   python -c "import json;d=json.load(open('gpurun_out/ab.json'));print('B=%4d $lib: %.1f samples/s  %.3f ms/step (median %.3f)' % ($B, d['value'], d['ms_per_step'], d['ms_per_step_median']))" || tail -3 gpurun_out/ab.err

@@ -1,7 +1,7 @@
 # round 6, session 6: where the small-token weight-gradient kernel stops winning (48 / 96 / 192 K tiles) at B = 24 ... 128
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-QUIET="--no-cpu-baseline --no-profile --no-h2d --no-parity --strict-dtype none --no-vendor-leg --pmc-traffic off --no-batch-curve"
+QUIET="--no-cpu-baseline --no-profile --no-h2d --no-parity --strict-dtype none --no-vendor-leg --pmc-traffic off --no-batch-curve --no-sparse-leg"
 for B in 24 32 48 64 128; do for r in 1 2; do for lib in visualbert_amd/libvisualbert_hip.so tools/libvisualbert_hip_ab_kt96.so tools/libvisualbert_hip_ab_kt192.so; do
   timeout 300 python bench.py --batch $B --steps 30 --warmup 8 --lib-path $lib $QUIET > gpurun_out/ab.json 2>gpurun_out/ab.err
   python -c "import json;d=json.load(open('gpurun_out/ab.json'));print('B=%4d $lib: %.1f samples/s  %.3f ms/step (median %.3f)' % ($B, d['value'], d['ms_per_step'], d['ms_per_step_median']))" || tail -3 gpurun_out/ab.err

@@ -3,7 +3,7 @@ export TMPDIR=/tmp
 mkdir -p gpurun_out
 timeout 1200 python -m pytest tests/test_bench_shape.py tests/test_kernels.py -m gpu -q -x --tb=short -p no:cacheprovider -k "layer or split_k or wgrad" > gpurun_out/r06_s7_pytest.log 2>&1
 echo "rc=$?" >> gpurun_out/r06_s7_pytest.log; tail -n 6 gpurun_out/r06_s7_pytest.log
-QUIET="--no-cpu-baseline --no-profile --no-h2d --no-parity --strict-dtype none --no-vendor-leg --pmc-traffic off --no-batch-curve"
+QUIET="--no-cpu-baseline --no-profile --no-h2d --no-parity --strict-dtype none --no-vendor-leg --pmc-traffic off --no-batch-curve --no-sparse-leg"
 for r in 1 2 3; do for lib in tools/libvisualbert_hip_ab_nofuse.so visualbert_amd/libvisualbert_hip.so tools/libvisualbert_hip_ab_fuse90.so; do
   timeout 300 python bench.py --steps 15 --warmup 4 --lib-path $lib $QUIET > gpurun_out/ab.json 2>gpurun_out/ab.err
   python -c "import json;d=json.load(open('gpurun_out/ab.json'));print('$lib: %.1f samples/s  %.3f ms/step (median %.3f)' % (d['value'], d['ms_per_step'], d['ms_per_step_median']))" || tail -3 gpurun_out/ab.err

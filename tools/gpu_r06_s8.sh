@@ -7,7 +7,7 @@ echo "rc=$?" >> gpurun_out/r06_s8_pytest_attn.log; tail -n 4 gpurun_out/r06_s8_p
 for r in 1 2; do for lib in tools/libvisualbert_hip_ab_attn_old.so tools/libvisualbert_hip_ab_attn_b.so visualbert_amd/libvisualbert_hip.so; do
   echo "== $lib"; VB_LIB_PATH=$lib timeout 300 python tools/attn_bench.py 1024 164 2>&1 | grep -E "p=0.1" | grep -E "one-pass backward|fwd .* us \("
 done; done 2>&1 | tee gpurun_out/r06_s8_attn_bench.txt
-QUIET="--no-cpu-baseline --no-profile --no-h2d --no-parity --strict-dtype none --no-vendor-leg --pmc-traffic off --no-batch-curve"
+QUIET="--no-cpu-baseline --no-profile --no-h2d --no-parity --strict-dtype none --no-vendor-leg --pmc-traffic off --no-batch-curve --no-sparse-leg"
 for r in 1 2 3; do for lib in tools/libvisualbert_hip_ab_attn_old.so tools/libvisualbert_hip_ab_attn_b.so visualbert_amd/libvisualbert_hip.so; do
   timeout 300 python bench.py --steps 15 --warmup 4 --lib-path $lib $QUIET > gpurun_out/ab.json 2>gpurun_out/ab.err
   python -c "import json;d=json.load(open('gpurun_out/ab.json'));print('$lib: %.1f samples/s  %.3f ms/step (median %.3f)' % (d['value'], d['ms_per_step'], d['ms_per_step_median']))" || tail -3 gpurun_out/ab.err

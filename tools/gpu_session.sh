@@ -20,7 +20,7 @@ TAG=${1:-r05}
 shift
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-QUIET="--no-cpu-baseline --no-profile --no-h2d --no-parity --strict-dtype none --no-vendor-leg --pmc-traffic off --no-batch-curve"
+QUIET="--no-cpu-baseline --no-profile --no-h2d --no-parity --strict-dtype none --no-vendor-leg --pmc-traffic off --no-batch-curve --no-sparse-leg"
 for step in "$@"; do
   echo "=== $step ($(date +%T))"
   case "$step" in

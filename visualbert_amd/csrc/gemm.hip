@@ -2928,11 +2928,24 @@ extern "C" int vb_gemm(int dtype, int out_dtype, int a_layout, int b_layout,
                            act, aux_in, aux_out, ld_aux, accumulate, colsum_out, 0.f, 0, 0, stream);
 }
 
+// internal (layer.hip): is the "dropout + residual in the producing GEMM" form of a BertLayer's output blocks armed?  Never in the product
+// library (it lost its A/B AND costs bf16 parity: below); developer library: debug bit 29.
+int vb_gemm_fuse_residual_armed() {
+#ifdef VB_DEV_KNOBS
+    return (g_debug >> 29) & 1;
+#else
+    return 0;
+#endif
+}
+
 // internal (layer.hip): vb_gemm + inverted dropout (p_drop, seed, drop_stream: the LayerNorm kernels' generator and indexing) of
 // alpha acc + bias in front of the addend -- BertSelfOutput / BertOutput's dropout(dense(x)) + residual in the producing GEMM, so that
 // the LayerNorm launch reads one tensor instead of two.
 // MEASURED, round 6 (profiles/r06_dropres_epilogue_ab.txt; three product builds on one box, three interleaved rounds at B = 1024):
-//   p_drop == 0 ("+ residual" only): free on every kernel (the "+ addend" epilogue) -- layer.hip uses it whenever hidden dropout is off;
+//   p_drop == 0 ("+ residual" only): free on every kernel (the "+ addend" epilogue) -- but the LayerNorm then normalises a bf16-ROUNDED
+//   residual stream z where the unfused pair adds bf16(y) + bf16(x) exactly in fp32: max |dlogit| against the real reference's golden
+//   3.2e-3 -> 5.8e-3 on micro_pretraining (tests/test_model_parity.py caught it; the residual stream is the largest term of the bf16 error
+//   budget, profiles/r02_bf16_error_budget.txt).  Not shipped either;
 //   p_drop  > 0: the LayerNorm forward drops 132.3 -> 112.2 us per launch (-0.48 ms per step) but the generator's ~50 VALU instructions
 //   per 8 elements sit in the persistent kernel's epilogue, where the matrix pipe idles: 397 -> 454 us per launch on the 24 fused GEMMs
 //   of a step (+1.09 ms), step 118.0 -> 118.45 ms (two-workgroup kernel for the K = 768 shape: 118.5).  So the dropout form LOSES and is

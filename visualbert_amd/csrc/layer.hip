@@ -111,9 +111,7 @@ int linear(const Dims& d, const void* x, int k, unsigned char* stage, const void
 }
 
 #define VB_TRY(expr) do { int rc_ = (expr); if (rc_ != VB_OK) return rc_; } while (0)
-#ifndef VB_FUSE_DROPRES
-#define VB_FUSE_DROPRES 1            // 0: dropout + residual stay in the LayerNorm launch everywhere (the A/B arm, tools/build_variant.sh)
-#endif
+
 
 }  // namespace
 
@@ -161,20 +159,18 @@ extern "C" int vb_bert_layer_fwd(int dtype, const void* h_in, const float* mask_
     // 3 + 4. attention output projection, dropout + residual + LayerNorm
     //    (the pre-LN sum z is NOT written by the LayerNorm when the backward can rebuild x-hat from the output it reads anyway --
     //     decided in the kernel from gamma / beta and recorded in sv.ln_flags)
-    //    bf16 (round 6, VB_FUSE_DROPRES): the GEMM's epilogue adds the residual itself and writes z = (ctx Wo^T + b) + h_in straight
-    //    into the saved slot; the LayerNorm launch then reads ONE tensor and writes one (two [M, H] streams instead of three:
-    //    modeling.py:271-273 / SURVEY 2.3 K5) -- taken whenever hidden dropout is OFF (eval, p = 0 configurations).  With dropout ON the
-    //    GEMM would have to run the mask generator in its epilogue, which was built, measured and lost (gemm.hip: vb_gemm_dropres;
-    //    profiles/r06_dropres_epilogue_ab.txt): the product's GEMM declines (VB_ERR_UNSUPPORTED, nothing launched) and dropout + residual
-    //    stay in the LayerNorm launch; the developer library's arm keeps the fused form testable.  The backward is the same either way: its
-    //    LayerNorm kernel regenerates the mask from (seed, site id, element index).
+    //    Round 6 built the other split of this block -- the GEMM's epilogue applies dropout + residual and writes z straight into the saved
+    //    slot, the LayerNorm launch reads ONE tensor -- measured it, and declined it: with dropout the mask
+    //    generator in the persistent kernel's epilogue costs more than the LayerNorm saves (step 118.0 -> 118.45 ms), and even the
+    //    residual-only form normalises a bf16-rounded residual stream (max |dlogit| against the reference 3.2e-3 -> 5.8e-3).  The arm
+    //    stays reachable in the developer library (debug bit 29: gemm.hip vb_gemm_dropres; profiles/r06_dropres_epilogue_ab.txt).
     const bool rb = H <= 768;                           // (wider rows: the backward's rebuild-capable form does not pay, layernorm.hip)
     int* rb1 = rb ? sv.ln_flags : nullptr;
     int* rb2 = rb ? sv.ln_flags + 1 : nullptr;
     auto out_block = [&](const void* x, int k, const void* w, const float* bias, const void* resid, unsigned char* tmp, unsigned char* zslot,
                          void* y, float* mean, float* rstd, const float* gam, const float* bet, uint32_t site, int* rbf,
                          void* y_split) -> int {
-        if (VB_FUSE_DROPRES && d.dtype == VB_BF16) {
+        if (d.dtype == VB_BF16 && vb_gemm_fuse_residual_armed()) {
             const int rc = vb_gemm_dropres(VB_BF16, VB_BF16, VB_KCONTIG, VB_KCONTIG, x, k, w, k, zslot, H, M, H, k, 1.f, nullptr, bias, resid, H,
                                            VB_ACT_NONE, nullptr, nullptr, H, 0, nullptr, p_hidden, seed, site, stream);
             if (rc == VB_OK)                            // z is in its slot already: x = z_out = the slot (the kernel reads a row before it writes it)

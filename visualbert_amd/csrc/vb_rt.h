@@ -707,6 +707,7 @@ __attribute__((visibility("hidden"))) int vb_attn_bwd_sp(int dtype, const void* 
     const float* lse, const uint64_t* keepbits, float* dsum_ws, void* dqkv, const void* ctx_fwd, float* dqkv_bias, int B, int S, int nh,
     int head_dim, float p_drop, uint64_t seed, uint32_t stream_id, void* dqkv_split, int split_only, void* stream);
 
+__attribute__((visibility("hidden"))) int vb_gemm_fuse_residual_armed();
 __attribute__((visibility("hidden"))) int vb_gemm_dropres(int dtype, int out_dtype, int a_layout, int b_layout, const void* A, int64_t lda,
     const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K, float alpha, const float* alpha_dev, const float* bias,
     const void* addend, int64_t ld_addend, int act, const void* aux_in, void* aux_out, int64_t ld_aux, int accumulate, float* colsum_out,

@@ -2535,7 +2535,7 @@ static int launch_tn_tail(const TnArgs& main, int row0, int rows, hipStream_t st
 struct TnSmallArgs {
     TnProblem p[VB_TN_MAX];
     int tile0[VB_TN_MAX + 1];                     // first 128x128 tile of each problem
-    int nprob, KT, rows_tail;                     // whole 64-token K tiles; rows of the last, partial K tile (0 .. 63)
+    int nprob, tokens;                            // the reduction length (the kernel cuts it into whole K tiles + a ragged one)
     float alpha;
     const float* alpha_dev;
 };
@@ -2544,9 +2544,22 @@ template <int N> VB_DEVICE void vb_wait_lgkmcnt() {}
 #else
 template <int N> VB_DEVICE void vb_wait_lgkmcnt() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
 #endif
-template <int STAGES>
+// KB: tokens per K tile.  64 = the persistent kernel's half-tile image as is (16 KB per operand, 32 MFMAs per wave and barrier);
+// 32 = the k < 32 half of that image (8 KB per operand: chunk = (r >> 6) 4 + ((k >> 2) & 1) 2 + ((k >> 4) & 1)), so that a FOUR-stage ring is
+// 64 KB and two workgroups still share a compute unit.  Built on the guess that the two-stage 64-token ring (one L2 round trip exposed per
+// K tile and workgroup) was what held an encoder layer's launch at 37 us; measured (profiles/r06_small_batch_ab.txt, session 10): the same
+// 36.9 us, as was fetching the dW tile behind the ring's first tiles instead of ahead of them.  What bounds the launch is the operand
+// DELIVERY of a 128x128 tile: 32 KB from L2 per 2.1 MFLOP, 432 tiles x 21 K tiles = 290 MB in the ~21 us the K loops take = 13.8 TB/s, 70 %
+// of the 19.8 TB/s this chip delivers L2 -> LDS (profiles/r02_glds_stream.txt), plus ~16 us of prologue / dW read-modify-write that nothing
+// overlaps because all 432 workgroups run in lockstep.  KB = 32 is compiled only with -DVB_TN_SMALL_KB32=1 (tools/build_variant.sh).
+template <int STAGES, int KB>
 VB_KERNEL VB_LAUNCH_BOUNDS(256) gemm_tn_small_kernel(TnSmallArgs g) {
-    constexpr int HALF = 128 * 128, STAGE_BYTES = 2 * HALF, PER_TILE = 8;
+    static_assert(KB == 64 || KB == 32, "K tile depth");
+    constexpr int HALF = KB * 128 * 2, STAGE_BYTES = 2 * HALF;
+    constexpr int CI = KB / 16;                  // copy instructions per wave, operand and K tile (1 KB each)
+    constexpr int PER_TILE = 2 * CI;
+    constexpr int KS = KB / 32;                  // MFMA K steps per tile
+    constexpr int RH = KB * 128;                 // byte offset of tile rows 64 .. 127 in the image (the r >> 6 bit of the chunk index)
     VB_DYN_SMEM(smem);
     const int t = threadIdx.x;
     const int lane = t & 63, wave = vb_uniform(t >> 6);
@@ -2567,61 +2580,53 @@ VB_KERNEL VB_LAUNCH_BOUNDS(256) gemm_tn_small_kernel(TnSmallArgs g) {
     const int ncol = nw0 + (lane & 7) * 8;
     const bool col_ok = ncol < P.Ni;             // Ni % 8 == 0 (launcher): a lane's 8 columns are inside or outside together
     f32x4 cin[2][4][2];
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass)
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            int m = mw0 + pass * 32 + it * 8 + (lane >> 3);
-            m = m < P.Mo ? m : P.Mo - 1;                                 // clamped: always readable, never stored
-            const float* cp = P.C + (long)m * P.ldc + (col_ok ? ncol : 0);
-            cin[pass][it][0] = *(const f32x4*)cp;
-            cin[pass][it][1] = *(const f32x4*)(cp + 4);
-        }
+    constexpr int CIN_LOADS = 16;                // issued BEHIND the ring's first STAGES - 1 tiles (below): a wave has ONE in-order vmcnt
 
-    // ---- copy stream: wave w, instruction i fills chunk q = 4 w + i of a half-tile (image: see gemm_tn_8ph_kernel's header)
-    const int kl = (wave & 1) * 32 + ((lane >> 3) & 1) * 8 + ((lane >> 1) & 3);      // + (i & 1) 16 + (i >> 1) 4
+    // ---- copy stream: wave w, instruction i fills chunk CI w + i of a half-tile (image: see gemm_tn_8ph_kernel's header); token row of
+    //      instruction i inside the K tile: KB = 64: (w & 1) 32 + (i & 1) 16 + (i >> 1) 4 + lane bits; KB = 32: i 16 + (w & 1) 4 + lane bits
+    const int kl = (KB == 64 ? (wave & 1) * 32 : (wave & 1) * 4) + ((lane >> 3) & 1) * 8 + ((lane >> 1) & 3);
+    auto krow = [&](int i) { return kl + (KB == 64 ? (i & 1) * 16 + (i >> 1) * 4 : i * 16); };
     const int cr = (wave >> 1) * 64 + (lane >> 4) * 16 + (lane & 1) * 8;
     const int mo8 = (P.Mo + 7) & ~7, ni8 = (P.Ni + 7) & ~7;                           // readable up to round_up(rows, 8) per token (ABI)
     int ca = m0 + cr, cb = n0 + cr;
     ca = ca <= mo8 - 8 ? ca : mo8 - 8;                                               // clamped pieces land in rows the epilogue masks
     cb = cb <= ni8 - 8 ? cb : ni8 - 8;
-    unsigned offA[4], offB[4];
+    unsigned offA[CI], offB[CI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int k = kl + (i & 1) * 16 + (i >> 1) * 4;
-        offA[i] = (unsigned)((k * (int)P.lda + ca) * 2);
-        offB[i] = (unsigned)((k * (int)P.ldb + cb) * 2);
+    for (int i = 0; i < CI; ++i) {
+        offA[i] = (unsigned)((krow(i) * (int)P.lda + ca) * 2);
+        offB[i] = (unsigned)((krow(i) * (int)P.ldb + cb) * 2);
     }
-    const long stepA = 64 * P.lda * 2, stepB = 64 * P.ldb * 2;
+    const long stepA = (long)KB * P.lda * 2, stepB = (long)KB * P.ldb * 2;
     const unsigned char* baseA = (const unsigned char*)P.A;
     const unsigned char* baseB = (const unsigned char*)P.B;
-    const int nk = g.KT + (g.rows_tail > 0 ? 1 : 0);
+    const int KT = g.tokens / KB, rows_tail = g.tokens - KT * KB;
+    const int nk = KT + (rows_tail > 0 ? 1 : 0);
     auto issue = [&](int kt) {                               // K tile kt -> ring stage kt % STAGES
-        unsigned char* dst = smem + (kt % STAGES) * STAGE_BYTES + wave * 4096;
-        if (kt < g.KT) {
+        unsigned char* dst = smem + (kt % STAGES) * STAGE_BYTES + wave * (CI * 1024);
+        if (kt < KT) {
             const unsigned char* sa = baseA + (long)kt * stepA;
             const unsigned char* sb = baseB + (long)kt * stepB;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) vb_glds16(sa + offA[i], dst + i * 1024);
+            for (int i = 0; i < CI; ++i) vb_glds16(sa + offA[i], dst + i * 1024);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) vb_glds16(sb + offB[i], dst + HALF + i * 1024);
+            for (int i = 0; i < CI; ++i) vb_glds16(sb + offB[i], dst + HALF + i * 1024);
         } else {
             // the ragged tile: rows >= rows_tail are zeros; through registers (a masked LDS-direct lane would leave stale LDS behind);
             // loads from a clamped (always readable) row, the zero chosen afterwards
-            const unsigned char* sa = baseA + (long)g.KT * stepA;
-            const unsigned char* sb = baseB + (long)g.KT * stepB;
-            u32x4 va[4], vb[4];
+            const unsigned char* sa = baseA + (long)KT * stepA;
+            const unsigned char* sb = baseB + (long)KT * stepB;
+            u32x4 va[CI], vb[CI];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int k = kl + (i & 1) * 16 + (i >> 1) * 4;
-                const int kc = k < g.rows_tail ? k : g.rows_tail - 1;
+            for (int i = 0; i < CI; ++i) {
+                const int k = krow(i);
+                const int kc = k < rows_tail ? k : rows_tail - 1;
                 va[i] = *(const u32x4*)(sa + (long)(kc * (int)P.lda + ca) * 2);
                 vb[i] = *(const u32x4*)(sb + (long)(kc * (int)P.ldb + cb) * 2);
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int k = kl + (i & 1) * 16 + (i >> 1) * 4;
-                const bool ok = k < g.rows_tail;
+            for (int i = 0; i < CI; ++i) {
+                const bool ok = krow(i) < rows_tail;
                 const u32x4 z = u32x4{0u, 0u, 0u, 0u};
                 *(u32x4*)(dst + i * 1024 + lane * 16) = ok ? va[i] : z;
                 *(u32x4*)(dst + HALF + i * 1024 + lane * 16) = ok ? vb[i] : z;
@@ -2638,16 +2643,40 @@ VB_KERNEL VB_LAUNCH_BOUNDS(256) gemm_tn_small_kernel(TnSmallArgs g) {
     // ---- fragment gathers (lane map of the transposing read: gemm_tn_8ph_kernel)
     const int s16 = lane & 15, kg = lane >> 4;
     const int lane_off = (kg >> 1) * 1024 + ((kg & 1) * 4 + (s16 >> 2)) * 32 + ((s16 >> 1) & 1) * 16 + (s16 & 1) * 8;
-    const int offa_w = wm * 8192 + lane_off, offb_w = HALF + wn * 8192 + lane_off;
-    bf16x4 fal[4][2], fah[4][2], fbl[4][2], fbh[4][2];
+    const int offa_w = wm * RH + lane_off, offb_w = HALF + wn * RH + lane_off;
+    bf16x4 fal[4][KS], fah[4][KS], fbl[4][KS], fbh[4][KS];
 
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s)
         if (s < nk) issue(s);
+    // the dW tile, fetched NOW: behind the first tiles in the wave's in-order vmcnt queue, so that the K loop starts as soon as tile 0 has
+    // landed instead of sitting through the read of the launch's dW tiles first (measured: no difference at B = 8 -- the launch is bound by
+    // operand delivery, see the header); the waits for tiles 0 .. STAGES - 2 count these loads as allowed to stay in flight
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            int m = mw0 + pass * 32 + it * 8 + (lane >> 3);
+            m = m < P.Mo ? m : P.Mo - 1;                                 // clamped: always readable, never stored
+            const float* cp = P.C + (long)m * P.ldc + (col_ok ? ncol : 0);
+            cin[pass][it][0] = *(const f32x4*)cp;
+            cin[pass][it][1] = *(const f32x4*)(cp + 4);
+        }
     for (int kt = 0; kt < nk; ++kt) {
         // tile kt has landed; the LDS-direct tiles issued after it (at most STAGES - 2, and only whole tiles: index < KT) may stay in flight
-        const int last = g.KT - 1;
-        if (STAGES >= 3 && kt + STAGES - 2 <= last) vb_wait_vmcnt<(STAGES - 2) * PER_TILE>();
+        // -- and, for the tiles of the prologue (kt <= STAGES - 2), the dW loads issued behind them
+        const int last = KT - 1;
+        if (kt <= STAGES - 2) {
+            // in flight behind tile kt: prologue tiles kt + 1 .. STAGES - 2, the dW loads, then tiles STAGES - 1 .. kt + STAGES - 2 (issued in
+            // iterations 0 .. kt - 1); every one of them that is a whole tile counts PER_TILE
+            int whole = 0;
+            for (int j = kt + 1; j <= kt + STAGES - 2; ++j) whole += j <= last ? 1 : 0;
+            if (kt > last) vb_wait_vmcnt<0>();               // (a ragged-only launch: the tile came through registers)
+            else if (whole >= 2 && STAGES >= 4) vb_wait_vmcnt<2 * PER_TILE + CIN_LOADS>();
+            else if (whole == 1 && STAGES >= 3) vb_wait_vmcnt<PER_TILE + CIN_LOADS>();
+            else vb_wait_vmcnt<CIN_LOADS>();
+        }
+        else if (STAGES >= 3 && kt + STAGES - 2 <= last) vb_wait_vmcnt<(STAGES - 2) * PER_TILE>();
         else if (STAGES >= 4 && kt + STAGES - 3 <= last) vb_wait_vmcnt<(STAGES >= 4 ? STAGES - 3 : 0) * PER_TILE>();
         else vb_wait_vmcnt<0>();
         vb_raw_barrier();                      // everyone's part of tile kt is in LDS; everyone finished reading tile kt - 1
@@ -2657,30 +2686,36 @@ VB_KERNEL VB_LAUNCH_BOUNDS(256) gemm_tn_small_kernel(TnSmallArgs g) {
         const unsigned char* pb = buf + offb_w;
         vb_static_for<0, 4>([&](auto f) { vb_lds_read_tr_pair<decltype(f)::value * 256>(fal[decltype(f)::value][0], fah[decltype(f)::value][0], pa); });
         vb_static_for<0, 4>([&](auto f) { vb_lds_read_tr_pair<decltype(f)::value * 256>(fbl[decltype(f)::value][0], fbh[decltype(f)::value][0], pb); });
-        vb_static_for<0, 4>([&](auto f) { vb_lds_read_tr_pair<4096 + decltype(f)::value * 256>(fal[decltype(f)::value][1], fah[decltype(f)::value][1], pa); });
-        vb_static_for<0, 4>([&](auto f) { vb_lds_read_tr_pair<4096 + decltype(f)::value * 256>(fbl[decltype(f)::value][1], fbh[decltype(f)::value][1], pb); });
-        vb_wait_lgkmcnt<15>();                 // 32 reads issued, the LDS returns them in order: the first 16 (the k = 0 .. 31 fragments) are in
+        if constexpr (KS == 2) {
+            vb_static_for<0, 4>([&](auto f) { vb_lds_read_tr_pair<4096 + decltype(f)::value * 256>(fal[decltype(f)::value][KS - 1], fah[decltype(f)::value][KS - 1], pa); });
+            vb_static_for<0, 4>([&](auto f) { vb_lds_read_tr_pair<4096 + decltype(f)::value * 256>(fbl[decltype(f)::value][KS - 1], fbh[decltype(f)::value][KS - 1], pb); });
+            vb_wait_lgkmcnt<15>();             // 32 reads issued, the LDS returns them in order: the first 16 (the k = 0 .. 31 fragments) are in
+        } else {
+            vb_wait_lgkmcnt<0>();
+        }
         vb_sched_fence();
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni)
                 acc[mi][ni] = vb_mma(vb_join(fal[mi][0], fah[mi][0]), vb_join(fbl[ni][0], fbh[ni][0]), acc[mi][ni]);
-        vb_sched_fence();
-        vb_wait_lgkmcnt<0>();
-        vb_sched_fence();
+        if constexpr (KS == 2) {
+            vb_sched_fence();
+            vb_wait_lgkmcnt<0>();
+            vb_sched_fence();
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-                acc[mi][ni] = vb_mma(vb_join(fal[mi][1], fah[mi][1]), vb_join(fbl[ni][1], fbh[ni][1]), acc[mi][ni]);
+                for (int ni = 0; ni < 4; ++ni)
+                    acc[mi][ni] = vb_mma(vb_join(fal[mi][KS - 1], fah[mi][KS - 1]), vb_join(fbl[ni][KS - 1], fbh[ni][KS - 1]), acc[mi][ni]);
+        }
     }
 
     // ---- dW tile += alpha * acc: through a wave-private slab (in the ring, dead by now) so that a lane owns 8 consecutive columns
     const float alpha = g.alpha_dev ? g.alpha * g.alpha_dev[0] : g.alpha;
     const int li = lane & 15, lg = lane >> 4;
     unsigned char* slab = smem + wave * EPI_BYTES_PER_WAVE;
-    static_assert(4 * EPI_BYTES_PER_WAVE <= 2 * STAGE_BYTES, "epilogue slabs live in the ring");
+    static_assert(4 * EPI_BYTES_PER_WAVE <= STAGES * STAGE_BYTES, "epilogue slabs live in the ring");
     __syncthreads();                           // every wave has finished reading the ring
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
@@ -2716,6 +2751,9 @@ static bool tn_eligible(const void* A, long lda, const void* B, long ldb, const 
 // the small-token kernel takes a group when: few K tiles (the persistent kernel's atomic drain would dominate), vector-aligned dW
 // rows, and no two problems adding into the same dW (plain read-modify-writes).  VB_TN_SMALL_MAX_KT: crossover measured on MI355X
 // (profiles/r06_small_batch_ab.txt): the persistent kernel's 256x256 tiles move half the LDS bytes per FLOP and win once the K loop is long
+#ifndef VB_TN_SMALL_KB32
+#define VB_TN_SMALL_KB32 0           // 1: the two-workgroups-per-CU case on four 16-KB stages of 32 tokens (measured: no gain, see the kernel)
+#endif
 #ifndef VB_TN_SMALL_MAX_KT
 #define VB_TN_SMALL_MAX_KT 96
 #endif
@@ -2735,7 +2773,7 @@ static bool tn_small_eligible(const TnArgs& g, int tokens) {
 static int launch_tn_small(const TnArgs& main, int tokens, hipStream_t stream) {
     TnSmallArgs g;
     g.nprob = main.nprob; g.alpha = main.alpha; g.alpha_dev = main.alpha_dev;
-    g.KT = tokens / 64; g.rows_tail = tokens % 64;
+    g.tokens = tokens;
     int tiles = 0;
     double flops = 0;
     for (int i = 0; i < main.nprob; ++i) {
@@ -2748,9 +2786,14 @@ static int launch_tn_small(const TnArgs& main, int tokens, hipStream_t stream) {
     const int cus = (t_opts.persistent_workgroups > 0 && t_opts.persistent_workgroups < vb_num_cus()) ? t_opts.persistent_workgroups : vb_num_cus();
     dim3 grid((unsigned)tiles), block(256);
     // key: weight-gradient family (4 | 2 | 1) + 32 = the small-token kernel
-    if (tiles <= cus)
-        return vb_prof_launch(flops, 4 | 2 | 1 | 32, stream, [&]() { VB_LAUNCH(gemm_tn_small_kernel<4>, grid, block, 4 * 2 * 128 * 128, stream, g); });
-    return vb_prof_launch(flops, 4 | 2 | 1 | 32, stream, [&]() { VB_LAUNCH(gemm_tn_small_kernel<2>, grid, block, 2 * 2 * 128 * 128, stream, g); });
+    if (tiles <= cus)                                        // one workgroup per CU at most: four 32-KB stages
+        return vb_prof_launch(flops, 4 | 2 | 1 | 32, stream, [&]() { VB_LAUNCH((gemm_tn_small_kernel<4, 64>), grid, block, 4 * 2 * 128 * 128, stream, g); });
+#if VB_TN_SMALL_KB32
+    // more tiles than compute units: two workgroups per CU, four 16-KB stages of 32 tokens (64 KB each)
+    return vb_prof_launch(flops, 4 | 2 | 1 | 32, stream, [&]() { VB_LAUNCH((gemm_tn_small_kernel<4, 32>), grid, block, 4 * 2 * 32 * 128 * 2, stream, g); });
+#else
+    return vb_prof_launch(flops, 4 | 2 | 1 | 32, stream, [&]() { VB_LAUNCH((gemm_tn_small_kernel<2, 64>), grid, block, 2 * 2 * 128 * 128, stream, g); });
+#endif
 }
 
 // kernel for a K-contiguous x K-contiguous problem (vb_stream_opts.nt_kernel): 0 = chosen from the shape; 1 = the generic

@@ -28,6 +28,12 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with extra objec
                   never `value`
   value_with_h2d -- the same step with every batch streamed from pinned host memory (SURVEY 8d's metric definition);
                   `value` is the HBM-resident rate the contract asks for
+The driver's record of this line keeps the SCALAR entries of `roofline` and drops nested objects (round 5), so what a reader needs to
+judge a round is ALSO there flat: strict_value / strict_ms_per_step / strict_max_dlogit / strict_frac / strict_meets_tolerance (the
+compliant mode), parity_bf16_max_dlogit, mfma_ceiling_before_loop / _after_loop and all_gemm_frac_of_measured_ceiling (every GEMM launch
+against the register-only MFMA ceiling measured right before and right after the timed loop: comparable across boxes), value_with_h2d,
+value_sparse_mlm_head_optin (the opt-in head that never materialises the dense logits; a short extra leg, never `value`),
+batch_curve_b<B>_ms for per-GPU batches 8 ... 512 + the headline's (the regime of the reference's own configs: 6-8 per GPU).
 """
 import argparse
 import json

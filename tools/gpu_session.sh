@@ -31,7 +31,7 @@ for step in "$@"; do
       timeout 900 python -m pytest tests/test_parity_at_scale.py -m gpu -q -k stress --tb=short -p no:cacheprovider -s > gpurun_out/${TAG}_stress.log 2>&1
       echo "rc=$?" >> gpurun_out/${TAG}_stress.log; grep -E "^stress @|passed|failed|rc=|Error|assert" gpurun_out/${TAG}_stress.log | cut -c1-900 ;;
     pytest)
-      timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/${TAG}_pytest.log 2>&1
+      timeout 2400 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider --timeout 900 > gpurun_out/${TAG}_pytest.log 2>&1
       echo "rc=$?" >> gpurun_out/${TAG}_pytest.log; tail -n 8 gpurun_out/${TAG}_pytest.log ;;
     smoke)
       timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${TAG}_smoke.log 2>&1; echo "rc=$?" >> gpurun_out/${TAG}_smoke.log

@@ -137,6 +137,20 @@ def test_gemm_split_k_across_compute_units(dev, shape, addend):
     with _lib.stream_opts(nt_kernel=22):                      # a pinned kernel is never split
         C22 = gemm(dev, dt, A, W, M, N, K, 0, 0, bias=bias, addend=add)
     assert (C22.float() - outs[0].float()).abs().max().item() <= 2e-2 * max(1.0, ref.abs().max().item())
+    # the hand-off under reuse: the slabs of launch i hold launch i - 1's partial tiles when launch i starts, and the reader may sit on
+    # another XCD than the writers -- alternate two inputs for many launches; a stale slab line (or a ticket that overtook its slab)
+    # would reproduce the OTHER input's partial sums somewhere.  Each result must be the bits its input gave the first time.
+    if dev.type == "cuda":
+        A2 = (0.5 * torch.randn(M, K, generator=g)).to(dt).to(dev)
+        want = [outs[0], gemm(dev, dt, A2, W, M, N, K, 0, 0, bias=bias, addend=add).clone()]
+        big = torch.randn(64 << 20, device=dev)               # 256 MB stream between launches: uneven load, L2 contents churned
+        bad = 0
+        for i in range(120):
+            if i % 3 == 0:
+                big.mul_(1.0001)
+            Ci = gemm(dev, dt, A2 if i & 1 else A, W, M, N, K, 0, 0, bias=bias, addend=add)
+            bad += int(not torch.equal(Ci, want[i & 1]))
+        assert bad == 0, "%d of 120 split-K launches differ from their input's first result" % bad
 
 
 def _wgrad_grouped(dev, dys, xs, dws, tokens, alpha=1.0, alpha_dev=None):

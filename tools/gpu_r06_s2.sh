@@ -1,4 +1,4 @@
-# round 6, session 1: kernel tests of the changed kernels, small-batch A/B of two product builds, kernel trace at B = 8
+# round 6, session 2: first split-K (plain slab stores + agent-scope release / acquire fences) + the decoder weight gradient on the small-token kernel: kernel tests, small-batch A/B, kernel traces at B = 8 / 16
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 START=$(date +%s)

@@ -69,6 +69,18 @@ for step in "$@"; do
       python tools/pmc_step_summary.py $A $B >> gpurun_out/${TAG}_pmc_step_bf16.txt 2>&1
       rm -rf gpurun_out/pa gpurun_out/pb
       head -n 16 gpurun_out/${TAG}_pmc_step_bf16.txt | cut -c1-200 ;;
+    pmcb:*)     # the same two PMC passes at another per-GPU batch: pmcb:<B>  (round 6: B = 8, the small-batch kernels)
+      PB=${step#pmcb:}
+      PQ="--steps 6 --warmup 2 $QUIET"
+      SETA="SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
+      SETB="GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_INSTS_LDS SQ_INST_LEVEL_VMEM"
+      timeout 400 rocprofv3 --kernel-trace --pmc $SETA -d gpurun_out/pa -o p -- python bench.py --batch $PB $PQ > gpurun_out/pa.log 2>&1
+      timeout 400 rocprofv3 --kernel-trace --pmc $SETB -d gpurun_out/pb -o p -- python bench.py --batch $PB $PQ > gpurun_out/pb.log 2>&1
+      A=$(find gpurun_out/pa -name "*_results.db" | head -1); B=$(find gpurun_out/pb -name "*_results.db" | head -1)
+      echo "# python bench.py --dtype bf16 --batch $PB (8 steps), rocprofv3 --kernel-trace --pmc, two passes; tools/pmc_step_summary.py" > gpurun_out/${TAG}_pmc_step_bf16_b$PB.txt
+      python tools/pmc_step_summary.py $A $B >> gpurun_out/${TAG}_pmc_step_bf16_b$PB.txt 2>&1
+      rm -rf gpurun_out/pa gpurun_out/pb
+      head -n 22 gpurun_out/${TAG}_pmc_step_bf16_b$PB.txt | cut -c1-200 ;;
     pyt:*)      # a subset of the GPU suite: pyt:<-k expression with '+' for spaces>
       expr=$(echo "${step#pyt:}" | tr '+' ' ')
       timeout 900 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -k "$expr" > gpurun_out/${TAG}_pytest_subset.log 2>&1

@@ -96,6 +96,11 @@ for step in "$@"; do
       timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/pf -o f -- python bench.py --workload nlvr2-real --steps 4 --warmup 2 $QUIET > gpurun_out/pf3.log 2>&1
       python tools/rocpd_summary.py gpurun_out/pf/f_results.db > gpurun_out/${TAG}_kernel_stats_nlvr2_real.txt 2>&1; rm -rf gpurun_out/pf
       head -n 16 gpurun_out/${TAG}_kernel_stats_nlvr2_real.txt | cut -c1-200 ;;
+    workloads)  # the other BASELINE configs' quiet bench lines: VQA (configs[3]) and NLVR2 (configs[4])
+      for wlk in vqa nlvr2; do
+        timeout 600 python bench.py --workload $wlk --steps 20 --warmup 5 $QUIET > gpurun_out/${TAG}_bench_$wlk.json 2> gpurun_out/${TAG}_bench_$wlk.err
+        python tools/bench_digest.py gpurun_out/${TAG}_bench_$wlk.json | head -n 2
+      done ;;
     sweep)
       timeout 900 python tools/batch_sweep.py > gpurun_out/${TAG}_batch_sweep.txt 2> gpurun_out/${TAG}_batch_sweep.err; cat gpurun_out/${TAG}_batch_sweep.txt ;;
     py:*)

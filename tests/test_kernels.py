@@ -153,6 +153,37 @@ def test_gemm_split_k_across_compute_units(dev, shape, addend):
         assert bad == 0, "%d of 120 split-K launches differ from their input's first result" % bad
 
 
+def test_split_k_scratch_is_per_stream(dev):
+    """the partial tiles and arrival counters of the split-K GEMMs live in scratch that belongs to a STREAM (vb_stream_set_scratch;
+    _lib.stream_ptr registers one buffer per stream on first use): two streams running split-K GEMMs at the same time must not see each
+    other's slabs or tickets.  Two different problems, 40 launches each, interleaved on two streams; every result bit-equal to the
+    problem's result computed alone."""
+    if dev.type != "cuda":
+        pytest.skip("needs two HIP streams")
+    g = torch.Generator().manual_seed(99)
+    dt = torch.bfloat16
+    M, N, K = 1312, 768, 3072
+    probs = []
+    for i in range(2):
+        A = (0.5 * torch.randn(M, K, generator=g)).to(dt).to(dev)
+        W = (0.05 * torch.randn(N, K, generator=g)).to(dt).to(dev)
+        bias = torch.randn(N, generator=g).to(dev)
+        probs.append((A, W, bias, gemm(dev, dt, A, W, M, N, K, 0, 0, bias=bias).clone()))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    outs = [[], []]
+    for rep in range(40):
+        for i, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                A, W, bias, _ = probs[i]
+                outs[i].append(gemm(dev, dt, A, W, M, N, K, 0, 0, bias=bias))
+    torch.cuda.synchronize()
+    for i in range(2):
+        bad = sum(int(not torch.equal(c, probs[i][3])) for c in outs[i])
+        assert bad == 0, "stream %d: %d of 40 results differ" % (i, bad)
+    assert len({k for k in _lib._scratch if k[2] in (streams[0].cuda_stream, streams[1].cuda_stream)}) == 2   # one buffer per stream
+
+
 def _wgrad_grouped(dev, dys, xs, dws, tokens, alpha=1.0, alpha_dev=None):
     L = _lib.lib()
     n = len(dys)

@@ -189,6 +189,65 @@ def test_bf16_matches_bf16_oracle(dev, stem):
     assert dl < lim[2], dl
 
 
+def test_layer_call_plans_follow_the_parameters(dev):
+    """ops._LayerPlan caches a layer's pointer arrays (round 6: the small-batch step had become host-bound).  The cache must notice every
+    way the parameters can change under it: a write through torch (version counter), a state-dict load, an optimizer step through the raw
+    kernel (shadows refreshed in place: nothing to notice, same addresses), a new arena (.to(device) / a rebuilt model) -- each time the
+    next forward must equal a FRESH model built from the same weights, bit for bit."""
+    from visualbert_amd import ops
+    cfg, head, sd, batch, g = load_case("micro_pretraining")
+    b = to_dev(batch, dev)
+
+    def fresh_logits(state):
+        m = build_model(cfg, head, state, dev, dtype=torch.bfloat16, dropout=0.0)
+        m.eval()
+        with torch.no_grad():
+            return m(**b)["logits"].float().cpu()
+
+    model = build_model(cfg, head, sd, dev, dtype=torch.bfloat16, dropout=0.0)
+    model.eval()
+    with torch.no_grad():
+        first = model(**b)["logits"].float().cpu()
+    layer = model.bert.bert.encoder.layer[0]
+    assert layer.__dict__.get("_vb_plan") is not None, "arena-managed bf16 layer: the plan is expected to exist"
+    assert torch.equal(first, fresh_logits(sd))
+    # (1) a write through torch: one FFN weight and one LayerNorm bias of layer 0, the packed query weight of layer 1
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    with torch.no_grad():
+        layer.output.dense.weight.mul_(1.5)
+        layer.attention.output.LayerNorm.bias.add_(0.25)
+        model.bert.bert.encoder.layer[1].attention.self.query.weight.mul_(0.5)
+    sd2["bert.encoder.layer.0.output.dense.weight"] *= 1.5
+    sd2["bert.encoder.layer.0.attention.output.LayerNorm.bias"] += 0.25
+    sd2["bert.encoder.layer.1.attention.self.query.weight"] *= 0.5
+    with torch.no_grad():
+        second = model(**b)["logits"].float().cpu()
+    assert not torch.equal(second, first)
+    assert torch.equal(second, fresh_logits(sd2))
+    # (2) a state-dict load back to the original weights
+    own = model.bert.state_dict()
+    with torch.no_grad():
+        for k, v in sd.items():
+            own[k].copy_(v)
+    with torch.no_grad():
+        third = model(**b)["logits"].float().cpu()
+    assert torch.equal(third, first)
+    # (3) training steps through the fused optimizer (raw writes into the arena + shadows refreshed by the kernel), then eval again:
+    #     equal to a fresh model loaded from the trained model's state dict
+    model.train()
+    from visualbert_amd.model import AttrDict, ModelWrapper
+    mw = ModelWrapper(AttrDict(train_batch_size=b["bert_input_ids"].size(0), learning_rate=1e-3, warmup_proportion=0.1, num_train_epochs=1,
+                               gradient_accumulation_steps=1), 100 * b["bert_input_ids"].size(0), model=model)
+    for _ in range(2):
+        mw.step(b)
+    model.eval()
+    with torch.no_grad():
+        fourth = model(**b)["logits"].float().cpu()
+    trained = {k: v.detach().float().cpu().clone() for k, v in model.bert.state_dict().items() if k in sd}
+    assert not torch.equal(fourth, first)
+    assert torch.equal(fourth, fresh_logits(trained))
+
+
 def test_dropout_training_step_runs_and_is_seed_deterministic(dev):
     cfg, head, sd, batch, g = load_case("micro_pretraining")
     losses = []

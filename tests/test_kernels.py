@@ -263,6 +263,30 @@ def test_wgrad_small_token_kernel(dev, tokens, wgs):
             assert (dw - ref).abs().max().item() <= 2e-4 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("tokens", [40, 200, 1312])
+def test_wgrad_small_token_kernel_256x128_tiles(dev, tokens):
+    """gemm_tn_small256_kernel: the eight-wave 256x128-tile form of the small-token weight gradients, taken when the 128x128 tiles
+    outnumber the compute units but the 256x128 tiles fit in one round -- an encoder layer's four Linears on the real chip (216
+    tiles), one ragged 300 x 200 problem on the simulator's four units.  Against fp32 matmul, accumulating twice."""
+    if dev.type == "cuda":
+        shapes = [(768, 3072), (3072, 768), (768, 768), (2304, 768)]
+    else:
+        if tokens > 200:
+            pytest.skip("simulator: the small cases cover the index logic")
+        shapes = [(300, 200)]
+    g = torch.Generator().manual_seed(tokens)
+    dt = torch.bfloat16
+    dys = [padded(tokens, o, dt, dev, g) for o, _ in shapes]          # (leading dimensions rounded up to 8: the ABI's requirement)
+    xs = [padded(tokens, i, dt, dev, g) for _, i in shapes]
+    dws = [torch.full((o, i), 0.25, device=dev) for o, i in shapes]
+    sc = torch.tensor([0.5], device=dev)
+    _wgrad_grouped(dev, dys, xs, dws, tokens, alpha=2.0, alpha_dev=sc)
+    _wgrad_grouped(dev, dys, xs, dws, tokens, alpha=1.0)
+    for dy, x, dw in zip(dys, xs, dws):
+        ref = 0.25 + 2.0 * (dy.float().t() @ x.float())
+        assert (dw - ref).abs().max().item() <= 2e-4 * max(1.0, ref.abs().max().item())
+
+
 def test_wgrad_grouped_problems_sharing_one_dw(dev):
     """two problems of one call that accumulate into the SAME dW (the ABI does not forbid it): the grouped kernel adds with atomics;
     the ragged rows' tail kernel uses plain read-modify-writes and must therefore run such problems one after the other."""

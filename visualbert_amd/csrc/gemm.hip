@@ -2544,6 +2544,39 @@ template <int N> VB_DEVICE void vb_wait_lgkmcnt() {}
 #else
 template <int N> VB_DEVICE void vb_wait_lgkmcnt() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
 #endif
+// dW block (64 x 64 per wave) += alpha * acc: through a wave-private slab (in the ring, dead by now) so that a lane owns 8 consecutive
+// columns; cin = the block's old values, fetched during the K loop.  Every wave of the workgroup must call it (one workgroup barrier).
+VB_DEVICE void tn_small_epilogue(f32x4 (&acc)[4][4], f32x4 (&cin)[2][4][2], unsigned char* smem, const TnSmallArgs& g, const TnProblem& P,
+                                 int mw0, int ncol, bool col_ok, int wave, int lane) {
+    const float alpha = g.alpha_dev ? g.alpha * g.alpha_dev[0] : g.alpha;
+    const int li = lane & 15, lg = lane >> 4;
+    unsigned char* slab = smem + wave * EPI_BYTES_PER_WAVE;
+    __syncthreads();                           // every wave has finished reading the ring
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass) vb_wave_sync();
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    *(float*)(slab + (mh * 16 + lg * 4 + r) * EPI_PITCH + (ni * 16 + li) * 4) = acc[pass * 2 + mh][ni][r];
+        vb_wave_sync();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = it * 8 + (lane >> 3);
+            const int m = mw0 + pass * 32 + row;
+            const unsigned char* src = slab + row * EPI_PITCH + (lane & 7) * 32;
+            const f32x4 lo = *(const f32x4*)src, hi = *(const f32x4*)(src + 16);
+            if (m < P.Mo && col_ok) {
+                float* cp = P.C + (long)m * P.ldc + ncol;
+                *(f32x4*)cp = cin[pass][it][0] + alpha * lo;
+                *(f32x4*)(cp + 4) = cin[pass][it][1] + alpha * hi;
+            }
+        }
+    }
+}
 // KB: tokens per K tile.  64 = the persistent kernel's half-tile image as is (16 KB per operand, 32 MFMAs per wave and barrier);
 // 32 = the k < 32 half of that image (8 KB per operand: chunk = (r >> 6) 4 + ((k >> 2) & 1) 2 + ((k >> 4) & 1)), so that a FOUR-stage ring is
 // 64 KB and two workgroups still share a compute unit.  Built on the guess that the two-stage 64-token ring (one L2 round trip exposed per
@@ -2553,7 +2586,8 @@ template <int N> VB_DEVICE void vb_wait_lgkmcnt() { asm volatile("s_waitcnt lgkm
 // of the 19.8 TB/s this chip delivers L2 -> LDS (profiles/r02_glds_stream.txt), plus ~16 us of prologue / dW read-modify-write that nothing
 // overlaps because all 432 workgroups run in lockstep.  KB = 32 is compiled only with -DVB_TN_SMALL_KB32=1 (tools/build_variant.sh).
 template <int STAGES, int KB>
-VB_KERNEL VB_LAUNCH_BOUNDS(256) gemm_tn_small_kernel(TnSmallArgs g) {
+VB_KERNEL VB_LAUNCH_BOUNDS2(256, 2) gemm_tn_small_kernel(TnSmallArgs g) {      // two waves per SIMD = two workgroups per CU: at most 256 registers
+                                                                              // (without the bound one build came out at 164 + 96 and ran ONE per CU)
     static_assert(KB == 64 || KB == 32, "K tile depth");
     constexpr int HALF = KB * 128 * 2, STAGE_BYTES = 2 * HALF;
     constexpr int CI = KB / 16;                  // copy instructions per wave, operand and K tile (1 KB each)
@@ -2711,36 +2745,148 @@ VB_KERNEL VB_LAUNCH_BOUNDS(256) gemm_tn_small_kernel(TnSmallArgs g) {
         }
     }
 
-    // ---- dW tile += alpha * acc: through a wave-private slab (in the ring, dead by now) so that a lane owns 8 consecutive columns
-    const float alpha = g.alpha_dev ? g.alpha * g.alpha_dev[0] : g.alpha;
-    const int li = lane & 15, lg = lane >> 4;
-    unsigned char* slab = smem + wave * EPI_BYTES_PER_WAVE;
     static_assert(4 * EPI_BYTES_PER_WAVE <= STAGES * STAGE_BYTES, "epilogue slabs live in the ring");
-    __syncthreads();                           // every wave has finished reading the ring
+    tn_small_epilogue(acc, cin, smem, g, P, mw0, ncol, col_ok, wave, lane);
+}
+// The same job on 256 x 128 tiles, EIGHT waves as 4 (M) x 2 (N): an A panel of two half-tiles and one B half-tile per K tile (48 KB: three
+// stages = 144 KB, one workgroup per compute unit).  The 128x128 form is bound by operand delivery -- 32 KB from L2 per 2.1 MFLOP; this
+// tile pulls 48 KB per 4.2 MFLOP, 1.33x the FLOPs per delivered byte -- and an encoder layer's four weight gradients are 216 such tiles:
+// one round on 256 compute units, eight waves per unit issuing copies instead of two workgroups of four in lockstep.  Copy stream and
+// fragment gathers are gemm_tn_8ph_kernel's (wave w, instruction i fills chunk 2 w + i of every half-tile); the epilogue is the
+// 128x128 kernel's (a wave owns a 64 x 64 block of dW, fetched behind the ring's first tiles, plain read-modify-write).
+VB_KERNEL VB_LAUNCH_BOUNDS(512) gemm_tn_small256_kernel(TnSmallArgs g) {
+    constexpr int STAGES = 3, HALF = 128 * 128, STAGE_BYTES = 3 * HALF, PER_TILE = 6, CIN_LOADS = 16;
+    VB_DYN_SMEM(smem);
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = vb_uniform(t >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntiles = g.tile0[g.nprob];
+    const int v = xcd_remap((int)blockIdx.x, ntiles);
+    int pi = 0;
+    for (int q = 1; q < g.nprob; ++q) if (v >= g.tile0[q]) pi = q;
+    const TnProblem& P = g.p[pi];
+    const int tl = v - g.tile0[pi];
+    const int tm = (P.Mo + 255) / 256, tn = (P.Ni + 127) / 128;
+    int m0, n0;
+    if (tm < tn) { m0 = (tl % tm) * 256; n0 = (tl / tm) * 128; }
+    else { m0 = (tl / tn) * 256; n0 = (tl % tn) * 128; }
+    const int mw0 = m0 + wm * 64, nw0 = n0 + wn * 64;
+    const int ncol = nw0 + (lane & 7) * 8;
+    const bool col_ok = ncol < P.Ni;
+    f32x4 cin[2][4][2];
+
+    // ---- copy stream (gemm_tn_8ph_kernel's lane map): token row ck + 16 i, feature offset cr inside a 128-row half-tile
+    const int ck = ((wave >> 1) & 1) * 32 + ((lane >> 3) & 1) * 8 + (wave & 1) * 4 + ((lane >> 1) & 3);
+    const int cr = (wave >> 2) * 64 + (lane >> 4) * 16 + (lane & 1) * 8;
+    const int mo8 = (P.Mo + 7) & ~7, ni8 = (P.Ni + 7) & ~7;
+    int ca0 = m0 + cr, ca1 = m0 + 128 + cr, cb = n0 + cr;
+    ca0 = ca0 <= mo8 - 8 ? ca0 : mo8 - 8;
+    ca1 = ca1 <= mo8 - 8 ? ca1 : mo8 - 8;
+    cb = cb <= ni8 - 8 ? cb : ni8 - 8;
+    unsigned offA0[2], offA1[2], offB[2];
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        if (pass) vb_wave_sync();
+    for (int i = 0; i < 2; ++i) {
+        offA0[i] = (unsigned)(((ck + 16 * i) * (int)P.lda + ca0) * 2);
+        offA1[i] = (unsigned)(((ck + 16 * i) * (int)P.lda + ca1) * 2);
+        offB[i] = (unsigned)(((ck + 16 * i) * (int)P.ldb + cb) * 2);
+    }
+    const long stepA = 64L * P.lda * 2, stepB = 64L * P.ldb * 2;
+    const unsigned char* baseA = (const unsigned char*)P.A;
+    const unsigned char* baseB = (const unsigned char*)P.B;
+    const int KT = g.tokens / 64, rows_tail = g.tokens - KT * 64;
+    const int nk = KT + (rows_tail > 0 ? 1 : 0);
+    auto issue = [&](int kt) {
+        unsigned char* dst = smem + (kt % STAGES) * STAGE_BYTES + wave * 2048;
+        if (kt < KT) {
+            const unsigned char* sa = baseA + (long)kt * stepA;
+            const unsigned char* sb = baseB + (long)kt * stepB;
 #pragma unroll
-        for (int mh = 0; mh < 2; ++mh)
+            for (int i = 0; i < 2; ++i) vb_glds16(sa + offA0[i], dst + i * 1024);
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
+            for (int i = 0; i < 2; ++i) vb_glds16(sa + offA1[i], dst + HALF + i * 1024);
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    *(float*)(slab + (mh * 16 + lg * 4 + r) * EPI_PITCH + (ni * 16 + li) * 4) = acc[pass * 2 + mh][ni][r];
-        vb_wave_sync();
+            for (int i = 0; i < 2; ++i) vb_glds16(sb + offB[i], dst + 2 * HALF + i * 1024);
+        } else {                                                 // the ragged tile: through registers, rows >= rows_tail are zeros
+            const unsigned char* sa = baseA + (long)KT * stepA;
+            const unsigned char* sb = baseB + (long)KT * stepB;
+            u32x4 v0[2], v1[2], vb[2];
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int row = it * 8 + (lane >> 3);
-            const int m = mw0 + pass * 32 + row;
-            const unsigned char* src = slab + row * EPI_PITCH + (lane & 7) * 32;
-            const f32x4 lo = *(const f32x4*)src, hi = *(const f32x4*)(src + 16);
-            if (m < P.Mo && col_ok) {
-                float* cp = P.C + (long)m * P.ldc + ncol;
-                *(f32x4*)cp = cin[pass][it][0] + alpha * lo;
-                *(f32x4*)(cp + 4) = cin[pass][it][1] + alpha * hi;
+            for (int i = 0; i < 2; ++i) {
+                const int k = ck + 16 * i;
+                const int kc = k < rows_tail ? k : rows_tail - 1;
+                v0[i] = *(const u32x4*)(sa + (long)(kc * (int)P.lda + ca0) * 2);
+                v1[i] = *(const u32x4*)(sa + (long)(kc * (int)P.lda + ca1) * 2);
+                vb[i] = *(const u32x4*)(sb + (long)(kc * (int)P.ldb + cb) * 2);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const bool ok = ck + 16 * i < rows_tail;
+                const u32x4 z = u32x4{0u, 0u, 0u, 0u};
+                *(u32x4*)(dst + i * 1024 + lane * 16) = ok ? v0[i] : z;
+                *(u32x4*)(dst + HALF + i * 1024 + lane * 16) = ok ? v1[i] : z;
+                *(u32x4*)(dst + 2 * HALF + i * 1024 + lane * 16) = ok ? vb[i] : z;
             }
         }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int s16 = lane & 15, kg = lane >> 4;
+    const int lane_off = (kg >> 1) * 1024 + ((kg & 1) * 4 + (s16 >> 2)) * 32 + ((s16 >> 1) & 1) * 16 + (s16 & 1) * 8;
+    const int offa_w = (wm >> 1) * HALF + (wm & 1) * 8192 + lane_off, offb_w = 2 * HALF + wn * 8192 + lane_off;
+    bf16x4 fal[4][2], fah[4][2], fbl[4][2], fbh[4][2];
+
+#pragma unroll
+    for (int s2 = 0; s2 < STAGES - 1; ++s2)
+        if (s2 < nk) issue(s2);
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            int m = mw0 + pass * 32 + it * 8 + (lane >> 3);
+            m = m < P.Mo ? m : P.Mo - 1;
+            const float* cp = P.C + (long)m * P.ldc + (col_ok ? ncol : 0);
+            cin[pass][it][0] = *(const f32x4*)cp;
+            cin[pass][it][1] = *(const f32x4*)(cp + 4);
+        }
+    for (int kt = 0; kt < nk; ++kt) {
+        const int last = KT - 1;
+        if (kt <= STAGES - 2) {                              // behind tile kt: at most one whole tile of the ring + the dW loads
+            if (kt > last) vb_wait_vmcnt<0>();
+            else if (kt + 1 <= last) vb_wait_vmcnt<PER_TILE + CIN_LOADS>();
+            else vb_wait_vmcnt<CIN_LOADS>();
+        }
+        else if (kt + 1 <= last) vb_wait_vmcnt<PER_TILE>();
+        else vb_wait_vmcnt<0>();
+        vb_raw_barrier();
+        if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1);
+        const unsigned char* buf = smem + (kt % STAGES) * STAGE_BYTES;
+        const unsigned char* pa = buf + offa_w;
+        const unsigned char* pb = buf + offb_w;
+        vb_static_for<0, 4>([&](auto f) { vb_lds_read_tr_pair<decltype(f)::value * 256>(fal[decltype(f)::value][0], fah[decltype(f)::value][0], pa); });
+        vb_static_for<0, 4>([&](auto f) { vb_lds_read_tr_pair<decltype(f)::value * 256>(fbl[decltype(f)::value][0], fbh[decltype(f)::value][0], pb); });
+        vb_static_for<0, 4>([&](auto f) { vb_lds_read_tr_pair<4096 + decltype(f)::value * 256>(fal[decltype(f)::value][1], fah[decltype(f)::value][1], pa); });
+        vb_static_for<0, 4>([&](auto f) { vb_lds_read_tr_pair<4096 + decltype(f)::value * 256>(fbl[decltype(f)::value][1], fbh[decltype(f)::value][1], pb); });
+        vb_wait_lgkmcnt<15>();
+        vb_sched_fence();
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                acc[mi][ni] = vb_mma(vb_join(fal[mi][0], fah[mi][0]), vb_join(fbl[ni][0], fbh[ni][0]), acc[mi][ni]);
+        vb_sched_fence();
+        vb_wait_lgkmcnt<0>();
+        vb_sched_fence();
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                acc[mi][ni] = vb_mma(vb_join(fal[mi][1], fah[mi][1]), vb_join(fbl[ni][1], fbh[ni][1]), acc[mi][ni]);
     }
+    tn_small_epilogue(acc, cin, smem, g, P, mw0, ncol, col_ok, wave, lane);
 }
 static bool tn_eligible(const void* A, long lda, const void* B, long ldb, const float* C, long ldc, int Mo, int Ni, int K) {
     return K >= 64 && (K % 64) == 0 && Mo >= 1 && Ni >= 1 && lda >= ((Mo + 7) & ~7) && ldb >= ((Ni + 7) & ~7) && (lda % 8) == 0 && (ldb % 8) == 0 &&
@@ -2751,11 +2897,14 @@ static bool tn_eligible(const void* A, long lda, const void* B, long ldb, const 
 // the small-token kernel takes a group when: few K tiles (the persistent kernel's atomic drain would dominate), vector-aligned dW
 // rows, and no two problems adding into the same dW (plain read-modify-writes).  VB_TN_SMALL_MAX_KT: crossover measured on MI355X
 // (profiles/r06_small_batch_ab.txt): the persistent kernel's 256x256 tiles move half the LDS bytes per FLOP and win once the K loop is long
+#ifndef VB_TN_SMALL_256
+#define VB_TN_SMALL_256 1
+#endif
 #ifndef VB_TN_SMALL_KB32
 #define VB_TN_SMALL_KB32 0           // 1: the two-workgroups-per-CU case on four 16-KB stages of 32 tokens (measured: no gain, see the kernel)
 #endif
 #ifndef VB_TN_SMALL_MAX_KT
-#define VB_TN_SMALL_MAX_KT 96
+#define VB_TN_SMALL_MAX_KT 128
 #endif
 static bool tn_small_eligible(const TnArgs& g, int tokens) {
     if ((tokens + 63) / 64 > VB_TN_SMALL_MAX_KT) return false;
@@ -2788,6 +2937,19 @@ static int launch_tn_small(const TnArgs& main, int tokens, hipStream_t stream) {
     // key: weight-gradient family (4 | 2 | 1) + 32 = the small-token kernel
     if (tiles <= cus)                                        // one workgroup per CU at most: four 32-KB stages
         return vb_prof_launch(flops, 4 | 2 | 1 | 32, stream, [&]() { VB_LAUNCH((gemm_tn_small_kernel<4, 64>), grid, block, 4 * 2 * 128 * 128, stream, g); });
+#if VB_TN_SMALL_256
+    {   // more 128x128 tiles than compute units, but the 256x128 tiles fit in one round: the eight-wave kernel (an encoder layer: 216 tiles)
+        TnSmallArgs g2 = g;
+        int t256 = 0;
+        for (int i = 0; i < main.nprob; ++i) {
+            g2.tile0[i] = t256;
+            t256 += ((main.p[i].Mo + 255) / 256) * ((main.p[i].Ni + 127) / 128);
+        }
+        g2.tile0[main.nprob] = t256;
+        if (t256 <= cus)
+            return vb_prof_launch(flops, 4 | 2 | 1 | 32, stream, [&]() { VB_LAUNCH(gemm_tn_small256_kernel, dim3((unsigned)t256), dim3(512), 3 * 3 * 128 * 128, stream, g2); });
+    }
+#endif
 #if VB_TN_SMALL_KB32
     // more tiles than compute units: two workgroups per CU, four 16-KB stages of 32 tokens (64 KB each)
     return vb_prof_launch(flops, 4 | 2 | 1 | 32, stream, [&]() { VB_LAUNCH((gemm_tn_small_kernel<4, 32>), grid, block, 4 * 2 * 32 * 128 * 2, stream, g); });

@@ -386,18 +386,24 @@ int vb_bert_layer_bwd(int dtype, const void* h_in, const void* h_out, const floa
  * event pair around itself (other streams are unaffected; nothing is recorded by default);
  * vb_stream_profile_read(stream, ...) (after synchronising the stream) returns per-launch {milliseconds, algorithmic FLOPs
  * 2MNK, key}; key bits: 8 = fp32 operands (else bf16), 4 = fp32 output, 2 = A K-strided, 1 = B K-strided, 16 = 256x256-tile
- * kernel, 64 = two-workgroup 256x128 kernel, 256 = split-operand (bf16x3) mode.  vb_stream_profile(stream, 0) stops and frees
- * the events. */
+ * kernel, 64 = two-workgroup 256x128 kernel, 256 = split-operand (bf16x3) mode, 1024 = the K range of each tile was split over
+ * several workgroups (vb_stream_set_scratch); 39 (= 32|4|2|1) is the one-workgroup-per-dW-tile form of vb_wgrad_grouped.
+ * vb_stream_profile(stream, 0) stops and frees the events. */
 int vb_stream_profile(void* stream, int enable);
 int64_t vb_stream_profile_read(void* stream, double* ms, double* flops, int* key, int64_t max_records);
 
 /* Weight gradients of a group of Linears that saw the same tokens (the four of an encoder layer), one launch:
  *   dw[i][n_out[i], n_in[i]] (fp32, ld_dw[i]) += alpha * dy[i]^T x[i],   dy[i]: [tokens, n_out[i]] (T, ld_dy[i]),
  *   x[i]: [tokens, n_in[i]] (T, ld_x[i]).  n <= 8.  alpha_dev: optional fp32 device scalar multiplying alpha.
- * bf16 with leading dimensions that are multiples of 8 (>= round_up(features, 8)) runs the whole 64-token tiles as ONE persistent kernel
- * (operands copied as stored, fragments gathered by transposing LDS reads, token slices added with fp32 atomics) and the ragged
- * tokens % 64 rows of all problems as one more launch (one after the other if two problems' dw ranges overlap);
- * anything else falls back to n vb_gemm calls.
+ * bf16 with leading dimensions that are multiples of 8 (>= round_up(features, 8)) takes one of two routes:
+ *   - up to 128 token tiles of 64 (tokens <= 8192; fewer than 64 tokens included), every n_in[i] % 8 == 0, ld_dw[i] % 4 == 0,
+ *     16-byte-aligned dw[i] and no two dw ranges overlapping: ONE launch with one workgroup per dW tile (128x128, or 256x128
+ *     when that many tiles still fit the compute units), each walking all the tokens (ragged last tile zero-filled in
+ *     registers) and finishing with a plain 16-byte read-modify-write of its dW tile - no atomics, no second launch;
+ *   - otherwise the whole 64-token tiles as ONE persistent kernel (operands copied as stored, fragments gathered by
+ *     transposing LDS reads, token slices added with fp32 atomics) and the ragged tokens % 64 rows of all problems as one
+ *     more launch (one after the other if two problems' dw ranges overlap).
+ * Anything else falls back to n vb_gemm calls.
  * Replaces: the dW = dy^T x half of autograd for nn.Linear at pytorch_pretrained_bert/modeling.py:232-234 (Q,K,V),
  * :271, :303, :316. */
 int vb_wgrad_grouped(int dtype, int n, const void* const* dy, const int64_t* ld_dy, const void* const* x,

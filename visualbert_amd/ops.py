@@ -316,6 +316,8 @@ def gemm_key_name(key):
     if key & 512:
         return "hipBLASLt (vendor yardstick, nt_kernel 200)<bf16->%s>" % ("fp32" if key & 4 else "bf16")
     x3 = " [bf16x3 split operands]" if key & 256 else ""
+    if key & 1024:
+        x3 += " [K range of each tile split over several workgroups]"
     key &= 255
     if not (key & 3):
         kind = ("gemm_nt_dual_kernel<%s->%s, 256x128 tile, two workgroups per CU, five-slot LDS-direct ring>" if key & 64 else

@@ -52,7 +52,6 @@ PEAK_HBM_GBPS = 8000.0
 # --dtype -> compute dtype handed to the model (visualbert_amd.modeling.set_compute_dtype)
 DTYPES = {"bf16": "bfloat16", "fp32": "float32", "bf16x3": "bf16x3"}
 # the short re-run of this command line that the PMC passes profile (measure_traffic)
-WRAPPER_EXTRA = {}          # extra ModelWrapper arguments of this run (--no-optimizer-overlap)
 PMC_CHILD_FLAGS = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-profile", "--no-h2d", "--no-parity", "--strict-dtype", "none",
                    "--no-vendor-leg", "--pmc-traffic", "off", "--no-batch-curve", "--no-sparse-leg"]
 
@@ -412,7 +411,7 @@ def strict_mode(dev, head, T, R, Dv, V, batch, steps, warmup, dtype_name, flops_
                                           compute_dtype=compute_dtype_of(dtype_name)).to(dev)
     model.train()
     mw = ModelWrapper(AttrDict(train_batch_size=batch, learning_rate=5e-5, warmup_proportion=0.1, num_train_epochs=1,
-                               gradient_accumulation_steps=1, **WRAPPER_EXTRA), 1000 * batch, model=model)
+                               gradient_accumulation_steps=1), 1000 * batch, model=model)
     b = synthetic_batch(head, batch, T, R, Dv, V, seed=0, device=dev)
     elapsed, median_ms, summ = timed_steps(mw, b, steps, warmup, torch.cuda.synchronize, profile=full)
     dt = elapsed / steps
@@ -532,7 +531,7 @@ def batch_curve(dev, head, T, R, Dv, V, dtype_name, fps, peak, steps=12, warmup=
                                               compute_dtype=compute_dtype_of(dtype_name)).to(dev)
         model.train()
         mw = ModelWrapper(AttrDict(train_batch_size=B, learning_rate=5e-5, warmup_proportion=0.1, num_train_epochs=1,
-                                   gradient_accumulation_steps=1, **WRAPPER_EXTRA), (steps + warmup + 20) * B, model=model)
+                                   gradient_accumulation_steps=1), (steps + warmup + 20) * B, model=model)
         b = synthetic_batch(head, B, T, R, Dv, V, seed=0, device=dev)
         _, med, _ = timed_steps(mw, b, steps, warmup, torch.cuda.synchronize, profile=False)
         out[B] = dict(ms_per_step=round(med, 3), samples_per_s=round(B / med * 1e3, 1),
@@ -577,9 +576,6 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=8, help="batch of the CPU baseline leg (SURVEY 8d: B = 8, >= 3 timed steps after 1 warm-up)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-GEMM HIP-event timing")
     ap.add_argument("--no-overlap", action="store_true")
-    ap.add_argument("--no-optimizer-overlap", action="store_true",
-                    help="BertAdam as one pass after the backward pass instead of layer by layer behind it (A/B of "
-                         "BertAdam.overlap_with_backward; the weights are bit-identical either way)")
     ap.add_argument("--no-h2d", action="store_true", help="skip the second timed loop that streams every batch from pinned host memory")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed/RCCL even with one rank")
@@ -605,7 +601,6 @@ def main():
                     help="skip the per-GPU batch sweep 8 ... 512 (N = 1, pre-training workload; ~15 s) reported as roofline.batch_curve")
     ap.add_argument("--selftest-launch", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
-    WRAPPER_EXTRA["overlap_optimizer"] = not args.no_optimizer_overlap
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         respawn_as_ranks(args.gpus)                       # does not return
@@ -671,7 +666,7 @@ def main():
         comm_kind = sync.comm_kind
     total_steps = args.steps * 3 + args.warmup + 20
     mw = ModelWrapper(AttrDict(train_batch_size=B * world, learning_rate=5e-5, warmup_proportion=0.1,
-                               num_train_epochs=1, gradient_accumulation_steps=1, **WRAPPER_EXTRA),
+                               num_train_epochs=1, gradient_accumulation_steps=1),
                       total_steps * B * world, model=model, grad_sync=sync)
     batch = synthetic_batch(head, B, T, R, Dv, V, seed=rank, device=dev)
 
@@ -886,10 +881,7 @@ def main():
                        "h2d": "excluded from `value` (batch resident in HBM, the bench contract); roofline.value_with_h2d = the same loop with "
                               "every batch streamed from pinned host memory (SURVEY 8d's definition)",
                        "grad_allreduce": ("fp32 %s (%s), %s" % ("gloo" if one_device else "RCCL", comm_kind, "overlapped with backward" if not args.no_overlap
-                                                                  else "after backward")) if use_dist else "none (1 rank)",
-                       "optimizer": "BertAdam, %s" % ("one pass after backward" if args.no_optimizer_overlap else
-                                                      "encoder layers stepped on a second stream as their gradients become final "
-                                                      "(bit-identical to the one-pass step), rest after backward")},
+                                                                  else "after backward")) if use_dist else "none (1 rank)"},
             "value_with_h2d": round(h2d, 2) if h2d is not None else None,
             "train_gflop_per_sample": round(fps / 1e9, 2),
             "step_mfu": round(value * fps / (world * peak * 1e12), 4),

@@ -280,19 +280,6 @@ int vb_bert_adam_step(float* params, const float* grads, float* exp_avg, float* 
                       const int64_t* tensor_table, int n_tensors, const float* touched, float* norm2_ws, int* step_counters,
                       float lr, float b1, float b2, float eps, float weight_decay,
                       float max_grad_norm, float warmup, float t_total, int schedule, void* stream);
-/* The same step over chunks [chunk_lo, chunk_hi) = tensors [tensor_lo, tensor_hi) of the tables only (a range begins and
- * ends at tensor boundaries): what lets the optimizer follow the backward pass bucket by bucket on a second stream -- the
- * reference clips every tensor by its own norm (optimization.py:272-273), so no tensor's step depends on another's gradient.
- * Ranges that do not overlap may be in flight on different streams (each chunk owns its norm2_ws slot).
- * zero_grads != 0: every gradient of the range is set to 0 as it is consumed (the zero_grad() that follows can skip the
- * range).  vb_bert_adam_step is this call over the whole tables with zero_grads = 0. */
-int vb_bert_adam_step_range(float* params, float* grads, float* exp_avg, float* exp_avg_sq,
-                            void* bf16_shadow, const int64_t* chunk_table, int n_chunks,
-                            const int64_t* tensor_table, int n_tensors, int chunk_lo, int chunk_hi,
-                            int tensor_lo, int tensor_hi, int zero_grads, const float* touched,
-                            float* norm2_ws, int* step_counters,
-                            float lr, float b1, float b2, float eps, float weight_decay,
-                            float max_grad_norm, float warmup, float t_total, int schedule, void* stream);
 int vb_refresh_bf16_shadow(const float* params, void* bf16_shadow, const int64_t* chunk_table,
                            int n_chunks, const int64_t* tensor_table, void* stream);
 /* W^T copies of the bf16 GEMM weights (so dgrad dx = dy W is a K-contiguous x K-contiguous GEMM):

@@ -51,8 +51,6 @@ SIGNATURES = {
     "vb_small_linear_fwd": (_i, [_i, _p, _i64, _p, _p, _p, _i, _i, _i, _p]),
     "vb_small_linear_bwd": (_i, [_i, _p, _p, _i64, _p, _p, _i64, _p, _p, _p, _i, _i, _i, _p]),
     "vb_bert_adam_step": (_i, [_p, _p, _p, _p, _p, _p, _i, _p, _i, _p, _p, _p, _f, _f, _f, _f, _f, _f, _f, _f, _i, _p]),
-    "vb_bert_adam_step_range": (_i, [_p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p,
-                                     _f, _f, _f, _f, _f, _f, _f, _f, _i, _p]),
     "vb_refresh_bf16_shadow": (_i, [_p, _p, _p, _i, _p, _p]),
     "vb_refresh_transposed_shadow": (_i, [_p, _p, _p, _p, _i, _p]),
     "vb_prepare_inputs": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),

@@ -30,11 +30,10 @@ struct AdamHyper {
 // Squared gradient norms per tensor, DETERMINISTICALLY: a chunk's partial goes to its own slot and one thread per tensor
 // adds its chunks' partials in table order.  (A float atomic per chunk made the clip coefficient differ in the last bit
 // from run to run -- and between data-parallel replicas, whose weights then drift apart ulp by ulp.)
-VB_KERNEL VB_LAUNCH_BOUNDS(NT) adam_norm_kernel(const float* grads, const int64_t* chunks, float* partial, int chunk_lo) {
+VB_KERNEL VB_LAUNCH_BOUNDS(NT) adam_norm_kernel(const float* grads, const int64_t* chunks, float* partial) {
     VB_DYN_SMEM(smem);
     float* red = (float*)smem;
-    const long j = (long)blockIdx.x + chunk_lo;
-    const int64_t* c = chunks + j * 4;
+    const int64_t* c = chunks + (long)blockIdx.x * 4;
     const long off = c[1], len = c[2];
     float s = 0.f;
     if (((off | len) & 3) == 0) {
@@ -55,14 +54,14 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) adam_norm_kernel(const float* grads, const int64_
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) partial[j] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 // one wave per tensor (the workgroup of the tensor's FIRST chunk; the others leave): lane l adds the partials of chunks
 // l, l + 64, ... in that order, then a fixed butterfly -- the same bits every time
-VB_KERNEL VB_LAUNCH_BOUNDS(64) adam_norm_finish_kernel(const int64_t* chunks, int chunk_lo, const float* partial, float* norm2) {
-    const int j = blockIdx.x + chunk_lo;
+VB_KERNEL VB_LAUNCH_BOUNDS(64) adam_norm_finish_kernel(const int64_t* chunks, int n_chunks, const float* partial, float* norm2) {
+    const int j = blockIdx.x;
     const int64_t id = chunks[(long)j * 4];
-    if (j > chunk_lo && chunks[(long)(j - 1) * 4] == id) return;      // (a range begins at a tensor's first chunk)
+    if (j > 0 && chunks[(long)(j - 1) * 4] == id) return;
     const int count = (int)chunks[(long)j * 4 + 3];                  // chunks of this tensor (adjacent in the table)
     float s = 0.f;
     for (int k = threadIdx.x; k < count; k += 64) s += partial[j + k];
@@ -96,20 +95,15 @@ VB_DEVICE bool adam_skips(const float* touched, const float* norm2, const int* s
     return !(norm2[tid] > 0.f);
 }
 
-// ZERO: the gradient is zeroed as it is consumed (the caller's next zero_grad() then skips this range: one 4-byte write here
-// instead of a separate pass over it)
-template <bool ZERO>
-VB_KERNEL VB_LAUNCH_BOUNDS(NT) adam_update_kernel(float* params, float* grads, float* m, float* v, bf16* shadow,
+VB_KERNEL VB_LAUNCH_BOUNDS(NT) adam_update_kernel(float* params, const float* grads, float* m, float* v, bf16* shadow,
                                                  const int64_t* chunks, const int64_t* tensors, const float* norm2,
-                                                 const int* steps, const float* touched, AdamHyper h, int chunk_lo) {
-    const int64_t* c = chunks + ((long)blockIdx.x + chunk_lo) * 4;
+                                                 const int* steps, const float* touched, AdamHyper h) {
+    const int64_t* c = chunks + (long)blockIdx.x * 4;
     const long tid = c[0], off = c[1], len = c[2];
     const int64_t* te = tensors + tid * 4;
     const long t_off = te[0], sh_off = te[2], flags = te[3];
-    if (!(flags & 1) || adam_skips(touched, norm2, steps, tid)) {
-        if (ZERO) for (long i = threadIdx.x; i < len; i += NT) grads[off + i] = 0.f;
-        return;
-    }
+    if (!(flags & 1)) return;
+    if (adam_skips(touched, norm2, steps, tid)) return;
     const float wd = (flags & 2) ? h.weight_decay : 0.0f;
     float clip = 1.0f;
     if (h.max_grad_norm > 0.f) {
@@ -127,13 +121,12 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) adam_update_kernel(float* params, float* grads, f
         if (wd > 0.f) u += wd * p;
         const float pn = p - lr * u;
         m[e] = mm; v[e] = vv; params[e] = pn;
-        if (ZERO) grads[e] = 0.f;
         if (shadow && sh_off >= 0) shadow[sh_off + (e - t_off)] = (bf16)pn;
     }
 }
 
-VB_KERNEL adam_step_inc_kernel(int* steps, const int64_t* tensors, int lo, int n, const float* touched, const float* norm2) {
-    const int i = lo + blockIdx.x * blockDim.x + threadIdx.x;
+VB_KERNEL adam_step_inc_kernel(int* steps, const int64_t* tensors, int n, const float* touched, const float* norm2) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n && (tensors[(long)i * 4 + 3] & 1) && !adam_skips(touched, norm2, steps, i)) steps[i] += 1;
 }
 
@@ -196,46 +189,28 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) shadow_transpose_kernel(const bf16* src, bf16* ds
 
 }  // namespace
 
-extern "C" int vb_bert_adam_step_range(float* params, float* grads, float* exp_avg, float* exp_avg_sq,
-                                       void* bf16_shadow, const int64_t* chunk_table, int n_chunks,
-                                       const int64_t* tensor_table, int n_tensors, int chunk_lo, int chunk_hi,
-                                       int tensor_lo, int tensor_hi, int zero_grads, const float* touched,
-                                       float* norm2_ws, int* step_counters,
-                                       float lr, float b1, float b2, float eps, float weight_decay,
-                                       float max_grad_norm, float warmup, float t_total, int schedule, void* stream) {
-    if (!params || !grads || !exp_avg || !exp_avg_sq || !chunk_table || !tensor_table || !norm2_ws || !step_counters)
-        return VB_ERR_ARG;
-    if (n_chunks <= 0 || n_tensors <= 0 || (schedule != 0 && schedule != 1)) return VB_ERR_ARG;
-    if (chunk_lo < 0 || chunk_hi > n_chunks || chunk_lo >= chunk_hi || tensor_lo < 0 || tensor_hi > n_tensors ||
-        tensor_lo >= tensor_hi) return VB_ERR_ARG;
-    hipStream_t s = (hipStream_t)stream;
-    const unsigned nc = (unsigned)(chunk_hi - chunk_lo);
-    AdamHyper h{lr, b1, b2, eps, max_grad_norm, warmup, t_total, weight_decay, schedule};
-    if (max_grad_norm > 0.f || touched) {                   // the skip decision reads the norms too
-        float* partial = norm2_ws + n_tensors;              // [n_chunks]: a chunk's slot is its own in every range
-        VB_LAUNCH(adam_norm_kernel, dim3(nc), dim3(NT), 64, s, (const float*)grads, chunk_table, partial, chunk_lo);
-        VB_LAUNCH(adam_norm_finish_kernel, dim3(nc), dim3(64), 0, s, chunk_table, chunk_lo, (const float*)partial, norm2_ws);
-    }
-    if (zero_grads)
-        VB_LAUNCH(adam_update_kernel<true>, dim3(nc), dim3(NT), 0, s, params, grads, exp_avg, exp_avg_sq, (bf16*)bf16_shadow,
-                  chunk_table, tensor_table, (const float*)norm2_ws, (const int*)step_counters, touched, h, chunk_lo);
-    else
-        VB_LAUNCH(adam_update_kernel<false>, dim3(nc), dim3(NT), 0, s, params, grads, exp_avg, exp_avg_sq, (bf16*)bf16_shadow,
-                  chunk_table, tensor_table, (const float*)norm2_ws, (const int*)step_counters, touched, h, chunk_lo);
-    VB_LAUNCH(adam_step_inc_kernel, dim3((unsigned)((tensor_hi - tensor_lo + 63) / 64)), dim3(64), 0, s, step_counters,
-              tensor_table, tensor_lo, tensor_hi, touched, (const float*)norm2_ws);
-    return vb_check_launch();
-}
-
 extern "C" int vb_bert_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                                  void* bf16_shadow, const int64_t* chunk_table, int n_chunks,
                                  const int64_t* tensor_table, int n_tensors, const float* touched, float* norm2_ws,
                                  int* step_counters,
                                  float lr, float b1, float b2, float eps, float weight_decay,
                                  float max_grad_norm, float warmup, float t_total, int schedule, void* stream) {
-    return vb_bert_adam_step_range(params, (float*)grads, exp_avg, exp_avg_sq, bf16_shadow, chunk_table, n_chunks, tensor_table,
-                                   n_tensors, 0, n_chunks, 0, n_tensors, 0, touched, norm2_ws, step_counters, lr, b1, b2, eps,
-                                   weight_decay, max_grad_norm, warmup, t_total, schedule, stream);
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !chunk_table || !tensor_table || !norm2_ws || !step_counters)
+        return VB_ERR_ARG;
+    if (n_chunks <= 0 || n_tensors <= 0 || (schedule != 0 && schedule != 1)) return VB_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    AdamHyper h{lr, b1, b2, eps, max_grad_norm, warmup, t_total, weight_decay, schedule};
+    if (max_grad_norm > 0.f || touched) {                   // the skip decision reads the norms too
+        float* partial = norm2_ws + n_tensors;              // [n_chunks]
+        VB_LAUNCH(adam_norm_kernel, dim3((unsigned)n_chunks), dim3(NT), 64, s, grads, chunk_table, partial);
+        VB_LAUNCH(adam_norm_finish_kernel, dim3((unsigned)n_chunks), dim3(64), 0, s, chunk_table, n_chunks,
+                  (const float*)partial, norm2_ws);
+    }
+    VB_LAUNCH(adam_update_kernel, dim3((unsigned)n_chunks), dim3(NT), 0, s, params, grads, exp_avg, exp_avg_sq,
+              (bf16*)bf16_shadow, chunk_table, tensor_table, (const float*)norm2_ws, (const int*)step_counters, touched, h);
+    VB_LAUNCH(adam_step_inc_kernel, dim3((unsigned)((n_tensors + 63) / 64)), dim3(64), 0, s, step_counters,
+              tensor_table, n_tensors, touched, (const float*)norm2_ws);
+    return vb_check_launch();
 }
 
 extern "C" int vb_refresh_bf16_shadow(const float* params, void* bf16_shadow, const int64_t* chunk_table,

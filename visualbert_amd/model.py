@@ -245,14 +245,6 @@ class ModelWrapper(object):
             args.get("num_train_epochs", 1)
         self.num_train_optimization_steps = steps
         self.optimizer = BertAdam(groups, lr=args.learning_rate, warmup=args.warmup_proportion, t_total=steps)
-        # step() below is a closed sequence (zero_grad -> forward -> backward -> optimizer.step, model_wrapper.py:64-98): nobody
-        # can observe the optimizer stepping a layer's tensors while the layers below it are still in their backward pass, and
-        # the weights come out bit-identical (BertAdam.overlap_with_backward).  `overlap_optimizer: false` (not a key of the
-        # reference's configs) keeps the one-pass step.
-        objective = getattr(self.model, "bert", None)
-        if args.get("overlap_optimizer", True) and hasattr(objective, "bucket_ranges"):
-            # (zero_grads stays off: the reference's step() leaves the gradients readable until the next call zeroes them)
-            self.optimizer.overlap_with_backward(objective, grad_sync=self.grad_sync, zero_grads=False)
 
     # -- checkpoints: the reference's file names and dictionary keys (models/model_wrapper.py:150-221,
     #    utils/pytorch_misc.py:110-330), so that a run can be resumed by either side ------------------------------------
@@ -352,8 +344,6 @@ class ModelWrapper(object):
             # the gradients of a micro-step that is not followed by optimizer.step() are zeroed by the next call (the reference's
             # order, model_wrapper.py:64): all-reducing them would be pure xGMI traffic
             self.grad_sync.begin_step(sync=(self.called_time + 1) % gas == 0)
-        if (self.called_time + 1) % gas == 0:
-            self.optimizer.arm_overlap(self.grad_sync)                # this backward's gradients are the ones optimizer.step() consumes
         output_dict = self.model(**batch)
         loss = output_dict["loss"].mean()
         if gas > 1:

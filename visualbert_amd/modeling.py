@@ -90,21 +90,6 @@ def _check_act(config):
 
 
 # ------------------------------------------------------------------------------------------------
-class _TouchedSet(set):
-    """ids of the parameters a backward pass wrote since zero_grad(), counting the writes: the optimizer can tell a gradient
-    arena it has itself left zeroed (BertAdam's zero-as-consumed mode) from one a later backward has written into."""
-
-    writes = 0
-
-    def add(self, x):
-        self.writes += 1
-        set.add(self, x)
-
-    def update(self, *a):
-        self.writes += 1
-        set.update(self, *a)
-
-
 class ParameterArena(object):
     """Flat fp32 storage for a list of parameters (+ gradient arena, bf16 shadow arena, and the device
     tables the fused BertAdam walks).  Offsets are 64-element aligned so every tensor starts on a
@@ -144,8 +129,7 @@ class ParameterArena(object):
                 p._vb_shadow_ver = -1
         # buckets for the gradient all-reduce: contiguous [start, end) ranges, in arena order
         self.bucket_of = bucket_of
-        self.touched = _TouchedSet()            # ids of the parameters a backward pass has written since zero_grad()
-        self._clean_token = None                # touched.writes at the moment the optimizer left the whole gradient arena zeroed
+        self.touched = set()                    # ids of the parameters a backward pass has written since zero_grad()
         self._touched_dev = None                # device fp32 [n_params] image of `touched` (rewritten when the set changes)
         self._touched_key = None
         self.touched_synced = None              # set by DataParallelGradSync: this step's flags combined over the ranks
@@ -170,17 +154,13 @@ class ParameterArena(object):
         off = 0
         table, tiles = [], []
         self._t_entries = []
-        self._t_first_tile = []                     # entry -> index of its first tile (entries and tiles are in arena order)
-        self._t_src = []                            # entry -> arena offset of its source weight(s)
         for ti, (plist, so, R, C) in enumerate(ents):
             ld = ops.round_up(R, 64)
             table += [so, R, C, off, ld]
-            self._t_first_tile.append(len(tiles) // 3)
             for tr in range((R + 63) // 64):
                 for tc in range((C + 63) // 64):
                     tiles += [ti, tr, tc]
             self._t_entries.append((plist, off, R, C, ld))
-            self._t_src.append(so)
             off += C * ld
         self.shadow_t = torch.zeros(max(off, 1), dtype=torch.bfloat16, device=self.device)
         self._t_table = torch.tensor(table, dtype=torch.int64).to(self.device) if table else None
@@ -195,46 +175,16 @@ class ParameterArena(object):
             else:
                 plist[0]._vb_packed_shadow_t = view
 
-    def refresh_transposed(self, tile_lo=None, tile_hi=None, stream=False):
-        """tile_lo / tile_hi: only that slice of the tile table (a bucket's weights: BertAdam's bucket-by-bucket step); the
-        version bookkeeping of the parameters is left to the whole-table call that ends the step."""
+    def refresh_transposed(self):
         if self._t_table is None:
-            return
-        if tile_lo is not None:
-            if tile_hi > tile_lo:
-                _lib.check(_lib.lib().vb_refresh_transposed_shadow(_lib.ptr(self.shadow), _lib.ptr(self.shadow_t),
-                                                                   _lib.ptr(self._t_table),
-                                                                   self._t_tiles.data_ptr() + 24 * tile_lo,
-                                                                   tile_hi - tile_lo,
-                                                                   _lib.stream_ptr() if stream is False else stream),
-                           "vb_refresh_transposed_shadow")
             return
         _lib.check(_lib.lib().vb_refresh_transposed_shadow(_lib.ptr(self.shadow), _lib.ptr(self.shadow_t),
                                                            _lib.ptr(self._t_table), _lib.ptr(self._t_tiles),
                                                            self._t_ntiles, _lib.stream_ptr()),
                    "vb_refresh_transposed_shadow")
-        self.mark_transposed_current()
-
-    def mark_transposed_current(self):
         for plist, _, _, _, _ in self._t_entries:
             for p in plist:
                 p._vb_shadow_t_ver = p._vb_shadow_ver
-
-    def range_tables(self, lo, hi):
-        """element range [lo, hi) of the arena (whole tensors: a bucket of bucket_ranges()) -> the slices of the optimizer's
-        chunk / tensor tables and of the W^T tile table that cover it: (chunk_lo, chunk_hi, tensor_lo, tensor_hi, tile_lo,
-        tile_hi).  tables() must have been called (the chunk table's layout is fixed by CHUNK and the parameter sizes)."""
-        ids = [i for i, o in enumerate(self.offsets) if lo <= o < hi]
-        if not ids or ids != list(range(ids[0], ids[-1] + 1)):
-            raise ValueError("ParameterArena.range_tables: [%s, %s) is not a run of whole tensors" % (lo, hi))
-        t_lo, t_hi = ids[0], ids[-1] + 1
-        ents = [k for k, (_, _, _, _, _) in enumerate(self._t_entries) if lo <= self._t_src[k] < hi]
-        if ents:
-            tile_lo = self._t_first_tile[ents[0]]
-            tile_hi = self._t_first_tile[ents[-1] + 1] if ents[-1] + 1 < len(self._t_first_tile) else self._t_ntiles
-        else:
-            tile_lo = tile_hi = 0
-        return self._chunk_start[t_lo], self._chunk_start[t_hi], t_lo, t_hi, tile_lo, tile_hi
 
     def range_of(self, names_prefixes):
         lo, hi = None, None
@@ -258,11 +208,7 @@ class ParameterArena(object):
         return self._touched_dev
 
     def zero_grad(self):
-        clean = self._clean_token is not None and self._clean_token == self.touched.writes
-        self._clean_token = None
         self.touched.clear()
-        if clean:                                   # the optimizer zeroed every gradient as it consumed it, nothing wrote since
-            return
         g = self.grad
         nbytes = g.numel() * 4
         if g.is_cuda and nbytes % 16 == 0 and g.data_ptr() % 16 == 0:
@@ -273,16 +219,13 @@ class ParameterArena(object):
     def tables(self, optimise_flags, decay_flags):
         """device int64 tables for vb_bert_adam_step / vb_refresh_bf16_shadow."""
         tens, chunks = [], []
-        self._chunk_start = []                      # tensor -> index of its first chunk (+ one closing entry)
         for i, (p, o) in enumerate(zip(self.params, self.offsets)):
             flags = (1 if optimise_flags[i] else 0) | (2 if decay_flags[i] else 0)
             tens += [o, p.numel(), o if p.dim() == 2 else -1, flags]
             n = p.numel()
-            self._chunk_start.append(len(chunks) // 4)
             count = (n + self.CHUNK - 1) // self.CHUNK
             for s in range(0, n, self.CHUNK):
                 chunks += [i, o + s, min(self.CHUNK, n - s), count]
-        self._chunk_start.append(len(chunks) // 4)
         t = torch.tensor(tens, dtype=torch.int64).to(self.device)
         c = torch.tensor(chunks, dtype=torch.int64).to(self.device)
         return t, c, len(self.params), len(chunks) // 4
@@ -606,7 +549,6 @@ class BertLayer(nn.Module):
         self.output_attention_weights = getattr(config, "output_attention_weights", False)
         self.layer_index = 0
         self.grad_ready_hook = None
-        self.optimizer_hook = None              # BertAdam.overlap_with_backward: fires after grad_ready_hook
 
     def set_index(self, i):
         self.layer_index = i
@@ -628,8 +570,7 @@ class BertLayer(nn.Module):
         return self._forward_fused(hidden_states, attention_mask)
 
     def _forward_fused(self, hidden_states, attention_mask):
-        if (self.grad_ready_hook is not None or self.optimizer_hook is not None) and torch.is_grad_enabled() and \
-                hidden_states.requires_grad:
+        if self.grad_ready_hook is not None and torch.is_grad_enabled() and hidden_states.requires_grad:
             hidden_states = _GradReadyFn.apply(hidden_states, self)
         (at, sa, so, im, om), _, params = ops.layer_params(self)     # the sub-modules and their 16 parameters, cached on the layer
         B, S, H = hidden_states.shape
@@ -663,9 +604,6 @@ class _GradReadyFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         hook = ctx.layer.grad_ready_hook
-        if hook is not None:
-            hook(ctx.layer.layer_index)
-        hook = ctx.layer.optimizer_hook          # after the bucket's all-reduce has been enqueued
         if hook is not None:
             hook(ctx.layer.layer_index)
         return g, None

@@ -11,8 +11,6 @@ from a mirror of the (common) step count and handed to the same kernel as the le
 """
 import math
 
-import ctypes
-
 import torch
 from torch.optim import Optimizer
 
@@ -141,7 +139,6 @@ class BertAdam(Optimizer):
                         max_grad_norm=max_grad_norm)
         super(BertAdam, self).__init__(params, defaults)
         self._fused = None
-        self._ov = None                          # overlap_with_backward's state
 
     # -- fused state -------------------------------------------------------------------------------
     def _build(self):
@@ -236,137 +233,6 @@ class BertAdam(Optimizer):
         flags = f["tt"].view(-1, 4)[:, 3].tolist()
         return [g["lr"] * g["schedule"].get_lr(s) for s, fl in zip(steps, flags) if fl & 1]
 
-    # -- the step, bucket by bucket behind the backward pass ------------------------------------------------------------
-    def overlap_with_backward(self, objective, grad_sync=None, zero_grads=True):
-        """Let the optimizer follow the backward pass: as soon as an encoder layer's gradients are final (BertLayer's
-        optimizer_hook; under data parallelism: once the layer's bucket has been all-reduced, on the communicator's stream),
-        that layer's tensors take their step on a second HIP stream while the compute stream goes on with the layers below;
-        step() then waits for that stream and steps what is left (embeddings, heads).  The reference clips every tensor by
-        its OWN norm (optimization.py:272-273), so no tensor's update depends on another tensor's gradient and the result is
-        bit-identical to the one-pass step (tests/test_optimizer_overlap.py).  The 3.4 GB pass of BertAdam is HBM-bound while
-        the small-batch backward is latency-bound: together they take less than one after the other.
-
-        Only a backward pass announced by arm_overlap() is followed (the trainer knows whether step() comes next; a
-        gradient-accumulation micro-step must not move the weights).  zero_grads: every gradient is set to zero as the step
-        consumes it, and the zero_grad() that follows costs nothing -- for callers that, like ModelWrapper.step
-        (models/model_wrapper.py:64), zero the gradients before every backward and do not read them after step()."""
-        self._ov = dict(obj=objective, sync=grad_sync, zero=bool(zero_grads), armed=False, done=[], stream=None,
-                        ranges=None, arena=None, events={})
-        for layer in objective.bert.encoder.layer:
-            layer.optimizer_hook = self._layer_grads_final
-
-    def arm_overlap(self, grad_sync=None):
-        """the next backward pass is the one step() will consume (grad_sync: the DataParallelGradSync reducing it, if any)."""
-        if self._ov is not None:
-            self._ov["armed"] = True
-            self._ov["done"] = []
-            self._ov["sync"] = grad_sync
-
-    def _bucket_tables(self, f):
-        ov = self._ov
-        a = f["arena"]
-        if ov["ranges"] is None or ov["arena"] is not a:
-            ov["ranges"] = {n: a.range_tables(lo, hi) for n, lo, hi in ov["obj"].bucket_ranges() if lo is not None}
-            ov["arena"] = a
-            ov["events"] = {}
-            for layer in ov["obj"].bert.encoder.layer:          # (layers of a rebuilt model)
-                layer.optimizer_hook = self._layer_grads_final
-        return ov["ranges"]
-
-    def _hyper(self, f):
-        g = self.param_groups[0]
-        lr, code = float(g["lr"]), f["code"]
-        if code < 0:
-            # every optimised tensor takes every step, so one host counter mirrors the device's per-tensor counters
-            # (optimization.py:283-284 evaluates the schedule at state['step'] BEFORE incrementing it)
-            lr, code = lr * float(g["schedule"].get_lr(f["host_step"])), 0
-        return lr, code
-
-    def _step_range(self, f, c_lo, c_hi, t_lo, t_hi, touched, zero, stream=False):
-        """stream: False = the current stream; else the raw handle (None on the CPU build)."""
-        a = f["arena"]
-        g = self.param_groups[0]
-        sch = g["schedule"]
-        lr, code = self._hyper(f)
-        rc = _lib.lib().vb_bert_adam_step_range(
-            _lib.ptr(a.data), _lib.ptr(a.grad), _lib.ptr(f["m"]), _lib.ptr(f["v"]), _lib.ptr(a.shadow), _lib.ptr(f["ct"]),
-            f["nc"], _lib.ptr(f["tt"]), f["nt"], c_lo, c_hi, t_lo, t_hi, 1 if zero else 0,
-            _lib.ptr(touched) if touched is not None else None, _lib.ptr(f["norm2"]), _lib.ptr(f["steps"]), lr,
-            float(g["b1"]), float(g["b2"]), float(g["e"]), float(f["wd"]), float(g["max_grad_norm"]), float(sch.warmup),
-            float(sch.t_total), code, _lib.stream_ptr() if stream is False else stream)
-        _lib.check(rc, "vb_bert_adam_step_range")
-
-    @torch.no_grad()
-    def _layer_grads_final(self, layer_index):
-        ov = self._ov
-        if ov is None or not ov["armed"]:
-            return
-        name = "layer%d" % layer_index
-        sync = ov["sync"]
-        side = None
-        if sync is not None:
-            # the bucket must already be on its way through the all-reduce, on a stream this step can be queued behind
-            if not getattr(sync, "_sync", True) or name not in sync._done or (sync.world > 1 and sync.comm is None):
-                return
-            side = sync.comm_stream
-        f = self.fused()
-        a = f["arena"]
-        rng = self._bucket_tables(f).get(name)
-        if rng is None or name in ov["done"]:
-            return
-        c_lo, c_hi, t_lo, t_hi, tile_lo, tile_hi = rng
-        if not a.data.is_cuda:                              # (CPU build of the kernels: the same calls, in line)
-            self._step_range(f, c_lo, c_hi, t_lo, t_hi, None, ov["zero"])
-            a.refresh_transposed(tile_lo, tile_hi)
-            ov["done"].append(name)
-            return
-        if side is None:
-            if ov["stream"] is None:
-                # the LOWEST priority the device offers: the optimizer's workgroups are to take what the backward pass leaves idle,
-                # not to queue in front of its kernels
-                import os
-                ov["stream"] = torch.cuda.Stream(device=a.data.device, priority=int(os.environ.get("VB_OV_PRIO", "1")))
-            side = ov["stream"]
-        # (this runs inside the backward pass of a step that is host-bound at small batches: one event per layer, made once;
-        # the raw stream handle instead of a stream context)
-        ready = ov["events"].get(name)
-        if ready is None:
-            ready = ov["events"][name] = torch.cuda.Event()
-        ready.record(torch.cuda.current_stream(a.data.device))   # this layer's weight-gradient kernels are enqueued there
-        side.wait_event(ready)
-        raw = ctypes.c_void_p(side.cuda_stream)
-        # every tensor of an encoder layer is written by every backward pass: no `touched` flags needed here
-        self._step_range(f, c_lo, c_hi, t_lo, t_hi, None, ov["zero"], raw)
-        a.refresh_transposed(tile_lo, tile_hi, raw)
-        ov["used_stream"] = side
-        ov["done"].append(name)
-
-    def _finish_overlapped(self, f, touched):
-        """step(): wait for the second stream, then everything the hooks did not step."""
-        ov = self._ov
-        a = f["arena"]
-        tables = self._bucket_tables(f)
-        done = sorted(tables[n] for n in ov["done"])
-        side = ov.pop("used_stream", None)
-        if side is not None:
-            fin = torch.cuda.Event()
-            fin.record(side)
-            torch.cuda.current_stream(a.data.device).wait_event(fin)
-        c, t = 0, 0
-        for c_lo, c_hi, t_lo, t_hi, _, _ in done + [(f["nc"], f["nc"], f["nt"], f["nt"], 0, 0)]:
-            if c_lo > c:                                    # the tensors between two stepped buckets
-                self._step_range(f, c, c_lo, t, t_lo, touched, ov["zero"])
-            c, t = c_hi, t_hi
-        tile = 0
-        for lo, hi in sorted((r[4], r[5]) for r in done if r[5] > r[4]) + [(a._t_ntiles, a._t_ntiles)]:
-            if lo > tile:
-                a.refresh_transposed(tile, lo)
-            tile = hi
-        if ov["zero"]:
-            a._clean_token = a.touched.writes
-        ov["armed"] = False
-        ov["done"] = []
-
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
@@ -379,17 +245,17 @@ class BertAdam(Optimizer):
         sch = g["schedule"]
         L = _lib.lib()
         touched = self._touched_flags(f)
-        overlapped = self._ov is not None and self._ov["armed"]
-        if overlapped:
-            self._finish_overlapped(f, touched)
-        else:
-            lr, code = self._hyper(f)
-            rc = L.vb_bert_adam_step(_lib.ptr(a.data), _lib.ptr(a.grad), _lib.ptr(f["m"]), _lib.ptr(f["v"]),
-                                     _lib.ptr(a.shadow), _lib.ptr(f["ct"]), f["nc"], _lib.ptr(f["tt"]), f["nt"],
-                                     _lib.ptr(touched), _lib.ptr(f["norm2"]), _lib.ptr(f["steps"]), lr, float(g["b1"]),
-                                     float(g["b2"]), float(g["e"]), float(f["wd"]), float(g["max_grad_norm"]),
-                                     float(sch.warmup), float(sch.t_total), code, _lib.stream_ptr())
-            _lib.check(rc, "vb_bert_adam_step")
+        lr, code = float(g["lr"]), f["code"]
+        if code < 0:
+            # every optimised tensor takes every step, so one host counter mirrors the device's per-tensor counters
+            # (optimization.py:283-284 evaluates the schedule at state['step'] BEFORE incrementing it)
+            lr, code = lr * float(sch.get_lr(f["host_step"])), 0
+        rc = L.vb_bert_adam_step(_lib.ptr(a.data), _lib.ptr(a.grad), _lib.ptr(f["m"]), _lib.ptr(f["v"]),
+                                 _lib.ptr(a.shadow), _lib.ptr(f["ct"]), f["nc"], _lib.ptr(f["tt"]), f["nt"],
+                                 _lib.ptr(touched), _lib.ptr(f["norm2"]), _lib.ptr(f["steps"]), lr, float(g["b1"]),
+                                 float(g["b2"]), float(g["e"]), float(f["wd"]), float(g["max_grad_norm"]),
+                                 float(sch.warmup), float(sch.t_total), code, _lib.stream_ptr())
+        _lib.check(rc, "vb_bert_adam_step")
         f["host_step"] += 1
         # the kernel refreshed the bf16 shadows of every optimised 2-D parameter
         shadowed = f.get("shadowed")
@@ -401,10 +267,7 @@ class BertAdam(Optimizer):
             shadowed = f["shadowed"] = [p for p in a.params if p.dim() == 2 and id(p) in member]
         for p in shadowed:
             p._vb_shadow_ver = p._version
-        if overlapped:
-            a.mark_transposed_current()              # (the W^T copies were refreshed range by range)
-        else:
-            a.refresh_transposed()                   # W^T copies for the next backward (one launch)
+        a.refresh_transposed()                       # W^T copies for the next backward (one launch)
         ops.bump_x3_epoch()                          # split (bf16x3) images of the weights are re-made at their next use
         return loss
 

@@ -8,6 +8,8 @@ import torch
 from visualbert_amd import _lib, ops
 if os.environ.get("VB_DEV") == "1":
     _lib.use_dev_library()
+elif os.environ.get("VB_LIB_PATH"):                     # A/B of two product builds: VB_LIB_PATH=tools/libvisualbert_hip_ab_<arm>.so
+    _lib.set_library(os.path.abspath(os.environ["VB_LIB_PATH"]))
 NOCHECK = os.environ.get("VB_NOCHECK") == "1"
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 arms = sys.argv[2:] or ["81", "90"]            # "90:8" = kernel 90 with the tile walk in stripes of 8 column tiles (VB_DEV=1)

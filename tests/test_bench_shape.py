@@ -126,6 +126,7 @@ def _scratch_views(D, scratch, mode=None):
     if mode is not None and mode.x3:
         L = _lib.lib()
         specs += [("dsum", torch.float32, (L.vb_attn_bwd_ws_floats(B, S, NH),)), ("ln_ws", torch.uint8, (L.vb_ln_bwd_ws_bytes(M, H),)),
+                  ("ln_ws1", torch.uint8, (L.vb_ln_bwd_ws_bytes(M, H),)),
                   ("sp_dfo", BF, (M, 2 * H)), ("sp_dpre", BF, (M, 2 * I)), ("sp_dao", BF, (M, 2 * H)), ("sp_dqkv", BF, (M, 6 * H))]
         v, total = _carve(scratch, specs)
         assert total == scratch.numel(), (total, scratch.numel())

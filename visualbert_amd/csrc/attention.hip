@@ -1664,6 +1664,8 @@ int vb_attn_bwd_sp(int dtype, const void* qkv, const float* mask_add, const void
     if (rc < 0 || !dqkv_bias) return rc < 0 ? rc : VB_OK;
     const int C = 3 * nh * D;
     if (rc == 1) {                                          // per-sample partial sums are in the workspace
+        // (deferred form: 32 row groups per workgroup already split the samples -- row slices only when there are many)
+        if (vb_reduce_defer((const float*)dsum_ws, dqkv_bias, B, C, C, B >= 256 ? 4 : 1)) return vb_check_launch();
         const int slices = B >= 64 ? 16 : (B >= 8 ? 4 : 1);
         const int rows = (B + slices - 1) / slices;
         VB_LAUNCH(attn_bias_reduce_kernel, dim3((unsigned)((C + 255) / 256), (unsigned)((B + rows - 1) / rows)), dim3(256), 0, s,

@@ -57,7 +57,8 @@ Saved carve_saved(unsigned char* base, const Dims& d, bool attn_dropout) {
 struct Scratch {
     unsigned char *t_h0, *t_h1, *t_h2, *t_h3, *t_h4, *t_h5, *t_i, *t_3h;
     float* dsum;
-    float* ln_ws;
+    float *ln_ws, *ln_ws1;      // column partials of the output / the attention-output LayerNorm's backward (both alive to the layer's
+                                // one second-stage reduction launch)
     // bf16x3 only: split (hi | lo) images of the backward's output gradients, [M, 2 x features] bf16 each, alive until the
     // grouped weight-gradient launch (the x operands' images come from the forward: Saved)
     unsigned char *sp_dfo, *sp_dpre, *sp_dao, *sp_dqkv;
@@ -77,6 +78,7 @@ Scratch carve_scratch(unsigned char* base, const Dims& d) {
     s.t_3h = take((size_t)d.M * 3 * d.H * d.es);
     s.dsum = (float*)take((size_t)vb_attn_bwd_ws_floats((int)d.B, (int)d.S, (int)d.nh) * 4);
     s.ln_ws = (float*)take((size_t)vb_ln_bwd_ws_bytes((int)d.M, d.H));
+    s.ln_ws1 = (float*)take((size_t)vb_ln_bwd_ws_bytes((int)d.M, d.H));
     const size_t sh = d.x3 ? (size_t)d.M * 2 * d.H * 2 : 0, si = d.x3 ? (size_t)d.M * 2 * d.I * 2 : 0;
     s.sp_dfo = take(sh); s.sp_dpre = take(si); s.sp_dao = take(sh); s.sp_dqkv = take(3 * sh);
     s.total = o;
@@ -110,6 +112,9 @@ int linear(const Dims& d, const void* x, int k, unsigned char* stage, const void
                    1.f, nullptr, bias, addend, n, act, aux_in, aux_out, n, 0, colsum, stream);
 }
 
+#ifndef VB_DEFER_REDUCE
+#define VB_DEFER_REDUCE 1       // 0: every second-stage reduction right behind its producer (the A/B arm of profiles/r06_small_batch_ab.txt)
+#endif
 #define VB_TRY(expr) do { int rc_ = (expr); if (rc_ != VB_OK) return rc_; } while (0)
 
 
@@ -239,6 +244,13 @@ extern "C" int vb_bert_layer_bwd(int dtype, const void* h_in, const void* h_out,
     // Every output gradient (dfo, dpre, dao, dqkv) stays alive to the end of the layer so that the four weight
     // gradients run as ONE grouped launch (vb_wgrad_grouped): 108 output tiles x 2 token slices fill the chip with
     // 164-K-tile items, where four separate launches had 9..36 tiles each and needed 7..28 slices (atomic traffic x4).
+    // the second stages of the two LayerNorm backwards' column reductions and of the attention backward's bias gradient run as ONE
+    // launch at the end of the layer (vb_rt.h: VbReduceJobs)
+    VbReduceJobs tail{};
+    struct DeferScope {
+        explicit DeferScope(VbReduceJobs* j) { vb_reduce_defer_slot() = VB_DEFER_REDUCE ? j : nullptr; }
+        ~DeferScope() { vb_reduce_defer_slot() = nullptr; }
+    } defer_scope(&tail);
     unsigned char* dz2 = sc.t_h0;                        // d(a_out) through the residual of the output LN
     unsigned char* dfo = p_hidden > 0.f ? sc.t_h1 : dz2; // d(FFN-out dense output)
     // 1. output LayerNorm backward (+ bias gradient of the FFN-out dense as a by-product)
@@ -257,7 +269,7 @@ extern "C" int vb_bert_layer_bwd(int dtype, const void* h_in, const void* h_out,
     unsigned char* dz1 = sc.t_h5;
     unsigned char* dao = p_hidden > 0.f ? sc.t_h4 : dz1;
     VB_TRY(vb_ln_bwd_sp(edt, sc.t_h2, sv.z1, sv.mean1, sv.rstd1, g1, dz1, d.x3 ? nullptr : dao, G[VB_LW_LN1_G], G[VB_LW_LN1_B],
-                        G[VB_LW_AO_B], M, H, p_hidden, sid + 1, 0.f, 0, seed, sc.ln_ws, d.x3 ? sc.sp_dao : nullptr, 2 * H, sv.a_out, b1, rb1, stream));
+                        G[VB_LW_AO_B], M, H, p_hidden, sid + 1, 0.f, 0, seed, sc.ln_ws1, d.x3 ? sc.sp_dao : nullptr, 2 * H, sv.a_out, b1, rb1, stream));
     // 5. dgrad attention-out: dctx = dao Wo
     VB_TRY(dgrad(d.x3 ? (const void*)sc.sp_dao : (const void*)dao, H, wo, VB_LWT_AO, H, sc.t_h3, nullptr, VB_ACT_NONE, nullptr, nullptr,
                  nullptr));
@@ -292,5 +304,5 @@ extern "C" int vb_bert_layer_bwd(int dtype, const void* h_in, const void* h_out,
         const int n_in[4] = {I, H, H, H};
         VB_TRY(vb_wgrad_grouped(dtype, 4, dys, ld_dy, xs, ld_x, dws, ld_dw, n_out, n_in, M, 1.f, nullptr, stream));
     }
-    return VB_OK;
+    return vb_reduce_jobs_launch(tail, stream);
 }

@@ -784,7 +784,15 @@ int vb_ln_bwd_sp(int dtype, const void* dy, const void* z, const float* mean, co
         else VB_LAUNCH((ln_bwd_kernel<float, 2, 4>), grid, dim3(NT), smem, s, a);
     } else return VB_ERR_ARG;
     if (ws && (dgamma || dbeta || dbias)) {
-        dim3 g2((unsigned)((H + 31) / 32), 3, grid.x >= 256 ? 4 : 1);
+        const int slices = grid.x >= 256 ? 4 : 1;
+        VbReduceJobs* defer = vb_reduce_defer_slot();
+        if (defer && defer->n + 3 <= 8) {       // the caller launches the second stage (vb_rt.h: VbReduceJobs)
+            float* outs[3] = {dgamma, dbeta, dbias};
+            for (int w = 0; w < 3; ++w)
+                if (outs[w]) vb_reduce_defer(ws + (long)w * H, outs[w], (int)grid.x, H, 3L * H, slices);
+            return vb_check_launch();
+        }
+        dim3 g2((unsigned)((H + 31) / 32), 3, slices);
         VB_LAUNCH(ln_bwd_reduce_kernel, g2, dim3(1024), 32 * 33 * sizeof(float), s, (const float*)ws, (int)grid.x, H,
                   dgamma, dbeta, dbias);
     }

@@ -324,6 +324,68 @@ int vb_colsum_image(const void* image, int64_t ld_image, float* out, int M, int 
     return colsum_launch(VB_BF16, image, ld_image, out, nullptr, M, 2 * C, C, stream);
 }
 
+// ---- deferred second-stage column reductions (vb_rt.h: VbReduceJobs) ---------------------------------------------------------
+namespace {
+struct ReduceLaunch { VbReduceJob j[8]; int first[9]; int n; };
+// 1024 threads = 32 columns x 32 row groups (coalesced 128-byte reads, 32 independent chains per column, LDS tree at the end -- the
+// shape of layernorm.hip's ln_bwd_reduce_kernel, whose results this reproduces bit for bit); workgroup -> (job, column block, row slice)
+VB_KERNEL VB_LAUNCH_BOUNDS(1024) reduce_jobs_kernel(ReduceLaunch L) {
+    VB_DYN_SMEM(smem);
+    float* red = (float*)smem;                         // [32][33]
+    int b = blockIdx.x, k = 0;
+    while (k + 1 < L.n && b >= L.first[k + 1]) ++k;
+    b -= L.first[k];
+    const float* src = L.j[k].src;
+    float* dst = L.j[k].dst;
+    const int rows = L.j[k].rows, cols = L.j[k].cols, slices = L.j[k].slices;
+    const long stride = L.j[k].stride;
+    const int colblocks = (cols + 31) / 32;
+    const int cb = b % colblocks, sl = b / colblocks;
+    const int cx = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int c = cb * 32 + cx;
+    const int per = (rows + slices - 1) / slices;
+    const int r0 = sl * per, r1 = r0 + per < rows ? r0 + per : rows;
+    float s = 0.f;
+    if (c < cols)
+        for (int r = r0 + rg; r < r1; r += 32) s += src[(long)r * stride + c];
+    red[rg * 33 + cx] = s;
+    __syncthreads();
+    if (rg == 0 && c < cols) {
+        float t = 0.f;
+        for (int r = 0; r < 32; ++r) t += red[r * 33 + cx];
+        if (slices == 1) dst[c] += t;
+        else atomicAdd(&dst[c], t);
+    }
+}
+}  // namespace
+
+VbReduceJobs*& vb_reduce_defer_slot() {
+    static thread_local VbReduceJobs* slot = nullptr;
+    return slot;
+}
+
+bool vb_reduce_defer(const float* src, float* dst, int rows, int cols, long stride, int slices) {
+    VbReduceJobs* J = vb_reduce_defer_slot();
+    if (!J || J->n >= 8 || !src || !dst || rows <= 0 || cols <= 0 || slices <= 0) return false;
+    J->j[J->n++] = VbReduceJob{src, dst, rows, cols, stride, slices};
+    return true;
+}
+
+int vb_reduce_jobs_launch(const VbReduceJobs& jobs, void* stream) {
+    if (jobs.n <= 0) return VB_OK;
+    ReduceLaunch L{};
+    int blocks = 0;
+    for (int k = 0; k < jobs.n; ++k) {
+        L.j[k] = jobs.j[k];
+        L.first[k] = blocks;
+        blocks += ((jobs.j[k].cols + 31) / 32) * jobs.j[k].slices;
+    }
+    L.first[jobs.n] = blocks;
+    L.n = jobs.n;
+    VB_LAUNCH(reduce_jobs_kernel, dim3((unsigned)blocks), dim3(1024), 32 * 33 * sizeof(float), (hipStream_t)stream, L);
+    return vb_check_launch();
+}
+
 extern "C" int vb_act_bwd(int dtype, const void* dy, const void* aux, void* dx, int64_t n, int act, void* stream) {
     if (!dy || !aux || !dx || n <= 0 || (act != VB_ACT_GELU && act != VB_ACT_TANH)) return VB_ERR_ARG;
     if (((uintptr_t)dy | (uintptr_t)aux | (uintptr_t)dx) & 15) return VB_ERR_ARG;

@@ -707,6 +707,18 @@ __attribute__((visibility("hidden"))) int vb_attn_bwd_sp(int dtype, const void* 
     const float* lse, const uint64_t* keepbits, float* dsum_ws, void* dqkv, const void* ctx_fwd, float* dqkv_bias, int B, int S, int nh,
     int head_dim, float p_drop, uint64_t seed, uint32_t stream_id, void* dqkv_split, int split_only, void* stream);
 
+// Second-stage column reductions -- dst[c] += sum over rows r of src[r * stride + c]: the LayerNorm backward's dgamma | dbeta | dbias
+// partials, the one-pass attention backward's per-sample bias-gradient sums -- deferred to ONE launch at the end of an encoder layer's
+// backward (vb_bert_layer_bwd) instead of one launch each behind their producers: at small per-GPU batches the step is a chain of
+// dependent 5-30 us kernels and these three 5 us launches per layer (+ their boundaries) are ~3 % of it.  While vb_reduce_defer_slot() points
+// at a list with room, vb_ln_bwd_sp / vb_attn_bwd_sp append their reductions there (their workspaces must then stay untouched until
+// vb_reduce_jobs_launch); otherwise they launch them themselves, as every other caller sees them do.
+struct VbReduceJob { const float* src; float* dst; int rows, cols; long stride; int slices; };
+struct VbReduceJobs { VbReduceJob j[8]; int n; };
+__attribute__((visibility("hidden"))) VbReduceJobs*& vb_reduce_defer_slot();      // this thread's list (NULL: nobody defers)
+__attribute__((visibility("hidden"))) bool vb_reduce_defer(const float* src, float* dst, int rows, int cols, long stride, int slices);
+__attribute__((visibility("hidden"))) int vb_reduce_jobs_launch(const VbReduceJobs& jobs, void* stream);
+
 __attribute__((visibility("hidden"))) int vb_gemm_fuse_residual_armed();
 __attribute__((visibility("hidden"))) int vb_gemm_dropres(int dtype, int out_dtype, int a_layout, int b_layout, const void* A, int64_t lda,
     const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K, float alpha, const float* alpha_dev, const float* bias,

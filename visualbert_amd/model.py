@@ -41,18 +41,25 @@ class VisualBERTFixedImageEmbedding(nn.Module):
             self.bert.bert.embeddings.special_intialize()            # models/model.py:224-225
         self.training_head_type = training_head_type
         self.cnn_loss_ratio = cnn_loss_ratio
+        self._arange_cache = {}
 
     def forward(self, bert_input_ids, bert_input_mask, bert_input_type_ids, image_dim_variable=None,
                 image_feat_variable=None, image_text_alignment=None, visual_embeddings_type=None, label=None,
                 flickr_position=None, masked_lm_labels=None, is_random_next=None, output_all_encoded_layers=False):
         if image_feat_variable is not None:
             # models/model.py:262-268: image_mask = arange(R) < image_dim_variable  (int64, bit-exact)
+            # (one launch: the arange is cached per (R, device) and the comparison writes int64 directly -- at the reference's own batch
+            # sizes the step is a chain of small launches, every ATen one counts)
             R = image_feat_variable.size(-2)
-            ar = torch.arange(R, device=image_feat_variable.device).expand(*image_feat_variable.size()[:-1])
+            key = (R, image_feat_variable.device)
+            ar = self._arange_cache.get(key)
+            if ar is None:
+                ar = self._arange_cache[key] = torch.arange(R, device=image_feat_variable.device)
+            ar = ar.expand(*image_feat_variable.size()[:-1])
             dim = image_dim_variable
             if dim.dim() < ar.dim():
                 dim = dim.unsqueeze(-1)
-            image_mask = (ar < dim).long()
+            image_mask = torch.lt(ar, dim, out=torch.empty(ar.shape, dtype=torch.long, device=ar.device))
         else:
             image_mask = None
         output_dict = self.bert(
@@ -345,7 +352,9 @@ class ModelWrapper(object):
             # order, model_wrapper.py:64): all-reducing them would be pure xGMI traffic
             self.grad_sync.begin_step(sync=(self.called_time + 1) % gas == 0)
         output_dict = self.model(**batch)
-        loss = output_dict["loss"].mean()
+        loss = output_dict["loss"]
+        if loss.dim() > 0:                                  # (one replica: the loss is a scalar already; .mean() would be a launch + two in backward)
+            loss = loss.mean()
         if gas > 1:
             loss = loss / gas
         loss.backward()

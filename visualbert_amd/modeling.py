@@ -89,6 +89,9 @@ def _check_act(config):
         raise NotImplementedError("visualbert_amd: only hidden_act='gelu' (erf GELU, modeling.py:56-61) has a kernel")
 
 
+_MASK_OFF = torch.tensor(-10000.0)           # (0-dim, host: a scalar operand of the additive attention mask)
+
+
 # ------------------------------------------------------------------------------------------------
 class ParameterArena(object):
     """Flat fp32 storage for a list of parameters (+ gradient arena, bf16 shadow arena, and the device
@@ -853,8 +856,8 @@ class BertVisualModel(PreTrainedBertModel):
         if token_type_ids is None:
             token_type_ids = torch.zeros_like(input_ids)
         extended_attention_mask = attention_mask.unsqueeze(1).unsqueeze(2)
-        extended_attention_mask = extended_attention_mask.to(dtype=torch.float32)
-        extended_attention_mask = (1.0 - extended_attention_mask) * -10000.0       # modeling.py:1293-1294
+        # (1.0 - mask) * -10000.0 in fp32 (modeling.py:1293-1294) as ONE launch: -10000 + 10000 * mask, the constant a 0-dim host tensor
+        extended_attention_mask = torch.add(_MASK_OFF, extended_attention_mask, alpha=10000.0)
         embedding_output = self.embeddings(input_ids, token_type_ids, visual_embeddings=visual_embeddings,
                                            position_embeddings_visual=position_embeddings_visual,
                                            visual_embeddings_type=visual_embeddings_type,
@@ -928,6 +931,7 @@ class TrainVisualBERTObjective(PreTrainedBertModel):
         self.hard_cap_seq_len = hard_cap_seq_len
         self.bert = BertVisualModel(config)
         self.training_head_type = training_head_type
+        self._zero_types = {}
         self.sparse_mlm_head = False       # opt-in: MLM head over the labelled positions only (changes `logits` to [n, V])
         if training_head_type == "pretraining":
             self.cls = BertPreTrainingHeads(config, self.bert.embeddings.word_embeddings.weight)
@@ -1097,7 +1101,12 @@ class TrainVisualBERTObjective(PreTrainedBertModel):
         if visual_embeddings_type is not None:
             visual_embeddings_type = transform_to_batch_sequence(visual_embeddings_type)
         elif flat_image_mask is not None:
-            visual_embeddings_type = torch.zeros_like(flat_image_mask, dtype=torch.long)
+            key = (tuple(flat_image_mask.shape), flat_image_mask.device)
+            visual_embeddings_type = self._zero_types.get(key)            # all-zero type ids, read-only: made once per shape
+            if visual_embeddings_type is None:
+                if len(self._zero_types) > 8:
+                    self._zero_types.clear()
+                visual_embeddings_type = self._zero_types[key] = torch.zeros_like(flat_image_mask, dtype=torch.long)
 
         if flat_image_mask is not None:
             assert image_lm_lables is None

@@ -856,8 +856,13 @@ class BertVisualModel(PreTrainedBertModel):
         if token_type_ids is None:
             token_type_ids = torch.zeros_like(input_ids)
         extended_attention_mask = attention_mask.unsqueeze(1).unsqueeze(2)
-        # (1.0 - mask) * -10000.0 in fp32 (modeling.py:1293-1294) as ONE launch: -10000 + 10000 * mask, the constant a 0-dim host tensor
-        extended_attention_mask = torch.add(_MASK_OFF, extended_attention_mask, alpha=10000.0)
+        if attention_mask.is_floating_point():
+            # the reference's own three operations (modeling.py:1293-1294): a fractional mask rounds as it does there
+            extended_attention_mask = (1.0 - extended_attention_mask.to(dtype=torch.float32)) * -10000.0
+        else:
+            # integer / bool masks (what every data path of the reference produces): (1.0 - mask) * -10000.0 in fp32 as ONE launch,
+            # -10000 + 10000 * mask with the constant a 0-dim host tensor -- the same values (0 or -10000) exactly
+            extended_attention_mask = torch.add(_MASK_OFF, extended_attention_mask, alpha=10000.0)
         embedding_output = self.embeddings(input_ids, token_type_ids, visual_embeddings=visual_embeddings,
                                            position_embeddings_visual=position_embeddings_visual,
                                            visual_embeddings_type=visual_embeddings_type,

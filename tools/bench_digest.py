@@ -17,7 +17,7 @@ def main():
             d.get("step_mfu"), d.get("step_mfu_executed")))
         if r:
             print("  roofline: %s frac %s  achieved %s %s  avg %s us  traffic %s" % (r.get("kernel", "")[:50], r.get("frac"), r.get("achieved"), r.get("unit"),
-                                                                                 r.get("avg_us"), r.get("traffic")))
+                                                                                 r.get("avg_launch_us"), r.get("traffic")))
             for k, v in sorted((r.get("hbm_bound") or {}).items()):
                 print("    hbm %-62s %7.1f us %7.1f GB/s" % (k[:62], v["us"], v["GBps"]))
         s = d.get("strict_mode")

@@ -111,6 +111,8 @@ VB_KERNEL VB_LAUNCH_BOUNDS(NT) adam_update_kernel(float* params, const float* gr
         clip = cc < 1.0f ? cc : 1.0f;
     }
     const float lr = h.lr * schedule_mult(h, steps[tid]);
+    // (4-byte accesses on purpose: a wave's load is 256 contiguous bytes per array and many of them are in flight.  The 16-byte form --
+    // a quarter of the memory instructions -- measured SLOWER in the step, 632 vs 554 us at B = 8 on the 3.3 GB pass; round 6, not kept)
     for (long i = threadIdx.x; i < len; i += NT) {
         const long e = off + i;
         const float g = grads[e] * clip;
